@@ -1,0 +1,511 @@
+"""CPU ORACLE — test infrastructure, not product code.
+
+A column-wise restatement, in plain fp32 torch CPU ops, of the reference's closed-loop
+rollout ``InfGenAgentDecoder.inference`` (reference infgen/modules/agent_decoder.py:1605-2389)
+and of its once-per-scene prologue ``InfGenMapDecoder.forward``
+(infgen/modules/map_decoder.py:70-130).  It keeps the reference's arithmetic (per-edge
+``k_j + W_kr r``, PyG softmax with ``+1e-16``, un-fused LayerNorms) but not its control flow:
+only the current column is processed each step and the per-layer inputs of past columns are
+cached.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; the product path (infgen_amd) never does.
+
+PINNED: tests/test_oracle_golden.py checks this file against fixtures produced by running
+the reference's own modules (tests/golden/make_golden.py) — tokens/states exact, poses and
+hooked logits to fp32 round-off.  Third-party semantics that no reference test pins
+(torch_cluster.radius first-K order, PyG softmax epsilon) are fixed by definition, see
+tests/golden/_standins.py; for those the parity is "unpinned by the reference, pinned by the
+stand-in definition".
+
+Weights are a flat ``{name: tensor}`` dict with the reference's ``state_dict`` keys
+(``agent_encoder.*`` / ``map_encoder.*``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+INVALID, VALID, ENTER, EXIT = 0, 1, 2, 3
+SEED_TYPE = 3
+NUM_SEED_FEATURE = 10          # agent_decoder.py:292
+INVALID_SHAPE = 0.1            # agent_decoder.py:192
+MOTION_GAP = 1.0               # agent_decoder.py:190
+HEADING_GAP = 1.0              # agent_decoder.py:191
+INVALID_MOTION = -2.0          # agent_decoder.py:193
+INVALID_HEAD = -2.0            # agent_decoder.py:194
+AGENT_SHAPE = {0: [4.3, 1.8, 1.0], 1: [0.5, 0.5, 1.0], 2: [1.9, 0.5, 1.0]}   # preprocess.py:14-18
+
+
+# ------------------------------------------------------------------------------ helpers
+def wrap_angle(a: torch.Tensor) -> torch.Tensor:
+    """infgen/utils/func.py:58-62"""
+    return -math.pi + (a + math.pi) % (2 * math.pi)
+
+
+def angle_between(ctr: torch.Tensor, nbr: torch.Tensor) -> torch.Tensor:
+    """infgen/utils/func.py:30-34"""
+    return torch.atan2(ctr[..., 0] * nbr[..., 1] - ctr[..., 1] * nbr[..., 0],
+                       (ctr[..., :2] * nbr[..., :2]).sum(dim=-1))
+
+
+def _lin(sd, p, x, bias=True):
+    return F.linear(x, sd[p + '.weight'], sd[p + '.bias'] if bias else None)
+
+
+def _ln(sd, p, x):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + '.weight'], sd[p + '.bias'])
+
+
+def fourier_embedding(sd, p, x: torch.Tensor, cat: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
+    """infgen/modules/layers.py:142-160"""
+    n = x.shape[-1]
+    f = x.unsqueeze(-1) * sd[p + '.freqs.weight'] * 2 * math.pi
+    f = torch.cat([f.cos(), f.sin(), x.unsqueeze(-1)], dim=-1)
+    embs = []
+    for i in range(n):
+        h = _lin(sd, f'{p}.mlps.{i}.0', f[:, i])
+        h = F.relu(_ln(sd, f'{p}.mlps.{i}.1', h))
+        embs.append(_lin(sd, f'{p}.mlps.{i}.3', h))
+    out = torch.stack(embs).sum(dim=0)
+    if cat is not None:
+        out = out + torch.stack(cat).sum(dim=0)
+    out = F.relu(_ln(sd, p + '.to_out.0', out))
+    return _lin(sd, p + '.to_out.2', out)
+
+
+def mlp_embedding(sd, p, x):
+    """infgen/modules/layers.py:163-192"""
+    h = F.relu(_ln(sd, p + '.mlp.1', _lin(sd, p + '.mlp.0', x)))
+    h = F.relu(_ln(sd, p + '.mlp.4', _lin(sd, p + '.mlp.3', h)))
+    return _lin(sd, p + '.mlp.6', h)
+
+
+def mlp_layer(sd, p, x):
+    """infgen/modules/layers.py:195-215"""
+    return _lin(sd, p + '.mlp.3', F.relu(_ln(sd, p + '.mlp.1', _lin(sd, p + '.mlp.0', x))))
+
+
+def attention_layer(sd, p, x_dst_raw, r, src, dst, x_src_raw=None, H=8, dh=16):
+    """infgen/modules/layers.py:61-113 with PyG propagate/softmax restated
+    (tests/golden/_standins.py).  ``src``/``dst`` are edge endpoints (long)."""
+    bip = x_src_raw is not None
+    if bip:
+        x_src = _ln(sd, p + '.attn_prenorm_x_src', x_src_raw)
+        x_dst = _ln(sd, p + '.attn_prenorm_x_dst', x_dst_raw)
+    else:
+        x_src = x_dst = _ln(sd, p + '.attn_prenorm_x_src', x_dst_raw)
+    n = x_dst.shape[0]
+    q = _lin(sd, p + '.to_q', x_dst).view(-1, H, dh)
+    k = _lin(sd, p + '.to_k', x_src, bias=False).view(-1, H, dh)
+    v = _lin(sd, p + '.to_v', x_src).view(-1, H, dh)
+    agg = torch.zeros(n, H, dh)
+    if src.numel() > 0:
+        kj, vj = k[src], v[src]
+        if r is not None:
+            rn = _ln(sd, p + '.attn_prenorm_r', r)
+            kj = kj + _lin(sd, p + '.to_k_r', rn, bias=False).view(-1, H, dh)
+            vj = vj + _lin(sd, p + '.to_v_r', rn).view(-1, H, dh)
+        sim = (q[dst] * kj).sum(-1) * (dh ** -0.5)
+        idx = dst.view(-1, 1).expand_as(sim)
+        mx = torch.full((n, H), float('-inf')).scatter_reduce(0, idx, sim, reduce='amax', include_self=True)
+        e = (sim - mx[dst]).exp()
+        s = torch.zeros(n, H).scatter_add(0, idx, e)
+        attn = e / (s[dst] + 1e-16)
+        agg.index_add_(0, dst, vj * attn.unsqueeze(-1))
+    agg = agg.view(n, H * dh)
+    g = torch.sigmoid(_lin(sd, p + '.to_g', torch.cat([agg, x_dst], dim=-1)))
+    upd = agg + g * (_lin(sd, p + '.to_s', x_dst) - agg)
+    x = x_dst_raw + _ln(sd, p + '.attn_postnorm', _lin(sd, p + '.to_out', upd))
+    ff = _lin(sd, p + '.ff_mlp.3', F.relu(_lin(sd, p + '.ff_mlp.0', _ln(sd, p + '.ff_prenorm', x))))
+    return x + _ln(sd, p + '.ff_postnorm', ff)
+
+
+def radius_first_k(x: torch.Tensor, y: torch.Tensor, r: float, k: int):
+    """torch_cluster.radius for one batch: for each y the first k x (ascending index) with
+    squared distance strictly below r*r.  Returns (y_idx, x_idx)."""
+    if x.shape[0] == 0 or y.shape[0] == 0:
+        z = torch.zeros(0, dtype=torch.long)
+        return z, z
+    d = ((y[:, None, :] - x[None, :, :]) ** 2).sum(-1)
+    within = d < float(r) * float(r)
+    keep = within & (torch.cumsum(within.long(), 1) <= k)
+    nz = torch.nonzero(keep)
+    return nz[:, 0], nz[:, 1]
+
+
+def rot_right(x: torch.Tensor, theta: torch.Tensor) -> torch.Tensor:
+    """x (..., L, 2) @ [[cos, sin], [-sin, cos]]  (agent_decoder.py:2180-2189, attr_tokenizer.py:45-55)"""
+    cos, sin = theta.cos(), theta.sin()
+    rot = torch.zeros(theta.shape + (2, 2))
+    rot[..., 0, 0] = cos
+    rot[..., 0, 1] = sin
+    rot[..., 1, 0] = -sin
+    rot[..., 1, 1] = cos
+    return torch.matmul(x, rot)
+
+
+def encode_pos(grid: torch.Tensor, x: torch.Tensor, y: torch.Tensor, theta_y: torch.Tensor) -> torch.Tensor:
+    """attr_tokenizer.py:77-89 (index only)"""
+    cx = x - y
+    cx = rot_right(cx[:, None], (-(theta_y - math.pi / 2)).expand(x.shape[0]))[:, 0]
+    d = ((cx[:, None] - grid[None]) ** 2).sum(-1).sqrt()
+    return torch.argmin(d, dim=-1)
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+    return t.to(dtype) if dtype is not None else t
+
+
+# ------------------------------------------------------------------------------ map prologue
+def map_encoder(sd: Dict[str, torch.Tensor], scene, cfg, map_vocab: np.ndarray, prefix='map_encoder') -> torch.Tensor:
+    """infgen/modules/map_decoder.py:70-130 -> x_pt (M, 128)"""
+    pt = scene['pt_token']
+    pos = _t(pt['position'])[:, :2].contiguous().float()
+    orient = _t(pt['orientation']).float()
+    ovec = torch.stack([orient.cos(), orient.sin()], dim=-1)
+    tok = mlp_embedding(sd, prefix + '.token_emb', _t(map_vocab).float().view(map_vocab.shape[0], -1))
+    x = tok[_t(pt['token_idx']).long()]
+    e = scene['pt_token__to__map_polygon']['edge_index']
+    light = _t(scene['map_polygon']['light_type']).long()[_t(e).long()[1]]
+    cat = [sd[prefix + '.type_pt_emb.weight'][_t(pt['type']).long()],
+           sd[prefix + '.polygon_type_emb.weight'][_t(pt['pl_type']).long()],
+           sd[prefix + '.light_pl_emb.weight'][light]]
+    x = x + torch.stack(cat).sum(dim=0)
+    # radius_graph(loop=False, max_num_neighbors=100): first 101 incl. self, self dropped
+    yi, xi = radius_first_k(pos, pos, cfg.pl2pl_radius, 100 + 1)
+    m = yi != xi
+    dst, src = yi[m], xi[m]
+    rel = pos[src] - pos[dst]
+    rel_o = wrap_angle(orient[src] - orient[dst])
+    r = torch.stack([torch.norm(rel, p=2, dim=-1), angle_between(ovec[dst], rel), rel_o], dim=-1)
+    r = fourier_embedding(sd, prefix + '.r_pt2pt_emb', r)
+    for i in range(cfg.num_map_layers):
+        x = attention_layer(sd, f'{prefix}.pt2pt_layers.{i}', x, r, src, dst)
+    return x
+
+
+# ------------------------------------------------------------------------------ rollout
+class RolloutOracle:
+    """Greedy closed-loop rollout of one scene, insertion disabled
+    (``motion_beam_size = 1``; ``disable_insertion`` as in BASELINE configs C1-C3)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], cfg, grid: np.ndarray, prefix: str = 'agent_encoder',
+                 live_state: bool = False):
+        self.sd, self.cfg, self.p = sd, cfg, prefix
+        self.grid = _t(grid).float()
+        self.live_state = live_state
+        self.W = cfg.window
+        self.H, self.dh = cfg.num_heads, cfg.head_dim
+
+    # ---- constant tables (agent_decoder.py:347-373)
+    def tables(self, vocab):
+        sd, p = self.sd, self.p
+        bos = sd[p + '.bos_token_emb.weight']
+        no = sd[p + '.no_token_emb.weight']
+        tabs = []
+        for name in ('veh', 'ped', 'cyc'):
+            v = _t(vocab[name]).float()
+            e = mlp_embedding(sd, f'{p}.token_emb_{name}', v[:, -1].flatten(1, 2))
+            tabs.append(torch.cat([e, bos, no]))
+        grid_tab = torch.cat([mlp_embedding(sd, p + '.token_emb_grid', self.grid),
+                              sd[p + '.invalid_offset_token_emb.weight']])
+        return torch.stack(tabs), grid_tab
+
+    # ---- raw per-column feature (agent_decoder.py:426-509, 2265-2287)
+    def raw_feature(self, st, j):
+        sd, p = self.sd, self.p
+        state = st['state']
+        pos, head = st['pos'], st['head']
+        A = pos.shape[0]
+        mv = pos[:, j] - pos[:, j - 1] if j > 0 else torch.zeros(A, 2)
+        mv = mv.clone()
+        inv = state[:, j] == INVALID
+        mv[inv] = INVALID_MOTION
+        if j > 0:
+            prev_inv = state[:, j - 1] == INVALID
+            mv[prev_inv & ~inv] = MOTION_GAP
+            mv[~prev_inv & inv] = -MOTION_GAP
+        else:
+            mv[state[:, 0] == ENTER] = MOTION_GAP
+        hv = torch.stack([head[:, j].cos(), head[:, j].sin()], dim=-1)
+        feat = torch.stack([torch.norm(mv, p=2, dim=-1), angle_between(hv, mv)], dim=-1)
+        cat = [st['type_emb'][:, j], st['shape_emb'][:, j]]
+        x_a = fourier_embedding(sd, p + '.x_a_emb', feat, cat)
+        tok = st['tok_tab'][st['type'].long(), st['token'][:, j]]
+        s_a = sd[p + '.state_a_emb.weight'][state[:, j]]
+        g = st['grid_tab'][st['gridtok'][:, j]]
+        return mlp_embedding(sd, p + '.fusion_emb', torch.cat([tok, x_a, s_a, g], dim=-1))
+
+    # ---- edges into column c
+    def temporal_edges(self, st, c):
+        """agent_decoder.py:540-610 -> (src_col (E,), dst_row (E,), r (E,128))"""
+        sd, p = self.sd, self.p
+        state, pos, head = st['state'], st['pos'], st['head']
+        A, T = state.shape
+        is_bos = state == ENTER
+        bos = torch.where(is_bos.any(1), torch.argmax(is_bos.long(), dim=1), torch.tensor(0))
+        cols = torch.arange(T)[None, :]
+        hist = st['tmask'].clone() & (cols >= bos[:, None])
+        lo = max(A - NUM_SEED_FEATURE, 0)
+        hist[lo:] = False
+        hist = hist & (cols < c) & (cols >= c - self.W)
+        nz = torch.nonzero(hist)
+        rows, js = nz[:, 0], nz[:, 1]
+        dp = pos[rows, js] - pos[rows, c]
+        dth = wrap_angle(head[rows, js] - head[rows, c])
+        s_inv = state[rows, js] == INVALID
+        d_inv = state[rows, c] == INVALID
+        dp[s_inv & ~d_inv] = -MOTION_GAP
+        dp[~s_inv & d_inv] = MOTION_GAP
+        dth[s_inv & ~d_inv] = -HEADING_GAP
+        # agent_decoder.py:598 is a no-op (always-false mask)
+        dp[s_inv & d_inv] = INVALID_MOTION
+        dth[s_inv & d_inv] = INVALID_HEAD
+        hv = torch.stack([head[rows, c].cos(), head[rows, c].sin()], dim=-1)
+        r = torch.stack([torch.norm(dp, p=2, dim=-1), angle_between(hv, dp), dth, (js - c).float()], dim=-1)
+        r = fourier_embedding(sd, p + '.r_t_emb', r) if rows.numel() else torch.zeros(0, 128)
+        return js, rows, r
+
+    def map_edges(self, st, c):
+        """agent_decoder.py:683-758 -> (src_map (E,), dst_row (E,), r)"""
+        sd, p = self.sd, self.p
+        pos, head, state = st['pos'][:, c], st['head'][:, c], st['state'][:, c]
+        yi, xi = radius_first_k(st['map_pos'], pos, self.cfg.pl2a_radius, 5)
+        keep = st['imask'][yi, c]
+        dst, src = yi[keep], xi[keep]
+        dp = st['map_pos'][src] - pos[dst]
+        dth = wrap_angle(st['map_orient'][src] - head[dst])
+        inv = state[dst] == INVALID
+        dp[inv] = MOTION_GAP
+        dth[inv] = HEADING_GAP
+        hv = torch.stack([head[dst].cos(), head[dst].sin()], dim=-1)
+        r = torch.stack([torch.norm(dp, p=2, dim=-1), angle_between(hv, dp), dth], dim=-1)
+        r = fourier_embedding(sd, p + '.r_pt2a_emb', r) if dst.numel() else torch.zeros(0, 128)
+        return src, dst, r
+
+    def agent_edges(self, st, c):
+        """agent_decoder.py:612-681 (inference branch) -> (src_row, dst_row, r)"""
+        sd, p = self.sd, self.p
+        pos, head, state = st['pos'][:, c], st['head'][:, c], st['state'][:, c]
+        yi, xi = radius_first_k(pos, pos, self.cfg.a2a_radius, 300 + 1)
+        m = (yi != xi) & st['imask'][yi, c] & st['imask'][xi, c]
+        dst, src = yi[m], xi[m]
+        dp = pos[src] - pos[dst]
+        dth = wrap_angle(head[src] - head[dst])
+        s_inv, d_inv = state[src] == INVALID, state[dst] == INVALID
+        dp[s_inv & ~d_inv] = -MOTION_GAP
+        dp[~s_inv & d_inv] = MOTION_GAP
+        dth[s_inv & ~d_inv] = -HEADING_GAP
+        dp[s_inv & d_inv] = INVALID_MOTION
+        dth[s_inv & d_inv] = INVALID_HEAD
+        hv = torch.stack([head[dst].cos(), head[dst].sin()], dim=-1)
+        r = torch.stack([torch.norm(dp, p=2, dim=-1), angle_between(hv, dp), dth], dim=-1)
+        r = fourier_embedding(sd, p + '.r_a2a_emb', r) if dst.numel() else torch.zeros(0, 128)
+        return src, dst, r
+
+    # ---- one triple stack on column c; `edgeless` reproduces column 0 (SURVEY a-Q3)
+    def run_stack(self, st, c, x, edgeless=False):
+        sd, p, cfg = self.sd, self.p, self.cfg
+        A = x.shape[0]
+        z = torch.zeros(0, dtype=torch.long)
+        if not edgeless:
+            tj, trow, r_t = self.temporal_edges(st, c)
+            msrc, mdst, r_m = self.map_edges(st, c)
+            asrc, adst, r_a = self.agent_edges(st, c)
+            st['edge_count'].append((int(trow.numel()), int(adst.numel()), int(mdst.numel())))
+        for i in range(cfg.num_agent_layers):
+            st['X'][i][:, c] = x
+            if edgeless:
+                x = attention_layer(sd, f'{p}.t_attn_layers.{i}', x, None, z, z)
+                x = attention_layer(sd, f'{p}.pt2a_attn_layers.{i}', x, None, z, z, x_src_raw=st['x_pt'])
+                x = attention_layer(sd, f'{p}.a2a_attn_layers.{i}', x, None, z, z)
+                continue
+            # temporal: sources are cached layer inputs of past columns (a-Q4)
+            if trow.numel():
+                xs = st['X'][i][trow, tj]
+                xin = torch.cat([x, xs], dim=0)
+                xo = attention_layer(sd, f'{p}.t_attn_layers.{i}', xin, r_t, A + torch.arange(trow.numel()), trow)
+                x = xo[:A]
+            else:
+                x = attention_layer(sd, f'{p}.t_attn_layers.{i}', x, None, z, z)
+            x = attention_layer(sd, f'{p}.pt2a_attn_layers.{i}', x, r_m, msrc, mdst, x_src_raw=st['x_pt'])
+            x = attention_layer(sd, f'{p}.a2a_attn_layers.{i}', x, r_a, asrc, adst)
+        return x
+
+    # ---- full rollout
+    @torch.no_grad()
+    def rollout(self, scene, x_pt: torch.Tensor, vocab, teacher_tokens: Optional[np.ndarray] = None,
+                teacher_states: Optional[np.ndarray] = None):
+        sd, p, cfg = self.sd, self.p, self.cfg
+        ag = scene['agent']
+        state0 = _t(ag['state_idx']).long()
+        filt = state0[:, 1] != INVALID
+        av0 = int(np.asarray(ag['av_index']).reshape(-1)[0])
+        av = av0 - int((~filt[:av0]).sum())
+        T = cfg.num_columns
+        R = cfg.num_recurrent_steps_val
+
+        def take(k, dtype=None):
+            return _t(ag[k])[filt].clone() if dtype is None else _t(ag[k])[filt].clone().to(dtype)
+
+        def pad(x, val):
+            if x.shape[1] >= T:
+                return x
+            shp = (x.shape[0], T - x.shape[1]) + tuple(x.shape[2:])
+            return torch.cat([x, torch.full(shp, val, dtype=x.dtype)], dim=1)
+        pos = pad(take('token_pos', torch.float32), 0.0)
+        head = pad(take('token_heading', torch.float32), 0.0)
+        token = pad(take('token_idx', torch.long), -1)
+        state = pad(state0[filt].clone(), INVALID)
+        gridtok = pad(take('grid_token_idx', torch.long), -1)
+        valid = pad(take('raw_agent_valid_mask', torch.bool), True)
+        atype = take('type', torch.long)
+        shape10 = _t(ag['shape'])[filt][:, cfg.num_historical_steps - 1].float()
+        eval_mask = _t(ag['valid_mask'])[filt][:, cfg.num_historical_steps - 1]
+        A = pos.shape[0]
+        hc = cfg.hist_columns  # 2
+        pos[:, hc:] = 0
+        head[:, hc:] = 0
+        token[:, hc:] = -1
+        state[:, hc:] = INVALID
+        gridtok[:, hc:] = -1
+        valid[:, hc:] = True
+        valid[~eval_mask] = False
+
+        # masks (agent_decoder.py:1695-1719)
+        is_bos, is_eos = state == ENTER, state == EXIT
+        bos = torch.where(is_bos.any(1), torch.argmax(is_bos.long(), 1), torch.tensor(0))
+        eos = torch.where(is_eos.any(1), torch.argmax(is_eos.long(), 1), torch.tensor(T - 1))
+        cols = torch.arange(T)[None, :]
+        motion = (cols > bos[:, None]) & (cols <= eos[:, None])
+        motion[:, cfg.num_historical_steps // cfg.shift:] = False
+        tmask = torch.ones(A, T, dtype=torch.bool)
+        tmask[motion] = valid[motion]
+        imask = torch.ones(A, T, dtype=torch.bool)
+        nonmotion = ~motion
+        nonmotion[:, cfg.num_historical_steps // cfg.shift:] = False
+        imask[nonmotion] = False
+        imask[state == ENTER] = True
+        imask[av] = True
+        tmask[:, hc:] = True
+        imask[:, hc:] = True
+
+        # categorical embeddings per (row, column) (agent_decoder.py:376-380; a-Q5)
+        seed_type_emb = sd[p + '.type_a_emb.weight'][SEED_TYPE]
+        seed_shape_emb = mlp_embedding(sd, p + '.shape_emb', torch.full((1, 3), INVALID_SHAPE))[0]
+        type_emb = sd[p + '.type_a_emb.weight'][atype][:, None, :].repeat(1, T, 1)
+        shape_emb = mlp_embedding(sd, p + '.shape_emb', shape10)[:, None, :].repeat(1, T, 1)
+        inv = state == INVALID
+        type_emb[inv] = seed_type_emb
+        shape_emb[inv] = seed_shape_emb
+
+        tok_tab, grid_tab = self.tables(vocab)
+        st = dict(pos=pos, head=head, token=token, state=state, gridtok=gridtok, type=atype,
+                  tmask=tmask, imask=imask, type_emb=type_emb, shape_emb=shape_emb,
+                  tok_tab=tok_tab, grid_tab=grid_tab, x_pt=x_pt,
+                  map_pos=_t(scene['pt_token']['position'])[:, :2].contiguous().float(),
+                  map_orient=_t(scene['pt_token']['orientation']).float(),
+                  X=[torch.zeros(A, T, cfg.hidden_dim) for _ in range(cfg.num_agent_layers)],
+                  edge_count=[])
+        tabs = torch.stack([_t(vocab[k]).float() for k in ('veh', 'ped', 'cyc')])   # (3, 2048, 6, 4, 2)
+
+        # column 0: edgeless chain (a-Q3); column 1 is the first current column
+        self.run_stack(st, 0, self.raw_feature(st, 0), edgeless=True)
+        raw_c = self.raw_feature(st, 1)
+
+        pred_traj = torch.zeros(A, R, 2)
+        pred_head = torch.zeros(A, R)
+        pred_state = torch.zeros(A, R)
+        tok_hist = [_t(ag['token_idx'])[filt][:, i:i + 1].long() for i in range(hc)]
+        st_hist = [state0[filt][:, i:i + 1] for i in range(hc)]
+        logits_all = []
+        for t in range(cfg.num_decode_steps):
+            c, n = hc - 1 + t, hc + t
+            x = self.run_stack(st, c, raw_c)
+            logits = mlp_layer(sd, p + '.token_predict_head', x)
+            logits_all.append(logits)
+            prob = torch.softmax(logits, dim=-1)
+            next_tok = torch.topk(prob, k=1, dim=-1)[1][:, 0]
+            s_prob = mlp_layer(sd, p + '.state_predict_head', x)
+            nstate = s_prob.softmax(dim=-1).argmax(dim=-1)
+            nstate[nstate == 2] = EXIT
+            nstate[av] = VALID
+            if cfg.disable_insertion and not self.live_state:
+                nstate[:] = VALID
+            if teacher_tokens is not None:
+                next_tok = _t(teacher_tokens[:, n]).long().clone()
+                next_tok[next_tok < 0] = 0
+            if teacher_states is not None:
+                nstate = _t(teacher_states[:, n]).long().clone()
+            # contour integrate (agent_decoder.py:2175-2212)
+            contour = tabs[atype, next_tok]                                    # (A, 6, 4, 2)
+            theta = head[:, c]
+            contour = rot_right(contour.view(A, 24, 2), theta).view(A, 6, 4, 2) + pos[:, None, None, c, :]
+            diff = contour[:, 1:, 0, :] - contour[:, 1:, 3, :]
+            pred_traj[:, t * 5:(t + 1) * 5] = contour[:, 1:].mean(dim=2)
+            pred_head[:, t * 5:(t + 1) * 5] = torch.arctan2(diff[:, :, 1], diff[:, :, 0])
+            pred_state[:, t * 5:(t + 1) * 5] = nstate[:, None].float().repeat(1, 5)
+            pos[:, n] = contour[:, -1].mean(dim=1)
+            d = contour[:, -1, 0, :] - contour[:, -1, 3, :]
+            th_n = torch.arctan2(d[:, 1], d[:, 0])
+            head[:, n] = th_n
+            state[:, n] = nstate
+            gridtok[:, n] = encode_pos(self.grid, pos[:, n], pos[av, n][None].expand(A, 2), th_n[av])
+            is_inv = nstate == INVALID
+            next_tok = next_tok.clone()
+            next_tok[is_inv] = -1
+            pos[is_inv, n] = 0.0
+            head[is_inv, n] = 0.0
+            gridtok[is_inv, n] = -1
+            imask[is_inv, n] = False
+            type_emb[is_inv, n] = seed_type_emb
+            shape_emb[is_inv, n] = seed_shape_emb
+            token[:, n] = next_tok
+            tok_hist.append(next_tok[:, None])
+            st_hist.append(nstate[:, None])
+            raw_c = self.raw_feature(st, n)
+
+        # epilogue (agent_decoder.py:2303-2345)
+        H = cfg.num_historical_steps
+        pred_traj = torch.cat([torch.zeros(A, H, 2), pred_traj], dim=1)
+        pred_head = torch.cat([torch.zeros(A, H), pred_head], dim=1)
+        pred_state = torch.cat([torch.zeros(A, H), pred_state], dim=1)
+        pred_traj[:, 0] = _t(ag['position'])[filt][:, 0, :2].float()
+        pred_head[:, 0] = _t(ag['heading'])[filt][:, 0].float()
+        pred_state[:, 1:H] = state0[filt][:, :hc].repeat_interleave(cfg.shift, dim=1).float()
+        htok = _t(ag['token_idx'])[filt][:, :hc].long().clone()
+        htok[htok < 0] = 0
+        hcont = tabs[atype[:, None].expand(A, hc), htok]                        # (A, hc, 6, 4, 2)
+        hcont = rot_right(hcont.view(A, hc * 24, 2), head[:, 0]).view(A, hc, 6, 4, 2) + pos[:, 0][:, None, None, None, :]
+        pred_traj[:, 1:H] = hcont[:, :, 1:].mean(dim=3).reshape(A, -1, 2)
+        dxy = hcont[..., 1:, 0, :] - hcont[..., 1:, 3, :]
+        pred_head[:, 1:H] = torch.arctan2(dxy[..., 1], dxy[..., 0]).reshape(A, -1)
+        pred_valid = (pred_state != INVALID) & (pred_state != ENTER)
+        eval_shape = torch.tensor([AGENT_SHAPE[int(k)] for k in atype])
+        return dict(
+            ego_index=av, agent_id=_t(ag['id'])[filt].clone(), valid_mask=valid, pos_a=pos, head_a=head,
+            pred_traj=pred_traj, pred_head=pred_head, pred_state=pred_state, pred_valid=pred_valid,
+            pred_type=atype, pred_shape=_t(ag['shape'])[filt][:, hc - 1].float(), eval_shape=eval_shape,
+            next_token_idx=torch.cat(tok_hist, dim=-1), next_state_idx=torch.cat(st_hist, dim=-1),
+            logits=torch.stack(logits_all), edge_count=np.asarray(st['edge_count'], dtype=np.int64),
+            X=st['X'], imask=imask, tmask=tmask, gridtok=gridtok,
+        )
+
+
+def run_scene(sd, scene, cfg, vocab, map_vocab, grid, live_state=False, teacher=None):
+    """map prologue + rollout; returns the rollout dict plus ``x_pt``."""
+    with torch.no_grad():
+        x_pt = map_encoder(sd, scene, cfg, map_vocab)
+        orc = RolloutOracle(sd, cfg, grid, live_state=live_state)
+        tt = ts = None
+        if teacher is not None:
+            tt, ts = teacher
+        out = orc.rollout(scene, x_pt, vocab, teacher_tokens=tt, teacher_states=ts)
+    out['x_pt'] = x_pt
+    return out
