@@ -1,0 +1,141 @@
+/*
+ * infgen_hip.h — C ABI of libinfgen_hip.so: the MI355X (gfx950) implementation of InfGen's
+ * closed-loop rollout hot path.
+ *
+ * The reference (OrangeSodahub/InfGen) is pure Python and has no FFI for this path; its native
+ * arithmetic lives in third-party wheels.  Each entry point below replaces one group of those
+ * calls (file:line are relative to the reference repository):
+ *
+ *   infgen_linear            torch.nn.Linear / LayerNorm / ReLU chains: MLPEmbedding, MLPLayer
+ *                            (infgen/modules/layers.py:163-215)
+ *   infgen_fourier_embed     FourierEmbedding.forward (infgen/modules/layers.py:142-160)
+ *   infgen_attn_pre          AttentionLayer: prenorm + to_q/to_k/to_v (+ absorbed to_k_r)
+ *                            (infgen/modules/layers.py:65-73,106-108)
+ *   infgen_edge_attn         MessagePassing.propagate + torch_geometric.utils.softmax
+ *                            (infgen/modules/layers.py:78-92,109)
+ *   infgen_attn_post         AttentionLayer.update / to_out / post-norm / FFN
+ *                            (infgen/modules/layers.py:74-75,94-99,110-112)
+ *   infgen_heads             token_predict_head / state_predict_head + greedy arg-max
+ *                            (infgen/modules/agent_decoder.py:2161-2167)
+ *   infgen_map_graph         torch_cluster.radius_graph over map tokens + relative features
+ *                            (infgen/modules/map_decoder.py:91-114)
+ *   infgen_build_edges       _build_temporal_edge / _build_interaction_edge / _build_map2agent_edge
+ *                            incl. torch_cluster.radius(max_num_neighbors=5)
+ *                            (infgen/modules/agent_decoder.py:540-758)
+ *   infgen_integrate         token -> contour -> pose, Attr_Tokenizer.encode_pos, invalid handling
+ *                            (infgen/modules/agent_decoder.py:2168-2239, attr_tokenizer.py:77-89)
+ *   infgen_raw_feature       _build_vector_a / x_a_emb / fusion_emb for one column
+ *                            (infgen/modules/agent_decoder.py:426-509,2265-2287)
+ *   infgen_decode_layers     the 6 x (temporal, map->agent, agent<->agent) stack on one column
+ *                            (infgen/modules/agent_decoder.py:2123-2158)
+ *   infgen_decode_step       one iteration of the rollout loop (infgen/modules/agent_decoder.py:1740-2301,
+ *                            insertion disabled)
+ *
+ * Conventions: every pointer is a DEVICE pointer (fp32 / int32 / uint8) borrowed for the duration
+ * of the call; outputs are pre-allocated by the caller; `stream` is a hipStream_t; nothing
+ * synchronises with the host; no global state; functions return 0 on success or a negative code
+ * and leave a message retrievable with infgen_last_error() (thread-local).
+ */
+#ifndef INFGEN_HIP_H_
+#define INFGEN_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INFGEN_MAX_LAYERS 8
+
+/* offsets / sizes (floats) of the packed weight layouts, see infgen_amd/csrc/layout.h */
+enum {
+  INFGEN_Q_ATTN_PACK_SIZE = 0,
+  INFGEN_Q_FOURIER_PACK_SIZE_N2 = 1,
+  INFGEN_Q_FOURIER_PACK_SIZE_N3 = 2,
+  INFGEN_Q_FOURIER_PACK_SIZE_N4 = 3,
+  INFGEN_Q_TILE_ROWS = 4,
+  INFGEN_Q_EDGE_ATTN_CAP = 5,
+  INFGEN_Q_MAX_AGENTS = 6,
+  INFGEN_Q_ABI_VERSION = 7,
+  INFGEN_Q_SIZEOF_ROLLOUT = 8,
+};
+int infgen_layout_query(int what);
+/* offset (floats) of a named field inside the AttentionLayer / Fourier pack; -1 if unknown */
+int infgen_attn_pack_offset(const char* field);
+int infgen_fourier_pack_offset(const char* field, int n_dims, int dim);
+const char* infgen_last_error(void);
+
+typedef struct InfgenEdgeBuf {
+  int* off;      /* [rows] */
+  int* cnt;      /* [rows] */
+  int* src;      /* [cap] */
+  float* raw;    /* [cap][4] */
+  float* rhat;   /* [cap][128] */
+  int* total;    /* [1] */
+  int cap;
+  int _pad;
+} InfgenEdgeBuf;
+
+typedef struct InfgenRollout {
+  /* sizes / hyper-parameters */
+  int S, A_cap, T, M_cap, W, ring, R, token_size, grid_size, num_layers;
+  int force_valid;      /* disable_insertion: predicted states are overridden with 'valid' */
+  int store_logits;     /* 1: logits[t] is written every step */
+  float r_map, r_agent; /* pl2a_radius, a2a_radius */
+  /* scene state, column-major per scene: [S][T][A_cap] */
+  const int* n_agents; const int* n_map; const int* av_index;
+  float* pos; float* head; int* state; int* token; int* grid;
+  uint8_t* tmask; uint8_t* imask; uint8_t* catflag;
+  const int* type; int* bos;
+  const float* map_pos; const float* map_orient;
+  /* packed weights */
+  const float* attn_t[INFGEN_MAX_LAYERS]; const float* attn_m[INFGEN_MAX_LAYERS]; const float* attn_a[INFGEN_MAX_LAYERS];
+  const float* four_t; const float* four_m; const float* four_a; const float* four_xa;
+  const float* fusion_pack;    /* MLPEmbedding(512): P(512,128) b ln | P(128,128) b ln | P(128,128) b */
+  const float* tok_head_pack; const float* st_head_pack;
+  const float* tok_tab; const float* grid_tab; const float* state_emb;
+  const float* cat_agent; const float* cat_seed; const float* vocab; const float* grid_xy;
+  /* caches */
+  float* ringK[INFGEN_MAX_LAYERS]; float* ringV[INFGEN_MAX_LAYERS];         /* [ring][rows][128] */
+  const float* mapK[INFGEN_MAX_LAYERS]; const float* mapV[INFGEN_MAX_LAYERS]; /* [S*M_cap][128] */
+  /* scratch */
+  float* X; float* Q; float* U; float* Ka; float* Va; float* AGG; float* Z; float* SIG;
+  InfgenEdgeBuf et, em, ea;
+  float* raw2; float* cat; float* fus_in; float* tmp1; float* tmp2;
+  int* next_token; int* next_state;
+  float* logits;               /* optional [steps][rows][token_size] */
+  const int* teacher_token; const int* teacher_state;   /* optional [S][T][A_cap] */
+  /* outputs */
+  float* pred_traj; float* pred_head; float* pred_state;   /* [S][A_cap][R](x2) */
+} InfgenRollout;
+
+int infgen_linear(const float* X, int ldx, const int* gather, int rows, int K,
+                  const float* Wp, int Np, const float* bias, int N,
+                  const float* pre_g, const float* pre_b, const float* post_g, const float* post_b, int relu,
+                  float* Y, int ldy, void* stream);
+int infgen_fourier_embed(const float* raw, int n_dims, const int* count_dev, int e_cap, const float* pack,
+                         const float* cat, int ldcat, float* out, int ldo, int normalize, void* stream);
+int infgen_attn_pre(const float* X, int rows, const float* pack, int use_src_ln,
+                    float* Q, float* U, float* K, float* V, void* stream);
+int infgen_edge_attn(int rows, const float* Q, const float* U, const float* Ksrc, const float* Vsrc,
+                     const int* off, const int* cnt, const int* src, const float* rhat,
+                     float* AGG, float* Z, float* SIG, void* stream);
+int infgen_attn_post(float* X, int rows, const float* pack, const float* AGG, const float* Z, const float* SIG,
+                     int has_pos, void* stream);
+int infgen_heads(const float* X, int rows, const float* tok_pack, const float* st_pack, int token_size,
+                 float* logits, int* next_token, int* next_state, void* stream);
+int infgen_map_graph(int S, int M_cap, const int* n_map, const float* pos, const float* orient, float radius,
+                     int max_nbr, int* off, int* cnt, int* src, float* raw, void* stream);
+
+int infgen_build_edges(const InfgenRollout* r, int c, int edgeless, void* stream);
+int infgen_integrate(const InfgenRollout* r, int t, void* stream);
+int infgen_raw_feature(const InfgenRollout* r, int col, void* stream);
+int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless, void* stream);
+int infgen_decode_step(const InfgenRollout* r, int t, void* stream);
+/* steps t0 .. t1-1 back to back (one host call per rollout) */
+int infgen_rollout_run(const InfgenRollout* r, int t0, int t1, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* INFGEN_HIP_H_ */

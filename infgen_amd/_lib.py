@@ -1,0 +1,113 @@
+"""ctypes binding of libinfgen_hip.so (C ABI: include/infgen_hip.h).
+
+The product path has NO fallback: if the shared library is missing or an entry point fails,
+an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libinfgen_hip.so')
+MAX_LAYERS = 8
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+
+
+class EdgeBuf(C.Structure):
+    _fields_ = [('off', _p), ('cnt', _p), ('src', _p), ('raw', _p), ('rhat', _p), ('total', _p),
+                ('cap', _i), ('_pad', _i)]
+
+
+class Rollout(C.Structure):
+    _fields_ = [
+        ('S', _i), ('A_cap', _i), ('T', _i), ('M_cap', _i), ('W', _i), ('ring', _i), ('R', _i),
+        ('token_size', _i), ('grid_size', _i), ('num_layers', _i), ('force_valid', _i), ('store_logits', _i),
+        ('r_map', _f), ('r_agent', _f),
+        ('n_agents', _p), ('n_map', _p), ('av_index', _p),
+        ('pos', _p), ('head', _p), ('state', _p), ('token', _p), ('grid', _p),
+        ('tmask', _p), ('imask', _p), ('catflag', _p), ('type', _p), ('bos', _p),
+        ('map_pos', _p), ('map_orient', _p),
+        ('attn_t', _p * MAX_LAYERS), ('attn_m', _p * MAX_LAYERS), ('attn_a', _p * MAX_LAYERS),
+        ('four_t', _p), ('four_m', _p), ('four_a', _p), ('four_xa', _p),
+        ('fusion_pack', _p), ('tok_head_pack', _p), ('st_head_pack', _p),
+        ('tok_tab', _p), ('grid_tab', _p), ('state_emb', _p), ('cat_agent', _p), ('cat_seed', _p),
+        ('vocab', _p), ('grid_xy', _p),
+        ('ringK', _p * MAX_LAYERS), ('ringV', _p * MAX_LAYERS), ('mapK', _p * MAX_LAYERS), ('mapV', _p * MAX_LAYERS),
+        ('X', _p), ('Q', _p), ('U', _p), ('Ka', _p), ('Va', _p), ('AGG', _p), ('Z', _p), ('SIG', _p),
+        ('et', EdgeBuf), ('em', EdgeBuf), ('ea', EdgeBuf),
+        ('raw2', _p), ('cat', _p), ('fus_in', _p), ('tmp1', _p), ('tmp2', _p),
+        ('next_token', _p), ('next_state', _p), ('logits', _p),
+        ('teacher_token', _p), ('teacher_state', _p),
+        ('pred_traj', _p), ('pred_head', _p), ('pred_state', _p),
+    ]
+
+
+# symbol -> (restype, argtypes); every symbol include/infgen_hip.h declares
+SYMBOLS = {
+    'infgen_layout_query': (_i, [_i]),
+    'infgen_attn_pack_offset': (_i, [C.c_char_p]),
+    'infgen_fourier_pack_offset': (_i, [C.c_char_p, _i, _i]),
+    'infgen_last_error': (C.c_char_p, []),
+    'infgen_linear': (_i, [_p, _i, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p]),
+    'infgen_fourier_embed': (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _p]),
+    'infgen_attn_pre': (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p]),
+    'infgen_edge_attn': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'infgen_attn_post': (_i, [_p, _i, _p, _p, _p, _p, _i, _p]),
+    'infgen_heads': (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _p]),
+    'infgen_map_graph': (_i, [_i, _i, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p]),
+    'infgen_build_edges': (_i, [C.POINTER(Rollout), _i, _i, _p]),
+    'infgen_integrate': (_i, [C.POINTER(Rollout), _i, _p]),
+    'infgen_raw_feature': (_i, [C.POINTER(Rollout), _i, _p]),
+    'infgen_decode_layers': (_i, [C.POINTER(Rollout), _i, _i, _p]),
+    'infgen_decode_step': (_i, [C.POINTER(Rollout), _i, _p]),
+    'infgen_rollout_run': (_i, [C.POINTER(Rollout), _i, _i, _p]),
+}
+
+Q_ATTN_PACK_SIZE, Q_FOURIER_N2, Q_FOURIER_N3, Q_FOURIER_N4, Q_TILE_ROWS, Q_EDGE_ATTN_CAP, Q_MAX_AGENTS, \
+    Q_ABI_VERSION, Q_SIZEOF_ROLLOUT = range(9)
+
+_lib: Optional[C.CDLL] = None
+
+
+class InfgenHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libinfgen_hip.so; raises if it is missing (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise InfgenHipError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'or `make -C infgen_amd/csrc` (there is no CPU fallback for the product path)')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.infgen_layout_query(Q_SIZEOF_ROLLOUT) != C.sizeof(Rollout):
+        raise InfgenHipError('InfgenRollout layout mismatch between include/infgen_hip.h and infgen_amd/_lib.py: '
+                             f'{lib.infgen_layout_query(Q_SIZEOF_ROLLOUT)} != {C.sizeof(Rollout)}')
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = '') -> None:
+    if rc != 0:
+        msg = load().infgen_last_error()
+        raise InfgenHipError(f'{what} failed ({rc}): {msg.decode() if msg else "?"}')
+
+
+def ptr(t) -> Optional[int]:
+    """device pointer of a torch tensor (None -> NULL)"""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'tensor must be contiguous'
+    return t.data_ptr()

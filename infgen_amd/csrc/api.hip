@@ -1,0 +1,258 @@
+// extern "C" entry points of libinfgen_hip.so (see include/infgen_hip.h) and the per-step
+// launch sequence.  No host synchronisation, no allocation: graph-capturable.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "kernels.h"
+#include "../../include/infgen_hip.h"
+
+using namespace ig;
+
+static thread_local std::string g_err;
+
+static int fail(const char* where, const char* what) {
+  g_err = std::string(where) + ": " + what;
+  return -1;
+}
+static int check_launch(const char* where) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(where, hipGetErrorString(e));
+  return 0;
+}
+#define RET_IF(x) do { int _r = (x); if (_r) return _r; } while (0)
+
+extern "C" const char* infgen_last_error(void) { return g_err.c_str(); }
+
+extern "C" int infgen_layout_query(int what) {
+  switch (what) {
+    case INFGEN_Q_ATTN_PACK_SIZE: return AL_SIZE;
+    case INFGEN_Q_FOURIER_PACK_SIZE_N2: return fourier_pack_size(2);
+    case INFGEN_Q_FOURIER_PACK_SIZE_N3: return fourier_pack_size(3);
+    case INFGEN_Q_FOURIER_PACK_SIZE_N4: return fourier_pack_size(4);
+    case INFGEN_Q_TILE_ROWS: return TR;
+    case INFGEN_Q_EDGE_ATTN_CAP: return 320;
+    case INFGEN_Q_MAX_AGENTS: return 256;
+    case INFGEN_Q_ABI_VERSION: return 1;
+    case INFGEN_Q_SIZEOF_ROLLOUT: return (int)sizeof(InfgenRollout);
+    default: return -1;
+  }
+}
+
+extern "C" int infgen_attn_pack_offset(const char* f) {
+#define F(name, val) if (!strcmp(f, name)) return val;
+  F("ln_src_g", AL_LN_SRC_G) F("ln_src_b", AL_LN_SRC_B) F("ln_dst_g", AL_LN_DST_G) F("ln_dst_b", AL_LN_DST_B)
+  F("wq", AL_WQ) F("bq", AL_BQ) F("wk", AL_WK) F("wv", AL_WV) F("bv", AL_BV)
+  F("wkr", AL_WKR) F("wvr", AL_WVR) F("bvr", AL_BVR) F("ws", AL_WS) F("bs", AL_BS)
+  F("wg", AL_WG) F("bg", AL_BG) F("wo", AL_WO) F("bo", AL_BO)
+  F("ln_post_g", AL_LN_POST_G) F("ln_post_b", AL_LN_POST_B)
+  F("ln_ffpre_g", AL_LN_FFPRE_G) F("ln_ffpre_b", AL_LN_FFPRE_B)
+  F("w1", AL_W1) F("b1", AL_B1) F("w2", AL_W2) F("b2", AL_B2)
+  F("ln_ffpost_g", AL_LN_FFPOST_G) F("ln_ffpost_b", AL_LN_FFPOST_B)
+#undef F
+  return -1;
+}
+
+extern "C" int infgen_fourier_pack_offset(const char* f, int n, int dim) {
+  const int d0 = FE_DIM0 + dim * FD_SIZE;
+  const int t0 = FE_DIM0 + n * FD_SIZE;
+#define F(name, val) if (!strcmp(f, name)) return val;
+  F("freq", FE_FREQ + dim * 64)
+  F("w1", d0 + FD_W1) F("w1x", d0 + FD_W1X) F("b1", d0 + FD_B1) F("ln_g", d0 + FD_LN_G) F("ln_b", d0 + FD_LN_B)
+  F("w2", d0 + FD_W2)
+  F("b2sum", t0 + FT_B2SUM) F("lno_g", t0 + FT_LN_G) F("lno_b", t0 + FT_LN_B) F("w3", t0 + FT_W3) F("b3", t0 + FT_B3)
+#undef F
+  return -1;
+}
+
+// ---------------------------------------------------------------------------------- launchers
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+extern "C" int infgen_linear(const float* X, int ldx, const int* gather, int rows, int K,
+                             const float* Wp, int Np, const float* bias, int N,
+                             const float* pre_g, const float* pre_b, const float* post_g, const float* post_b, int relu,
+                             float* Y, int ldy, void* stream) {
+  if (rows <= 0) return 0;
+  if (Np % 32) return fail("infgen_linear", "Np must be a multiple of 32");
+  if (K > 128 && Np > 128) return fail("infgen_linear", "K > 128 requires N <= 128");
+  if ((pre_g && K != 128) || (post_g && (N != 128 || Np != 128)))
+    return fail("infgen_linear", "LayerNorm prologue/epilogue needs K == 128 / N == 128");
+  LinearArgs a{X, ldx, gather, rows, K, ((K + 7) / 8) * 8, Wp, Np, bias, N, pre_g, pre_b, post_g, post_b, relu, Y, ldy};
+  hipLaunchKernelGGL(k_linear, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_linear");
+}
+
+extern "C" int infgen_fourier_embed(const float* raw, int n, const int* count_dev, int e_cap, const float* pack,
+                                    const float* cat, int ldcat, float* out, int ldo, int normalize, void* stream) {
+  if (e_cap <= 0) return 0;
+  if (n < 1 || n > 4) return fail("infgen_fourier_embed", "n_dims must be in 1..4");
+  FourierArgs a{raw, n, count_dev, e_cap, pack, cat, ldcat, out, ldo, normalize};
+  int grid = ceil_div(e_cap, TR);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(k_fourier, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_fourier_embed");
+}
+
+extern "C" int infgen_attn_pre(const float* X, int rows, const float* pack, int use_src_ln,
+                               float* Q, float* U, float* K, float* V, void* stream) {
+  if (rows <= 0) return 0;
+  AttnPreArgs a{X, rows, pack, use_src_ln, Q, U, K, V};
+  hipLaunchKernelGGL(k_attn_pre, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_attn_pre");
+}
+
+extern "C" int infgen_edge_attn(int rows, const float* Q, const float* U, const float* Ksrc, const float* Vsrc,
+                                const int* off, const int* cnt, const int* src, const float* rhat,
+                                float* AGG, float* Z, float* SIG, void* stream) {
+  if (rows <= 0) return 0;
+  EdgeAttnArgs a{rows, Q, U, Ksrc, Vsrc, EdgeSet{off, cnt, src, rhat}, AGG, Z, SIG};
+  hipLaunchKernelGGL(k_edge_attn, dim3(rows), dim3(64), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_edge_attn");
+}
+
+extern "C" int infgen_attn_post(float* X, int rows, const float* pack, const float* AGG, const float* Z,
+                                const float* SIG, int has_pos, void* stream) {
+  if (rows <= 0) return 0;
+  AttnPostArgs a{X, rows, pack, AGG, Z, SIG, has_pos};
+  hipLaunchKernelGGL(k_attn_post, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_attn_post");
+}
+
+extern "C" int infgen_heads(const float* X, int rows, const float* tok_pack, const float* st_pack, int token_size,
+                            float* logits, int* next_token, int* next_state, void* stream) {
+  if (rows <= 0) return 0;
+  if (token_size % 128) return fail("infgen_heads", "token_size must be a multiple of 128");
+  HeadsArgs a{X, rows, tok_pack, st_pack, token_size, logits, next_token, next_state};
+  hipLaunchKernelGGL(k_heads, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_heads");
+}
+
+extern "C" int infgen_map_graph(int S, int M_cap, const int* n_map, const float* pos, const float* orient,
+                                float radius, int max_nbr, int* off, int* cnt, int* src, float* raw, void* stream) {
+  if (S <= 0 || M_cap <= 0) return 0;
+  MapGraphArgs a{S, M_cap, n_map, pos, orient, radius, max_nbr, EdgeBuf{off, cnt, src, raw, nullptr, 0}};
+  hipLaunchKernelGGL(k_map_graph, dim3(ceil_div(S * M_cap, 4)), dim3(NT), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_map_graph");
+}
+
+// ---------------------------------------------------------------------------------- rollout context
+static SceneState scene_of(const InfgenRollout* r) {
+  SceneState st;
+  st.S = r->S; st.A_cap = r->A_cap; st.T = r->T; st.M_cap = r->M_cap; st.W = r->W; st.ring = r->ring;
+  st.n_agents = r->n_agents; st.n_map = r->n_map; st.av_index = r->av_index;
+  st.pos = r->pos; st.head = r->head; st.state = r->state; st.token = r->token; st.grid = r->grid;
+  st.tmask = r->tmask; st.imask = r->imask; st.catflag = r->catflag; st.type = r->type; st.bos = r->bos;
+  st.map_pos = r->map_pos; st.map_orient = r->map_orient;
+  return st;
+}
+static EdgeBuf ebuf(const InfgenEdgeBuf& e) { return EdgeBuf{e.off, e.cnt, e.src, e.raw, e.total, e.cap}; }
+
+static int validate(const InfgenRollout* r, const char* where) {
+  if (!r) return fail(where, "null context");
+  if (r->A_cap > 256 || r->A_cap <= 0) return fail(where, "A_cap must be in 1..256");
+  if (r->A_cap % 32) return fail(where, "A_cap must be a multiple of 32");
+  if (r->num_layers <= 0 || r->num_layers > INFGEN_MAX_LAYERS) return fail(where, "bad num_layers");
+  if (r->ring <= r->W) return fail(where, "ring must exceed the temporal window");
+  return 0;
+}
+
+extern "C" int infgen_build_edges(const InfgenRollout* r, int c, int edgeless, void* stream) {
+  RET_IF(validate(r, "infgen_build_edges"));
+  hipStream_t s = (hipStream_t)stream;
+  if (!edgeless) {
+    if (hipMemsetAsync(r->et.total, 0, sizeof(int), s) != hipSuccess ||
+        hipMemsetAsync(r->em.total, 0, sizeof(int), s) != hipSuccess ||
+        hipMemsetAsync(r->ea.total, 0, sizeof(int), s) != hipSuccess)
+      return fail("infgen_build_edges", "memset failed");
+  }
+  BuildEdgesArgs a;
+  a.st = scene_of(r); a.c = c; a.edgeless = edgeless; a.r_map = r->r_map; a.r_agent = r->r_agent;
+  a.rows = r->S * r->A_cap; a.t = ebuf(r->et); a.m = ebuf(r->em); a.a = ebuf(r->ea);
+  hipLaunchKernelGGL(k_build_edges, dim3(r->S), dim3(NT), 0, s, a);
+  return check_launch("infgen_build_edges");
+}
+
+extern "C" int infgen_integrate(const InfgenRollout* r, int t, void* stream) {
+  RET_IF(validate(r, "infgen_integrate"));
+  IntegrateArgs a;
+  a.st = scene_of(r); a.c = 1 + t; a.t = t; a.R = r->R; a.force_valid = r->force_valid;
+  a.next_token = r->next_token; a.next_state = r->next_state;
+  a.teacher_token = r->teacher_token; a.teacher_state = r->teacher_state;
+  a.vocab = r->vocab; a.token_size = r->token_size; a.grid_xy = r->grid_xy; a.grid_size = r->grid_size;
+  a.pred_traj = r->pred_traj; a.pred_head = r->pred_head; a.pred_state = r->pred_state;
+  hipLaunchKernelGGL(k_integrate, dim3(r->S), dim3(NT), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_integrate");
+}
+
+// MLPEmbedding pack (first Linear K0 -> 128): P(K0p,128) b ln_g ln_b | P(128,128) b ln_g ln_b | P(128,128) b
+static inline int mlpemb_off2(int K0p) { return K0p * 128 + 3 * 128; }
+static inline int mlpemb_off3(int K0p) { return mlpemb_off2(K0p) + 16384 + 3 * 128; }
+
+extern "C" int infgen_raw_feature(const InfgenRollout* r, int col, void* stream) {
+  RET_IF(validate(r, "infgen_raw_feature"));
+  const int rows = r->S * r->A_cap;
+  RawFeatArgs a;
+  a.st = scene_of(r); a.col = col; a.tok_tab = r->tok_tab; a.token_size = r->token_size;
+  a.grid_tab = r->grid_tab; a.grid_size = r->grid_size; a.state_emb = r->state_emb;
+  a.cat_agent = r->cat_agent; a.cat_seed = r->cat_seed; a.raw2 = r->raw2; a.cat = r->cat; a.fus_in = r->fus_in;
+  hipLaunchKernelGGL(k_rawfeat_prep, dim3(ceil_div(rows * 32, NT)), dim3(NT), 0, (hipStream_t)stream, a);
+  RET_IF(check_launch("infgen_raw_feature/prep"));
+  RET_IF(infgen_fourier_embed(r->raw2, 2, nullptr, rows, r->four_xa, r->cat, 128, r->fus_in + 128, 512, 0, stream));
+  const float* P = r->fusion_pack;
+  const int o2 = mlpemb_off2(512), o3 = mlpemb_off3(512);
+  RET_IF(infgen_linear(r->fus_in, 512, nullptr, rows, 512, P, 128, P + 512 * 128, 128, nullptr, nullptr,
+                       P + 512 * 128 + 128, P + 512 * 128 + 256, 1, r->tmp1, 128, stream));
+  RET_IF(infgen_linear(r->tmp1, 128, nullptr, rows, 128, P + o2, 128, P + o2 + 16384, 128, nullptr, nullptr,
+                       P + o2 + 16384 + 128, P + o2 + 16384 + 256, 1, r->tmp2, 128, stream));
+  RET_IF(infgen_linear(r->tmp2, 128, nullptr, rows, 128, P + o3, 128, P + o3 + 16384, 128, nullptr, nullptr,
+                       nullptr, nullptr, 0, r->X, 128, stream));
+  return 0;
+}
+
+extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless, void* stream) {
+  RET_IF(validate(r, "infgen_decode_layers"));
+  const int rows = r->S * r->A_cap;
+  RET_IF(infgen_build_edges(r, c, edgeless, stream));
+  if (!edgeless) {
+    RET_IF(infgen_fourier_embed(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, stream));
+    RET_IF(infgen_fourier_embed(r->em.raw, 3, r->em.total, r->em.cap, r->four_m, nullptr, 0, r->em.rhat, 128, 1, stream));
+    RET_IF(infgen_fourier_embed(r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, stream));
+  }
+  const size_t slot = (size_t)(c % r->ring) * rows * D;
+  for (int i = 0; i < r->num_layers; ++i) {
+    // temporal: K/V of this column go to the ring (they are the cached layer inputs' projections)
+    RET_IF(infgen_attn_pre(r->X, rows, r->attn_t[i], 0, r->Q, r->U, r->ringK[i] + slot, r->ringV[i] + slot, stream));
+    RET_IF(infgen_edge_attn(rows, r->Q, r->U, r->ringK[i], r->ringV[i], r->et.off, r->et.cnt, r->et.src, r->et.rhat,
+                            r->AGG, r->Z, r->SIG, stream));
+    RET_IF(infgen_attn_post(r->X, rows, r->attn_t[i], r->AGG, r->Z, r->SIG, 1, stream));
+    // map -> agent (bipartite: K/V of the map tokens are per-scene constants)
+    RET_IF(infgen_attn_pre(r->X, rows, r->attn_m[i], 0, r->Q, r->U, nullptr, nullptr, stream));
+    RET_IF(infgen_edge_attn(rows, r->Q, r->U, r->mapK[i], r->mapV[i], r->em.off, r->em.cnt, r->em.src, r->em.rhat,
+                            r->AGG, r->Z, r->SIG, stream));
+    RET_IF(infgen_attn_post(r->X, rows, r->attn_m[i], r->AGG, r->Z, r->SIG, 1, stream));
+    // agent <-> agent
+    RET_IF(infgen_attn_pre(r->X, rows, r->attn_a[i], 0, r->Q, r->U, r->Ka, r->Va, stream));
+    RET_IF(infgen_edge_attn(rows, r->Q, r->U, r->Ka, r->Va, r->ea.off, r->ea.cnt, r->ea.src, r->ea.rhat,
+                            r->AGG, r->Z, r->SIG, stream));
+    RET_IF(infgen_attn_post(r->X, rows, r->attn_a[i], r->AGG, r->Z, r->SIG, 1, stream));
+  }
+  return 0;
+}
+
+extern "C" int infgen_decode_step(const InfgenRollout* r, int t, void* stream) {
+  RET_IF(validate(r, "infgen_decode_step"));
+  const int rows = r->S * r->A_cap;
+  const int c = 1 + t;
+  if (t < 0 || c + 1 > r->T - 1) return fail("infgen_decode_step", "step beyond the column range");
+  RET_IF(infgen_decode_layers(r, c, 0, stream));
+  float* lg = (r->store_logits && r->logits) ? r->logits + (size_t)t * rows * r->token_size : nullptr;
+  RET_IF(infgen_heads(r->X, rows, r->tok_head_pack, r->st_head_pack, r->token_size, lg, r->next_token,
+                      r->next_state, stream));
+  RET_IF(infgen_integrate(r, t, stream));
+  RET_IF(infgen_raw_feature(r, c + 1, stream));
+  return 0;
+}
+
+extern "C" int infgen_rollout_run(const InfgenRollout* r, int t0, int t1, void* stream) {
+  for (int t = t0; t < t1; ++t) RET_IF(infgen_decode_step(r, t, stream));
+  return 0;
+}

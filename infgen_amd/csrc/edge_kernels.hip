@@ -1,0 +1,567 @@
+// Edge-side kernels: per-step edge-set construction (temporal window / first-K map radius /
+// agent-agent radius), the per-destination edge attention, contour integration + grid
+// tokenisation, raw per-column feature gathers and the map-token radius graph.
+#include "kernels.h"
+
+namespace ig {
+
+constexpr int INVALID = 0, VALID = 1, ENTER = 2, EXIT = 3;
+constexpr int NUM_SEED_FEATURE = 10;     // reference agent_decoder.py:292
+constexpr float MOTION_GAP = 1.0f, HEADING_GAP = 1.0f, INVALID_MOTION = -2.0f, INVALID_HEAD = -2.0f;
+
+// ------------------------------------------------------------------------------------------
+// k_edge_attn: one wavefront (= one 64-thread workgroup) per destination row.
+//   phase 1  lane = (edge-in-chunk, head): score = q_h . k_src,h + u_h . rhat_e   (8 edges / pass)
+//   phase 2  PyG softmax per head: exp(s - max) / (sum + 1e-16)   (layers.py:89)
+//   phase 3  lane = column pair: z_h += a_e,h * rhat_e ; agg += a_e,head(col) * v_src
+// ------------------------------------------------------------------------------------------
+constexpr int SC_CAP = 320;    // max incoming edges per destination handled here (a2a cap 300)
+constexpr int ULD = 132;
+
+__global__ __launch_bounds__(64) void k_edge_attn(EdgeAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float Us[H * ULD];
+  __shared__ __attribute__((aligned(16))) float Rs[8 * ULD];
+  __shared__ __attribute__((aligned(16))) float sc[SC_CAP * H];
+  __shared__ int srcs[SC_CAP];
+  const int row = blockIdx.x;
+  if (row >= a.rows) return;
+  const int lane = threadIdx.x;
+  int E = a.es.cnt[row];
+  if (E > SC_CAP) E = SC_CAP;
+  float* aggp = a.AGG + (size_t)row * D;
+  float* zp = a.Z ? a.Z + (size_t)row * (H * D) : nullptr;
+  const bool has_r = a.es.rhat != nullptr && a.U != nullptr;
+  if (E <= 0) {
+    *reinterpret_cast<float2*>(aggp + 2 * lane) = make_float2(0.f, 0.f);
+    if (zp) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) *reinterpret_cast<float2*>(zp + h * D + 2 * lane) = make_float2(0.f, 0.f);
+    }
+    if (lane < H) a.SIG[(size_t)row * H + lane] = 0.f;
+    return;
+  }
+  const int e_base = a.es.off[row];
+  for (int e = lane; e < E; e += 64) srcs[e] = a.es.src[e_base + e];
+  if (has_r) {
+    // U[row] (8 x 128) -> LDS, padded rows
+    const float* up = a.U + (size_t)row * (H * D);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int idx = p * 64 + lane;          // float4 slot 0..255
+      const int h = idx >> 5, c4 = idx & 31;
+      *reinterpret_cast<float4*>(Us + h * ULD + 4 * c4) = *reinterpret_cast<const float4*>(up + h * D + 4 * c4);
+    }
+  }
+  const int el = lane >> 3, h = lane & 7;
+  float qh[DH];
+  {
+    const float* qp = a.Q + (size_t)row * D + DH * h;
+#pragma unroll
+    for (int i = 0; i < DH; i += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(qp + i);
+      qh[i] = v.x; qh[i + 1] = v.y; qh[i + 2] = v.z; qh[i + 3] = v.w;
+    }
+  }
+  __syncthreads();
+  // ---- phase 1
+  for (int c0 = 0; c0 < E; c0 += 8) {
+    const int nE = min(8, E - c0);
+    if (has_r) {
+      __syncthreads();
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int idx = p * 64 + lane;
+        const int er = idx >> 5, c4 = idx & 31;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (er < nE) v = *reinterpret_cast<const float4*>(a.es.rhat + (size_t)(e_base + c0 + er) * D + 4 * c4);
+        *reinterpret_cast<float4*>(Rs + er * ULD + 4 * c4) = v;
+      }
+      __syncthreads();
+    }
+    float s = 0.f;
+    if (el < nE) {
+      const float* kp = a.Ksrc + (size_t)srcs[c0 + el] * D + DH * h;
+#pragma unroll
+      for (int i = 0; i < DH; i += 4) {
+        const float4 kv = *reinterpret_cast<const float4*>(kp + i);
+        s = fmaf(qh[i], kv.x, s); s = fmaf(qh[i + 1], kv.y, s);
+        s = fmaf(qh[i + 2], kv.z, s); s = fmaf(qh[i + 3], kv.w, s);
+      }
+      if (has_r) {
+        const float* up = Us + h * ULD;
+        const float* rp = Rs + el * ULD;
+        float s2 = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < D; d += 4) {
+          const float4 u = *reinterpret_cast<const float4*>(up + d);
+          const float4 r = *reinterpret_cast<const float4*>(rp + d);
+          s2 = fmaf(u.x, r.x, s2); s2 = fmaf(u.y, r.y, s2); s2 = fmaf(u.z, r.z, s2); s2 = fmaf(u.w, r.w, s2);
+        }
+        s += s2;
+      }
+      sc[(c0 + el) * H + h] = s;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: per-head max / exp / sum over the row's edges
+  float m = -INFINITY;
+  for (int e = el; e < E; e += 8) m = fmaxf(m, sc[e * H + h]);
+  m = fmaxf(m, __shfl_xor(m, 8, 64));
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float ssum = 0.f;
+  for (int e = el; e < E; e += 8) {
+    const float p = expf(sc[e * H + h] - m);
+    sc[e * H + h] = p;
+    ssum += p;
+  }
+  ssum += __shfl_xor(ssum, 8, 64);
+  ssum += __shfl_xor(ssum, 16, 64);
+  ssum += __shfl_xor(ssum, 32, 64);
+  const float inv = 1.0f / (ssum + 1e-16f);
+  float sig = 0.f;
+  for (int e = el; e < E; e += 8) {
+    const float at = sc[e * H + h] * inv;
+    sc[e * H + h] = at;
+    sig += at;
+  }
+  sig += __shfl_xor(sig, 8, 64);
+  sig += __shfl_xor(sig, 16, 64);
+  sig += __shfl_xor(sig, 32, 64);
+  if (lane < H) a.SIG[(size_t)row * H + lane] = sig;
+  __syncthreads();
+  // ---- phase 3
+  float z[H][2];
+#pragma unroll
+  for (int hh = 0; hh < H; ++hh) { z[hh][0] = 0.f; z[hh][1] = 0.f; }
+  float ag0 = 0.f, ag1 = 0.f;
+  const int myh = lane >> 3;     // head of columns 2*lane, 2*lane+1
+  for (int e = 0; e < E; ++e) {
+    const float4 a0 = *reinterpret_cast<const float4*>(sc + e * H);
+    const float4 a1 = *reinterpret_cast<const float4*>(sc + e * H + 4);
+    const float2 vv = *reinterpret_cast<const float2*>(a.Vsrc + (size_t)srcs[e] * D + 2 * lane);
+    const float am = sc[e * H + myh];
+    ag0 = fmaf(am, vv.x, ag0);
+    ag1 = fmaf(am, vv.y, ag1);
+    if (has_r) {
+      const float2 rr = *reinterpret_cast<const float2*>(a.es.rhat + (size_t)(e_base + e) * D + 2 * lane);
+      z[0][0] = fmaf(a0.x, rr.x, z[0][0]); z[0][1] = fmaf(a0.x, rr.y, z[0][1]);
+      z[1][0] = fmaf(a0.y, rr.x, z[1][0]); z[1][1] = fmaf(a0.y, rr.y, z[1][1]);
+      z[2][0] = fmaf(a0.z, rr.x, z[2][0]); z[2][1] = fmaf(a0.z, rr.y, z[2][1]);
+      z[3][0] = fmaf(a0.w, rr.x, z[3][0]); z[3][1] = fmaf(a0.w, rr.y, z[3][1]);
+      z[4][0] = fmaf(a1.x, rr.x, z[4][0]); z[4][1] = fmaf(a1.x, rr.y, z[4][1]);
+      z[5][0] = fmaf(a1.y, rr.x, z[5][0]); z[5][1] = fmaf(a1.y, rr.y, z[5][1]);
+      z[6][0] = fmaf(a1.z, rr.x, z[6][0]); z[6][1] = fmaf(a1.z, rr.y, z[6][1]);
+      z[7][0] = fmaf(a1.w, rr.x, z[7][0]); z[7][1] = fmaf(a1.w, rr.y, z[7][1]);
+    }
+  }
+  *reinterpret_cast<float2*>(aggp + 2 * lane) = make_float2(ag0, ag1);
+  if (zp) {
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh)
+      *reinterpret_cast<float2*>(zp + hh * D + 2 * lane) = make_float2(z[hh][0], z[hh][1]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// helpers on the column-major scene state
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t sidx(const SceneState& st, int s, int col, int a) {
+  return ((size_t)s * st.T + col) * st.A_cap + a;
+}
+
+// block-wide exclusive scan of one int per thread (256 threads); returns exclusive prefix, total in *tot
+__device__ __forceinline__ int block_excl_scan(int v, int* sh /*[NT+1]*/, int* tot) {
+  const int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int o = 1; o < NT; o <<= 1) {
+    int x = (t >= o) ? sh[t - o] : 0;
+    __syncthreads();
+    sh[t] += x;
+    __syncthreads();
+  }
+  const int incl = sh[t];
+  *tot = sh[NT - 1];
+  __syncthreads();
+  return incl - v;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_build_edges: one workgroup per scene; builds the three edge sets of column c.
+//   temporal  reference agent_decoder.py:540-610   (window W, bos, tmask, NOT the last 10 rows)
+//   map->agent  :683-758  first 5 map tokens in ascending index with d^2 < r^2 (torch_cluster.radius)
+//   agent<->agent :612-681  all ordered pairs within r, both interact-valid
+// Raw continuous edge features (before the Fourier embedding) are written as float4.
+// src holds the row index into the K/V source array of that edge type:
+//   temporal: (j % ring) * rows + row ; map: s * M_cap + m ; agent: s * A_cap + j
+// ------------------------------------------------------------------------------------------
+constexpr int MAXA = 256;     // max agents per scene handled by one workgroup pass
+
+__global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
+  __shared__ float px[MAXA], py[MAXA], hd[MAXA], hc[MAXA], hs[MAXA];
+  __shared__ int stt[MAXA];
+  __shared__ unsigned char im[MAXA];
+  __shared__ int scan[NT + 1];
+  __shared__ int mapidx[MAXA * 5];
+  __shared__ int mapcnt[MAXA];
+  __shared__ int base_t, base_m, base_a;
+  const SceneState& st = a.st;
+  const int s = blockIdx.x;
+  const int t = threadIdx.x;
+  const int A = st.n_agents[s];
+  const int c = a.c;
+  const int rows_total = a.rows;
+  const int row = s * st.A_cap + t;
+  if (a.edgeless) {
+    if (t < st.A_cap) {
+      a.t.off[row] = 0; a.t.cnt[row] = 0;
+      a.m.off[row] = 0; a.m.cnt[row] = 0;
+      a.a.off[row] = 0; a.a.cnt[row] = 0;
+    }
+    return;
+  }
+  if (t < st.A_cap) {
+    const size_t i = sidx(st, s, c, t);
+    const float h = st.head[i];
+    px[t] = st.pos[2 * i]; py[t] = st.pos[2 * i + 1];
+    hd[t] = h; hc[t] = cosf(h); hs[t] = sinf(h);
+    stt[t] = st.state[i];
+    im[t] = (t < A) ? st.imask[i] : 0;
+  }
+  __syncthreads();
+
+  // ---------------- temporal
+  {
+    int cnt = 0;
+    const int lo = max(c - st.W, 0);
+    const bool dst_ok = (t < A) && (t < A - NUM_SEED_FEATURE);
+    int bos = 0;
+    if (dst_ok) {
+      bos = st.bos[s * st.A_cap + t];
+      for (int j = lo; j < c; ++j)
+        if (j >= bos && st.tmask[sidx(st, s, j, t)]) ++cnt;
+    }
+    int tot;
+    const int excl = block_excl_scan(cnt, scan, &tot);
+    if (t == 0) base_t = atomicAdd(a.t.total, tot);
+    __syncthreads();
+    if (t < st.A_cap) {
+      int e = base_t + excl;
+      a.t.off[row] = e;
+      a.t.cnt[row] = cnt;
+      if (cnt > 0) {
+        const bool d_inv = stt[t] == INVALID;
+        for (int j = lo; j < c; ++j) {
+          const size_t i = sidx(st, s, j, t);
+          if (!(j >= bos && st.tmask[i])) continue;
+          float dx = st.pos[2 * i] - px[t], dy = st.pos[2 * i + 1] - py[t];
+          float dth = wrap_angle(st.head[i] - hd[t]);
+          const bool s_inv = st.state[i] == INVALID;
+          if (s_inv && !d_inv) { dx = -MOTION_GAP; dy = -MOTION_GAP; dth = -HEADING_GAP; }
+          if (!s_inv && d_inv) { dx = MOTION_GAP; dy = MOTION_GAP; }      // :598 is a no-op
+          if (s_inv && d_inv) { dx = INVALID_MOTION; dy = INVALID_MOTION; dth = INVALID_HEAD; }
+          if (e < a.t.cap) {
+            a.t.src[e] = (j % st.ring) * rows_total + row;
+            *reinterpret_cast<float4*>(a.t.raw + 4 * (size_t)e) =
+                make_float4(norm2(dx, dy), angle_between(hc[t], hs[t], dx, dy), dth, (float)(j - c));
+          }
+          ++e;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---------------- map -> agent (first 5 within radius, ascending index): one wave per agent
+  {
+    const int M = st.n_map[s];
+    const float r2 = a.r_map * a.r_map;
+    const float* mp = st.map_pos + (size_t)s * st.M_cap * 2;
+    const int lane = lane_id();
+    for (int ag = wave_id(); ag < st.A_cap; ag += 4) {
+      int found = 0;
+      if (ag < A && im[ag]) {
+        const float ax = px[ag], ay = py[ag];
+        for (int m0 = 0; m0 < M && found < 5; m0 += 64) {
+          const int m = m0 + lane;
+          bool in = false;
+          if (m < M) {
+            const float dx = ax - mp[2 * m], dy = ay - mp[2 * m + 1];
+            in = (dx * dx + dy * dy) < r2;
+          }
+          const unsigned long long bal = __ballot(in);
+          const int before = __popcll(bal & ((1ull << lane) - 1ull));
+          if (in && found + before < 5) mapidx[ag * 5 + found + before] = m;
+          found = min(5, found + (int)__popcll(bal));
+        }
+      }
+      if (lane == 0) mapcnt[ag] = found;
+    }
+    __syncthreads();
+    const int cnt = (t < st.A_cap) ? mapcnt[t] : 0;
+    int tot;
+    const int excl = block_excl_scan(cnt, scan, &tot);
+    if (t == 0) base_m = atomicAdd(a.m.total, tot);
+    __syncthreads();
+    if (t < st.A_cap) {
+      int e = base_m + excl;
+      a.m.off[row] = e;
+      a.m.cnt[row] = cnt;
+      const bool d_inv = stt[t] == INVALID;
+      const float* mo = st.map_orient + (size_t)s * st.M_cap;
+      for (int k = 0; k < cnt; ++k, ++e) {
+        const int m = mapidx[t * 5 + k];
+        float dx = mp[2 * m] - px[t], dy = mp[2 * m + 1] - py[t];
+        float dth = wrap_angle(mo[m] - hd[t]);
+        if (d_inv) { dx = MOTION_GAP; dy = MOTION_GAP; dth = HEADING_GAP; }
+        if (e < a.m.cap) {
+          a.m.src[e] = s * st.M_cap + m;
+          *reinterpret_cast<float4*>(a.m.raw + 4 * (size_t)e) =
+              make_float4(norm2(dx, dy), angle_between(hc[t], hs[t], dx, dy), dth, 0.f);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---------------- agent <-> agent
+  {
+    const float r2 = a.r_agent * a.r_agent;
+    int cnt = 0;
+    const bool dst_ok = (t < A) && im[t];
+    if (dst_ok) {
+      for (int j = 0; j < A; ++j) {
+        if (j == t || !im[j]) continue;
+        const float dx = px[t] - px[j], dy = py[t] - py[j];
+        if (dx * dx + dy * dy < r2) ++cnt;
+      }
+    }
+    int tot;
+    const int excl = block_excl_scan(cnt, scan, &tot);
+    if (t == 0) base_a = atomicAdd(a.a.total, tot);
+    __syncthreads();
+    if (t < st.A_cap) {
+      int e = base_a + excl;
+      a.a.off[row] = e;
+      a.a.cnt[row] = cnt;
+      if (cnt > 0) {
+        const bool d_inv = stt[t] == INVALID;
+        for (int j = 0; j < A; ++j) {
+          if (j == t || !im[j]) continue;
+          const float ddx = px[t] - px[j], ddy = py[t] - py[j];
+          if (!(ddx * ddx + ddy * ddy < r2)) continue;
+          float dx = px[j] - px[t], dy = py[j] - py[t];
+          float dth = wrap_angle(hd[j] - hd[t]);
+          const bool s_inv = stt[j] == INVALID;
+          if (s_inv && !d_inv) { dx = -MOTION_GAP; dy = -MOTION_GAP; dth = -HEADING_GAP; }
+          if (!s_inv && d_inv) { dx = MOTION_GAP; dy = MOTION_GAP; }      // :650 is a no-op
+          if (s_inv && d_inv) { dx = INVALID_MOTION; dy = INVALID_MOTION; dth = INVALID_HEAD; }
+          if (e < a.a.cap) {
+            a.a.src[e] = s * st.A_cap + j;
+            *reinterpret_cast<float4*>(a.a.raw + 4 * (size_t)e) =
+                make_float4(norm2(dx, dy), angle_between(hc[t], hs[t], dx, dy), dth, 0.f);
+          }
+          ++e;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_map_graph: radius_graph(pos, r, loop=False, max_num_neighbors=K) of the map tokens of each
+// scene (reference map_decoder.py:91-93): per centre the first K+1 tokens in ascending index
+// with d^2 < r^2 (self included), self dropped.  One wave per centre token; fixed-stride CSR
+// (off = row * K_cap) so no scan is needed (the prologue runs once per scene).
+// raw = (|d|, angle(orient_vec[dst], d), wrap(orient[src] - orient[dst]), 0)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_map_graph(MapGraphArgs a) {
+  const int lane = lane_id();
+  const int gw = blockIdx.x * 4 + wave_id();
+  const int s = gw / a.M_cap, i = gw % a.M_cap;
+  if (s >= a.S) return;
+  const int M = a.n_map[s];
+  const int row = s * a.M_cap + i;
+  const int stride = a.max_nbr + 1;
+  if (i >= M) {
+    if (lane == 0) { a.e.off[row] = row * stride; a.e.cnt[row] = 0; }
+    return;
+  }
+  const float* mp = a.pos + (size_t)s * a.M_cap * 2;
+  const float* mo = a.orient + (size_t)s * a.M_cap;
+  const float cx = mp[2 * i], cy = mp[2 * i + 1], co = mo[i];
+  const float ocs = cosf(co), osn = sinf(co);
+  const float r2 = a.radius * a.radius;
+  int found = 0;      // counts self too (first K+1 semantics)
+  int written = 0;
+  const int e0 = row * stride;
+  for (int m0 = 0; m0 < M && found < a.max_nbr + 1; m0 += 64) {
+    const int m = m0 + lane;
+    bool in = false;
+    if (m < M) {
+      const float dx = cx - mp[2 * m], dy = cy - mp[2 * m + 1];
+      in = (dx * dx + dy * dy) < r2;
+    }
+    const unsigned long long bal = __ballot(in);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    const bool keep = in && (found + before < a.max_nbr + 1);
+    const bool emit = keep && (m != i);
+    const unsigned long long ebal = __ballot(emit);
+    const int ebefore = __popcll(ebal & ((1ull << lane) - 1ull));
+    if (emit) {
+      const int e = e0 + written + ebefore;
+      float dx = mp[2 * m] - cx, dy = mp[2 * m + 1] - cy;
+      a.e.src[e] = s * a.M_cap + m;
+      *reinterpret_cast<float4*>(a.e.raw + 4 * (size_t)e) =
+          make_float4(norm2(dx, dy), angle_between(ocs, osn, dx, dy), wrap_angle(mo[m] - co), 0.f);
+    }
+    written += (int)__popcll(ebal);
+    found += (int)__popcll(bal);
+  }
+  if (lane == 0) { a.e.off[row] = e0; a.e.cnt[row] = written; }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_integrate: token -> contour -> next pose (reference agent_decoder.py:2168-2239), grid
+// tokenisation of the new position (attr_tokenizer.py:77-89), invalid handling.
+// One workgroup per scene.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_integrate(IntegrateArgs a) {
+  __shared__ float npx[MAXA], npy[MAXA], nth[MAXA];
+  __shared__ int nst[MAXA];
+  const SceneState& st = a.st;
+  const int s = blockIdx.x, t = threadIdx.x;
+  const int A = st.n_agents[s];
+  const int av = st.av_index[s];
+  const int c = a.c, n = a.c + 1;
+  if (t < A) {
+    const int row = s * st.A_cap + t;
+    int tok = a.next_token[row];
+    int ns = a.next_state[row];
+    if (ns == 2) ns = EXIT;                     // valid_state_type index 2 == 'exit'
+    if (t == av) ns = VALID;                    // ego forced valid
+    if (a.force_valid) ns = VALID;              // disable_insertion
+    if (a.teacher_token) { tok = a.teacher_token[sidx(st, s, n, t)]; if (tok < 0) tok = 0; }
+    if (a.teacher_state) ns = a.teacher_state[sidx(st, s, n, t)];
+    const size_t ic = sidx(st, s, c, t);
+    const float th = st.head[ic];
+    const float cs = cosf(th), sn = sinf(th);
+    const float bx = st.pos[2 * ic], by = st.pos[2 * ic + 1];
+    const int ty = st.type[s * st.A_cap + t];
+    const float* ct = a.vocab + ((size_t)ty * a.token_size + tok) * 48;
+    float lx = 0.f, ly = 0.f, lth = 0.f;
+    for (int k = 1; k < 6; ++k) {
+      float cx[4], cy[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float x = ct[k * 8 + q * 2], y = ct[k * 8 + q * 2 + 1];
+        // [x y] @ [[cos, sin], [-sin, cos]] + pos
+        cx[q] = (x * cs + y * (-sn)) + bx;
+        cy[q] = (x * sn + y * cs) + by;
+      }
+      const float mx = (((cx[0] + cx[1]) + cx[2]) + cx[3]) / 4.0f;
+      const float my = (((cy[0] + cy[1]) + cy[2]) + cy[3]) / 4.0f;
+      const float hh = atan2f(cy[0] - cy[3], cx[0] - cx[3]);
+      const size_t o = ((size_t)row * a.R + a.t * 5 + (k - 1));
+      a.pred_traj[2 * o] = mx; a.pred_traj[2 * o + 1] = my;
+      a.pred_head[o] = hh;
+      a.pred_state[o] = (float)ns;
+      if (k == 5) { lx = mx; ly = my; lth = hh; }
+    }
+    npx[t] = lx; npy[t] = ly; nth[t] = lth; nst[t] = ns;
+  }
+  __syncthreads();
+  // grid token of every agent: one wave per agent, lanes over grid cells
+  {
+    const float ex = npx[av], ey = npy[av];
+    const float phi = -(nth[av] - HALF_PI_F);
+    const float cs = cosf(phi), sn = sinf(phi);
+    const int lane = lane_id();
+    for (int ag = wave_id(); ag < A; ag += 4) {
+      const float dx = npx[ag] - ex, dy = npy[ag] - ey;
+      const float rx = dx * cs + dy * (-sn);
+      const float ry = dx * sn + dy * cs;
+      float best = INFINITY;
+      int bi = 0x7fffffff;
+      for (int g = lane; g < a.grid_size; g += 64) {
+        const float ux = rx - a.grid_xy[2 * g], uy = ry - a.grid_xy[2 * g + 1];
+        const float d = sqrtf(ux * ux + uy * uy);
+        if (d < best) { best = d; bi = g; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      if (lane == 0) {
+        const size_t in_ = sidx(st, s, n, ag);
+        const int ns = nst[ag];
+        const bool inv = ns == INVALID;
+        st.state[in_] = ns;
+        st.pos[2 * in_] = inv ? 0.f : npx[ag];
+        st.pos[2 * in_ + 1] = inv ? 0.f : npy[ag];
+        st.head[in_] = inv ? 0.f : nth[ag];
+        st.grid[in_] = inv ? -1 : bi;
+        int tok = a.next_token[s * st.A_cap + ag];
+        if (a.teacher_token) { tok = a.teacher_token[in_]; }
+        st.token[in_] = inv ? -1 : tok;
+        if (inv) { st.imask[in_] = 0; st.catflag[in_] = 0; }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rawfeat_prep: inputs of the raw per-column agent feature (reference agent_decoder.py:426-509,
+// 2265-2287) for column `col`: motion/heading 2-vector for x_a_emb, the categorical
+// embedding row, and the gathered token / state / grid embedding rows of the fusion input.
+// One thread per float4 of a row (32 threads per row).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_rawfeat_prep(RawFeatArgs a) {
+  const SceneState& st = a.st;
+  const int gid = blockIdx.x * NT + threadIdx.x;
+  const int row = gid >> 5, c4 = gid & 31;
+  const int rows = st.S * st.A_cap;
+  if (row >= rows) return;
+  const int s = row / st.A_cap, ag = row % st.A_cap;
+  const int j = a.col;
+  const size_t i = sidx(st, s, j, ag);
+  const int stj = st.state[i];
+  if (c4 == 0) {
+    float mx = 0.f, my = 0.f;
+    const bool inv = stj == INVALID;
+    if (j > 0) {
+      const size_t ip = sidx(st, s, j - 1, ag);
+      mx = st.pos[2 * i] - st.pos[2 * ip];
+      my = st.pos[2 * i + 1] - st.pos[2 * ip + 1];
+      if (inv) { mx = INVALID_MOTION; my = INVALID_MOTION; }
+      const bool pinv = st.state[ip] == INVALID;
+      if (pinv && !inv) { mx = MOTION_GAP; my = MOTION_GAP; }
+      if (!pinv && inv) { mx = -MOTION_GAP; my = -MOTION_GAP; }
+    } else {
+      if (inv) { mx = INVALID_MOTION; my = INVALID_MOTION; }
+      if (stj == ENTER) { mx = MOTION_GAP; my = MOTION_GAP; }
+    }
+    const float h = st.head[i];
+    *reinterpret_cast<float4*>(a.raw2 + 4 * (size_t)row) =
+        make_float4(norm2(mx, my), angle_between(cosf(h), sinf(h), mx, my), 0.f, 0.f);
+  }
+  const float* catsrc = st.catflag[i] ? a.cat_agent + (size_t)row * D : a.cat_seed;
+  *reinterpret_cast<float4*>(a.cat + (size_t)row * D + 4 * c4) = *reinterpret_cast<const float4*>(catsrc + 4 * c4);
+  int tok = st.token[i];
+  if (tok < 0) tok += a.token_size + 2;             // python negative indexing: -1 no_token, -2 bos
+  const int ty = st.type[row];
+  const float* tsrc = a.tok_tab + ((size_t)ty * (a.token_size + 2) + tok) * D;
+  int g = st.grid[i];
+  if (g < 0) g += a.grid_size + 1;                  // -1 -> invalid row
+  const float* gsrc = a.grid_tab + (size_t)g * D;
+  const float* ssrc = a.state_emb + (size_t)stj * D;
+  float* f = a.fus_in + (size_t)row * 512;
+  *reinterpret_cast<float4*>(f + 4 * c4) = *reinterpret_cast<const float4*>(tsrc + 4 * c4);
+  *reinterpret_cast<float4*>(f + 256 + 4 * c4) = *reinterpret_cast<const float4*>(ssrc + 4 * c4);
+  *reinterpret_cast<float4*>(f + 384 + 4 * c4) = *reinterpret_cast<const float4*>(gsrc + 4 * c4);
+}
+
+}  // namespace ig

@@ -1,0 +1,154 @@
+// Kernel argument blocks (plain structs, device pointers) and kernel declarations.
+#pragma once
+#include "tile.cuh"
+#include "layout.h"
+
+namespace ig {
+
+struct LinearArgs {
+  const float* X; int ldx; const int* gather;
+  int rows; int K; int Kp;
+  const float* Wp; int Np; const float* bias; int N;
+  const float* pre_g; const float* pre_b;
+  const float* post_g; const float* post_b; int relu;
+  float* Y; int ldy;
+};
+
+struct FourierArgs {
+  const float* raw;        // [E][4]
+  int n;                   // continuous dims (2..4)
+  const int* count_dev;    // optional device-side row count
+  int e_cap;               // row count (or capacity when count_dev != null)
+  const float* pack;       // FourierLayout
+  const float* cat; int ldcat;   // optional [E][ldcat] categorical embedding sum
+  float* out; int ldo;
+  int normalize;
+};
+
+// One edge set in CSR-by-destination form (built on the device every decode step).
+struct EdgeSet {
+  const int* off;          // [rows] first edge of the row
+  const int* cnt;          // [rows] number of incoming edges
+  const int* src;          // [E] row index into the K/V source arrays
+  const float* rhat;       // [E][128] normalised relative-position embedding (nullptr: no pos emb)
+};
+
+struct AttnPreArgs {
+  const float* X; int rows;          // [rows][128] layer input
+  const float* pack;                 // AttnLayout
+  int use_src_ln;                    // 1: LayerNorm with the *_src parameters (K/V of a bipartite source)
+  float* Q;                          // [rows][128]   (scaled q), may be null
+  float* U;                          // [rows][8][128] absorbed relative-position query, may be null
+  float* K; float* V;                // [rows][128] each, may be null
+};
+
+struct EdgeAttnArgs {
+  int rows;
+  const float* Q; const float* U;
+  const float* Ksrc; const float* Vsrc;    // source K/V arrays, row stride 128
+  EdgeSet es;
+  float* AGG;                        // [rows][128]  sum_e attn * v_src
+  float* Z;                          // [rows][8][128] sum_e attn * rhat   (pos-emb layers only)
+  float* SIG;                        // [rows][8]    sum_e attn
+};
+
+struct AttnPostArgs {
+  float* X; int rows;                // in/out residual stream
+  const float* pack;
+  const float* AGG; const float* Z; const float* SIG;
+  int has_pos;
+};
+
+struct HeadsArgs {
+  const float* X; int rows;
+  const float* tok_pack;    // MLPLayer pack: P(128,128) W0, b0, ln g/b, P(128,2048) W3, b3
+  const float* st_pack;     // MLPLayer pack: P(128,128) W0, b0, ln g/b, W3 [3][128] row-major, b3[3]
+  int token_size;
+  float* logits;            // optional [rows][token_size]
+  int* next_token;          // [rows]
+  int* next_state;          // [rows] raw argmax in {0,1,2}
+};
+
+// ---- per-scene state (column-major per scene: [S][T][A_cap]) -----------------------------------
+struct SceneState {
+  int S, A_cap, T, M_cap, W;        // W = temporal window (time_span / shift)
+  int ring;                         // ring slots of the temporal K/V cache (> W)
+  const int* n_agents;              // [S]
+  const int* n_map;                 // [S]
+  const int* av_index;              // [S]
+  float* pos;                       // [S][T][A_cap][2]
+  float* head;                      // [S][T][A_cap]
+  int* state;                       // [S][T][A_cap]
+  int* token;                       // [S][T][A_cap]
+  int* grid;                        // [S][T][A_cap]
+  unsigned char* tmask;             // [S][T][A_cap]
+  unsigned char* imask;             // [S][T][A_cap]
+  unsigned char* catflag;           // [S][T][A_cap] 1: own type/shape embedding, 0: seed/invalid-shape
+  const int* type;                  // [S][A_cap]
+  int* bos;                         // [S][A_cap] first 'enter' column (0 if none)
+  const float* map_pos;             // [S][M_cap][2]
+  const float* map_orient;          // [S][M_cap]
+};
+
+struct EdgeBuf {                    // device-side builder outputs for one edge type
+  int* off; int* cnt; int* src; float* raw; int* total; int cap;
+};
+
+struct BuildEdgesArgs {
+  SceneState st;
+  int c;                            // current column
+  int edgeless;                     // 1: write empty edge sets (column 0 chain)
+  float r_map, r_agent;             // pl2a_radius, a2a_radius
+  int rows;                         // S * A_cap
+  EdgeBuf t, m, a;
+};
+
+struct IntegrateArgs {
+  SceneState st;
+  int c;                            // current column; writes column c + 1
+  int t;                            // decode step
+  int R;                            // num_recurrent_steps_val
+  int force_valid;                  // disable_insertion: every state := valid
+  const int* next_token; const int* next_state;   // [rows] from the heads
+  const int* teacher_token; const int* teacher_state;   // optional [S][T][A_cap]
+  const float* vocab;               // [3][token_size][6][4][2]
+  int token_size;
+  const float* grid_xy; int grid_size;    // [G][2]
+  float* pred_traj;                 // [S][A_cap][R][2]
+  float* pred_head;                 // [S][A_cap][R]
+  float* pred_state;                // [S][A_cap][R]
+};
+
+struct RawFeatArgs {
+  SceneState st;
+  int col;
+  const float* tok_tab;             // [3][token_size + 2][128]
+  int token_size;
+  const float* grid_tab;            // [grid_size + 1][128]
+  int grid_size;
+  const float* state_emb;           // [4][128]
+  const float* cat_agent;           // [rows][128] type_emb[type] + shape_emb(shape)
+  const float* cat_seed;            // [128]
+  float* raw2;                      // [rows][4]  (|mv|, angle, -, -)
+  float* cat;                       // [rows][128]
+  float* fus_in;                    // [rows][512]
+};
+
+struct MapGraphArgs {
+  int S, M_cap; const int* n_map;
+  const float* pos; const float* orient; float radius; int max_nbr;
+  EdgeBuf e;
+};
+
+__global__ void k_linear(LinearArgs a);
+__global__ void k_fourier(FourierArgs a);
+__global__ void k_attn_pre(AttnPreArgs a);
+__global__ void k_edge_attn(EdgeAttnArgs a);
+__global__ void k_attn_post(AttnPostArgs a);
+__global__ void k_heads(HeadsArgs a);
+__global__ void k_build_edges(BuildEdgesArgs a);
+__global__ void k_integrate(IntegrateArgs a);
+__global__ void k_rawfeat_prep(RawFeatArgs a);
+__global__ void k_map_graph(MapGraphArgs a);
+
+}  // namespace ig

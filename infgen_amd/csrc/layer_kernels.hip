@@ -1,0 +1,274 @@
+// Node-side kernels of one AttentionLayer (reference infgen/modules/layers.py:61-113) and the
+// token/state heads.  The relative-position projections are ABSORBED into the query and the
+// aggregate (never materialised per edge):
+//     sim_e,h   = q_h . (k_j,h + W_kr,h LN(r_e))          = q_h . k_j,h + u_h . rhat_e + const(h)
+//     sum_e a_e (v_j,h + W_vr,h LN(r_e) + b)             = sum_e a_e v_j,h + W'_vr,h z_h + b'_h sigma_h
+// with rhat_e the affine-free LayerNorm of r_e, u_h = gamma (.) W_kr,h^T q_h, z_h = sum_e a_e rhat_e,
+// W'_vr = W_vr diag(gamma), b' = W_vr beta + b_vr, sigma_h = sum_e a_e.  The per-destination constant
+// q_h . W_kr,h beta cancels in the softmax (max-shift and ratio are shift invariant).
+#include "kernels.h"
+
+namespace ig {
+
+// ------------------------------------------------------------------------------------------
+// k_attn_pre: Xn = LN(X); Q = scale*(Xn Wq^T + bq); K = Xn Wk^T; V = Xn Wv^T + bv; U_h = Q_h W'_kr,h
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT, 2) void k_attn_pre(AttnPreArgs a) {
+  __shared__ __attribute__((aligned(16))) float Xs[TR * LDT];
+  __shared__ __attribute__((aligned(16))) float Qs[TR * LDT];
+  const int row0 = blockIdx.x * TR;
+  const int nvalid = min(TR, a.rows - row0);
+  if (nvalid <= 0) return;
+  const int w = wave_id(), n0 = 32 * w;
+  stage_rows_128(Xs, [&](int r) { return a.X + (size_t)(row0 + r) * D; }, nvalid);
+  __syncthreads();
+  const float* g = a.pack + (a.use_src_ln ? AL_LN_SRC_G : AL_LN_DST_G);
+  const float* b = a.pack + (a.use_src_ln ? AL_LN_SRC_B : AL_LN_DST_B);
+  ln_tile(Xs, LDT, Xs, LDT, g, b, false);
+  __syncthreads();
+  const int col = n0 + acc_col();
+  if (a.Q || a.U) {
+    f32x16 acc = zero16();
+    mfma_32x32<128>(acc, Xs, LDT, a.pack + AL_WQ, 128, n0);
+    const float bq = a.pack[AL_BQ + col];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int r = acc_row(reg);
+      const float q = acc[reg] + bq;
+      Qs[r * LDT + col] = q;
+      if (a.Q && r < nvalid) a.Q[(size_t)(row0 + r) * D + col] = q;
+    }
+  }
+  if (a.K) {
+    f32x16 acc = zero16();
+    mfma_32x32<128>(acc, Xs, LDT, a.pack + AL_WK, 128, n0);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int r = acc_row(reg);
+      if (r < nvalid) a.K[(size_t)(row0 + r) * D + col] = acc[reg];
+    }
+  }
+  if (a.V) {
+    f32x16 acc = zero16();
+    mfma_32x32<128>(acc, Xs, LDT, a.pack + AL_WV, 128, n0);
+    const float bv = a.pack[AL_BV + col];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int r = acc_row(reg);
+      if (r < nvalid) a.V[(size_t)(row0 + r) * D + col] = acc[reg] + bv;
+    }
+  }
+  if (a.U) {
+    __syncthreads();
+    for (int h = 0; h < H; ++h) {
+      f32x16 acc = zero16();
+      mfma_32x32<16>(acc, Qs + DH * h, LDT, a.pack + AL_WKR + h * (DH * D), 128, n0);
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = acc_row(reg);
+        if (r < nvalid) a.U[(size_t)(row0 + r) * (H * D) + h * D + col] = acc[reg];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_attn_post: agg = AGG + W'_vr z + b' sigma ; gate ; out-proj ; post-norm residual ; FFN residual
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT, 2) void k_attn_post(AttnPostArgs a) {
+  __shared__ __attribute__((aligned(16))) float B0[TR * LDT];   // x (raw) -> x1 -> x2
+  __shared__ __attribute__((aligned(16))) float B1[TR * LDT];   // LN_dst(x) -> LN_ffpre(x1)
+  __shared__ __attribute__((aligned(16))) float B2[TR * LDT];   // agg -> to_out(...) -> ffn out
+  __shared__ __attribute__((aligned(16))) float B3[TR * LDT];   // upd -> relu(hidden chunk)
+  const int row0 = blockIdx.x * TR;
+  const int nvalid = min(TR, a.rows - row0);
+  if (nvalid <= 0) return;
+  const int w = wave_id(), n0 = 32 * w, lane = lane_id();
+  const float* P = a.pack;
+
+  stage_rows_128(B0, [&](int r) { return a.X + (size_t)(row0 + r) * D; }, nvalid);
+  stage_rows_128(B2, [&](int r) { return a.AGG + (size_t)(row0 + r) * D; }, nvalid);
+  __syncthreads();
+  ln_tile(B0, LDT, B1, LDT, P + AL_LN_DST_G, P + AL_LN_DST_B, false);
+
+  if (a.has_pos) {
+    // z-GEMM on v_mfma_f32_16x16x4_f32: per head h, out[row][16h + c] = sum_d Z[row][h][d] * B_h[d][c]
+    // lane l supplies A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; C: col = l&15, row = 4*(l>>4) + reg
+    const int i16 = lane & 15, kq = lane >> 4;
+    for (int hh = 0; hh < 2; ++hh) {
+      const int h = 2 * w + hh;
+      const float* Bh = P + AL_WVR + h * (DH * D);
+      for (int mt = 0; mt < 2; ++mt) {
+        const int r = mt * 16 + i16;
+        const bool ok = r < nvalid;
+        const float* zrow = a.Z + (size_t)(row0 + (ok ? r : 0)) * (H * D) + h * D + 4 * kq;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok) av = *reinterpret_cast<const float4*>(zrow + 16 * s);
+          const float4 bv = *reinterpret_cast<const float4*>(Bh + ((s * 16 + i16) * 4 + kq) * 4);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+        }
+        const int c = DH * h + i16;
+        const float bvr = P[AL_BVR + c];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int rr = mt * 16 + 4 * kq + reg;
+          const float sg = rr < nvalid ? a.SIG[(size_t)(row0 + rr) * H + h] : 0.f;
+          B2[rr * LDT + c] += acc[reg] + bvr * sg;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // gate / self projection / update (layers.py:94-99)
+  {
+    f32x16 accg = zero16(), accs = zero16();
+    mfma_32x32<128>(accg, B2, LDT, P + AL_WG, 128, n0);
+    mfma_32x32<128>(accg, B1, LDT, P + AL_WG + 16384, 128, n0);
+    mfma_32x32<128>(accs, B1, LDT, P + AL_WS, 128, n0);
+    const int col = n0 + acc_col();
+    const float bg = P[AL_BG + col], bs = P[AL_BS + col];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int r = acc_row(reg);
+      const float gate = 1.0f / (1.0f + expf(-(accg[reg] + bg)));
+      const float ag = B2[r * LDT + col];
+      B3[r * LDT + col] = ag + gate * ((accs[reg] + bs) - ag);
+    }
+  }
+  __syncthreads();
+  {
+    f32x16 acco = zero16();
+    mfma_32x32<128>(acco, B3, LDT, P + AL_WO, 128, n0);
+    acc_to_lds(acco, B2, LDT, n0, P + AL_BO);
+  }
+  __syncthreads();
+  ln_tile(B2, LDT, B0, LDT, P + AL_LN_POST_G, P + AL_LN_POST_B, false, B0, LDT);   // x1 = x + LN(out)
+  __syncthreads();
+  ln_tile(B0, LDT, B1, LDT, P + AL_LN_FFPRE_G, P + AL_LN_FFPRE_B, false);
+  __syncthreads();
+  f32x16 accf = zero16();
+  for (int cc = 0; cc < 4; ++cc) {
+    f32x16 acch = zero16();
+    mfma_32x32<128>(acch, B1, LDT, P + AL_W1, 512, 128 * cc + n0);
+    {
+      const int col = n0 + acc_col();
+      const float b1 = P[AL_B1 + 128 * cc + col];
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) B3[acc_row(reg) * LDT + col] = fmaxf(acch[reg] + b1, 0.f);
+    }
+    __syncthreads();
+    mfma_32x32<128>(accf, B3, LDT, P + AL_W2 + (size_t)(16 * cc) * 128 * 8, 128, n0);
+    __syncthreads();
+  }
+  acc_to_lds(accf, B2, LDT, n0, P + AL_B2);
+  __syncthreads();
+  ln_tile(B2, LDT, B0, LDT, P + AL_LN_FFPOST_G, P + AL_LN_FFPOST_B, false, B0, LDT);   // x2 = x1 + LN(ffn)
+  __syncthreads();
+  unstage_rows_128(B0, [&](int r) { return a.X + (size_t)(row0 + r) * D; }, nvalid);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_heads: token_predict_head (128 -> 128 LN ReLU -> token_size) with fused arg-max and optional
+// logits store; state_predict_head (128 -> 128 LN ReLU -> 3) arg-max.
+// reference agent_decoder.py:2161-2167 (greedy: motion_beam_size = 1)
+// MLPLayer pack: [0] P(128,128) W0 | [16384] b0 | [16512] ln g | [16640] ln b | [16768] W3 ... | b3
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT, 2) void k_heads(HeadsArgs a) {
+  __shared__ __attribute__((aligned(16))) float Xs[TR * LDT];
+  __shared__ __attribute__((aligned(16))) float Hs[TR * LDT];
+  __shared__ float red_v[4][TR];
+  __shared__ int red_i[4][TR];
+  const int row0 = blockIdx.x * TR;
+  const int nvalid = min(TR, a.rows - row0);
+  if (nvalid <= 0) return;
+  const int w = wave_id(), n0 = 32 * w, lane = lane_id();
+  stage_rows_128(Xs, [&](int r) { return a.X + (size_t)(row0 + r) * D; }, nvalid);
+  __syncthreads();
+  {
+    const float* P = a.tok_pack;
+    f32x16 acc = zero16();
+    mfma_32x32<128>(acc, Xs, LDT, P, 128, n0);
+    acc_to_lds(acc, Hs, LDT, n0, P + 16384);
+    __syncthreads();
+    ln_tile(Hs, LDT, Hs, LDT, P + 16512, P + 16640, true);
+    __syncthreads();
+    const float* W3 = P + 16768;
+    const float* b3 = W3 + (size_t)128 * a.token_size;
+    float bv[16];
+    int bi[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) { bv[reg] = -INFINITY; bi[reg] = 0; }
+    for (int p = 0; p < a.token_size / 128; ++p) {
+      const int c0 = 128 * p + n0;
+      f32x16 acc2 = zero16();
+      mfma_32x32<128>(acc2, Hs, LDT, W3, a.token_size, c0);
+      const int col = c0 + acc_col();
+      const float bb = b3[col];
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const float v = acc2[reg] + bb;
+        const int r = acc_row(reg);
+        if (a.logits && r < nvalid) a.logits[(size_t)(row0 + r) * a.token_size + col] = v;
+        if (v > bv[reg]) { bv[reg] = v; bi[reg] = col; }
+      }
+    }
+    // reduce over the 32 lanes (columns) that share a row; ties -> smaller index
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      float v = bv[reg];
+      int i = bi[reg];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(i, o, 64);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+      }
+      if ((lane & 31) == 0) { red_v[w][acc_row(reg)] = v; red_i[w][acc_row(reg)] = i; }
+    }
+    __syncthreads();
+    if (threadIdx.x < nvalid) {
+      const int r = threadIdx.x;
+      float v = red_v[0][r];
+      int i = red_i[0][r];
+      for (int ww = 1; ww < 4; ++ww) {
+        const float ov = red_v[ww][r];
+        const int oi = red_i[ww][r];
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+      }
+      a.next_token[row0 + r] = i;
+    }
+  }
+  __syncthreads();
+  {
+    const float* P = a.st_pack;
+    f32x16 acc = zero16();
+    mfma_32x32<128>(acc, Xs, LDT, P, 128, n0);
+    acc_to_lds(acc, Hs, LDT, n0, P + 16384);
+    __syncthreads();
+    ln_tile(Hs, LDT, Hs, LDT, P + 16512, P + 16640, true);
+    __syncthreads();
+    if (threadIdx.x < nvalid) {
+      const int r = threadIdx.x;
+      const float* W3 = P + 16768;        // [3][128] row-major
+      const float* b3 = W3 + 3 * 128;
+      float best = -INFINITY;
+      int bi = 0;
+      for (int o = 0; o < 3; ++o) {
+        float s = 0.f;
+        for (int k = 0; k < 128; ++k) s = fmaf(Hs[r * LDT + k], W3[o * 128 + k], s);
+        s += b3[o];
+        if (s > best) { best = s; bi = o; }
+      }
+      a.next_state[row0 + r] = bi;
+    }
+  }
+}
+
+}  // namespace ig

@@ -1,0 +1,63 @@
+// Packed-weight layouts shared by the kernels and (through infgen_layout_query) the host packer.
+// All offsets are in floats.  "P(K,N)" = a GEMM operand packed as Wp[K/8][N][8] (tile.cuh).
+#pragma once
+
+namespace ig {
+
+// ---- AttentionLayer (reference infgen/modules/layers.py:16-113) ------------------------------
+enum AttnLayout : int {
+  AL_LN_SRC_G = 0,                       // attn_prenorm_x_src
+  AL_LN_SRC_B = AL_LN_SRC_G + 128,
+  AL_LN_DST_G = AL_LN_SRC_B + 128,       // attn_prenorm_x_dst (== src when not bipartite)
+  AL_LN_DST_B = AL_LN_DST_G + 128,
+  AL_WQ = AL_LN_DST_B + 128,             // P(128,128) of head_dim^-0.5 * to_q.weight
+  AL_BQ = AL_WQ + 16384,                 // head_dim^-0.5 * to_q.bias
+  AL_WK = AL_BQ + 128,                   // P(128,128) to_k
+  AL_WV = AL_WK + 16384,                 // P(128,128) to_v
+  AL_BV = AL_WV + 16384,
+  AL_WKR = AL_BV + 128,                  // 8 x P(16,128): B_h[c][d] = to_k_r.weight[16h+c][d] * ln_r.gamma[d]
+  AL_WVR = AL_WKR + 16384,               // 8 x [8][16][4][4]: B_h[d][c] = to_v_r.weight[16h+c][d] * ln_r.gamma[d]
+  AL_BVR = AL_WVR + 16384,               // to_v_r.weight @ ln_r.beta + to_v_r.bias
+  AL_WS = AL_BVR + 128,                  // P(128,128) to_s
+  AL_BS = AL_WS + 16384,
+  AL_WG = AL_BS + 128,                   // P(256,128) to_g  (k < 128: agg part, k >= 128: x_dst part)
+  AL_BG = AL_WG + 32768,
+  AL_WO = AL_BG + 128,                   // P(128,128) to_out
+  AL_BO = AL_WO + 16384,
+  AL_LN_POST_G = AL_BO + 128,
+  AL_LN_POST_B = AL_LN_POST_G + 128,
+  AL_LN_FFPRE_G = AL_LN_POST_B + 128,
+  AL_LN_FFPRE_B = AL_LN_FFPRE_G + 128,
+  AL_W1 = AL_LN_FFPRE_B + 128,           // P(128,512) ff_mlp.0
+  AL_B1 = AL_W1 + 65536,
+  AL_W2 = AL_B1 + 512,                   // P(512,128) ff_mlp.3
+  AL_B2 = AL_W2 + 65536,
+  AL_LN_FFPOST_G = AL_B2 + 128,
+  AL_LN_FFPOST_B = AL_LN_FFPOST_G + 128,
+  AL_SIZE = AL_LN_FFPOST_B + 128,
+};
+
+// ---- FourierEmbedding (layers.py:116-160), n input dims (n <= 4) -------------------------------
+// header, then n per-dim blocks, then the tail
+enum FourierLayout : int {
+  FE_FREQ = 0,                 // [4][64] freqs.weight (rows >= n unused)
+  FE_DIM0 = 256,               // start of per-dim blocks
+  // per-dim block
+  FD_W1 = 0,                   // P(128,128): k < 64 -> cos weights, k >= 64 -> sin weights (mlps.i.0.weight[:, :128])
+  FD_W1X = FD_W1 + 16384,      // mlps.i.0.weight[:, 128]
+  FD_B1 = FD_W1X + 128,
+  FD_LN_G = FD_B1 + 128,
+  FD_LN_B = FD_LN_G + 128,
+  FD_W2 = FD_LN_B + 128,       // P(128,128) mlps.i.3.weight
+  FD_SIZE = FD_W2 + 16384,
+  // tail (offsets relative to FE_DIM0 + n * FD_SIZE)
+  FT_B2SUM = 0,                // sum_i mlps.i.3.bias
+  FT_LN_G = 128,
+  FT_LN_B = 256,
+  FT_W3 = 384,                 // P(128,128) to_out.2
+  FT_B3 = FT_W3 + 16384,
+  FT_SIZE = FT_B3 + 128,
+};
+__host__ __device__ inline int fourier_pack_size(int n) { return FE_DIM0 + n * FD_SIZE + FT_SIZE; }
+
+}  // namespace ig

@@ -1,0 +1,180 @@
+// Tile-level device helpers for gfx950 (CDNA4): fp32 MFMA row-tile GEMMs, LayerNorm on LDS
+// tiles, wave reductions and the scalar math helpers that mirror the reference's
+// elementwise formulas.  Everything here assumes 64-wide wavefronts and 256-thread
+// workgroups (4 waves) unless stated otherwise.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace ig {
+
+constexpr int D = 128;        // hidden size (reference configs/ours_standard.yaml:60)
+constexpr int H = 8;          // heads
+constexpr int DH = 16;        // head dim
+constexpr int TR = 32;        // rows per GEMM tile (one 32x32 MFMA M-tile)
+constexpr int LDT = 132;      // LDS row stride in floats: 16-B aligned rows, conflict-free b128 reads
+constexpr int NT = 256;       // threads per GEMM workgroup
+constexpr float LN_EPS = 1e-5f;
+constexpr float PI_F = 3.14159274101257324f;      // float(math.pi)
+constexpr float TWO_PI_F = 6.28318548202514648f;  // float(2 * math.pi)
+constexpr float HALF_PI_F = 1.57079637050628662f; // float(math.pi / 2)
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- elementwise formulas of the reference ------------------------------------------------
+// infgen/utils/func.py:58-62   wrap_angle(a) = -pi + (a + pi) % (2 pi)   (python-style remainder)
+__device__ __forceinline__ float wrap_angle(float a) {
+  float x = a + PI_F;
+  float r = fmodf(x, TWO_PI_F);
+  if (r != 0.0f && r < 0.0f) r += TWO_PI_F;
+  return -PI_F + r;
+}
+// infgen/utils/func.py:30-34   atan2(cx*ny - cy*nx, (ctr * nbr).sum(-1))
+// torch's sum() starts from +0, so for a zero neighbour vector (a stationary agent, or column 0 of
+// a row without bos) the second argument is +0 even when both products are -0: atan2 then gives
+// +-0 where the naive expression gives +-pi.  Keep the explicit "+0.0f +" (IEEE: +0 + -0 = +0).
+__device__ __forceinline__ float angle_between(float cx, float cy, float nx, float ny) {
+  volatile float zero = 0.0f;
+  return atan2f(cx * ny - cy * nx, (zero + cx * nx) + cy * ny);
+}
+__device__ __forceinline__ float norm2(float x, float y) { return sqrtf(x * x + y * y); }
+
+// ---- packed weight layout -----------------------------------------------------------------
+// A logical GEMM operand B[k][n] (= torch Linear.weight[n][k]) with K padded to a multiple of
+// 8 and N to a multiple of 32 is stored as Wp[k/8][n][k%8]: one lane reads the 4 k-values it
+// feeds to 4 consecutive MFMAs with ONE 16-byte load, and a wave reads 1 KiB contiguous.
+__host__ __device__ __forceinline__ size_t packed_index(int k, int n, int N) {
+  return ((size_t)(k >> 3) * N + n) * 8 + (k & 7);
+}
+
+// acc(32x32 tile at columns [n0, n0+32)) += A[32][K] (LDS, row stride lda) * B (packed, N cols)
+// v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].
+// Lane-half kh reads k = 8g + 4kh .. 8g + 4kh + 3 with one ds_read_b128 / global_load_dwordx4
+// and uses them in 4 MFMAs, so MFMA m of group g contracts k in {8g + m, 8g + 4 + m}.
+template <int K>
+__device__ __forceinline__ void mfma_32x32(f32x16& acc, const float* __restrict__ A, int lda,
+                                           const float* __restrict__ Wp, int N, int n0) {
+  const int lane = lane_id();
+  const int r = lane & 31, kh = lane >> 5;
+  const float* ap = A + r * lda + 4 * kh;
+  const float* bp = Wp + ((size_t)(n0 + r)) * 8 + 4 * kh;
+#pragma unroll 4
+  for (int g = 0; g < K / 8; ++g) {
+    const float4 a = *reinterpret_cast<const float4*>(ap + g * 8);
+    const float4 b = *reinterpret_cast<const float4*>(bp + (size_t)g * N * 8);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  }
+}
+// runtime-K variant (K multiple of 8)
+__device__ __forceinline__ void mfma_32x32_rt(f32x16& acc, const float* __restrict__ A, int lda, int K,
+                                              const float* __restrict__ Wp, int N, int n0) {
+  const int lane = lane_id();
+  const int r = lane & 31, kh = lane >> 5;
+  const float* ap = A + r * lda + 4 * kh;
+  const float* bp = Wp + ((size_t)(n0 + r)) * 8 + 4 * kh;
+  for (int g = 0; g < K / 8; ++g) {
+    const float4 a = *reinterpret_cast<const float4*>(ap + g * 8);
+    const float4 b = *reinterpret_cast<const float4*>(bp + (size_t)g * N * 8);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  }
+}
+
+// C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+__device__ __forceinline__ int acc_row(int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane_id() >> 5); }
+__device__ __forceinline__ int acc_col() { return lane_id() & 31; }
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+  return z;
+}
+
+// acc (+ bias[col]) -> LDS tile O[32][ldo] at columns n0..n0+31
+__device__ __forceinline__ void acc_to_lds(const f32x16& acc, float* O, int ldo, int n0, const float* __restrict__ bias) {
+  const int col = n0 + acc_col();
+  const float b = bias ? bias[col] : 0.0f;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) O[acc_row(reg) * ldo + col] = acc[reg] + b;
+}
+
+// Stage a [32][128] fp32 tile from global rows (row r -> src + rowoff(r)) into LDS with stride LDT.
+// Rows >= nvalid are zero-filled.  256 threads, 16 B per thread per pass.
+template <typename RowPtr>
+__device__ __forceinline__ void stage_rows_128(float* dst, RowPtr rowptr, int nvalid) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int idx = p * NT + t;       // 0..1023 float4 slots
+    const int r = idx >> 5, c4 = idx & 31;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nvalid) {
+      const float* src = rowptr(r);
+      if (src) v = *reinterpret_cast<const float4*>(src + c4 * 4);
+    }
+    *reinterpret_cast<float4*>(dst + r * LDT + c4 * 4) = v;
+  }
+}
+
+// Write a [32][128] LDS tile to global rows (coalesced float4), rows < nvalid
+template <typename RowPtr>
+__device__ __forceinline__ void unstage_rows_128(const float* src, RowPtr rowptr, int nvalid) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int idx = p * NT + t;
+    const int r = idx >> 5, c4 = idx & 31;
+    if (r < nvalid) {
+      float* d = rowptr(r);
+      if (d) *reinterpret_cast<float4*>(d + c4 * 4) = *reinterpret_cast<const float4*>(src + r * LDT + c4 * 4);
+    }
+  }
+}
+
+// LayerNorm over the 128 columns of each row of an LDS tile (biased variance, eps 1e-5, like
+// torch.nn.LayerNorm); wave w handles rows w, w+4, ...; lane handles columns 2l, 2l+1.
+// gamma == nullptr -> no affine (plain normalisation).  res != nullptr -> dst = res + LN(src).
+__device__ __forceinline__ void ln_tile(const float* src, int lds_, float* dst, int ldd,
+                                        const float* __restrict__ gamma, const float* __restrict__ beta, bool relu,
+                                        const float* res = nullptr, int ldr = 0) {
+  const int lane = lane_id();
+  float g0 = 1.f, g1 = 1.f, b0 = 0.f, b1 = 0.f;
+  if (gamma) { g0 = gamma[2 * lane]; g1 = gamma[2 * lane + 1]; b0 = beta[2 * lane]; b1 = beta[2 * lane + 1]; }
+  for (int row = wave_id(); row < TR; row += 4) {
+    const float2 v = *reinterpret_cast<const float2*>(src + row * lds_ + 2 * lane);
+    const float mean = wave_sum(v.x + v.y) * (1.0f / 128.0f);
+    const float dx = v.x - mean, dy = v.y - mean;
+    const float var = wave_sum(dx * dx + dy * dy) * (1.0f / 128.0f);
+    const float rstd = 1.0f / sqrtf(var + LN_EPS);
+    float y0 = dx * rstd * g0 + b0, y1 = dy * rstd * g1 + b1;
+    if (relu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
+    if (res) {
+      const float2 rr = *reinterpret_cast<const float2*>(res + row * ldr + 2 * lane);
+      y0 += rr.x; y1 += rr.y;
+    }
+    *reinterpret_cast<float2*>(dst + row * ldd + 2 * lane) = make_float2(y0, y1);
+  }
+}
+
+}  // namespace ig

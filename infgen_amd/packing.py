@@ -1,0 +1,140 @@
+"""Host-side weight packing: reference ``state_dict`` tensors -> the kernel-ready flat fp32
+layouts of infgen_amd/csrc/layout.h (offsets are queried from the shared library, so the C
+header is the single source of truth).
+
+GEMM operands are stored as P(K, N) = Wp[K/8][N][8] (see tile.cuh); the relative-position
+projections ``to_k_r`` / ``to_v_r`` are stored with the layer's ``attn_prenorm_r`` affine folded in
+(DESIGN.md "absorbed relative-position attention").
+"""
+from __future__ import annotations
+
+from typing import Dict, Mapping
+
+import numpy as np
+
+from . import _lib
+
+HEADS, HEAD_DIM, D = 8, 16, 128
+
+
+def pack_matrix(w: np.ndarray) -> np.ndarray:
+    """torch Linear.weight [N][K] -> P(Kp, Np) flat float32 (K padded to 8, N to 32)."""
+    w = np.asarray(w, dtype=np.float32)
+    n, k = w.shape
+    kp, npad = (k + 7) // 8 * 8, (n + 31) // 32 * 32
+    wt = np.zeros((kp, npad), dtype=np.float32)
+    wt[:k, :n] = w.T
+    return np.ascontiguousarray(wt.reshape(kp // 8, 8, npad).transpose(0, 2, 1)).reshape(-1)
+
+
+def _get(sd: Mapping[str, np.ndarray], key: str) -> np.ndarray:
+    v = sd[key]
+    if hasattr(v, 'detach'):
+        v = v.detach().cpu().numpy()
+    return np.asarray(v, dtype=np.float32)
+
+
+def pack_attention_layer(sd, prefix: str, has_pos_emb: bool = True) -> np.ndarray:
+    """AttentionLayer (reference infgen/modules/layers.py:16-59) -> AttnLayout."""
+    lib = _lib.load()
+    out = np.zeros(lib.infgen_layout_query(_lib.Q_ATTN_PACK_SIZE), dtype=np.float32)
+
+    def put(field, arr):
+        o = lib.infgen_attn_pack_offset(field.encode())
+        assert o >= 0, field
+        arr = np.asarray(arr, dtype=np.float32).reshape(-1)
+        out[o:o + arr.size] = arr
+
+    g = lambda k: _get(sd, f'{prefix}.{k}')
+    scale = np.float32(HEAD_DIM ** -0.5)
+    put('ln_src_g', g('attn_prenorm_x_src.weight')); put('ln_src_b', g('attn_prenorm_x_src.bias'))
+    put('ln_dst_g', g('attn_prenorm_x_dst.weight')); put('ln_dst_b', g('attn_prenorm_x_dst.bias'))
+    put('wq', pack_matrix(g('to_q.weight') * scale)); put('bq', g('to_q.bias') * scale)
+    put('wk', pack_matrix(g('to_k.weight')))
+    put('wv', pack_matrix(g('to_v.weight'))); put('bv', g('to_v.bias'))
+    if has_pos_emb:
+        gam, bet = g('attn_prenorm_r.weight'), g('attn_prenorm_r.bias')
+        wkr = g('to_k_r.weight') * gam[None, :]            # [c'][d]
+        wvr = g('to_v_r.weight') * gam[None, :]
+        kr = [pack_matrix(wkr[HEAD_DIM * h:HEAD_DIM * (h + 1), :].T) for h in range(HEADS)]   # B_h[c][d]: N=128, K=16
+        put('wkr', np.concatenate(kr))
+        vr = []
+        for h in range(HEADS):
+            wh = wvr[HEAD_DIM * h:HEAD_DIM * (h + 1), :]                    # [c][d]
+            vr.append(np.ascontiguousarray(wh.reshape(HEAD_DIM, 8, 4, 4).transpose(1, 0, 2, 3)).reshape(-1))
+        put('wvr', np.concatenate(vr))
+        put('bvr', g('to_v_r.weight') @ bet + g('to_v_r.bias'))
+    put('ws', pack_matrix(g('to_s.weight'))); put('bs', g('to_s.bias'))
+    put('wg', pack_matrix(g('to_g.weight'))); put('bg', g('to_g.bias'))
+    put('wo', pack_matrix(g('to_out.weight'))); put('bo', g('to_out.bias'))
+    put('ln_post_g', g('attn_postnorm.weight')); put('ln_post_b', g('attn_postnorm.bias'))
+    put('ln_ffpre_g', g('ff_prenorm.weight')); put('ln_ffpre_b', g('ff_prenorm.bias'))
+    put('w1', pack_matrix(g('ff_mlp.0.weight'))); put('b1', g('ff_mlp.0.bias'))
+    put('w2', pack_matrix(g('ff_mlp.3.weight'))); put('b2', g('ff_mlp.3.bias'))
+    put('ln_ffpost_g', g('ff_postnorm.weight')); put('ln_ffpost_b', g('ff_postnorm.bias'))
+    return out
+
+
+def pack_fourier(sd, prefix: str, n: int) -> np.ndarray:
+    """FourierEmbedding (layers.py:116-141) -> FourierLayout."""
+    lib = _lib.load()
+    size = lib.infgen_layout_query({2: _lib.Q_FOURIER_N2, 3: _lib.Q_FOURIER_N3, 4: _lib.Q_FOURIER_N4}[n])
+    out = np.zeros(size, dtype=np.float32)
+
+    def put(field, dim, arr):
+        o = lib.infgen_fourier_pack_offset(field.encode(), n, dim)
+        assert o >= 0, field
+        arr = np.asarray(arr, dtype=np.float32).reshape(-1)
+        out[o:o + arr.size] = arr
+
+    g = lambda k: _get(sd, f'{prefix}.{k}')
+    freqs = g('freqs.weight')
+    b2sum = np.zeros(D, dtype=np.float32)
+    for i in range(n):
+        w1 = g(f'mlps.{i}.0.weight')                    # [128][129]
+        put('freq', i, freqs[i])
+        put('w1', i, pack_matrix(w1[:, :128]))
+        put('w1x', i, w1[:, 128])
+        put('b1', i, g(f'mlps.{i}.0.bias'))
+        put('ln_g', i, g(f'mlps.{i}.1.weight')); put('ln_b', i, g(f'mlps.{i}.1.bias'))
+        put('w2', i, pack_matrix(g(f'mlps.{i}.3.weight')))
+        b2sum = b2sum + g(f'mlps.{i}.3.bias')
+    put('b2sum', 0, b2sum)
+    put('lno_g', 0, g('to_out.0.weight')); put('lno_b', 0, g('to_out.0.bias'))
+    put('w3', 0, pack_matrix(g('to_out.2.weight'))); put('b3', 0, g('to_out.2.bias'))
+    return out
+
+
+def pack_mlp_embedding(sd, prefix: str) -> np.ndarray:
+    """MLPEmbedding (layers.py:163-179): P(K0p,128) b ln_g ln_b | P(128,128) b ln_g ln_b | P(128,128) b"""
+    g = lambda k: _get(sd, f'{prefix}.{k}')
+    return np.concatenate([
+        pack_matrix(g('mlp.0.weight')), g('mlp.0.bias'), g('mlp.1.weight'), g('mlp.1.bias'),
+        pack_matrix(g('mlp.3.weight')), g('mlp.3.bias'), g('mlp.4.weight'), g('mlp.4.bias'),
+        pack_matrix(g('mlp.6.weight')), g('mlp.6.bias')]).astype(np.float32)
+
+
+def mlp_embedding_offsets(k0: int):
+    """float offsets of the three stages inside a pack_mlp_embedding() buffer"""
+    k0p = (k0 + 7) // 8 * 8
+    o1 = 0
+    o2 = k0p * 128 + 3 * 128
+    o3 = o2 + 16384 + 3 * 128
+    return k0p, o1, o2, o3
+
+
+def pack_mlp_layer(sd, prefix: str, row_major_out: bool = False) -> np.ndarray:
+    """MLPLayer (layers.py:195-212): P(128,128) W0 | b0 | ln_g | ln_b | W3 | b3
+    W3 is P(128, Np) unless ``row_major_out`` (tiny heads read by scalar code)."""
+    g = lambda k: _get(sd, f'{prefix}.{k}')
+    w3 = g('mlp.3.weight')
+    w3p = w3.reshape(-1) if row_major_out else pack_matrix(w3)
+    b3 = g('mlp.3.bias')
+    if not row_major_out:
+        npad = (w3.shape[0] + 31) // 32 * 32
+        b3 = np.concatenate([b3, np.zeros(npad - b3.size, dtype=np.float32)])
+    return np.concatenate([pack_matrix(g('mlp.0.weight')), g('mlp.0.bias'), g('mlp.1.weight'), g('mlp.1.bias'),
+                           w3p, b3]).astype(np.float32)
+
+
+MLP_LAYER_W3_OFFSET = 16384 + 3 * 128

@@ -1,0 +1,163 @@
+"""GPU: operator-level parity of the HIP kernels (through the C ABI) against the CPU oracle's
+restatement of the reference operators (oracle/rollout_oracle.py).  fp32 tolerances are
+written next to each check."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+    from infgen_amd import _lib, packing, engine
+    assert torch.cuda.is_available(), 'these tests need the GPU box'
+    dev = torch.device('cuda:0')
+    sd = make_weights(seed=3)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    return dict(lib=_lib.load(), packing=packing, ops=engine.Ops(dev), dev=dev, sd=sd, tsd=tsd)
+
+
+def _dev(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+@pytest.mark.parametrize('rows,k,n', [(1, 8, 128), (70, 3, 128), (33, 22, 128), (64, 128, 128), (40, 128, 2048),
+                                      (37, 512, 128), (5, 1961, 128), (96, 128, 3), (31, 128, 120)])
+def test_linear_matches_fp32(env, rows, k, n):
+    """MFMA tile GEMM incl. A/B fragment and C/D layouts: asymmetric random operands."""
+    rng = np.random.default_rng(rows * 1000 + k)
+    x = rng.standard_normal((rows, k)).astype(np.float32)
+    w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    npad = (n + 31) // 32 * 32
+    pack = np.concatenate([env['packing'].pack_matrix(w), b, np.zeros(npad - n, np.float32)])
+    wp = _dev(pack, env['dev'])
+    y = env['ops'].linear(_dev(x, env['dev']), wp, 0, n, k, bias_off=pack.size - npad)
+    ref = x.astype(np.float64) @ w.T.astype(np.float64) + b
+    err = np.abs(y.cpu().numpy() - ref).max()
+    assert err <= 2e-5 * max(1.0, np.abs(ref).max()), err      # fp32 fmaf chain vs fp64
+
+
+def test_linear_layernorm_relu_epilogue(env):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((50, 128)).astype(np.float32)
+    w = (rng.standard_normal((128, 128)) / 11).astype(np.float32)
+    b, g, be = (rng.standard_normal(128).astype(np.float32) for _ in range(3))
+    pack = np.concatenate([env['packing'].pack_matrix(w), b, g, be])
+    y = env['ops'].linear(_dev(x, env['dev']), _dev(pack, env['dev']), 0, 128, 128, bias_off=16384,
+                          post_ln_off=16384 + 128, relu=True)
+    ref = torch.relu(torch.nn.functional.layer_norm(torch.from_numpy(x) @ torch.from_numpy(w).T + torch.from_numpy(b),
+                                                    (128,), torch.from_numpy(g), torch.from_numpy(be)))
+    assert np.abs(y.cpu().numpy() - ref.numpy()).max() <= 2e-5
+
+
+@pytest.mark.parametrize('n,prefix', [(2, 'agent_encoder.x_a_emb'), (3, 'agent_encoder.r_a2a_emb'),
+                                      (4, 'agent_encoder.r_t_emb'), (3, 'map_encoder.r_pt2pt_emb')])
+def test_fourier_embedding(env, n, prefix):
+    from oracle import rollout_oracle as ro
+    rng = np.random.default_rng(n)
+    E = 77
+    raw = np.zeros((E, 4), np.float32)
+    raw[:, 0] = rng.uniform(0, 60, E)
+    raw[:, 1:n] = rng.uniform(-np.pi, np.pi, (E, n - 1))
+    if n == 4:
+        raw[:, 3] = -rng.integers(1, 13, E)
+    cat = rng.standard_normal((E, 128)).astype(np.float32) * 0.1 if n == 2 else None
+    pack = _dev(env['packing'].pack_fourier(env['sd'], prefix, n), env['dev'])
+    out = torch.empty(E, 128, device=env['dev'])
+    env['ops'].fourier(_dev(raw, env['dev']), n, pack, out, cat=_dev(cat, env['dev']) if cat is not None else None)
+    with torch.no_grad():
+        ref = ro.fourier_embedding(env['tsd'], prefix, torch.from_numpy(raw[:, :n]),
+                                   [torch.from_numpy(cat), torch.zeros(E, 128)] if cat is not None else None)
+    err = np.abs(out.cpu().numpy() - ref.numpy()).max()
+    assert err <= 5e-5, err       # sin/cos arguments up to ~25 rad: ocml vs sleef differ by an ulp or two
+    # normalised variant == affine-free LayerNorm of the same
+    out2 = torch.empty(E, 128, device=env['dev'])
+    env['ops'].fourier(_dev(raw, env['dev']), n, pack, out2, cat=_dev(cat, env['dev']) if cat is not None else None,
+                       normalize=True)
+    ref2 = torch.nn.functional.layer_norm(ref, (128,))
+    assert np.abs(out2.cpu().numpy() - ref2.numpy()).max() <= 2e-4
+
+
+def _random_graph(rng, n_dst, n_src, max_deg, empty_rows=()):
+    off, cnt, src, dst = [], [], [], []
+    e = 0
+    for i in range(n_dst):
+        d = 0 if i in empty_rows else int(rng.integers(1, max_deg + 1))
+        s = rng.choice(n_src, size=min(d, n_src), replace=False)
+        off.append(e); cnt.append(len(s))
+        src += list(s); dst += [i] * len(s)
+        e += len(s)
+    return np.array(off, np.int32), np.array(cnt, np.int32), np.array(src, np.int32), np.array(dst, np.int64)
+
+
+@pytest.mark.parametrize('prefix,bip', [('agent_encoder.a2a_attn_layers.2', False),
+                                        ('agent_encoder.pt2a_attn_layers.1', True),
+                                        ('agent_encoder.t_attn_layers.0', False)])
+def test_attention_layer(env, prefix, bip):
+    """pre + edge attention + post == AttentionLayer.forward (layers.py:61-113), incl. rows without
+    incoming edges (exact-zero aggregate) and ragged degrees up to 70."""
+    from oracle import rollout_oracle as ro
+    rng = np.random.default_rng(11)
+    n_dst, n_src = 45, (60 if bip else 45)
+    x = rng.standard_normal((n_dst, 128)).astype(np.float32)
+    xs = rng.standard_normal((n_src, 128)).astype(np.float32) if bip else None
+    off, cnt, src, dst = _random_graph(rng, n_dst, n_src, 44 if not bip else 59, empty_rows=(0, 7, 44))
+    E = len(src)
+    r = rng.standard_normal((E, 128)).astype(np.float32)
+    with torch.no_grad():
+        ref = ro.attention_layer(env['tsd'], prefix, torch.from_numpy(x), torch.from_numpy(r),
+                                 torch.from_numpy(src).long(), torch.from_numpy(dst),
+                                 x_src_raw=torch.from_numpy(xs) if bip else None).numpy()
+    dev = env['dev']
+    pack = _dev(env['packing'].pack_attention_layer(env['sd'], prefix), dev)
+    rhat = torch.nn.functional.layer_norm(torch.from_numpy(r), (128,)).to(dev).contiguous()
+    xd = _dev(x, dev)
+    env['ops'].attention_layer(xd, pack, torch.from_numpy(off).to(dev), torch.from_numpy(cnt).to(dev),
+                               torch.from_numpy(src).to(dev), rhat, x_src=_dev(xs, dev) if bip else None)
+    err = np.abs(xd.cpu().numpy() - ref).max()
+    assert err <= 1e-4, err
+
+
+def test_attention_layer_edgeless(env):
+    from oracle import rollout_oracle as ro
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((20, 128)).astype(np.float32)
+    z = torch.zeros(0, dtype=torch.long)
+    prefix = 'agent_encoder.t_attn_layers.3'
+    with torch.no_grad():
+        ref = ro.attention_layer(env['tsd'], prefix, torch.from_numpy(x), None, z, z).numpy()
+    dev = env['dev']
+    pack = _dev(env['packing'].pack_attention_layer(env['sd'], prefix), dev)
+    xd = _dev(x, dev)
+    zi = torch.zeros(20, dtype=torch.int32, device=dev)
+    env['ops'].attention_layer(xd, pack, zi, zi, torch.zeros(1, dtype=torch.int32, device=dev),
+                               torch.zeros(1, 128, device=dev))
+    assert np.abs(xd.cpu().numpy() - ref).max() <= 5e-5
+
+
+def test_heads_argmax_and_logits(env):
+    from oracle import rollout_oracle as ro
+    rng = np.random.default_rng(13)
+    rows = 50
+    x = rng.standard_normal((rows, 128)).astype(np.float32)
+    dev = env['dev']
+    tokp = _dev(env['packing'].pack_mlp_layer(env['sd'], 'agent_encoder.token_predict_head'), dev)
+    stp = _dev(env['packing'].pack_mlp_layer(env['sd'], 'agent_encoder.state_predict_head', row_major_out=True), dev)
+    logits = torch.empty(rows, 2048, device=dev)
+    nt = torch.zeros(rows, dtype=torch.int32, device=dev)
+    ns = torch.zeros(rows, dtype=torch.int32, device=dev)
+    from infgen_amd import _lib
+    _lib.check(env['lib'].infgen_heads(_dev(x, dev).data_ptr(), rows, tokp.data_ptr(), stp.data_ptr(), 2048,
+                                       logits.data_ptr(), nt.data_ptr(), ns.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream))
+    with torch.no_grad():
+        ref = ro.mlp_layer(env['tsd'], 'agent_encoder.token_predict_head', torch.from_numpy(x))
+        refs = ro.mlp_layer(env['tsd'], 'agent_encoder.state_predict_head', torch.from_numpy(x))
+    lg = logits.cpu().numpy()
+    assert np.abs(lg - ref.numpy()).max() <= 2e-5
+    assert np.array_equal(nt.cpu().numpy(), lg.argmax(-1))
+    assert np.array_equal(ns.cpu().numpy(), refs.numpy().argmax(-1))

@@ -1,0 +1,36 @@
+"""CPU: the oracle restatement is pinned against fixtures produced by the REFERENCE's own
+modules (tests/golden/make_golden.py): tokens/states exact, poses bit-identical, hooked logits
+to fp32 round-off (scaled by the sharpening gain of the fixture)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_CASES, load_case
+from oracle import rollout_oracle as ro
+
+
+@pytest.mark.parametrize('case', GOLDEN_CASES)
+def test_oracle_matches_reference_fixture(case):
+    c = load_case(case)
+    z, m = c['z'], c['meta']
+    sd = {k: torch.from_numpy(v) for k, v in c['sd'].items()}
+    torch.set_num_threads(8)
+    out = ro.run_scene(sd, c['scene'], c['cfg'], c['vocab'], c['map_vocab'], c['grid'], live_state=m['live_state'])
+    assert np.abs(out['x_pt'].numpy() - z['x_pt']).max() <= 1e-5
+    assert np.array_equal(out['next_token_idx'].numpy(), z['next_token_idx'])
+    assert np.array_equal(out['next_state_idx'].numpy(), z['next_state_idx'])
+    assert np.abs(out['logits'].numpy() - z['logits']).max() <= 1e-5 * max(1.0, m['head_gain']) * 4
+    for k in ('pos_a', 'head_a', 'pred_traj', 'pred_head', 'pred_state'):
+        assert np.abs(out[k].numpy() - z[k]).max() <= 1e-5, k
+    assert np.array_equal(out['pred_valid'].numpy(), z['pred_valid'])
+    assert np.array_equal(out['agent_id'].numpy(), z['agent_id'])
+    assert out['ego_index'] == int(z['ego_index'])
+    assert np.array_equal(out['edge_count'], z['edge_count'])
+
+
+def test_quirk_last_ten_rows_have_no_temporal_edges():
+    """SURVEY a-Q1: with A <= 10 there are no temporal edges at all (fixture c1 has A = 8)."""
+    z = load_case('c1_a8_m128')['z']
+    assert (z['edge_count'][:, 0] == 0).all()
+    z = load_case('a24_m256_edge')['z']
+    assert (z['edge_count'][:, 0] > 0).all()
