@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Closed-loop rollout throughput on MI355X (BASELINE.json metric: agent-steps/s).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE full pass of the hot path over the per-GPU batch of synthetic scenes: state
+reset, map-encoder prologue, the edgeless column-0 chain and all R/5 decode steps
+(reference InfGenDecoder.inference, infgen/modules/infgen_decoder.py:123-130).  Inputs
+(scene arrays, packed weights) are resident in HBM before the timed region.
+
+Workload (config.workload): BASELINE config C3 shapes — configs/ours_standard.yaml
+hyper-parameters, 64 agents / 1024 map tokens per scene, R = 80 (16 decode steps), greedy
+decoding, insertion disabled — with `--scenes` scenes per GPU (weak scaling: every rank owns
+its own scenes, no data-path collective; one all-reduce of the timing/counters at the end).
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the roofline arithmetic).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from infgen_amd import engine, synth, _lib  # noqa: E402
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+
+
+def load_shapes():
+    with open(os.path.join(REPO, 'tests', 'golden', 'state_dict_shapes.json')) as f:
+        return {k: tuple(v) for k, v in json.load(f).items()}
+
+
+def build_scenes(cfg, n, agents, map_tokens, first_idx):
+    vocab = synth.make_agent_vocab(cfg.token_size)
+    map_vocab = synth.make_map_vocab()
+    grid = synth.build_grid(cfg.grid_range, cfg.grid_interval, cfg.pl2seed_radius)
+    scenes = [synth.make_scene(synth.scene_seed(3, first_idx + i), agents, map_tokens, cfg, half_extent=60.0,
+                               ego_last=True, vocab=vocab, grid=grid) for i in range(n)]
+    return scenes, vocab, map_vocab, grid
+
+
+def cpu_baseline(cfg, sd, scene, vocab, map_vocab, grid, budget_s=20.0):
+    """The CPU oracle (a port of the reference algorithm, column-wise) timed on this host's cores
+    on a bounded sample: whole rollouts of ONE scene of the same workload until ~budget_s."""
+    from oracle import rollout_oracle as ro
+    # torch's intra-op pool degrades badly beyond a few dozen threads on these small operators
+    # (256 hardware threads on the GPU box): use 16 and say so in `cores`.
+    ncores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(ncores)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    ro.run_scene(tsd, scene, cfg, vocab, map_vocab, grid)       # warm-up (thread pools, allocator)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        out = ro.run_scene(tsd, scene, cfg, vocab, map_vocab, grid)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 8:
+            break
+    agent_steps = out['pos_a'].shape[0] * cfg.num_recurrent_steps_val * n
+    return dict(value=agent_steps / dt, unit='agent-steps/s', cores=ncores, kind='port',
+                sample=f'{n} full rollout(s) of 1 scene (A={out["pos_a"].shape[0]}, M={len(scene["pt_token"]["orientation"])}, '
+                       f'R={cfg.num_recurrent_steps_val}) incl. map encoder, {dt:.1f} s, torch {torch.get_num_threads()} threads')
+
+
+def log(msg):
+    if os.environ.get('BENCH_VERBOSE'):
+        print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--scenes', type=int, default=64, help='scenes per GPU')
+    ap.add_argument('--agents', type=int, default=64)
+    ap.add_argument('--map-tokens', type=int, default=1024)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget', type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    log(f'cpu_count={os.cpu_count()} device={torch.cuda.get_device_name(dev)}')
+    cfg = synth.standard_config(disable_insertion=True)
+    sd = synth.fill_state_dict(load_shapes(), seed=1, rich=True)
+    scenes, vocab, map_vocab, grid = build_scenes(cfg, args.scenes, args.agents, args.map_tokens, rank * args.scenes)
+    log('scenes built')
+    w = engine.PackedWeights(sd, cfg, dev)
+    eng = engine.RolloutEngine(w, scenes, vocab, map_vocab, grid, store_logits=False)
+
+    log('engine built')
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, sd, scenes[0], vocab, map_vocab, grid, args.cpu_budget)
+
+    log(f'cpu baseline done: {cpu}')
+    lib = _lib.load()
+    for _ in range(args.warmup):
+        eng.rollout()
+        torch.cuda.synchronize(dev)
+        log('warmup rollout done')
+    prof_on = hasattr(lib, 'infgen_prof_enable')
+    if prof_on:
+        lib.infgen_prof_enable(1)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.rollout()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    roof = None
+    if prof_on:
+        roof = eng.roofline_report() if hasattr(eng, 'roofline_report') else None
+        lib.infgen_prof_enable(0)
+
+    agent_steps = float(eng.agent_steps() * args.steps)
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        cnt = torch.tensor([agent_steps], device=dev, dtype=torch.float64)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        dt, agent_steps = float(tt.item()), float(cnt.item())
+    if rank == 0:
+        line = {
+            'metric': 'agent-steps/sec (closed-loop rollout)',
+            'value': agent_steps / dt,
+            'unit': 'agent-steps/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {
+                'workload': f'C3 shapes: configs/ours_standard.yaml, {args.agents} agents / {args.map_tokens} map tokens '
+                            f'per scene, R=80 (16 decode steps), greedy, insertion disabled, '
+                            f'{args.scenes} scenes per GPU, one step = reset + map encoder + full rollout',
+                'scenes_per_gpu': args.scenes, 'agents': args.agents, 'map_tokens': args.map_tokens,
+                'decode_steps': cfg.num_decode_steps, 'agent_token_steps_per_s': agent_steps / dt / cfg.shift,
+                'parallelism': f'scenes sharded over {world} rank(s), no data-path collective',
+            },
+            'roofline': roof,
+            'cpu_baseline': cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -124,8 +124,10 @@ int infgen_attn_post(float* X, int rows, const float* pack, const float* AGG, co
                      int has_pos, void* stream);
 int infgen_heads(const float* X, int rows, const float* tok_pack, const float* st_pack, int token_size,
                  float* logits, int* next_token, int* next_state, void* stream);
+/* compacted CSR: `total` (device int) receives the edge count; rows whose edges would exceed `cap`
+ * get cnt = 0 and the caller must retry with a larger buffer when *total > cap */
 int infgen_map_graph(int S, int M_cap, const int* n_map, const float* pos, const float* orient, float radius,
-                     int max_nbr, int* off, int* cnt, int* src, float* raw, void* stream);
+                     int max_nbr, int* off, int* cnt, int* src, float* raw, int* total, int cap, void* stream);
 
 int infgen_build_edges(const InfgenRollout* r, int c, int edgeless, void* stream);
 int infgen_integrate(const InfgenRollout* r, int t, void* stream);

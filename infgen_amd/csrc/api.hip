@@ -127,9 +127,12 @@ extern "C" int infgen_heads(const float* X, int rows, const float* tok_pack, con
 }
 
 extern "C" int infgen_map_graph(int S, int M_cap, const int* n_map, const float* pos, const float* orient,
-                                float radius, int max_nbr, int* off, int* cnt, int* src, float* raw, void* stream) {
+                                float radius, int max_nbr, int* off, int* cnt, int* src, float* raw, int* total,
+                                int cap, void* stream) {
   if (S <= 0 || M_cap <= 0) return 0;
-  MapGraphArgs a{S, M_cap, n_map, pos, orient, radius, max_nbr, EdgeBuf{off, cnt, src, raw, nullptr, 0}};
+  if (hipMemsetAsync(total, 0, sizeof(int), (hipStream_t)stream) != hipSuccess)
+    return fail("infgen_map_graph", "memset failed");
+  MapGraphArgs a{S, M_cap, n_map, pos, orient, radius, max_nbr, EdgeBuf{off, cnt, src, raw, total, cap}};
   hipLaunchKernelGGL(k_map_graph, dim3(ceil_div(S * M_cap, 4)), dim3(NT), 0, (hipStream_t)stream, a);
   return check_launch("infgen_map_graph");
 }

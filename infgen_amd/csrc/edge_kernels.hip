@@ -372,30 +372,57 @@ __global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
 // ------------------------------------------------------------------------------------------
 // k_map_graph: radius_graph(pos, r, loop=False, max_num_neighbors=K) of the map tokens of each
 // scene (reference map_decoder.py:91-93): per centre the first K+1 tokens in ascending index
-// with d^2 < r^2 (self included), self dropped.  One wave per centre token; fixed-stride CSR
-// (off = row * K_cap) so no scan is needed (the prologue runs once per scene).
+// with d^2 < r^2 (self included), self dropped.  One wave per centre token, 4 tokens per
+// workgroup; edges are compacted (one atomicAdd per workgroup reserves the block's range).
 // raw = (|d|, angle(orient_vec[dst], d), wrap(orient[src] - orient[dst]), 0)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_map_graph(MapGraphArgs a) {
-  const int lane = lane_id();
-  const int gw = blockIdx.x * 4 + wave_id();
+  __shared__ int wcnt[4];
+  __shared__ int wbase[4];
+  const int lane = lane_id(), w = wave_id();
+  const int gw = blockIdx.x * 4 + w;
   const int s = gw / a.M_cap, i = gw % a.M_cap;
-  if (s >= a.S) return;
-  const int M = a.n_map[s];
+  const bool live = s < a.S;
+  const int M = live ? a.n_map[s] : 0;
   const int row = s * a.M_cap + i;
-  const int stride = a.max_nbr + 1;
-  if (i >= M) {
-    if (lane == 0) { a.e.off[row] = row * stride; a.e.cnt[row] = 0; }
-    return;
-  }
-  const float* mp = a.pos + (size_t)s * a.M_cap * 2;
-  const float* mo = a.orient + (size_t)s * a.M_cap;
-  const float cx = mp[2 * i], cy = mp[2 * i + 1], co = mo[i];
-  const float ocs = cosf(co), osn = sinf(co);
+  const float* mp = a.pos + (size_t)(live ? s : 0) * a.M_cap * 2;
+  const float* mo = a.orient + (size_t)(live ? s : 0) * a.M_cap;
+  const bool centre = live && i < M;
+  float cx = 0.f, cy = 0.f, co = 0.f;
+  if (centre) { cx = mp[2 * i]; cy = mp[2 * i + 1]; co = mo[i]; }
   const float r2 = a.radius * a.radius;
-  int found = 0;      // counts self too (first K+1 semantics)
+  // pass 1: count kept neighbours (self excluded)
+  int found = 0, kept = 0;
+  if (centre) {
+    for (int m0 = 0; m0 < M && found < a.max_nbr + 1; m0 += 64) {
+      const int m = m0 + lane;
+      bool in = false;
+      if (m < M) {
+        const float dx = cx - mp[2 * m], dy = cy - mp[2 * m + 1];
+        in = (dx * dx + dy * dy) < r2;
+      }
+      const unsigned long long bal = __ballot(in);
+      const int before = __popcll(bal & ((1ull << lane) - 1ull));
+      const bool emit = in && (found + before < a.max_nbr + 1) && (m != i);
+      kept += (int)__popcll(__ballot(emit));
+      found += (int)__popcll(bal);
+    }
+  }
+  if (lane == 0) wcnt[w] = kept;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    const int base = tot > 0 ? atomicAdd(a.e.total, tot) : 0;
+    wbase[0] = base; wbase[1] = base + wcnt[0]; wbase[2] = wbase[1] + wcnt[1]; wbase[3] = wbase[2] + wcnt[2];
+  }
+  __syncthreads();
+  if (!live) return;
+  const int e0 = wbase[w];
+  if (lane == 0) { a.e.off[row] = e0; a.e.cnt[row] = (e0 + kept <= a.e.cap) ? kept : 0; }
+  if (!centre || kept == 0 || e0 + kept > a.e.cap) return;   // overflow: total > cap is reported by the host
+  const float ocs = cosf(co), osn = sinf(co);
+  found = 0;
   int written = 0;
-  const int e0 = row * stride;
   for (int m0 = 0; m0 < M && found < a.max_nbr + 1; m0 += 64) {
     const int m = m0 + lane;
     bool in = false;
@@ -405,13 +432,12 @@ __global__ __launch_bounds__(NT) void k_map_graph(MapGraphArgs a) {
     }
     const unsigned long long bal = __ballot(in);
     const int before = __popcll(bal & ((1ull << lane) - 1ull));
-    const bool keep = in && (found + before < a.max_nbr + 1);
-    const bool emit = keep && (m != i);
+    const bool emit = in && (found + before < a.max_nbr + 1) && (m != i);
     const unsigned long long ebal = __ballot(emit);
     const int ebefore = __popcll(ebal & ((1ull << lane) - 1ull));
     if (emit) {
       const int e = e0 + written + ebefore;
-      float dx = mp[2 * m] - cx, dy = mp[2 * m + 1] - cy;
+      const float dx = mp[2 * m] - cx, dy = mp[2 * m + 1] - cy;
       a.e.src[e] = s * a.M_cap + m;
       *reinterpret_cast<float4*>(a.e.raw + 4 * (size_t)e) =
           make_float4(norm2(dx, dy), angle_between(ocs, osn, dx, dy), wrap_angle(mo[m] - co), 0.f);
@@ -419,7 +445,6 @@ __global__ __launch_bounds__(NT) void k_map_graph(MapGraphArgs a) {
     written += (int)__popcll(ebal);
     found += (int)__popcll(bal);
   }
-  if (lane == 0) { a.e.off[row] = e0; a.e.cnt[row] = written; }
 }
 
 // ------------------------------------------------------------------------------------------

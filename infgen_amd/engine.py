@@ -71,6 +71,29 @@ class PackedWeights:
         self.type_pt_emb = g(f'{mp}.type_pt_emb.weight')
         self.polygon_type_emb = g(f'{mp}.polygon_type_emb.weight')
         self.light_pl_emb = g(f'{mp}.light_pl_emb.weight')
+        self._tables = None
+
+    def tables(self, ops: 'Ops', vocab_dev: torch.Tensor, grid_dev: torch.Tensor, map_vocab_dev: torch.Tensor):
+        """Per-checkpoint constants (the reference recomputes them in every inference call,
+        agent_decoder.py:347-373, map_decoder.py:77-78): token-embedding tables with the bos /
+        no_token rows appended, the grid-embedding table with the invalid row, the seed
+        categorical embedding and the map-token embedding table."""
+        if self._tables is not None:
+            return self._tables
+        dev, ts, G = self.device, self.cfg.token_size, grid_dev.shape[0]
+        tok_tab = torch.empty(3, ts + 2, D, device=dev)
+        for k in range(3):
+            ops.mlp_embedding(vocab_dev[k][:, -1].reshape(ts, 8).contiguous(), self.tok_emb[k], 8, out=tok_tab[k, :ts])
+            tok_tab[k, ts] = self.bos_token[0]
+            tok_tab[k, ts + 1] = self.no_token[0]
+        grid_tab = torch.empty(G + 1, D, device=dev)
+        ops.mlp_embedding(grid_dev, self.grid_emb, 2, out=grid_tab[:G])
+        grid_tab[G] = self.invalid_offset[0]
+        seed_shape = ops.mlp_embedding(torch.full((1, 3), INVALID_SHAPE, device=dev), self.shape_emb, 3)
+        cat_seed = (self.type_a_emb[SEED_TYPE] + seed_shape[0]).contiguous()
+        map_tab = ops.mlp_embedding(map_vocab_dev, self.map_tok_emb, map_vocab_dev.shape[1])
+        self._tables = dict(tok_tab=tok_tab, grid_tab=grid_tab, cat_seed=cat_seed, map_tab=map_tab)
+        return self._tables
 
 
 class Ops:
@@ -258,6 +281,10 @@ class RolloutEngine:
         self.tok_tab = self.grid_tab = self.cat_agent = self.cat_seed = None
         self.x_pt = None
         self._ctx = None
+        self._init = None
+        self._mg = None
+        self._mg_checked = False
+        self._map_nbr_cap = 40          # compacted pt<->pt edges per map token (grown on overflow)
         self._prologue_done = False
 
     # ------------------------------------------------------------------ host setup of one scene
@@ -319,63 +346,88 @@ class RolloutEngine:
             map_tok=np.asarray(pt['token_idx']).astype(np.int64), map_type=np.asarray(pt['type']).astype(np.int64),
             map_pl=np.asarray(pt['pl_type']).astype(np.int64), map_light=light)
 
-    # ------------------------------------------------------------------ prologue (once per batch)
+    # ------------------------------------------------------------------ prologue (once per rollout)
+    def reset(self):
+        """restore the scene state to the rollout's initial condition (device-to-device copies)"""
+        if self._init is None:
+            self._init = {k: getattr(self, k).clone() for k in self._STATE}
+        else:
+            for k in self._STATE:
+                getattr(self, k).copy_(self._init[k])
+
+    _STATE = ('pos', 'head', 'state', 'token', 'gridtok', 'imask', 'catflag')
+
     def prologue(self):
-        """constant tables, map encoder (map_decoder.py:70-130), map K/V, column-0 edgeless chain."""
+        """per-scene constants and the first columns: agent categorical embeddings, map encoder
+        (map_decoder.py:70-130), map K/V of the six map->agent layers, the edgeless column-0 chain
+        (SURVEY a-Q3) and column 1's raw feature."""
         ops, w, cfg, dev = self.ops, self.w, self.cfg, self.device
         S, A_cap, M_cap, rows = self.S, self.A_cap, self.M_cap, self.rows
-        ts = cfg.token_size
-        # token-embedding tables (agent_decoder.py:347-373): MLP over the last contour of each template
-        tok_tab = torch.empty(3, ts + 2, D, device=dev)
-        for k in range(3):
-            ops.mlp_embedding(self.vocab[k][:, -1].reshape(ts, 8).contiguous(), w.tok_emb[k], 8, out=tok_tab[k, :ts])
-            tok_tab[k, ts] = w.bos_token[0]
-            tok_tab[k, ts + 1] = w.no_token[0]
-        self.tok_tab = tok_tab
-        grid_tab = torch.empty(self.G + 1, D, device=dev)
-        ops.mlp_embedding(self.grid_xy, w.grid_emb, 2, out=grid_tab[:self.G])
-        grid_tab[self.G] = w.invalid_offset[0]
-        self.grid_tab = grid_tab
+        tabs = w.tables(ops, self.vocab, self.grid_xy, self._map_vocab)
+        self.tok_tab, self.grid_tab, self.cat_seed = tabs['tok_tab'], tabs['grid_tab'], tabs['cat_seed']
+        self.reset()
         # categorical embedding rows (agent_decoder.py:376-380,492)
-        shp = ops.mlp_embedding(self._shape10.reshape(rows, 3).contiguous(), w.shape_emb, 3)
-        self.cat_agent = (w.type_a_emb[self.atype.reshape(-1).long()] + shp).contiguous()
-        seed_shape = ops.mlp_embedding(torch.full((1, 3), INVALID_SHAPE, device=dev), w.shape_emb, 3)
-        self.cat_seed = (w.type_a_emb[SEED_TYPE] + seed_shape[0]).contiguous()
+        if self.cat_agent is None:
+            self.cat_agent = torch.empty(rows, D, device=dev)
+        shp = ops.mlp_embedding(self._shape10.reshape(rows, 3), w.shape_emb, 3)
+        torch.add(w.type_a_emb[self.atype.reshape(-1).long()], shp, out=self.cat_agent)
 
         # ---- map encoder
         mrows = S * M_cap
-        map_tab = ops.mlp_embedding(self._map_vocab, w.map_tok_emb, self._map_vocab.shape[1])
         mtok, mtype, mpl, mlight = self._map_cat
-        x_pt = map_tab[mtok.reshape(-1)]
+        x_pt = tabs['map_tab'][mtok.reshape(-1)]
         cat = (w.type_pt_emb[mtype.reshape(-1)] + w.polygon_type_emb[mpl.reshape(-1)]) + w.light_pl_emb[mlight.reshape(-1)]
-        x_pt = (x_pt + cat).contiguous()
+        if self.x_pt is None:
+            self.x_pt = torch.empty(mrows, D, device=dev)
+        torch.add(x_pt, cat, out=self.x_pt)
+        x_pt = self.x_pt
         K = 100
-        stride = K + 1
-        off = torch.zeros(mrows, device=dev, dtype=torch.int32)
-        cnt = torch.zeros(mrows, device=dev, dtype=torch.int32)
-        src = torch.zeros(mrows * stride, device=dev, dtype=torch.int32)
-        raw = torch.zeros(mrows * stride, 4, device=dev)
+        if self._mg is None:
+            cap = mrows * self._map_nbr_cap
+            self._mg = dict(off=torch.zeros(mrows, device=dev, dtype=torch.int32),
+                            cnt=torch.zeros(mrows, device=dev, dtype=torch.int32),
+                            src=torch.zeros(cap, device=dev, dtype=torch.int32), raw=torch.zeros(cap, 4, device=dev),
+                            rhat=torch.empty(cap, D, device=dev), total=torch.zeros(1, device=dev, dtype=torch.int32),
+                            cap=cap, K=torch.empty(mrows, D, device=dev), V=torch.empty(mrows, D, device=dev),
+                            Q=torch.empty(mrows, D, device=dev), U=torch.empty(mrows, 8 * D, device=dev),
+                            AGG=torch.empty(mrows, D, device=dev), Z=torch.empty(mrows, 8 * D, device=dev),
+                            SIG=torch.empty(mrows, 8, device=dev))
+        g = self._mg
         _lib.check(self.lib.infgen_map_graph(S, M_cap, _lib.ptr(self.n_map), _lib.ptr(self.map_pos),
-                                             _lib.ptr(self.map_orient), float(cfg.pl2pl_radius), K, _lib.ptr(off),
-                                             _lib.ptr(cnt), _lib.ptr(src), _lib.ptr(raw), ops.stream),
-                   'infgen_map_graph')
-        rhat = torch.empty(mrows * stride, D, device=dev)
-        ops.fourier(raw, 3, w.four_pt, rhat, normalize=True)
+                                             _lib.ptr(self.map_orient), float(cfg.pl2pl_radius), K, _lib.ptr(g['off']),
+                                             _lib.ptr(g['cnt']), _lib.ptr(g['src']), _lib.ptr(g['raw']),
+                                             _lib.ptr(g['total']), g['cap'], ops.stream), 'infgen_map_graph')
+        if not self._mg_checked:
+            tot = int(g['total'].item())           # one host sync, first prologue only
+            if tot > g['cap']:
+                self._map_nbr_cap = (tot + mrows - 1) // mrows + 4
+                self._mg = None
+                return self.prologue()
+            self._mg_checked = True
+        ops.fourier(g['raw'], 3, w.four_pt, g['rhat'], count_dev=g['total'], rows=g['cap'], normalize=True)
         for i in range(cfg.num_map_layers):
-            ops.attention_layer(x_pt, w.attn_pt[i], off, cnt, src, rhat)
-        self.x_pt = x_pt
-        self._map_edges = (off, cnt)
+            ops.attn_pre(x_pt, w.attn_pt[i], q=g['Q'], u=g['U'], k=g['K'], v=g['V'])
+            ops.edge_attn(mrows, g['Q'], g['U'], g['K'], g['V'], g['off'], g['cnt'], g['src'], g['rhat'],
+                          g['AGG'], g['Z'], g['SIG'])
+            ops.attn_post(x_pt, w.attn_pt[i], g['AGG'], g['Z'], g['SIG'])
         # map K/V of the six pt2a layers (bipartite source LayerNorm)
         for i in range(cfg.num_agent_layers):
             ops.attn_pre(x_pt, w.attn_m[i], use_src_ln=True, k=self.mapK[i], v=self.mapV[i])
 
-        self._build_ctx()
+        if self._ctx is None:
+            self._build_ctx()
         st = ops.stream
         # column 0: edgeless chain, its K/V land in ring slot 0 (SURVEY a-Q3); then column 1's raw feature
         _lib.check(self.lib.infgen_raw_feature(C.byref(self._ctx), 0, st), 'raw_feature(0)')
         _lib.check(self.lib.infgen_decode_layers(C.byref(self._ctx), 0, 1, st), 'decode_layers(0)')
         _lib.check(self.lib.infgen_raw_feature(C.byref(self._ctx), 1, st), 'raw_feature(1)')
         self._prologue_done = True
+
+    def rollout(self):
+        """one full pass of the hot path over the batch: prologue + every decode step"""
+        self.prologue()
+        _lib.check(self.lib.infgen_rollout_run(C.byref(self._ctx), 0, self.cfg.num_decode_steps, self.ops.stream),
+                   'infgen_rollout_run')
 
     def _build_ctx(self):
         cfg, w = self.cfg, self.w
