@@ -83,7 +83,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--scenes', type=int, default=64, help='scenes per GPU')
+    ap.add_argument('--scenes', type=int, default=256, help='scenes per GPU')
     ap.add_argument('--agents', type=int, default=64)
     ap.add_argument('--map-tokens', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -122,9 +122,14 @@ def main():
         eng.rollout()
         torch.cuda.synchronize(dev)
         log('warmup rollout done')
-    prof_on = hasattr(lib, 'infgen_prof_enable')
-    if prof_on:
-        lib.infgen_prof_enable(1)
+    # roofline leg 1 (untimed): one rollout with HIP events around EVERY kernel -> which kernel dominates
+    _lib.prof_enable((1 << len(_lib.KERNEL_IDS)) - 1)
+    eng.rollout()
+    per_kernel = _lib.prof_collect()
+    dominant = max(per_kernel, key=lambda k: per_kernel[k]['ms'])
+    log('per-kernel ms of one rollout: ' + ', '.join(f'{k}={v["ms"]:.2f}' for k, v in per_kernel.items()))
+    # roofline leg 2: events only around the dominant kernel's launches, inside the timed region
+    _lib.prof_enable(1 << _lib.KERNEL_IDS.index(dominant))
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -135,10 +140,18 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    dom = _lib.prof_collect()[dominant]
+    _lib.prof_enable(0)
     roof = None
-    if prof_on:
-        roof = eng.roofline_report() if hasattr(eng, 'roofline_report') else None
-        lib.infgen_prof_enable(0)
+    if dom['calls'] > 0 and dom['macs'] > 0:
+        avg_s = dom['ms'] * 1e-3 / dom['calls']
+        flops_per_launch = 2.0 * dom['macs'] / dom['calls']
+        ach = flops_per_launch / avg_s / 1e12
+        roof = {'bound': 'mfma', 'kernel': dominant, 'achieved': ach, 'peak': FP32_MATRIX_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': ach / FP32_MATRIX_PEAK_TFLOPS, 'traffic': None,
+                'launches': dom['calls'], 'avg_launch_us': avg_s * 1e6, 'flops_per_launch': flops_per_launch,
+                'share_of_gpu_time': per_kernel[dominant]['ms'] / max(1e-9, sum(v['ms'] for v in per_kernel.values())),
+                'per_kernel_ms_one_rollout': {k: round(v['ms'], 3) for k, v in per_kernel.items()}}
 
     agent_steps = float(eng.agent_steps() * args.steps)
     if dist is not None:

@@ -137,6 +137,19 @@ int infgen_decode_step(const InfgenRollout* r, int t, void* stream);
 /* steps t0 .. t1-1 back to back (one host call per rollout) */
 int infgen_rollout_run(const InfgenRollout* r, int t0, int t1, void* stream);
 
+/* ---- optional profiling (bench.py roofline leg; process-global, off by default) ----
+ * HIP events are recorded on the launch stream around every launch of the kernels selected by
+ * `mask` (bit = INFGEN_KID_*).  infgen_prof_collect synchronises the device, returns the summed
+ * duration (ms), launch count and algorithmic multiply-accumulates per kernel id and the rows processed by the Fourier kernel per
+ * number of input dims, then clears the event log. */
+enum {
+  INFGEN_KID_LINEAR = 0, INFGEN_KID_FOURIER, INFGEN_KID_ATTN_PRE, INFGEN_KID_EDGE_ATTN, INFGEN_KID_ATTN_POST,
+  INFGEN_KID_HEADS, INFGEN_KID_BUILD_EDGES, INFGEN_KID_INTEGRATE, INFGEN_KID_RAWFEAT, INFGEN_KID_MAP_GRAPH,
+  INFGEN_KID_COUNT
+};
+int infgen_prof_enable(unsigned mask, int max_launches);
+int infgen_prof_collect(double* total_ms, int* calls, double* total_macs, unsigned long long* fourier_rows);
+
 #ifdef __cplusplus
 }
 #endif

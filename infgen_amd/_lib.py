@@ -66,10 +66,15 @@ SYMBOLS = {
     'infgen_decode_layers': (_i, [C.POINTER(Rollout), _i, _i, _p]),
     'infgen_decode_step': (_i, [C.POINTER(Rollout), _i, _p]),
     'infgen_rollout_run': (_i, [C.POINTER(Rollout), _i, _i, _p]),
+    'infgen_prof_enable': (_i, [C.c_uint, _i]),
+    'infgen_prof_collect': (_i, [C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]),
 }
 
 Q_ATTN_PACK_SIZE, Q_FOURIER_N2, Q_FOURIER_N3, Q_FOURIER_N4, Q_TILE_ROWS, Q_EDGE_ATTN_CAP, Q_MAX_AGENTS, \
     Q_ABI_VERSION, Q_SIZEOF_ROLLOUT = range(9)
+
+KERNEL_IDS = ['k_linear', 'k_fourier', 'k_attn_pre', 'k_edge_attn', 'k_attn_post', 'k_heads', 'k_build_edges',
+              'k_integrate', 'k_rawfeat_prep', 'k_map_graph']
 
 _lib: Optional[C.CDLL] = None
 
@@ -111,3 +116,22 @@ def ptr(t) -> Optional[int]:
         return None
     assert t.is_contiguous(), 'tensor must be contiguous'
     return t.data_ptr()
+
+
+def prof_enable(mask: int, max_launches: int = 20000) -> None:
+    check(load().infgen_prof_enable(mask, max_launches), 'infgen_prof_enable')
+
+
+def prof_collect():
+    """-> {kernel: dict(ms, calls, macs)} of the launches recorded since prof_enable; synchronises"""
+    n = len(KERNEL_IDS)
+    ms = (C.c_double * n)()
+    calls = (_i * n)()
+    macs = (C.c_double * n)()
+    rows = (C.c_ulonglong * 8)()
+    check(load().infgen_prof_collect(ms, calls, macs, rows), 'infgen_prof_collect')
+    out = {k: dict(ms=ms[i], calls=calls[i], macs=macs[i]) for i, k in enumerate(KERNEL_IDS)}
+    # FourierEmbedding: n x (129x128 + 128x128) + 128x128 MACs per row (reference layers.py:126-141)
+    out['k_fourier']['macs'] = float(sum(rows[nd] * (nd * 32896 + 16384) for nd in range(8)))
+    out['k_fourier']['rows'] = {nd: int(rows[nd]) for nd in range(8) if rows[nd]}
+    return out

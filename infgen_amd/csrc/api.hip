@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 #include "kernels.h"
 #include "../../include/infgen_hip.h"
 
@@ -23,6 +24,77 @@ static int check_launch(const char* where) {
 
 extern "C" const char* infgen_last_error(void) { return g_err.c_str(); }
 
+// ---------------------------------------------------------------------------------- profiling
+// Optional, process-global, off by default: HIP events recorded on the launch stream around the
+// launches of the selected kernels (bench.py's roofline leg).  Not used by the product path.
+namespace {
+struct Prof {
+  unsigned mask = 0;
+  std::vector<hipEvent_t> e0, e1;
+  std::vector<int> kid;
+  std::vector<double> macs;                 // algorithmic multiply-accumulates of the launch (0: not a GEMM kernel)
+  size_t used = 0;
+  unsigned long long* rows_dev = nullptr;   // [8] rows processed by k_fourier, indexed by n_dims
+} g_prof;
+
+struct ProfScope {
+  int slot = -1;
+  hipStream_t s;
+  ProfScope(int kid, void* stream, double macs = 0.0) : s((hipStream_t)stream) {
+    if ((g_prof.mask >> kid) & 1u) {
+      if (g_prof.used < g_prof.e0.size()) {
+        slot = (int)g_prof.used++;
+        g_prof.kid[slot] = kid;
+        g_prof.macs[slot] = macs;
+        (void)hipEventRecord(g_prof.e0[slot], s);
+      }
+    }
+  }
+  ~ProfScope() { if (slot >= 0) (void)hipEventRecord(g_prof.e1[slot], s); }
+};
+}  // namespace
+
+extern "C" int infgen_prof_enable(unsigned mask, int max_launches) {
+  if (mask && (int)g_prof.e0.size() < max_launches) {
+    const size_t old = g_prof.e0.size();
+    g_prof.e0.resize(max_launches); g_prof.e1.resize(max_launches); g_prof.kid.resize(max_launches);
+    g_prof.macs.resize(max_launches);
+    for (size_t i = old; i < (size_t)max_launches; ++i) {
+      if (hipEventCreate(&g_prof.e0[i]) != hipSuccess || hipEventCreate(&g_prof.e1[i]) != hipSuccess)
+        return fail("infgen_prof_enable", "hipEventCreate failed");
+    }
+  }
+  if (mask && !g_prof.rows_dev) {
+    if (hipMalloc(&g_prof.rows_dev, 8 * sizeof(unsigned long long)) != hipSuccess)
+      return fail("infgen_prof_enable", "hipMalloc failed");
+  }
+  if (g_prof.rows_dev) (void)hipMemset(g_prof.rows_dev, 0, 8 * sizeof(unsigned long long));
+  g_prof.mask = mask;
+  g_prof.used = 0;
+  return 0;
+}
+
+// total_ms / calls: [INFGEN_KID_COUNT]; fourier_rows: [8] rows processed per n_dims.  Synchronises.
+extern "C" int infgen_prof_collect(double* total_ms, int* calls, double* total_macs, unsigned long long* fourier_rows) {
+  for (int k = 0; k < INFGEN_KID_COUNT; ++k) { total_ms[k] = 0.0; calls[k] = 0; total_macs[k] = 0.0; }
+  if (hipDeviceSynchronize() != hipSuccess) return fail("infgen_prof_collect", "sync failed");
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_prof.e0[i], g_prof.e1[i]) != hipSuccess)
+      return fail("infgen_prof_collect", "hipEventElapsedTime failed");
+    total_ms[g_prof.kid[i]] += ms;
+    calls[g_prof.kid[i]] += 1;
+    total_macs[g_prof.kid[i]] += g_prof.macs[i];
+  }
+  if (fourier_rows) {
+    for (int i = 0; i < 8; ++i) fourier_rows[i] = 0;
+    if (g_prof.rows_dev) (void)hipMemcpy(fourier_rows, g_prof.rows_dev, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  }
+  const int dropped = 0;
+  g_prof.used = 0;
+  return dropped;
+}
+
 extern "C" int infgen_layout_query(int what) {
   switch (what) {
     case INFGEN_Q_ATTN_PACK_SIZE: return AL_SIZE;
@@ -30,7 +102,7 @@ extern "C" int infgen_layout_query(int what) {
     case INFGEN_Q_FOURIER_PACK_SIZE_N3: return fourier_pack_size(3);
     case INFGEN_Q_FOURIER_PACK_SIZE_N4: return fourier_pack_size(4);
     case INFGEN_Q_TILE_ROWS: return TR;
-    case INFGEN_Q_EDGE_ATTN_CAP: return 320;
+    case INFGEN_Q_EDGE_ATTN_CAP: return 1 << 30;   /* single-pass kernel: no per-row edge cap */
     case INFGEN_Q_MAX_AGENTS: return 256;
     case INFGEN_Q_ABI_VERSION: return 1;
     case INFGEN_Q_SIZEOF_ROLLOUT: return (int)sizeof(InfgenRollout);
@@ -77,7 +149,8 @@ extern "C" int infgen_linear(const float* X, int ldx, const int* gather, int row
   if ((pre_g && K != 128) || (post_g && (N != 128 || Np != 128)))
     return fail("infgen_linear", "LayerNorm prologue/epilogue needs K == 128 / N == 128");
   LinearArgs a{X, ldx, gather, rows, K, ((K + 7) / 8) * 8, Wp, Np, bias, N, pre_g, pre_b, post_g, post_b, relu, Y, ldy};
-  hipLaunchKernelGGL(k_linear, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a);
+  { ProfScope _ps(INFGEN_KID_LINEAR, stream, (double)rows * K * N);
+    hipLaunchKernelGGL(k_linear, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_linear");
 }
 
@@ -85,10 +158,12 @@ extern "C" int infgen_fourier_embed(const float* raw, int n, const int* count_de
                                     const float* cat, int ldcat, float* out, int ldo, int normalize, void* stream) {
   if (e_cap <= 0) return 0;
   if (n < 1 || n > 4) return fail("infgen_fourier_embed", "n_dims must be in 1..4");
-  FourierArgs a{raw, n, count_dev, e_cap, pack, cat, ldcat, out, ldo, normalize};
+  FourierArgs a{raw, n, count_dev, e_cap, pack, cat, ldcat, out, ldo, normalize,
+                (g_prof.mask >> INFGEN_KID_FOURIER) & 1u ? g_prof.rows_dev : nullptr};
   int grid = ceil_div(e_cap, TR);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(k_fourier, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a);
+  { ProfScope _ps(INFGEN_KID_FOURIER, stream);
+    hipLaunchKernelGGL(k_fourier, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_fourier_embed");
 }
 
@@ -96,7 +171,8 @@ extern "C" int infgen_attn_pre(const float* X, int rows, const float* pack, int 
                                float* Q, float* U, float* K, float* V, void* stream) {
   if (rows <= 0) return 0;
   AttnPreArgs a{X, rows, pack, use_src_ln, Q, U, K, V};
-  hipLaunchKernelGGL(k_attn_pre, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a);
+  { ProfScope _ps(INFGEN_KID_ATTN_PRE, stream, (double)rows * 16384.0 * ((Q || U ? 1 : 0) + (K ? 1 : 0) + (V ? 1 : 0) + (U ? 1 : 0)));
+    hipLaunchKernelGGL(k_attn_pre, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_attn_pre");
 }
 
@@ -105,7 +181,8 @@ extern "C" int infgen_edge_attn(int rows, const float* Q, const float* U, const 
                                 float* AGG, float* Z, float* SIG, void* stream) {
   if (rows <= 0) return 0;
   EdgeAttnArgs a{rows, Q, U, Ksrc, Vsrc, EdgeSet{off, cnt, src, rhat}, AGG, Z, SIG};
-  hipLaunchKernelGGL(k_edge_attn, dim3(rows), dim3(64), 0, (hipStream_t)stream, a);
+  { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
+    hipLaunchKernelGGL(k_edge_attn, dim3(ceil_div(rows, 4)), dim3(NT), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_edge_attn");
 }
 
@@ -113,7 +190,8 @@ extern "C" int infgen_attn_post(float* X, int rows, const float* pack, const flo
                                 const float* SIG, int has_pos, void* stream) {
   if (rows <= 0) return 0;
   AttnPostArgs a{X, rows, pack, AGG, Z, SIG, has_pos};
-  hipLaunchKernelGGL(k_attn_post, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a);
+  { ProfScope _ps(INFGEN_KID_ATTN_POST, stream, (double)rows * (196608.0 + (has_pos ? 16384.0 : 0.0)));
+    hipLaunchKernelGGL(k_attn_post, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_attn_post");
 }
 
@@ -122,7 +200,8 @@ extern "C" int infgen_heads(const float* X, int rows, const float* tok_pack, con
   if (rows <= 0) return 0;
   if (token_size % 128) return fail("infgen_heads", "token_size must be a multiple of 128");
   HeadsArgs a{X, rows, tok_pack, st_pack, token_size, logits, next_token, next_state};
-  hipLaunchKernelGGL(k_heads, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a);
+  { ProfScope _ps(INFGEN_KID_HEADS, stream, (double)rows * (2 * 16384.0 + 128.0 * token_size + 384.0));
+    hipLaunchKernelGGL(k_heads, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_heads");
 }
 
@@ -133,7 +212,8 @@ extern "C" int infgen_map_graph(int S, int M_cap, const int* n_map, const float*
   if (hipMemsetAsync(total, 0, sizeof(int), (hipStream_t)stream) != hipSuccess)
     return fail("infgen_map_graph", "memset failed");
   MapGraphArgs a{S, M_cap, n_map, pos, orient, radius, max_nbr, EdgeBuf{off, cnt, src, raw, total, cap}};
-  hipLaunchKernelGGL(k_map_graph, dim3(ceil_div(S * M_cap, 4)), dim3(NT), 0, (hipStream_t)stream, a);
+  { ProfScope _ps(INFGEN_KID_MAP_GRAPH, stream);
+    hipLaunchKernelGGL(k_map_graph, dim3(ceil_div(S * M_cap, 4)), dim3(NT), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_map_graph");
 }
 
@@ -170,7 +250,8 @@ extern "C" int infgen_build_edges(const InfgenRollout* r, int c, int edgeless, v
   BuildEdgesArgs a;
   a.st = scene_of(r); a.c = c; a.edgeless = edgeless; a.r_map = r->r_map; a.r_agent = r->r_agent;
   a.rows = r->S * r->A_cap; a.t = ebuf(r->et); a.m = ebuf(r->em); a.a = ebuf(r->ea);
-  hipLaunchKernelGGL(k_build_edges, dim3(r->S), dim3(NT), 0, s, a);
+  { ProfScope _ps(INFGEN_KID_BUILD_EDGES, stream);
+    hipLaunchKernelGGL(k_build_edges, dim3(r->S), dim3(NT), 0, s, a); }
   return check_launch("infgen_build_edges");
 }
 
@@ -182,7 +263,8 @@ extern "C" int infgen_integrate(const InfgenRollout* r, int t, void* stream) {
   a.teacher_token = r->teacher_token; a.teacher_state = r->teacher_state;
   a.vocab = r->vocab; a.token_size = r->token_size; a.grid_xy = r->grid_xy; a.grid_size = r->grid_size;
   a.pred_traj = r->pred_traj; a.pred_head = r->pred_head; a.pred_state = r->pred_state;
-  hipLaunchKernelGGL(k_integrate, dim3(r->S), dim3(NT), 0, (hipStream_t)stream, a);
+  { ProfScope _ps(INFGEN_KID_INTEGRATE, stream);
+    hipLaunchKernelGGL(k_integrate, dim3(r->S), dim3(NT), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_integrate");
 }
 
@@ -197,7 +279,8 @@ extern "C" int infgen_raw_feature(const InfgenRollout* r, int col, void* stream)
   a.st = scene_of(r); a.col = col; a.tok_tab = r->tok_tab; a.token_size = r->token_size;
   a.grid_tab = r->grid_tab; a.grid_size = r->grid_size; a.state_emb = r->state_emb;
   a.cat_agent = r->cat_agent; a.cat_seed = r->cat_seed; a.raw2 = r->raw2; a.cat = r->cat; a.fus_in = r->fus_in;
-  hipLaunchKernelGGL(k_rawfeat_prep, dim3(ceil_div(rows * 32, NT)), dim3(NT), 0, (hipStream_t)stream, a);
+  { ProfScope _ps(INFGEN_KID_RAWFEAT, stream);
+    hipLaunchKernelGGL(k_rawfeat_prep, dim3(ceil_div(rows * 32, NT)), dim3(NT), 0, (hipStream_t)stream, a); }
   RET_IF(check_launch("infgen_raw_feature/prep"));
   RET_IF(infgen_fourier_embed(r->raw2, 2, nullptr, rows, r->four_xa, r->cat, 128, r->fus_in + 128, 512, 0, stream));
   const float* P = r->fusion_pack;

@@ -10,157 +10,124 @@ constexpr int NUM_SEED_FEATURE = 10;     // reference agent_decoder.py:292
 constexpr float MOTION_GAP = 1.0f, HEADING_GAP = 1.0f, INVALID_MOTION = -2.0f, INVALID_HEAD = -2.0f;
 
 // ------------------------------------------------------------------------------------------
-// k_edge_attn: one wavefront (= one 64-thread workgroup) per destination row.
-//   phase 1  lane = (edge-in-chunk, head): score = q_h . k_src,h + u_h . rhat_e   (8 edges / pass)
-//   phase 2  PyG softmax per head: exp(s - max) / (sum + 1e-16)   (layers.py:89)
-//   phase 3  lane = column pair: z_h += a_e,h * rhat_e ; agg += a_e,head(col) * v_src
+// k_edge_attn: one wavefront per destination row (4 rows per workgroup), single pass over the
+// row's incoming edges with an online (running-max) softmax; no LDS, every global access is a
+// coalesced 512-byte row.  Lane l owns columns 2l, 2l+1 (head l >> 3):
+//   score_h = q_h . k_src,h + u_h . rhat_e      reduced with wave shuffles; the 8 per-head partial
+//             sums are folded with a halving exchange (4 + 2 + 1 shuffles over lane bits 5,4,3) so
+//             that lane l ends with the score of ITS head, then 3 more over bits 0..2
+//   softmax   PyG semantics (layers.py:89): exp(s - max) / (sum + 1e-16), max/sum kept per head and
+//             rescaled when the running max grows
+//   outputs   AGG = sum_e a_e v_src (own columns), Z_h = sum_e a_e,h rhat_e (all heads), SIG_h = sum_e a_e,h
+// Rows without incoming edges produce exact zeros (0 / (0 + 1e-16)).
 // ------------------------------------------------------------------------------------------
-constexpr int SC_CAP = 320;    // max incoming edges per destination handled here (a2a cap 300)
-constexpr int ULD = 132;
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
 
-__global__ __launch_bounds__(64) void k_edge_attn(EdgeAttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float Us[H * ULD];
-  __shared__ __attribute__((aligned(16))) float Rs[8 * ULD];
-  __shared__ __attribute__((aligned(16))) float sc[SC_CAP * H];
-  __shared__ int srcs[SC_CAP];
-  const int row = blockIdx.x;
+__global__ __launch_bounds__(NT) void k_edge_attn(EdgeAttnArgs a) {
+  const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave_id());
   if (row >= a.rows) return;
-  const int lane = threadIdx.x;
-  int E = a.es.cnt[row];
-  if (E > SC_CAP) E = SC_CAP;
-  float* aggp = a.AGG + (size_t)row * D;
-  float* zp = a.Z ? a.Z + (size_t)row * (H * D) : nullptr;
+  const int lane = lane_id();
+  const int E = __builtin_amdgcn_readfirstlane(a.es.cnt[row]);
+  const int e_base = __builtin_amdgcn_readfirstlane(a.es.off[row]);
   const bool has_r = a.es.rhat != nullptr && a.U != nullptr;
-  if (E <= 0) {
-    *reinterpret_cast<float2*>(aggp + 2 * lane) = make_float2(0.f, 0.f);
-    if (zp) {
+  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+
+  const float2 q = *reinterpret_cast<const float2*>(a.Q + (size_t)row * D + 2 * lane);
+  float2 u[H];
 #pragma unroll
-      for (int h = 0; h < H; ++h) *reinterpret_cast<float2*>(zp + h * D + 2 * lane) = make_float2(0.f, 0.f);
-    }
-    if (lane < H) a.SIG[(size_t)row * H + lane] = 0.f;
-    return;
+  for (int h = 0; h < H; ++h) {
+    u[h] = has_r ? *reinterpret_cast<const float2*>(a.U + (size_t)row * (H * D) + h * D + 2 * lane)
+                 : make_float2(0.f, 0.f);
   }
-  const int e_base = a.es.off[row];
-  for (int e = lane; e < E; e += 64) srcs[e] = a.es.src[e_base + e];
-  if (has_r) {
-    // U[row] (8 x 128) -> LDS, padded rows
-    const float* up = a.U + (size_t)row * (H * D);
+  float2 z[H];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int idx = p * 64 + lane;          // float4 slot 0..255
-      const int h = idx >> 5, c4 = idx & 31;
-      *reinterpret_cast<float4*>(Us + h * ULD + 4 * c4) = *reinterpret_cast<const float4*>(up + h * D + 4 * c4);
-    }
+  for (int h = 0; h < H; ++h) z[h] = make_float2(0.f, 0.f);
+  float2 ag = make_float2(0.f, 0.f);
+  float m = -INFINITY, lsum = 0.f;
+
+  // software pipeline: operands of edge e+1 are requested before edge e is consumed
+  float2 kn = make_float2(0.f, 0.f), vn = kn, rn = kn;
+  if (E > 0) {
+    const int s0 = __builtin_amdgcn_readfirstlane(a.es.src[e_base]);
+    kn = *reinterpret_cast<const float2*>(a.Ksrc + (size_t)s0 * D + 2 * lane);
+    vn = *reinterpret_cast<const float2*>(a.Vsrc + (size_t)s0 * D + 2 * lane);
+    if (has_r) rn = *reinterpret_cast<const float2*>(a.es.rhat + (size_t)e_base * D + 2 * lane);
   }
-  const int el = lane >> 3, h = lane & 7;
-  float qh[DH];
-  {
-    const float* qp = a.Q + (size_t)row * D + DH * h;
-#pragma unroll
-    for (int i = 0; i < DH; i += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(qp + i);
-      qh[i] = v.x; qh[i + 1] = v.y; qh[i + 2] = v.z; qh[i + 3] = v.w;
-    }
-  }
-  __syncthreads();
-  // ---- phase 1
-  for (int c0 = 0; c0 < E; c0 += 8) {
-    const int nE = min(8, E - c0);
-    if (has_r) {
-      __syncthreads();
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int idx = p * 64 + lane;
-        const int er = idx >> 5, c4 = idx & 31;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (er < nE) v = *reinterpret_cast<const float4*>(a.es.rhat + (size_t)(e_base + c0 + er) * D + 4 * c4);
-        *reinterpret_cast<float4*>(Rs + er * ULD + 4 * c4) = v;
-      }
-      __syncthreads();
-    }
-    float s = 0.f;
-    if (el < nE) {
-      const float* kp = a.Ksrc + (size_t)srcs[c0 + el] * D + DH * h;
-#pragma unroll
-      for (int i = 0; i < DH; i += 4) {
-        const float4 kv = *reinterpret_cast<const float4*>(kp + i);
-        s = fmaf(qh[i], kv.x, s); s = fmaf(qh[i + 1], kv.y, s);
-        s = fmaf(qh[i + 2], kv.z, s); s = fmaf(qh[i + 3], kv.w, s);
-      }
-      if (has_r) {
-        const float* up = Us + h * ULD;
-        const float* rp = Rs + el * ULD;
-        float s2 = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < D; d += 4) {
-          const float4 u = *reinterpret_cast<const float4*>(up + d);
-          const float4 r = *reinterpret_cast<const float4*>(rp + d);
-          s2 = fmaf(u.x, r.x, s2); s2 = fmaf(u.y, r.y, s2); s2 = fmaf(u.z, r.z, s2); s2 = fmaf(u.w, r.w, s2);
-        }
-        s += s2;
-      }
-      sc[(c0 + el) * H + h] = s;
-    }
-  }
-  __syncthreads();
-  // ---- phase 2: per-head max / exp / sum over the row's edges
-  float m = -INFINITY;
-  for (int e = el; e < E; e += 8) m = fmaxf(m, sc[e * H + h]);
-  m = fmaxf(m, __shfl_xor(m, 8, 64));
-  m = fmaxf(m, __shfl_xor(m, 16, 64));
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
-  float ssum = 0.f;
-  for (int e = el; e < E; e += 8) {
-    const float p = expf(sc[e * H + h] - m);
-    sc[e * H + h] = p;
-    ssum += p;
-  }
-  ssum += __shfl_xor(ssum, 8, 64);
-  ssum += __shfl_xor(ssum, 16, 64);
-  ssum += __shfl_xor(ssum, 32, 64);
-  const float inv = 1.0f / (ssum + 1e-16f);
-  float sig = 0.f;
-  for (int e = el; e < E; e += 8) {
-    const float at = sc[e * H + h] * inv;
-    sc[e * H + h] = at;
-    sig += at;
-  }
-  sig += __shfl_xor(sig, 8, 64);
-  sig += __shfl_xor(sig, 16, 64);
-  sig += __shfl_xor(sig, 32, 64);
-  if (lane < H) a.SIG[(size_t)row * H + lane] = sig;
-  __syncthreads();
-  // ---- phase 3
-  float z[H][2];
-#pragma unroll
-  for (int hh = 0; hh < H; ++hh) { z[hh][0] = 0.f; z[hh][1] = 0.f; }
-  float ag0 = 0.f, ag1 = 0.f;
-  const int myh = lane >> 3;     // head of columns 2*lane, 2*lane+1
   for (int e = 0; e < E; ++e) {
-    const float4 a0 = *reinterpret_cast<const float4*>(sc + e * H);
-    const float4 a1 = *reinterpret_cast<const float4*>(sc + e * H + 4);
-    const float2 vv = *reinterpret_cast<const float2*>(a.Vsrc + (size_t)srcs[e] * D + 2 * lane);
-    const float am = sc[e * H + myh];
-    ag0 = fmaf(am, vv.x, ag0);
-    ag1 = fmaf(am, vv.y, ag1);
+    const float2 k2 = kn, v2 = vn, r2 = rn;
+    if (e + 1 < E) {
+      const int s1 = __builtin_amdgcn_readfirstlane(a.es.src[e_base + e + 1]);
+      kn = *reinterpret_cast<const float2*>(a.Ksrc + (size_t)s1 * D + 2 * lane);
+      vn = *reinterpret_cast<const float2*>(a.Vsrc + (size_t)s1 * D + 2 * lane);
+      if (has_r) rn = *reinterpret_cast<const float2*>(a.es.rhat + (size_t)(e_base + e + 1) * D + 2 * lane);
+    }
+    float val = fmaf(q.y, k2.y, q.x * k2.x);
     if (has_r) {
-      const float2 rr = *reinterpret_cast<const float2*>(a.es.rhat + (size_t)(e_base + e) * D + 2 * lane);
-      z[0][0] = fmaf(a0.x, rr.x, z[0][0]); z[0][1] = fmaf(a0.x, rr.y, z[0][1]);
-      z[1][0] = fmaf(a0.y, rr.x, z[1][0]); z[1][1] = fmaf(a0.y, rr.y, z[1][1]);
-      z[2][0] = fmaf(a0.z, rr.x, z[2][0]); z[2][1] = fmaf(a0.z, rr.y, z[2][1]);
-      z[3][0] = fmaf(a0.w, rr.x, z[3][0]); z[3][1] = fmaf(a0.w, rr.y, z[3][1]);
-      z[4][0] = fmaf(a1.x, rr.x, z[4][0]); z[4][1] = fmaf(a1.x, rr.y, z[4][1]);
-      z[5][0] = fmaf(a1.y, rr.x, z[5][0]); z[5][1] = fmaf(a1.y, rr.y, z[5][1]);
-      z[6][0] = fmaf(a1.z, rr.x, z[6][0]); z[6][1] = fmaf(a1.z, rr.y, z[6][1]);
-      z[7][0] = fmaf(a1.w, rr.x, z[7][0]); z[7][1] = fmaf(a1.w, rr.y, z[7][1]);
+      float p[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) p[h] = fmaf(u[h].y, r2.y, u[h].x * r2.x);
+      float k4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float send = b5 ? p[i] : p[4 + i];
+        const float keep = b5 ? p[4 + i] : p[i];
+        k4[i] = keep + __shfl_xor(send, 32, 64);
+      }
+      float k2v[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float send = b4 ? k4[i] : k4[2 + i];
+        const float keep = b4 ? k4[2 + i] : k4[i];
+        k2v[i] = keep + __shfl_xor(send, 16, 64);
+      }
+      {
+        const float send = b3 ? k2v[0] : k2v[1];
+        const float keep = b3 ? k2v[1] : k2v[0];
+        val += keep + __shfl_xor(send, 8, 64);
+      }
+    }
+    val += __shfl_xor(val, 1, 64);
+    val += __shfl_xor(val, 2, 64);
+    val += __shfl_xor(val, 4, 64);            // score of head (lane >> 3), uniform over its 8 lanes
+    const float mn = fmaxf(m, val);
+    const float pe = expf(val - mn);
+    if (__any(mn > m)) {                      // some head's running max grew: rescale the accumulators
+      const float sc = expf(m - mn);          // exp(-inf) = 0 on the first edge (accumulators are 0)
+      lsum *= sc;
+      ag.x *= sc; ag.y *= sc;
+      if (has_r) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const float sh = readlane_f(sc, 8 * h);
+          z[h].x *= sh; z[h].y *= sh;
+        }
+      }
+      m = mn;
+    }
+    lsum += pe;
+    ag.x = fmaf(pe, v2.x, ag.x);
+    ag.y = fmaf(pe, v2.y, ag.y);
+    if (has_r) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float ph = readlane_f(pe, 8 * h);
+        z[h].x = fmaf(ph, r2.x, z[h].x);
+        z[h].y = fmaf(ph, r2.y, z[h].y);
+      }
     }
   }
-  *reinterpret_cast<float2*>(aggp + 2 * lane) = make_float2(ag0, ag1);
-  if (zp) {
+  const float inv = 1.0f / (lsum + 1e-16f);
+  *reinterpret_cast<float2*>(a.AGG + (size_t)row * D + 2 * lane) = make_float2(ag.x * inv, ag.y * inv);
+  if (a.Z) {
 #pragma unroll
-    for (int hh = 0; hh < H; ++hh)
-      *reinterpret_cast<float2*>(zp + hh * D + 2 * lane) = make_float2(z[hh][0], z[hh][1]);
+    for (int h = 0; h < H; ++h) {
+      const float ih = readlane_f(inv, 8 * h);
+      *reinterpret_cast<float2*>(a.Z + (size_t)row * (H * D) + h * D + 2 * lane) = make_float2(z[h].x * ih, z[h].y * ih);
+    }
   }
+  if ((lane & 7) == 0) a.SIG[(size_t)row * H + (lane >> 3)] = lsum * inv;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(NT, 2) void k_fourier(FourierArgs a) {
   const int ntiles = (E + TR - 1) / TR;
   const int w = wave_id();
   const int n0 = 32 * w;
+  if (a.prof_rows && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.prof_rows + a.n, (unsigned long long)E);
   const float* tail = a.pack + FE_DIM0 + a.n * FD_SIZE;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int e0 = tile * TR;

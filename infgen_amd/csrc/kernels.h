@@ -23,6 +23,7 @@ struct FourierArgs {
   const float* cat; int ldcat;   // optional [E][ldcat] categorical embedding sum
   float* out; int ldo;
   int normalize;
+  unsigned long long* prof_rows;   // optional [8]: rows processed, indexed by n (profiling only)
 };
 
 // One edge set in CSR-by-destination form (built on the device every decode step).
