@@ -31,6 +31,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 from infgen_amd import engine, synth, _lib  # noqa: E402
+from infgen_amd import dist as igdist  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
 
@@ -106,7 +107,8 @@ def main():
     log(f'cpu_count={os.cpu_count()} device={torch.cuda.get_device_name(dev)}')
     cfg = synth.standard_config(disable_insertion=True)
     sd = synth.fill_state_dict(load_shapes(), seed=1, rich=True)
-    scenes, vocab, map_vocab, grid = build_scenes(cfg, args.scenes, args.agents, args.map_tokens, rank * args.scenes)
+    first = igdist.scenes_for_rank_weak(rank, args.scenes)[0]
+    scenes, vocab, map_vocab, grid = build_scenes(cfg, args.scenes, args.agents, args.map_tokens, first)
     log('scenes built')
     w = engine.PackedWeights(sd, cfg, dev)
     eng = engine.RolloutEngine(w, scenes, vocab, map_vocab, grid, store_logits=False)
@@ -154,12 +156,7 @@ def main():
                 'per_kernel_ms_one_rollout': {k: round(v['ms'], 3) for k, v in per_kernel.items()}}
 
     agent_steps = float(eng.agent_steps() * args.steps)
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        cnt = torch.tensor([agent_steps], device=dev, dtype=torch.float64)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        dt, agent_steps = float(tt.item()), float(cnt.item())
+    dt, agent_steps = igdist.reduce_run(dt, agent_steps, dev)
     if rank == 0:
         line = {
             'metric': 'agent-steps/sec (closed-loop rollout)',

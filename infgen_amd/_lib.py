@@ -54,6 +54,7 @@ SYMBOLS = {
     'infgen_fourier_pack_offset': (_i, [C.c_char_p, _i, _i]),
     'infgen_last_error': (C.c_char_p, []),
     'infgen_linear': (_i, [_p, _i, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p]),
+    'infgen_layernorm': (_i, [_p, _i, _p, _p, _p, _p]),
     'infgen_fourier_embed': (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _p]),
     'infgen_attn_pre': (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p]),
     'infgen_edge_attn': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

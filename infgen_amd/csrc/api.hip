@@ -154,6 +154,12 @@ extern "C" int infgen_linear(const float* X, int ldx, const int* gather, int row
   return check_launch("infgen_linear");
 }
 
+extern "C" int infgen_layernorm(const float* X, int rows, const float* gamma, const float* beta, float* Y, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(k_layernorm, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, X, rows, gamma, beta, Y);
+  return check_launch("infgen_layernorm");
+}
+
 extern "C" int infgen_fourier_embed(const float* raw, int n, const int* count_dev, int e_cap, const float* pack,
                                     const float* cat, int ldcat, float* out, int ldo, int normalize, void* stream) {
   if (e_cap <= 0) return 0;

@@ -183,4 +183,20 @@ __global__ __launch_bounds__(NT, 2) void k_fourier(FourierArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// k_layernorm: Y = LN(X) over 128 columns (gamma == nullptr: affine-free).  torch.nn.LayerNorm.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_layernorm(const float* X, int rows, const float* g, const float* b, float* Y) {
+  __shared__ __attribute__((aligned(16))) float Xs[TR * LDT];
+  const int row0 = blockIdx.x * TR;
+  const int nvalid = min(TR, rows - row0);
+  if (nvalid <= 0) return;
+  stage_rows_128(Xs, [&](int r) { return X + (size_t)(row0 + r) * D; }, nvalid);
+  __syncthreads();
+  ln_tile(Xs, LDT, Xs, LDT, g, b, false);
+  __syncthreads();
+  unstage_rows_128(Xs, [&](int r) { return Y + (size_t)(row0 + r) * D; }, nvalid);
+}
+
 }  // namespace ig

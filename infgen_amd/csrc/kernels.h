@@ -151,5 +151,6 @@ __global__ void k_build_edges(BuildEdgesArgs a);
 __global__ void k_integrate(IntegrateArgs a);
 __global__ void k_rawfeat_prep(RawFeatArgs a);
 __global__ void k_map_graph(MapGraphArgs a);
+__global__ void k_layernorm(const float* X, int rows, const float* g, const float* b, float* Y);
 
 }  // namespace ig

@@ -185,7 +185,7 @@ class RolloutEngine:
     def __init__(self, weights: PackedWeights, scenes: Sequence[Mapping], vocab: Mapping[str, np.ndarray],
                  map_vocab: np.ndarray, grid: np.ndarray, a_cap: Optional[int] = None, m_cap: Optional[int] = None,
                  store_logits: bool = False, live_state: bool = False,
-                 teacher: Optional[Sequence] = None):
+                 teacher: Optional[Sequence] = None, x_pt_override: Optional[Sequence] = None):
         self.w = weights
         self.cfg = cfg = weights.cfg
         self.device = dev = weights.device
@@ -200,6 +200,7 @@ class RolloutEngine:
         self.W = cfg.window
         self.ring = self.W + 1
         self.store_logits = store_logits
+        self._x_pt_override = x_pt_override
         self.force_valid = bool(cfg.disable_insertion) and not live_state
 
         # ------------------------------------------------ host-side scene setup
@@ -357,7 +358,7 @@ class RolloutEngine:
 
     _STATE = ('pos', 'head', 'state', 'token', 'gridtok', 'imask', 'catflag')
 
-    def prologue(self):
+    def prologue(self, map_only: bool = False):
         """per-scene constants and the first columns: agent categorical embeddings, map encoder
         (map_decoder.py:70-130), map K/V of the six map->agent layers, the edgeless column-0 chain
         (SURVEY a-Q3) and column 1's raw feature."""
@@ -372,6 +373,8 @@ class RolloutEngine:
         shp = ops.mlp_embedding(self._shape10.reshape(rows, 3), w.shape_emb, 3)
         torch.add(w.type_a_emb[self.atype.reshape(-1).long()], shp, out=self.cat_agent)
 
+        if self._x_pt_override is not None:
+            return self._prologue_with_given_map()
         # ---- map encoder
         mrows = S * M_cap
         mtok, mtype, mpl, mlight = self._map_cat
@@ -410,6 +413,23 @@ class RolloutEngine:
             ops.edge_attn(mrows, g['Q'], g['U'], g['K'], g['V'], g['off'], g['cnt'], g['src'], g['rhat'],
                           g['AGG'], g['Z'], g['SIG'])
             ops.attn_post(x_pt, w.attn_pt[i], g['AGG'], g['Z'], g['SIG'])
+        if map_only:
+            return
+        self._finish_prologue()
+
+    def _prologue_with_given_map(self):
+        """inference_no_map: x_pt comes from the caller (reference infgen_decoder.py:132-134)"""
+        S, M_cap, dev = self.S, self.M_cap, self.device
+        if self.x_pt is None:
+            self.x_pt = torch.zeros(S * M_cap, D, device=dev)
+        for s, xp in enumerate(self._x_pt_override):
+            M = self.hosts[s]['M']
+            self.x_pt[s * M_cap:s * M_cap + M] = xp.detach().to(dev, torch.float32)
+        self._finish_prologue()
+
+    def _finish_prologue(self):
+        ops, w, cfg = self.ops, self.w, self.cfg
+        x_pt = self.x_pt
         # map K/V of the six pt2a layers (bipartite source LayerNorm)
         for i in range(cfg.num_agent_layers):
             ops.attn_pre(x_pt, w.attn_m[i], use_src_ln=True, k=self.mapK[i], v=self.mapV[i])

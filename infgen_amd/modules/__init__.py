@@ -1,0 +1,8 @@
+from .layers import AttentionLayer, FourierEmbedding, MLPEmbedding, MLPLayer
+from .attr_tokenizer import Attr_Tokenizer
+from .map_decoder import InfGenMapDecoder
+from .agent_decoder import InfGenAgentDecoder
+from .infgen_decoder import InfGenDecoder
+
+__all__ = ['AttentionLayer', 'FourierEmbedding', 'MLPEmbedding', 'MLPLayer', 'Attr_Tokenizer',
+           'InfGenMapDecoder', 'InfGenAgentDecoder', 'InfGenDecoder']

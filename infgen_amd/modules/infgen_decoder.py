@@ -1,0 +1,192 @@
+"""InfGenDecoder: the drop-in boundary of the hot path (reference
+infgen/modules/infgen_decoder.py:15-143).  Same constructor signature, same sub-module names
+(``map_encoder`` / ``agent_encoder``), ``forward`` / ``inference`` / ``inference_no_map`` with the
+reference's return dicts.  ``inference`` runs map encoder + closed-loop rollout on the GPU through
+libinfgen_hip.so; ``inference_batch`` is the throughput entry (many scenes in lockstep).
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Dict, List, Mapping, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..engine import PackedWeights, RolloutEngine
+from ..synth import RolloutConfig
+from .agent_decoder import InfGenAgentDecoder
+from .attr_tokenizer import Attr_Tokenizer
+from .map_decoder import InfGenMapDecoder
+
+_AGENT_KEYS = ('state_idx', 'valid_mask', 'id', 'raw_agent_valid_mask', 'token_pos', 'token_idx', 'token_heading',
+               'shape', 'type', 'grid_token_idx', 'position', 'heading', 'av_index',
+               'trajectory_token_veh', 'trajectory_token_ped', 'trajectory_token_cyc')
+
+
+def _np(v):
+    if isinstance(v, torch.Tensor):
+        return v.detach().cpu().numpy()
+    return np.asarray(v)
+
+
+def scene_from_data(data) -> Dict[str, Dict[str, np.ndarray]]:
+    """the reference's HeteroData-style ``data`` (dict access) -> host scene dict of numpy arrays"""
+    ag = data['agent']
+    agent = {k: _np(ag[k]) for k in _AGENT_KEYS}
+    pt = data['pt_token']
+    ptd = {k: _np(pt[k]) for k in ('position', 'orientation', 'type', 'pl_type', 'token_idx')}
+    key = ('pt_token', 'to', 'map_polygon')
+    try:
+        e = data[key]['edge_index']
+    except (KeyError, TypeError):
+        e = data['pt_token__to__map_polygon']['edge_index']
+    return {'agent': agent, 'pt_token': ptd, 'map_polygon': {'light_type': _np(data['map_polygon']['light_type'])},
+            'pt_token__to__map_polygon': {'edge_index': _np(e)}}
+
+
+class InfGenDecoder(nn.Module):
+
+    def __init__(self, decoder_type: str, dataset: str, input_dim: int, hidden_dim: int, num_historical_steps: int,
+                 pl2pl_radius: float, time_span: Optional[int], pl2a_radius: float, pl2seed_radius: float,
+                 a2a_radius: float, a2sa_radius: float, pl2sa_radius: float, num_freq_bands: int, num_map_layers: int,
+                 num_agent_layers: int, num_heads: int, head_dim: int, dropout: float, map_token: Dict,
+                 token_size=512, attr_tokenizer: Attr_Tokenizer = None, predict_motion: bool = False,
+                 predict_state: bool = False, predict_map: bool = False, predict_occ: bool = False,
+                 use_grid_token: bool = True, use_head_token: bool = True, use_state_token: bool = True,
+                 disable_insertion: bool = False, state_token: Dict[str, int] = None, seed_size: int = 5,
+                 buffer_size: int = 32, num_recurrent_steps_val: int = -1, loss_weight: dict = None, logger=None) -> None:
+        super().__init__()
+        if decoder_type != 'agent_decoder':
+            raise ValueError(f'Unsupport decoder type: {decoder_type} (the HIP path implements agent_decoder)')
+        self.map_encoder = InfGenMapDecoder(dataset=dataset, input_dim=input_dim, hidden_dim=hidden_dim,
+                                            num_historical_steps=num_historical_steps, pl2pl_radius=pl2pl_radius,
+                                            num_freq_bands=num_freq_bands, num_layers=num_map_layers, num_heads=num_heads,
+                                            head_dim=head_dim, dropout=dropout, map_token=map_token)
+        self.agent_encoder = InfGenAgentDecoder(
+            dataset=dataset, input_dim=input_dim, hidden_dim=hidden_dim, num_historical_steps=num_historical_steps,
+            time_span=time_span, pl2a_radius=pl2a_radius, pl2seed_radius=pl2seed_radius, a2a_radius=a2a_radius,
+            a2sa_radius=a2sa_radius, pl2sa_radius=pl2sa_radius, num_freq_bands=num_freq_bands, num_layers=num_agent_layers,
+            num_heads=num_heads, head_dim=head_dim, dropout=dropout, token_size=token_size, attr_tokenizer=attr_tokenizer,
+            predict_motion=predict_motion, predict_state=predict_state, predict_map=predict_map, predict_occ=predict_occ,
+            state_token=state_token, use_grid_token=use_grid_token, use_head_token=use_head_token,
+            use_state_token=use_state_token, disable_insertion=disable_insertion, seed_size=seed_size,
+            buffer_size=buffer_size, num_recurrent_steps_val=num_recurrent_steps_val, loss_weight=loss_weight, logger=logger)
+        ref = weakref.ref(self)
+        self.map_encoder._owner = ref
+        self.agent_encoder._owner = ref
+        self.map_enc = None
+        self.predict_motion, self.predict_state, self.predict_map, self.predict_occ = predict_motion, predict_state, predict_map, predict_occ
+        self.data_keys = ["agent_valid_mask", "category", "valid_mask", "av_index", "scenario_id", "shape"]
+        self._cfg_kw = dict(input_dim=input_dim, hidden_dim=hidden_dim, num_heads=num_heads, head_dim=head_dim,
+                            num_freq_bands=num_freq_bands, num_map_layers=num_map_layers, num_agent_layers=num_agent_layers,
+                            num_historical_steps=num_historical_steps, token_size=token_size, a2a_radius=a2a_radius,
+                            pl2a_radius=pl2a_radius, pl2pl_radius=pl2pl_radius, a2sa_radius=a2sa_radius,
+                            pl2sa_radius=pl2sa_radius, pl2seed_radius=pl2seed_radius,
+                            time_span=time_span if time_span is not None else num_historical_steps,
+                            seed_size=seed_size, buffer_size=buffer_size, disable_insertion=disable_insertion,
+                            state_token=dict(state_token))
+        self._packed = None
+        self._packed_ver = None
+
+    # ------------------------------------------------------------------ weights
+    def _weights(self) -> PackedWeights:
+        ps = list(self.parameters())
+        dev = ps[0].device
+        if dev.type != 'cuda':
+            raise _lib.InfgenHipError('InfGenDecoder must live on a cuda device: the product path has no CPU fallback')
+        ver = (dev, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
+        if self._packed_ver != ver:
+            tok = self.agent_encoder.attr_tokenizer
+            R = self.agent_encoder.num_recurrent_steps_val
+            cfg = RolloutConfig(num_recurrent_steps_val=R if R != -1 else 80, grid_range=tok.grid_range,
+                                grid_interval=tok.grid_interval, angle_interval=tok.angle_interval, **self._cfg_kw)
+            sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items()}
+            self._packed = PackedWeights(sd, cfg, dev)
+            self._packed_ver = ver
+        return self._packed
+
+    # ------------------------------------------------------------------ driver
+    def _run(self, data, x_pt=None, map_only=False, batch: Optional[Sequence] = None):
+        ae = self.agent_encoder
+        if not map_only and not ae.disable_insertion:
+            raise NotImplementedError('scenario insertion (agent_decoder.py:1773-2105) is not implemented in the HIP '
+                                      'path yet: construct with disable_insertion=True')
+        datas = list(batch) if batch is not None else [data]
+        scenes = [scene_from_data(d) for d in datas]
+        w = self._weights()
+        if ae.num_recurrent_steps_val == -1:
+            # sticky like the reference (agent_decoder.py:1633-1635)
+            ae.num_recurrent_steps_val = scenes[0]['agent']['position'].shape[1] - ae.num_historical_steps
+            w.cfg.num_recurrent_steps_val = ae.num_recurrent_steps_val
+        vocab = {k: scenes[0]['agent'][f'trajectory_token_{k}'] for k in ('veh', 'ped', 'cyc')}
+        map_vocab = _np(self.map_encoder.map_token['traj_src']).astype(np.float32)
+        grid = ae.attr_tokenizer.grid.detach().cpu().numpy()
+        xo = None
+        if x_pt is not None:
+            xo = [x_pt] if batch is None else list(x_pt)
+        eng = RolloutEngine(w, scenes, vocab, map_vocab, grid, x_pt_override=xo)
+        if map_only:
+            eng.prologue(map_only=True)
+            return eng.x_pt[:eng.hosts[0]['M']].clone()
+        eng.rollout()
+        outs = eng.outputs()
+        dev = w.device
+        res = []
+        for d, o in zip(datas, outs):
+            n_map = o.pop('x_pt')
+            r = {k: (torch.from_numpy(np.ascontiguousarray(v)).to(dev) if isinstance(v, np.ndarray) else v)
+                 for k, v in o.items()}
+            steps = w.cfg.num_decode_steps
+            G = ae.grid_size
+            z = lambda *s: torch.zeros(*s, device=dev)
+            r.update(next_state_prob_seed=z(11, steps), next_pos_rel_prob_seed=z(11, steps, G),
+                     grid_agent_occ_seed=z(11, steps, G), grid_pt_occ_seed=z(11, steps, G),
+                     grid_agent_occ_gt_seed=z(11, steps, G),
+                     agent_labels=[[None] * w.cfg.num_columns for _ in range(o['pos_a'].shape[0])],
+                     log_message='No agents inserted!')
+            # the callee mutates data['batch_size_a'] like the reference (agent_decoder.py:1649)
+            try:
+                filt = eng.hosts[len(res)]['filt']
+                av0 = int(_np(d['agent']['av_index']).reshape(-1)[0])
+                d['batch_size_a'] -= int((~filt[:av0]).sum())
+            except (KeyError, TypeError):
+                pass
+            r['_x_pt'] = torch.from_numpy(n_map).to(dev)
+            res.append(r)
+        return res if batch is not None else res[0]
+
+    def get_agent_inputs(self, data):
+        raise NotImplementedError('training-only helper (agent_decoder.py:933) — out of the hot path')
+
+    def forward(self, data):
+        raise NotImplementedError('teacher-forced forward (agent_decoder.py:1104-1603) is out of scope of the rollout '
+                                  'hot path; use inference()')
+
+    @torch.no_grad()
+    def inference(self, data) -> Dict[str, torch.Tensor]:
+        """map encoder + closed-loop rollout of one scene (reference infgen_decoder.py:123-130)"""
+        r = self._run(data)
+        x_pt = r.pop('_x_pt')
+        map_enc = {'x_pt': x_pt, 'map_next_token_idx': torch.zeros(0, 10, dtype=torch.long, device=x_pt.device),
+                   'map_next_token_prob': torch.zeros(0, self.map_encoder.token_size, device=x_pt.device),
+                   'map_next_token_idx_gt': torch.zeros(0, dtype=torch.long, device=x_pt.device),
+                   'map_next_token_eval_mask': torch.zeros(0, dtype=torch.bool, device=x_pt.device)}
+        return {**map_enc, **r, **{k: data[k] for k in self.data_keys if k in data}}
+
+    @torch.no_grad()
+    def inference_no_map(self, data, map_enc) -> Dict[str, torch.Tensor]:
+        r = self._run(data, x_pt=map_enc['x_pt'])
+        r.pop('_x_pt')
+        return {**map_enc, **r}
+
+    @torch.no_grad()
+    def inference_batch(self, datas: Sequence) -> List[Dict[str, torch.Tensor]]:
+        """throughput entry: many independent scenes decoded in lockstep on this GPU"""
+        rs = self._run(None, batch=datas)
+        out = []
+        for d, r in zip(datas, rs):
+            x_pt = r.pop('_x_pt')
+            out.append({'x_pt': x_pt, **r, **{k: d[k] for k in self.data_keys if k in d}})
+        return out

@@ -1,0 +1,143 @@
+"""GPU: the reference-shaped module API (infgen_amd.modules) — same constructor/forward
+signatures as infgen/modules/{layers,infgen_decoder}.py — against the oracle and the golden
+fixtures.  These read like tests of the reference's own modules would."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_case, make_weights
+from test_boundary_cpu import _decoder
+
+pytestmark = pytest.mark.gpu
+
+
+def _to_data(scene, dev):
+    d = {}
+    for k, v in scene.items():
+        if isinstance(v, dict):
+            d[k] = {kk: (torch.from_numpy(vv).to(dev) if isinstance(vv, np.ndarray) else vv) for kk, vv in v.items()}
+        else:
+            d[k] = torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v
+    d[('pt_token', 'to', 'map_polygon')] = d.pop('pt_token__to__map_polygon')
+    a = d['agent']
+    for k in ('agent_valid_mask', 'category', 'valid_mask', 'av_index', 'shape'):
+        d[k] = a[k]
+    return d
+
+
+def _load(dec, sd):
+    full = {k: torch.from_numpy(sd[k]) if k in sd else v for k, v in dec.state_dict().items()}
+    dec.load_state_dict(full, strict=True)
+
+
+@pytest.mark.parametrize('name', ['c1_a8_m128', 'a24_m256_edge'])
+def test_infgen_decoder_inference_drop_in(name):
+    c = load_case(name)
+    z = c['z']
+    dev = torch.device('cuda:0')
+    dec = _decoder(c['cfg'])
+    _load(dec, c['sd'])
+    dec = dec.to(dev).eval()
+    data = _to_data(c['scene'], dev)
+    bs_before = int(data['batch_size_a'][0])
+    out = dec.inference(data)
+    for k in ('ego_index', 'agent_id', 'valid_mask', 'pos_a', 'head_a', 'gt_traj', 'pred_traj', 'pred_head', 'pred_type',
+              'pred_state', 'pred_z', 'pred_shape', 'eval_shape', 'pred_valid', 'next_state_prob_seed',
+              'next_pos_rel_prob_seed', 'next_token_idx', 'next_state_idx', 'grid_agent_occ_seed', 'grid_pt_occ_seed',
+              'grid_agent_occ_gt_seed', 'agent_labels', 'log_message', 'x_pt', 'scenario_id', 'av_index'):
+        assert k in out, k
+    assert np.array_equal(out['next_token_idx'].cpu().numpy(), z['next_token_idx'])
+    assert np.array_equal(out['next_state_idx'].cpu().numpy(), z['next_state_idx'])
+    assert np.abs(out['pos_a'].cpu().numpy() - z['pos_a']).max() <= 1e-3
+    assert np.abs(out['pred_traj'].cpu().numpy() - z['pred_traj']).max() <= 1e-3
+    assert np.array_equal(out['pred_valid'].cpu().numpy(), z['pred_valid'])
+    assert np.abs(out['x_pt'].cpu().numpy() - z['x_pt']).max() <= 1e-4
+    # reference side effect: batch_size_a reduced by the rows filtered before the ego (agent_decoder.py:1649)
+    removed = c['meta']['A'] - z['pos_a'].shape[0]
+    assert int(data['batch_size_a'][0]) == bs_before - removed
+    # inference_no_map with the map encoder's own output reproduces the same rollout
+    me = dec.map_encoder(data)
+    assert np.abs(me['x_pt'].cpu().numpy() - z['x_pt']).max() <= 1e-4
+    out2 = dec.inference_no_map(_to_data(c['scene'], dev), me)
+    assert np.array_equal(out2['next_token_idx'].cpu().numpy(), z['next_token_idx'])
+
+
+def test_inference_batch_equals_single():
+    c = load_case('c1_a8_m128')
+    dev = torch.device('cuda:0')
+    dec = _decoder(c['cfg'])
+    _load(dec, c['sd'])
+    dec = dec.to(dev).eval()
+    from infgen_amd import synth
+    scenes = [c['scene'], synth.make_scene(77, 11, 90, c['cfg'], vocab=c['vocab'], grid=c['grid'])]
+    outs = dec.inference_batch([_to_data(s, dev) for s in scenes])
+    single = dec.inference(_to_data(scenes[1], dev))
+    assert np.array_equal(outs[0]['next_token_idx'].cpu().numpy(), c['z']['next_token_idx'])
+    assert torch.equal(outs[1]['next_token_idx'], single['next_token_idx'])
+
+
+def test_insertion_not_silently_ignored():
+    c = load_case('c1_a8_m128')
+    dev = torch.device('cuda:0')
+    dec = _decoder(c['cfg'])
+    dec.agent_encoder.disable_insertion = False
+    dec = dec.to(dev)
+    with pytest.raises(NotImplementedError):
+        dec.inference(_to_data(c['scene'], dev))
+
+
+def test_operator_modules_match_oracle():
+    """AttentionLayer / FourierEmbedding / MLPEmbedding / MLPLayer forward(...) with the reference's
+    argument conventions (edge_index = [src; dst] COO in arbitrary order)."""
+    from infgen_amd.modules import AttentionLayer, FourierEmbedding, MLPEmbedding, MLPLayer
+    from oracle import rollout_oracle as ro
+    dev = torch.device('cuda:0')
+    sd = make_weights(seed=4)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    rng = np.random.default_rng(0)
+
+    def load(m, prefix):
+        st = {k[len(prefix) + 1:]: torch.from_numpy(v) for k, v in sd.items() if k.startswith(prefix + '.')}
+        m.load_state_dict(st, strict=True)
+        return m.to(dev)
+
+    p = 'agent_encoder.a2a_attn_layers.1'
+    layer = load(AttentionLayer(128, 8, 16, 0.1, bipartite=False, has_pos_emb=True), p)
+    n, e = 30, 200
+    x = torch.from_numpy(rng.standard_normal((n, 128)).astype(np.float32))
+    r = torch.from_numpy(rng.standard_normal((e, 128)).astype(np.float32))
+    ei = torch.from_numpy(np.stack([rng.integers(0, n, e), rng.integers(0, n - 3, e)]))   # rows n-3.. get no edges
+    with torch.no_grad():
+        ref = ro.attention_layer(tsd, p, x, r, ei[0], ei[1])
+    out = layer(x.to(dev), r.to(dev), ei.to(dev))
+    assert (out.cpu() - ref).abs().max() <= 1e-4
+
+    p = 'agent_encoder.pt2a_attn_layers.4'
+    layer = load(AttentionLayer(128, 8, 16, 0.1, bipartite=True, has_pos_emb=True), p)
+    xs = torch.from_numpy(rng.standard_normal((50, 128)).astype(np.float32))
+    ei = torch.from_numpy(np.stack([rng.integers(0, 50, e), rng.integers(0, n, e)]))
+    with torch.no_grad():
+        ref = ro.attention_layer(tsd, p, x, r, ei[0], ei[1], x_src_raw=xs)
+    out = layer((xs.to(dev), x.to(dev)), r.to(dev), ei.to(dev))
+    assert (out.cpu() - ref).abs().max() <= 1e-4
+
+    p = 'agent_encoder.r_t_emb'
+    fe = load(FourierEmbedding(4, 128, 64), p)
+    ci = torch.from_numpy(rng.uniform(-3, 3, (41, 4)).astype(np.float32))
+    with torch.no_grad():
+        ref = ro.fourier_embedding(tsd, p, ci)
+    assert (fe(continuous_inputs=ci.to(dev), categorical_embs=None).cpu() - ref).abs().max() <= 5e-5
+
+    p = 'agent_encoder.fusion_emb'
+    me = load(MLPEmbedding(512, 128), p)
+    xi = torch.from_numpy(rng.standard_normal((19, 512)).astype(np.float32))
+    with torch.no_grad():
+        ref = ro.mlp_embedding(tsd, p, xi)
+    assert (me(xi.to(dev)).cpu() - ref).abs().max() <= 5e-5
+
+    p = 'agent_encoder.seed_heading_rel_token_predict_head'
+    ml = load(MLPLayer(128, 128, 120), p)
+    xi = torch.from_numpy(rng.standard_normal((19, 128)).astype(np.float32))
+    with torch.no_grad():
+        ref = ro.mlp_layer(tsd, p, xi)
+    assert (ml(xi.to(dev)).cpu() - ref).abs().max() <= 5e-5
