@@ -85,12 +85,10 @@ __global__ __launch_bounds__(NT) void k_edge_attn(EdgeAttnArgs a) {
       {
         const float send = b3 ? k2v[0] : k2v[1];
         const float keep = b3 ? k2v[1] : k2v[0];
-        val += keep + __shfl_xor(send, 8, 64);
+        val += keep + dpp_xor8(send);
       }
     }
-    val += __shfl_xor(val, 1, 64);
-    val += __shfl_xor(val, 2, 64);
-    val += __shfl_xor(val, 4, 64);            // score of head (lane >> 3), uniform over its 8 lanes
+    val = sum8(val);                          // score of head (lane >> 3), uniform over its 8 lanes
     const float mn = fmaxf(m, val);
     const float pe = expf(val - mn);
     if (__any(mn > m)) {                      // some head's running max grew: rescale the accumulators

@@ -36,6 +36,24 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- DPP lane exchanges (VALU data path, no LDS round trip like ds_bpermute) -----------------------
+// value of lane (l ^ 1), (l ^ 2) via quad_perm; lane (7 - l%8) via row_half_mirror; lane (l ^ 8) via row_ror:8
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_xor1(float v) { return dpp_f<0xB1>(v); }        // quad_perm [1,0,3,2]
+__device__ __forceinline__ float dpp_xor2(float v) { return dpp_f<0x4E>(v); }        // quad_perm [2,3,0,1]
+__device__ __forceinline__ float dpp_half_mirror(float v) { return dpp_f<0x141>(v); }  // l -> 7 - l (within 8)
+__device__ __forceinline__ float dpp_xor8(float v) { return dpp_f<0x128>(v); }       // row_ror:8
+// sum over the 8 lanes {l & ~7 ... l | 7}; every lane gets the total
+__device__ __forceinline__ float sum8(float v) {
+  v += dpp_xor1(v);
+  v += dpp_xor2(v);
+  v += dpp_half_mirror(v);
+  return v;
+}
+
 // ---- elementwise formulas of the reference ------------------------------------------------
 // infgen/utils/func.py:58-62   wrap_angle(a) = -pi + (a + pi) % (2 pi)   (python-style remainder)
 __device__ __forceinline__ float wrap_angle(float a) {
@@ -152,28 +170,47 @@ __device__ __forceinline__ void unstage_rows_128(const float* src, RowPtr rowptr
   }
 }
 
-// LayerNorm over the 128 columns of each row of an LDS tile (biased variance, eps 1e-5, like
-// torch.nn.LayerNorm); wave w handles rows w, w+4, ...; lane handles columns 2l, 2l+1.
+// LayerNorm over the 128 columns of each row of a [32][128] LDS tile (biased variance, eps 1e-5,
+// like torch.nn.LayerNorm).  All 256 threads take part: thread t owns row t >> 3 and the four
+// 4-column groups {4*(t&7) + 32*j}; the row reductions are 3 DPP steps over the 8 lanes of the row.
 // gamma == nullptr -> no affine (plain normalisation).  res != nullptr -> dst = res + LN(src).
+// src == dst (in place) is allowed.
 __device__ __forceinline__ void ln_tile(const float* src, int lds_, float* dst, int ldd,
                                         const float* __restrict__ gamma, const float* __restrict__ beta, bool relu,
                                         const float* res = nullptr, int ldr = 0) {
-  const int lane = lane_id();
-  float g0 = 1.f, g1 = 1.f, b0 = 0.f, b1 = 0.f;
-  if (gamma) { g0 = gamma[2 * lane]; g1 = gamma[2 * lane + 1]; b0 = beta[2 * lane]; b1 = beta[2 * lane + 1]; }
-  for (int row = wave_id(); row < TR; row += 4) {
-    const float2 v = *reinterpret_cast<const float2*>(src + row * lds_ + 2 * lane);
-    const float mean = wave_sum(v.x + v.y) * (1.0f / 128.0f);
-    const float dx = v.x - mean, dy = v.y - mean;
-    const float var = wave_sum(dx * dx + dy * dy) * (1.0f / 128.0f);
-    const float rstd = 1.0f / sqrtf(var + LN_EPS);
-    float y0 = dx * rstd * g0 + b0, y1 = dy * rstd * g1 + b1;
-    if (relu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
-    if (res) {
-      const float2 rr = *reinterpret_cast<const float2*>(res + row * ldr + 2 * lane);
-      y0 += rr.x; y1 += rr.y;
+  const int t = threadIdx.x;
+  const int row = t >> 3, c0 = 4 * (t & 7);
+  float4 v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float4*>(src + row * lds_ + c0 + 32 * j);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  const float mean = sum8(s) * (1.0f / 128.0f);
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+    q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+  }
+  const float var = sum8(q) * (1.0f / 128.0f);
+  const float rstd = 1.0f / sqrtf(var + LN_EPS);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + 32 * j;
+    float4 g = make_float4(1.f, 1.f, 1.f, 1.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gamma) {
+      g = *reinterpret_cast<const float4*>(gamma + c);
+      b = *reinterpret_cast<const float4*>(beta + c);
     }
-    *reinterpret_cast<float2*>(dst + row * ldd + 2 * lane) = make_float2(y0, y1);
+    float4 y = make_float4(v[j].x * rstd * g.x + b.x, v[j].y * rstd * g.y + b.y,
+                           v[j].z * rstd * g.z + b.z, v[j].w * rstd * g.w + b.w);
+    if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+    if (res) {
+      const float4 rr = *reinterpret_cast<const float4*>(res + row * ldr + c);
+      y.x += rr.x; y.y += rr.y; y.z += rr.z; y.w += rr.w;
+    }
+    *reinterpret_cast<float4*>(dst + row * ldd + c) = y;
   }
 }
 
