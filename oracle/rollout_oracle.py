@@ -242,6 +242,18 @@ class RolloutOracle:
         g = st['grid_tab'][st['gridtok'][:, j]]
         return mlp_embedding(sd, p + '.fusion_emb', torch.cat([tok, x_a, s_a, g], dim=-1))
 
+    def _hv(self, st, rows, c):
+        """centre head vector of `rows` at column c.  SURVEY a-Q13: during the motion stage of a step
+        that inserted agents, every row inserted in that step carries the NEWEST row's head vector
+        (agent_decoder.py:2083 `head_vector_a[-num_new_agents:] = head_vector_sa`)."""
+        h = st['head'][rows, c]
+        hv = torch.stack([h.cos(), h.sin()], dim=-1)
+        ov = st.get('hv_override')
+        if ov is not None and ov[0] == c:
+            first_new, vec = ov[1], ov[2]
+            hv = torch.where((rows >= first_new)[:, None], vec[None, :].expand_as(hv), hv)
+        return hv
+
     # ---- edges into column c (SURVEY A.4)
     def temporal_edges(self, st, c):
         """agent_decoder.py:540-610 -> (src_col (E,), dst_row (E,), r (E,128))"""
@@ -267,7 +279,7 @@ class RolloutOracle:
         # agent_decoder.py:598 is a no-op (always-false mask)
         dp[s_inv & d_inv] = INVALID_MOTION
         dth[s_inv & d_inv] = INVALID_HEAD
-        hv = torch.stack([head[rows, c].cos(), head[rows, c].sin()], dim=-1)
+        hv = self._hv(st, rows, c)
         r = torch.stack([torch.norm(dp, p=2, dim=-1), angle_between(hv, dp), dth, (js - c).float()], dim=-1)
         r = fourier_embedding(sd, p + '.r_t_emb', r) if rows.numel() else torch.zeros(0, 128)
         return js, rows, r
@@ -284,7 +296,7 @@ class RolloutOracle:
         inv = state[dst] == INVALID
         dp[inv] = MOTION_GAP
         dth[inv] = HEADING_GAP
-        hv = torch.stack([head[dst].cos(), head[dst].sin()], dim=-1)
+        hv = self._hv(st, dst, c)
         r = torch.stack([torch.norm(dp, p=2, dim=-1), angle_between(hv, dp), dth], dim=-1)
         r = fourier_embedding(sd, p + '.r_pt2a_emb', r) if dst.numel() else torch.zeros(0, 128)
         return src, dst, r
@@ -304,7 +316,7 @@ class RolloutOracle:
         dth[s_inv & ~d_inv] = -HEADING_GAP
         dp[s_inv & d_inv] = INVALID_MOTION
         dth[s_inv & d_inv] = INVALID_HEAD
-        hv = torch.stack([head[dst].cos(), head[dst].sin()], dim=-1)
+        hv = self._hv(st, dst, c)
         r = torch.stack([torch.norm(dp, p=2, dim=-1), angle_between(hv, dp), dth], dim=-1)
         r = fourier_embedding(sd, p + '.r_a2a_emb', r) if dst.numel() else torch.zeros(0, 128)
         return src, dst, r

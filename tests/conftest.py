@@ -32,6 +32,7 @@ def load_case(name):
     z = np.load(os.path.join(GOLDEN, name + '.npz'))
     meta = json.loads(str(z['meta']))
     cfg = synth.smart_config() if meta['cfg'] == 'smart' else synth.standard_config()
+    meta.setdefault('insertion', '')
     vocab = synth.make_agent_vocab(cfg.token_size)
     map_vocab = synth.make_map_vocab()
     grid = synth.build_grid(cfg.grid_range, cfg.grid_interval, cfg.pl2seed_radius)

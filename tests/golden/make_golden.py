@@ -51,6 +51,11 @@ CASES = {
     # let the state head run by clearing the flag after construction -> see run_case)
     'a16_m128_egofirst_state': dict(cfg='standard', A=16, M=128, seed=synth.scene_seed(9, 2), ego_last=False,
                                     edge_cases=True, head_gain=64.0, live_state=True),
+    # scenario insertion (agent_decoder.py:1773-2105): forced "enter" (DEBUG=1) and the natural seed head
+    'ins_forced_a16_m256': dict(cfg='standard', A=16, M=256, seed=synth.scene_seed(9, 3), ego_last=True,
+                                edge_cases=False, head_gain=64.0, insertion='forced'),
+    'ins_natural_a20_m256': dict(cfg='standard', A=20, M=256, seed=synth.scene_seed(9, 4), ego_last=False,
+                                 edge_cases=False, head_gain=64.0, insertion='natural'),
     # C2-shaped, unsharpened head (teacher-forced logits comparison only)
     'c2_a32_m512': dict(cfg='standard', A=32, M=512, seed=synth.scene_seed(2, 0), ego_last=True, edge_cases=False,
                         head_gain=1.0),
@@ -125,6 +130,10 @@ def load_weights(dec, seed: int, head_gain: float):
 
 def run_case(name: str, spec: dict, out_dir: str):
     cfg = synth.smart_config() if spec['cfg'] == 'smart' else synth.standard_config()
+    ins = spec.get('insertion')
+    if ins:
+        cfg.disable_insertion = False
+    os.environ['DEBUG'] = '1' if ins == 'forced' else '0'
     vocab = synth.make_agent_vocab(cfg.token_size)
     map_vocab = synth.make_map_vocab()
     grid = synth.build_grid(cfg.grid_range, cfg.grid_interval, cfg.pl2seed_radius)
@@ -174,12 +183,18 @@ def run_case(name: str, spec: dict, out_dir: str):
 
     meta = dict(case=name, cfg=spec['cfg'], A=spec['A'], M=spec['M'], seed=spec['seed'], ego_last=spec['ego_last'],
                 edge_cases=spec['edge_cases'], head_gain=spec['head_gain'], weight_seed=1,
-                live_state=bool(spec.get('live_state', False)),
+                live_state=bool(spec.get('live_state', False)), insertion=ins or '',
                 num_params=int(sum(int(np.prod(s)) for s in shapes.values())))
     # top-1/top-2 logit margin per (step, agent): tells the parity test where a flip is legitimate
-    lg = np.stack(logits)  # (steps, A', 2048)
-    part = np.partition(lg, -2, axis=-1)
+    # with insertion the row count grows step by step: pad to the final count with NaN
+    a_fin = max(l.shape[0] for l in logits)
+    n_agents_step = np.asarray([l.shape[0] for l in logits], dtype=np.int64)
+    lg = np.full((len(logits), a_fin, logits[0].shape[1]), np.nan, dtype=np.float32)
+    for i, l in enumerate(logits):
+        lg[i, :l.shape[0]] = l
+    part = np.partition(np.nan_to_num(lg, nan=-1e30), -2, axis=-1)
     margin = (part[..., -1] - part[..., -2]).astype(np.float32)
+    margin[np.isnan(lg[..., 0])] = np.inf          # rows that did not exist yet at that step
     np.savez_compressed(
         os.path.join(out_dir, name + '.npz'),
         meta=json.dumps(meta),
@@ -192,9 +207,11 @@ def run_case(name: str, spec: dict, out_dir: str):
         pred_traj=out['pred_traj'].numpy(), pred_head=out['pred_head'].numpy(),
         pred_state=out['pred_state'].numpy(), pred_valid=out['pred_valid'].numpy(),
         agent_id=out['agent_id'].numpy(), ego_index=np.int64(out['ego_index']),
-        edge_count=ecount,
+        edge_count=ecount, n_agents_step=n_agents_step,
+        pred_type=out['pred_type'].numpy(), pred_shape=out['pred_shape'].numpy(),
     )
-    print(f'{name}: A\'={out["pos_a"].shape[0]} steps={nsteps} min margin={margin.min():.3e} '
+    os.environ['DEBUG'] = '0'
+    print(f'{name}: A\'={out["pos_a"].shape[0]} steps={nsteps} min margin={margin.min():.3e} agents/step={n_agents_step.tolist()} '
           f'edges(t,a,m) first/last={ecount[0].tolist()}/{ecount[-1].tolist()}')
 
 

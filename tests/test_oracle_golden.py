@@ -34,3 +34,31 @@ def test_quirk_last_ten_rows_have_no_temporal_edges():
     assert (z['edge_count'][:, 0] == 0).all()
     z = load_case('a24_m256_edge')['z']
     assert (z['edge_count'][:, 0] > 0).all()
+
+
+INSERTION_CASES = ['ins_forced_a16_m256', 'ins_natural_a20_m256']
+
+
+@pytest.mark.parametrize('case', INSERTION_CASES)
+def test_insertion_oracle_matches_reference_fixture(case):
+    """scenario insertion (agent_decoder.py:1773-2105): forced enter (DEBUG=1) and the natural seed head"""
+    from oracle import insertion_oracle as io
+    c = load_case(case)
+    z, m = c['z'], c['meta']
+    cfg = c['cfg']
+    cfg.disable_insertion = False
+    sd = {k: torch.from_numpy(v) for k, v in c['sd'].items()}
+    out = io.run_scene_with_insertion(sd, c['scene'], cfg, c['vocab'], c['map_vocab'], c['grid'],
+                                      force_enter=(m['insertion'] == 'forced'))
+    assert out['n_agents'].tolist() == z['n_agents_step'].tolist()          # same insertions at the same steps
+    assert out['n_agents'][-1] > out['n_agents'][0]
+    assert np.array_equal(out['next_token_idx'].numpy(), z['next_token_idx'])
+    assert np.array_equal(out['next_state_idx'].numpy(), z['next_state_idx'])
+    assert np.array_equal(out['agent_id'].numpy(), z['agent_id'])
+    assert np.array_equal(out['pred_type'].numpy(), z['pred_type'])
+    assert np.abs(out['pred_shape'].numpy() - z['pred_shape']).max() <= 1e-5
+    for i, l in enumerate(out['logits']):
+        assert np.abs(l.numpy() - z['logits'][i, :l.shape[0]]).max() <= 1e-5 * m['head_gain'] * 4
+    for k in ('pos_a', 'head_a', 'pred_traj', 'pred_head', 'pred_state'):
+        assert np.abs(out[k].numpy() - z[k]).max() <= 1e-4, k
+    assert np.array_equal(out['edge_count'], z['edge_count'])
