@@ -107,6 +107,9 @@ typedef struct InfgenRollout {
   const int* teacher_token; const int* teacher_state;   /* optional [S][T][A_cap] */
   /* outputs */
   float* pred_traj; float* pred_head; float* pred_state;   /* [S][A_cap][R](x2) */
+  /* scenario insertion (optional, NULL when unused): rows >= first_new[s] inserted in the current step use
+   * hv_ovr[s] as their head vector during the motion stage (agent_decoder.py:2083) */
+  const int* first_new; const float* hv_ovr;
 } InfgenRollout;
 
 int infgen_linear(const float* X, int ldx, const int* gather, int rows, int K,
@@ -138,6 +141,24 @@ int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless, void* stre
 int infgen_decode_step(const InfgenRollout* r, int t, void* stream);
 /* steps t0 .. t1-1 back to back (one host call per rollout) */
 int infgen_rollout_run(const InfgenRollout* r, int t0, int t1, void* stream);
+
+/* ---- scenario insertion (reference agent_decoder.py:1773-2105); the sub-loop is sequenced by the host ----
+ *   infgen_occupancy        one-hot sum of the grid tokens of column c (:1852-1854)
+ *   infgen_point_edges      _build_a2sa_edge / _build_map2sa_edge for one query point per scene (:760-904):
+ *                           first-K agents / map tokens (ascending index) within a radius of centre_row's pose
+ *   infgen_insert_decide    seed heads -> enter / type / shape / cell, occupied-cell rejection, row append (:1883-1999)
+ *   infgen_insert_finalize  heading token + xy offset of the new row (:2060-2074) */
+int infgen_occupancy(const InfgenRollout* r, int c, float* occ, void* stream);
+int infgen_point_edges(const InfgenRollout* r, int c, const int* centre_row, const int* active, int exclude_centre,
+                       int which /* bit0 agents, bit1 map */, float r_agent, int k_agent, float r_map, int k_map,
+                       const InfgenEdgeBuf* ea, const InfgenEdgeBuf* em, void* stream);
+int infgen_insert_decide(const InfgenRollout* r, int t, int force_enter, int max_new,
+                         const float* lg_state, const float* lg_type, const float* shape, const float* lg_pos,
+                         const float* occ, int* active, int* n_new, int* inserted, int* new_row, float* new_shape,
+                         int* new_cell, void* stream);
+int infgen_insert_finalize(const InfgenRollout* r, int c, float angle_interval, const int* inserted,
+                           const int* new_row, const float* lg_heading, int n_heading, const float* offset,
+                           float* hv_ovr, void* stream);
 
 /* ---- optional profiling (bench.py roofline leg; process-global, off by default) ----
  * HIP events are recorded on the launch stream around every launch of the kernels selected by

@@ -44,6 +44,7 @@ class Rollout(C.Structure):
         ('next_token', _p), ('next_state', _p), ('logits', _p),
         ('teacher_token', _p), ('teacher_state', _p),
         ('pred_traj', _p), ('pred_head', _p), ('pred_state', _p),
+        ('first_new', _p), ('hv_ovr', _p),
     ]
 
 
@@ -67,6 +68,10 @@ SYMBOLS = {
     'infgen_decode_layers': (_i, [C.POINTER(Rollout), _i, _i, _p]),
     'infgen_decode_step': (_i, [C.POINTER(Rollout), _i, _p]),
     'infgen_rollout_run': (_i, [C.POINTER(Rollout), _i, _i, _p]),
+    'infgen_occupancy': (_i, [C.POINTER(Rollout), _i, _p, _p]),
+    'infgen_point_edges': (_i, [C.POINTER(Rollout), _i, _p, _p, _i, _i, _f, _i, _f, _i, C.POINTER(EdgeBuf), C.POINTER(EdgeBuf), _p]),
+    'infgen_insert_decide': (_i, [C.POINTER(Rollout), _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'infgen_insert_finalize': (_i, [C.POINTER(Rollout), _i, _f, _p, _p, _p, _i, _p, _p, _p]),
     'infgen_prof_enable': (_i, [C.c_uint, _i]),
     'infgen_prof_collect': (_i, [C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]),
 }

@@ -231,6 +231,7 @@ static SceneState scene_of(const InfgenRollout* r) {
   st.pos = r->pos; st.head = r->head; st.state = r->state; st.token = r->token; st.grid = r->grid;
   st.tmask = r->tmask; st.imask = r->imask; st.catflag = r->catflag; st.type = r->type; st.bos = r->bos;
   st.map_pos = r->map_pos; st.map_orient = r->map_orient;
+  st.first_new = r->first_new; st.hv_ovr = r->hv_ovr;
   return st;
 }
 static EdgeBuf ebuf(const InfgenEdgeBuf& e) { return EdgeBuf{e.off, e.cnt, e.src, e.raw, e.total, e.cap}; }
@@ -347,4 +348,50 @@ extern "C" int infgen_decode_step(const InfgenRollout* r, int t, void* stream) {
 extern "C" int infgen_rollout_run(const InfgenRollout* r, int t0, int t1, void* stream) {
   for (int t = t0; t < t1; ++t) RET_IF(infgen_decode_step(r, t, stream));
   return 0;
+}
+
+// ---------------------------------------------------------------------------------- scenario insertion
+extern "C" int infgen_occupancy(const InfgenRollout* r, int c, float* occ, void* stream) {
+  RET_IF(validate(r, "infgen_occupancy"));
+  OccupancyArgs a{scene_of(r), c, r->grid_size, occ};
+  hipLaunchKernelGGL(k_occupancy, dim3(r->S), dim3(NT), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_occupancy");
+}
+
+extern "C" int infgen_point_edges(const InfgenRollout* r, int c, const int* centre_row, const int* active,
+                                  int exclude_centre, int which, float r_agent, int k_agent, float r_map, int k_map,
+                                  const InfgenEdgeBuf* ea, const InfgenEdgeBuf* em, void* stream) {
+  RET_IF(validate(r, "infgen_point_edges"));
+  hipStream_t s = (hipStream_t)stream;
+  if (((which & 1) && hipMemsetAsync(ea->total, 0, sizeof(int), s) != hipSuccess) ||
+      ((which & 2) && hipMemsetAsync(em->total, 0, sizeof(int), s) != hipSuccess))
+    return fail("infgen_point_edges", "memset failed");
+  PointEdgesArgs a{scene_of(r), c, centre_row, active, exclude_centre, which, r_agent, k_agent, r_map, k_map,
+                   ebuf(*ea), ebuf(*em)};
+  hipLaunchKernelGGL(k_point_edges, dim3(r->S), dim3(128), 0, s, a);
+  return check_launch("infgen_point_edges");
+}
+
+extern "C" int infgen_insert_decide(const InfgenRollout* r, int t, int force_enter, int max_new,
+                                    const float* lg_state, const float* lg_type, const float* shape, const float* lg_pos,
+                                    const float* occ, int* active, int* n_new, int* inserted, int* new_row,
+                                    float* new_shape, int* new_cell, void* stream) {
+  RET_IF(validate(r, "infgen_insert_decide"));
+  InsertDecideArgs a;
+  a.st = scene_of(r); a.c = 1 + t; a.t = t; a.R = r->R; a.grid_size = r->grid_size; a.force_enter = force_enter;
+  a.max_new = max_new; a.grid_xy = r->grid_xy; a.lg_state = lg_state; a.lg_type = lg_type; a.shape = shape;
+  a.lg_pos = lg_pos; a.occ = occ; a.n_agents = const_cast<int*>(r->n_agents); a.type = const_cast<int*>(r->type);
+  a.active = active; a.n_new = n_new; a.inserted = inserted; a.new_row = new_row; a.new_shape = new_shape;
+  a.new_cell = new_cell; a.pred_traj = r->pred_traj; a.pred_head = r->pred_head; a.pred_state = r->pred_state;
+  hipLaunchKernelGGL(k_insert_decide, dim3(r->S), dim3(64), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_insert_decide");
+}
+
+extern "C" int infgen_insert_finalize(const InfgenRollout* r, int c, float angle_interval, const int* inserted,
+                                      const int* new_row, const float* lg_heading, int n_heading, const float* offset,
+                                      float* hv_ovr, void* stream) {
+  RET_IF(validate(r, "infgen_insert_finalize"));
+  InsertFinalizeArgs a{scene_of(r), c, angle_interval, inserted, new_row, lg_heading, n_heading, offset, hv_ovr};
+  hipLaunchKernelGGL(k_insert_finalize, dim3(r->S), dim3(64), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_insert_finalize");
 }

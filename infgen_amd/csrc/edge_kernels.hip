@@ -191,6 +191,7 @@ __global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
     const float h = st.head[i];
     px[t] = st.pos[2 * i]; py[t] = st.pos[2 * i + 1];
     hd[t] = h; hc[t] = cosf(h); hs[t] = sinf(h);
+    if (st.first_new && t >= st.first_new[s] && t < A) { hc[t] = st.hv_ovr[2 * s]; hs[t] = st.hv_ovr[2 * s + 1]; }
     stt[t] = st.state[i];
     im[t] = (t < A) ? st.imask[i] : 0;
   }
@@ -552,6 +553,180 @@ __global__ __launch_bounds__(NT) void k_rawfeat_prep(RawFeatArgs a) {
   *reinterpret_cast<float4*>(f + 4 * c4) = *reinterpret_cast<const float4*>(tsrc + 4 * c4);
   *reinterpret_cast<float4*>(f + 256 + 4 * c4) = *reinterpret_cast<const float4*>(ssrc + 4 * c4);
   *reinterpret_cast<float4*>(f + 384 + 4 * c4) = *reinterpret_cast<const float4*>(gsrc + 4 * c4);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Scenario insertion (reference agent_decoder.py:1773-2105)
+// ------------------------------------------------------------------------------------------
+// k_point_edges: _build_a2sa_edge / _build_map2sa_edge for ONE query point per scene (:760-904).
+// wave 0: agents, wave 1: map tokens; two passes (count, reserve with one atomicAdd, write).
+__global__ __launch_bounds__(128) void k_point_edges(PointEdgesArgs a) {
+  const SceneState& st = a.st;
+  const int s = blockIdx.x, lane = lane_id(), w = wave_id();
+  const bool is_map = w == 1;
+  if (!((a.which >> (is_map ? 1 : 0)) & 1)) return;
+  EdgeBuf& eb = is_map ? a.em : a.ea;
+  const int c = a.c;
+  const bool on = a.active == nullptr || a.active[s] != 0;
+  const int A = st.n_agents[s];
+  const int N = is_map ? st.n_map[s] : A;
+  const int K = is_map ? a.k_map : a.k_agent;
+  const float r = is_map ? a.r_map : a.r_agent;
+  const float r2 = r * r;
+  const int crow = a.centre_row[s];
+  const size_t ic = sidx(st, s, c, crow);
+  const float cx = st.pos[2 * ic], cy = st.pos[2 * ic + 1], ch = st.head[ic];
+  const float ccs = cosf(ch), csn = sinf(ch);
+  const float* mp = st.map_pos + (size_t)s * st.M_cap * 2;
+  const float* mo = st.map_orient + (size_t)s * st.M_cap;
+  int kept = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    int found = 0, written = 0, e0 = 0;
+    if (pass == 1) {
+      e0 = kept > 0 ? __shfl(lane == 0 ? atomicAdd(eb.total, kept) : 0, 0, 64) : 0;
+      if (lane == 0) { eb.off[s] = e0; eb.cnt[s] = (e0 + kept <= eb.cap) ? kept : 0; }
+      if (kept == 0 || e0 + kept > eb.cap) break;
+    }
+    if (on) {
+      for (int j0 = 0; j0 < N && found < K; j0 += 64) {
+        const int j = j0 + lane;
+        bool in = false;
+        float px = 0.f, py = 0.f;
+        if (j < N) {
+          if (is_map) { px = mp[2 * j]; py = mp[2 * j + 1]; }
+          else { const size_t ij = sidx(st, s, c, j); px = st.pos[2 * ij]; py = st.pos[2 * ij + 1]; }
+          const float dx = cx - px, dy = cy - py;
+          in = (dx * dx + dy * dy) < r2;
+        }
+        const unsigned long long bal = __ballot(in);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        bool emit = in && (found + before < K);
+        if (emit && !is_map) {
+          emit = st.imask[sidx(st, s, c, j)] != 0 && !(a.exclude_centre && j == crow);
+        }
+        const unsigned long long ebal = __ballot(emit);
+        if (pass == 1 && emit) {
+          const int e = e0 + written + __popcll(ebal & ((1ull << lane) - 1ull));
+          const float dx = px - cx, dy = py - cy;
+          const float oh = is_map ? mo[j] : st.head[sidx(st, s, c, j)];
+          eb.src[e] = (is_map ? s * st.M_cap : s * st.A_cap) + j;
+          *reinterpret_cast<float4*>(eb.raw + 4 * (size_t)e) =
+              make_float4(norm2(dx, dy), angle_between(ccs, csn, dx, dy), wrap_angle(oh - ch), 0.f);
+        }
+        written += (int)__popcll(ebal);
+        found += (int)__popcll(bal);
+      }
+    }
+    if (pass == 0) kept = written;
+  }
+}
+
+// k_occupancy: one-hot sum of the grid tokens of column c (:1852-1854)
+__global__ __launch_bounds__(NT) void k_occupancy(OccupancyArgs a) {
+  const SceneState& st = a.st;
+  const int s = blockIdx.x;
+  float* o = a.occ + (size_t)s * a.grid_size;
+  for (int g = threadIdx.x; g < a.grid_size; g += NT) o[g] = 0.f;
+  __syncthreads();
+  const int A = st.n_agents[s];
+  if (threadIdx.x < A) {
+    const int g = st.grid[sidx(st, s, a.c, threadIdx.x)];
+    if (g >= 0) o[g] = 1.f;
+  }
+}
+
+// k_insert_decide: heads of the seed node -> enter? / type / shape / grid cell; occupied-cell
+// rejection; append the new row (:1883-1999).  One wave per scene.
+__global__ __launch_bounds__(64) void k_insert_decide(InsertDecideArgs a) {
+  const SceneState& st = a.st;
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int c = a.c;
+  if (!a.active[s]) { if (lane == 0) a.inserted[s] = 0; return; }
+  // arg-max of the position head (softmax is monotone; first index on ties)
+  const float* lp = a.lg_pos + (size_t)s * a.grid_size;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int g = lane; g < a.grid_size; g += 64) {
+    const float v = lp[g];
+    if (v > best) { best = v; bi = g; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane != 0) return;
+  const int cell = bi;
+  const float* ls = a.lg_state + 2 * s;
+  bool enter = ls[1] > ls[0];
+  if (a.force_enter) enter = true;
+  const float* lt = a.lg_type + 3 * s;
+  int ty = 0;
+  if (lt[1] > lt[ty]) ty = 1;
+  if (lt[2] > lt[ty]) ty = 2;
+  const bool occupied = a.occ[(size_t)s * a.grid_size + cell] != 0.f;
+  const int A = a.n_agents[s];
+  const bool ok = enter && !occupied && a.n_new[s] + 1 <= a.max_new && A < st.A_cap;
+  if (!ok) { a.inserted[s] = 0; a.active[s] = 0; return; }
+  const int av = st.av_index[s];
+  const size_t ie = sidx(st, s, c, av);
+  const float ex = st.pos[2 * ie], ey = st.pos[2 * ie + 1], eh = st.head[ie];
+  // decode_pos (attr_tokenizer.py:91-99): grid[cell] @ Rot(theta_ego - pi/2) + ego pos
+  const float phi = eh - HALF_PI_F;
+  const float cs = cosf(phi), sn = sinf(phi);
+  const float gx = a.grid_xy[2 * cell], gy = a.grid_xy[2 * cell + 1];
+  const float nx = (gx * cs + gy * (-sn)) + ex;
+  const float ny = (gx * sn + gy * cs) + ey;
+  const int row = s * st.A_cap + A;
+  for (int j = 0; j < st.T; ++j) {
+    const size_t i = sidx(st, s, j, A);
+    st.pos[2 * i] = 0.f; st.pos[2 * i + 1] = 0.f; st.head[i] = 0.f;
+    st.state[i] = INVALID; st.token[i] = -1; st.grid[i] = -1;
+    st.tmask[i] = 1; st.imask[i] = j >= c ? 1 : 0; st.catflag[i] = j >= c ? 1 : 0;
+  }
+  const size_t in_ = sidx(st, s, c, A);
+  st.pos[2 * in_] = nx; st.pos[2 * in_ + 1] = ny; st.head[in_] = eh;
+  st.state[in_] = ENTER; st.token[in_] = -2; st.grid[in_] = cell;
+  a.type[row] = ty;
+  st.bos[row] = c;
+  a.new_shape[3 * s] = a.shape[3 * s]; a.new_shape[3 * s + 1] = a.shape[3 * s + 1]; a.new_shape[3 * s + 2] = a.shape[3 * s + 2];
+  a.new_cell[s] = cell;
+  if (a.t > 0) {
+    for (int k = 0; k < 5; ++k) {
+      const size_t o = (size_t)row * a.R + (a.t - 1) * 5 + k;
+      a.pred_traj[2 * o] = nx; a.pred_traj[2 * o + 1] = ny;
+      a.pred_head[o] = eh; a.pred_state[o] = (float)ENTER;
+    }
+  }
+  a.n_agents[s] = A + 1;
+  a.n_new[s] += 1;
+  a.new_row[s] = row;
+  a.inserted[s] = 1;
+}
+
+// k_insert_finalize: heading token + xy offset of the new row (:2060-2074), head-vector override
+__global__ __launch_bounds__(64) void k_insert_finalize(InsertFinalizeArgs a) {
+  const SceneState& st = a.st;
+  const int s = blockIdx.x;
+  if (threadIdx.x != 0 || !a.inserted[s]) return;
+  const int row = a.new_row[s];
+  const int ag = row - s * st.A_cap;
+  const float* lh = a.lg_heading + (size_t)s * a.n_heading;
+  int bi = 0;
+  for (int k = 1; k < a.n_heading; ++k) if (lh[k] > lh[bi]) bi = k;
+  const size_t ie = sidx(st, s, a.c, st.av_index[s]);
+  const float eh = st.head[ie];
+  // decode_heading (attr_tokenizer.py:106-110): (idx * interval - 180) / 360 * 2 pi
+  const float dec = ((float)bi * a.angle_interval - 180.0f) / 360.0f * TWO_PI_F;
+  const float nh = wrap_angle(dec + eh);
+  const size_t in_ = sidx(st, s, a.c, ag);
+  st.head[in_] = nh;
+  st.pos[2 * in_] += tanhf(a.offset[2 * s]) * 2.0f;
+  st.pos[2 * in_ + 1] += tanhf(a.offset[2 * s + 1]) * 2.0f;
+  a.hv_ovr[2 * s] = cosf(nh);
+  a.hv_ovr[2 * s + 1] = sinf(nh);
 }
 
 }  // namespace ig

@@ -89,6 +89,10 @@ struct SceneState {
   int* bos;                         // [S][A_cap] first 'enter' column (0 if none)
   const float* map_pos;             // [S][M_cap][2]
   const float* map_orient;          // [S][M_cap]
+  // scenario insertion (optional, may be null): rows >= first_new[s] inserted in the current step carry
+  // the newest row's head vector during the motion stage (reference agent_decoder.py:2083, SURVEY a-Q13)
+  const int* first_new;             // [S]
+  const float* hv_ovr;              // [S][2]
 };
 
 struct EdgeBuf {                    // device-side builder outputs for one edge type
@@ -135,6 +139,53 @@ struct RawFeatArgs {
   float* fus_in;                    // [rows][512]
 };
 
+// edges into ONE query point per scene (insertion: the seed node at the ego pose, or a freshly
+// inserted row during its heading stage): first-K agents / map tokens within a radius of the
+// centre row's position, ascending index (torch_cluster.radius), filtered afterwards.
+struct PointEdgesArgs {
+  SceneState st;
+  int c;
+  const int* centre_row;            // [S] agent row whose column-c pose is the query point
+  const int* active;                // [S] 0: emit nothing for this scene
+  int exclude_centre;               // 1: the centre row is not a source (heading stage)
+  int which;                        // bit 0: agents, bit 1: map tokens
+  float r_agent; int k_agent;
+  float r_map; int k_map;
+  EdgeBuf ea, em;                   // one destination per scene: off[s], cnt[s]
+};
+
+struct OccupancyArgs { SceneState st; int c; int grid_size; float* occ; /* [S][grid_size] */ };
+
+struct InsertDecideArgs {
+  SceneState st;
+  int c, t, R, grid_size, force_enter, max_new;
+  const float* grid_xy;
+  const float* lg_state;            // [S][2]
+  const float* lg_type;             // [S][3]
+  const float* shape;               // [S][3]
+  const float* lg_pos;              // [S][grid_size]
+  const float* occ;                 // [S][grid_size]
+  int* n_agents;                    // [S] (mutable view of st.n_agents)
+  int* type;                        // [S][A_cap]
+  int* active;                      // [S] in/out
+  int* n_new;                       // [S] in/out
+  int* inserted;                    // [S] out
+  int* new_row;                     // [S] out (global row index s*A_cap + a)
+  float* new_shape;                 // [S][3] out
+  int* new_cell;                    // [S] out
+  float* pred_traj; float* pred_head; float* pred_state;
+};
+
+struct InsertFinalizeArgs {
+  SceneState st;
+  int c;
+  float angle_interval;
+  const int* inserted; const int* new_row;
+  const float* lg_heading; int n_heading;     // [S][n_heading]
+  const float* offset;                        // [S][2] (pre-tanh)
+  float* hv_ovr;                              // [S][2]
+};
+
 struct MapGraphArgs {
   int S, M_cap; const int* n_map;
   const float* pos; const float* orient; float radius; int max_nbr;
@@ -151,6 +202,10 @@ __global__ void k_build_edges(BuildEdgesArgs a);
 __global__ void k_integrate(IntegrateArgs a);
 __global__ void k_rawfeat_prep(RawFeatArgs a);
 __global__ void k_map_graph(MapGraphArgs a);
+__global__ void k_point_edges(PointEdgesArgs a);
+__global__ void k_occupancy(OccupancyArgs a);
+__global__ void k_insert_decide(InsertDecideArgs a);
+__global__ void k_insert_finalize(InsertFinalizeArgs a);
 __global__ void k_layernorm(const float* X, int rows, const float* g, const float* b, float* Y);
 
 }  // namespace ig

@@ -71,6 +71,17 @@ class PackedWeights:
         self.type_pt_emb = g(f'{mp}.type_pt_emb.weight')
         self.polygon_type_emb = g(f'{mp}.polygon_type_emb.weight')
         self.light_pl_emb = g(f'{mp}.light_pl_emb.weight')
+        # scenario insertion (agent_decoder.py:236-290)
+        self.attn_pt2sa = [dev(packing.pack_attention_layer(sd, f'{ap}.pt2sa_attn_layers.{i}')) for i in range(3)]
+        self.attn_a2sa = [dev(packing.pack_attention_layer(sd, f'{ap}.a2sa_attn_layers.{i}')) for i in range(3)]
+        self.attn_occ2sa = [dev(packing.pack_attention_layer(sd, f'{ap}.occ2sa_attn_layers.{i}', has_pos_emb=False))
+                            for i in range(3)]
+        self.four_pt2sa = dev(packing.pack_fourier(sd, f'{ap}.r_pt2sa_emb', 3))
+        self.four_a2sa = dev(packing.pack_fourier(sd, f'{ap}.r_a2sa_emb', 3))
+        self.heads = {k: dev(packing.pack_mlp_layer(sd, f'{ap}.{k}')) for k in
+                      ('seed_state_predict_head', 'seed_type_predict_head', 'seed_shape_predict_head',
+                       'seed_pos_rel_token_predict_head', 'seed_heading_rel_token_predict_head',
+                       'seed_offset_xy_predict_head', 'seed_agent_occ_embed')}
         self._tables = None
 
     def tables(self, ops: 'Ops', vocab_dev: torch.Tensor, grid_dev: torch.Tensor, map_vocab_dev: torch.Tensor):
@@ -92,7 +103,15 @@ class PackedWeights:
         seed_shape = ops.mlp_embedding(torch.full((1, 3), INVALID_SHAPE, device=dev), self.shape_emb, 3)
         cat_seed = (self.type_a_emb[SEED_TYPE] + seed_shape[0]).contiguous()
         map_tab = ops.mlp_embedding(map_vocab_dev, self.map_tok_emb, map_vocab_dev.shape[1])
-        self._tables = dict(tok_tab=tok_tab, grid_tab=grid_tab, cat_seed=cat_seed, map_tab=map_tab)
+        # the all-invalid seed query row (agent_decoder.py:1814-1818): a constant of the weights
+        raw = torch.tensor([[2.0 * 2.0 ** 0.5, -2.356194490192345, 0.0, 0.0]], device=dev)   # |(-2,-2)|, atan2(-2,-2)
+        fus = torch.zeros(1, 4 * D, device=dev)
+        fus[0, :D] = self.no_token[0]
+        fus[0, 2 * D:3 * D] = self.state_a_emb[0]
+        fus[0, 3 * D:] = grid_tab[G // 2]
+        ops.fourier(raw, 2, self.four_xa, fus[:, D:2 * D], cat=cat_seed[None].contiguous())
+        f_seed = ops.mlp_embedding(fus, self.fusion, 4 * D)
+        self._tables = dict(tok_tab=tok_tab, grid_tab=grid_tab, cat_seed=cat_seed, map_tab=map_tab, f_seed=f_seed)
         return self._tables
 
 
@@ -130,6 +149,14 @@ class Ops:
         h = self.linear(x, pack, o1, 128, k0, bias_off=o1 + k0p * 128, post_ln_off=o1 + k0p * 128 + 128, relu=True)
         h = self.linear(h, pack, o2, 128, 128, bias_off=o2 + 16384, post_ln_off=o2 + 16384 + 128, relu=True)
         return self.linear(h, pack, o3, 128, 128, bias_off=o3 + 16384, out=out)
+
+    def mlp_layer(self, x, pack, k0, n_out, out=None):
+        """MLPLayer.forward (reference infgen/modules/layers.py:214): pack = packing.pack_mlp_layer"""
+        k0p = _round_up(k0, 8)
+        o_b0 = k0p * 128
+        h = self.linear(x, pack, 0, 128, k0, bias_off=o_b0, post_ln_off=o_b0 + 128, relu=True)
+        o_w3 = o_b0 + 3 * 128
+        return self.linear(h, pack, o_w3, n_out, 128, bias_off=o_w3 + 128 * _round_up(n_out, 32), out=out)
 
     def fourier(self, raw, n, pack, out, count_dev=None, rows=None, cat=None, normalize=False):
         rows = raw.shape[0] if rows is None else rows
@@ -185,7 +212,8 @@ class RolloutEngine:
     def __init__(self, weights: PackedWeights, scenes: Sequence[Mapping], vocab: Mapping[str, np.ndarray],
                  map_vocab: np.ndarray, grid: np.ndarray, a_cap: Optional[int] = None, m_cap: Optional[int] = None,
                  store_logits: bool = False, live_state: bool = False,
-                 teacher: Optional[Sequence] = None, x_pt_override: Optional[Sequence] = None):
+                 teacher: Optional[Sequence] = None, x_pt_override: Optional[Sequence] = None,
+                 force_enter: bool = False, insert_headroom: Optional[int] = None):
         self.w = weights
         self.cfg = cfg = weights.cfg
         self.device = dev = weights.device
@@ -202,13 +230,18 @@ class RolloutEngine:
         self.store_logits = store_logits
         self._x_pt_override = x_pt_override
         self.force_valid = bool(cfg.disable_insertion) and not live_state
+        self.insertion = not cfg.disable_insertion
+        self.force_enter = force_enter
 
         # ------------------------------------------------ host-side scene setup
         hosts = [self._setup_scene(sc) for sc in scenes]
         self.hosts = hosts
         amax = max(h['A'] for h in hosts)
         mmax = max(h['M'] for h in hosts)
-        self.A_cap = A_cap = a_cap or _round_up(max(amax, 1), 32)
+        head = 0
+        if self.insertion:
+            head = insert_headroom if insert_headroom is not None else min(10 * cfg.num_decode_steps, 96)
+        self.A_cap = A_cap = a_cap or min(_round_up(max(amax + head, 1), 32), 256)
         self.M_cap = M_cap = m_cap or _round_up(max(mmax, 1), 32)
         assert amax <= A_cap <= self.lib.infgen_layout_query(_lib.Q_MAX_AGENTS) and A_cap % 32 == 0
         assert mmax <= M_cap
@@ -283,6 +316,7 @@ class RolloutEngine:
         self.x_pt = None
         self._ctx = None
         self._init = None
+        self.ins = None
         self._mg = None
         self._mg_checked = False
         self._map_nbr_cap = 40          # compacted pt<->pt edges per map token (grown on overflow)
@@ -355,8 +389,10 @@ class RolloutEngine:
         else:
             for k in self._STATE:
                 getattr(self, k).copy_(self._init[k])
+        for buf in (self.pred_traj, self.pred_head, self.pred_state):
+            buf.zero_()
 
-    _STATE = ('pos', 'head', 'state', 'token', 'gridtok', 'imask', 'catflag')
+    _STATE = ('pos', 'head', 'state', 'token', 'gridtok', 'imask', 'catflag', 'tmask', 'atype', 'bos', 'n_agents')
 
     def prologue(self, map_only: bool = False):
         """per-scene constants and the first columns: agent categorical embeddings, map encoder
@@ -434,6 +470,10 @@ class RolloutEngine:
         for i in range(cfg.num_agent_layers):
             ops.attn_pre(x_pt, w.attn_m[i], use_src_ln=True, k=self.mapK[i], v=self.mapV[i])
 
+        if self.insertion:
+            self._alloc_insertion()
+            for i in range(3):
+                ops.attn_pre(x_pt, w.attn_pt2sa[i], use_src_ln=True, k=self.ins['mapK'][i], v=self.ins['mapV'][i])
         if self._ctx is None:
             self._build_ctx()
         st = ops.stream
@@ -446,8 +486,155 @@ class RolloutEngine:
     def rollout(self):
         """one full pass of the hot path over the batch: prologue + every decode step"""
         self.prologue()
-        _lib.check(self.lib.infgen_rollout_run(C.byref(self._ctx), 0, self.cfg.num_decode_steps, self.ops.stream),
-                   'infgen_rollout_run')
+        self.run()
+
+    # ------------------------------------------------------------------ scenario insertion (host-sequenced)
+    def _alloc_insertion(self):
+        if self.ins is not None:
+            for k in ('n_new', 'active', 'inserted'):
+                self.ins[k].zero_()
+            self.ins['shape_all'].fill_(INVALID_SHAPE)
+            self.ins['first_new'].fill_(self.A_cap)
+            self.ins['inserted_rows'] = [[] for _ in range(self.S)]
+            return
+        dev, S, rows, A_cap, M_cap, G = self.device, self.S, self.rows, self.A_cap, self.M_cap, self.G
+        f = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.float32)
+        i32 = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.int32)
+
+        def ebuf(cap):
+            cap = max(cap, 32)
+            return dict(off=i32(S), cnt=i32(S), src=i32(cap), raw=f(cap, 4), rhat=f(cap, D), total=i32(1), cap=cap)
+        ar = torch.arange(S, device=dev, dtype=torch.int32)
+        self.ins = dict(
+            occ=f(S, G), Kocc=[f(S, D) for _ in range(3)], Vocc=[f(S, D) for _ in range(3)],
+            mapK=[f(S * M_cap, D) for _ in range(3)], mapV=[f(S * M_cap, D) for _ in range(3)],
+            Ksa=[f(rows, D) for _ in range(3)], Vsa=[f(rows, D) for _ in range(3)],
+            Kh=[f(rows, D) for _ in range(3)], Vh=[f(rows, D) for _ in range(3)],
+            Xc=f(rows, D), AGG0=f(rows, D), Z0=f(rows, 8 * D), SIG0=f(rows, 8),
+            XS=f(S, D), QS=f(S, D), US=f(S, 8 * D), AGGS=f(S, D), ZS=f(S, 8 * D), SIGS=f(S, 8),
+            ea_s=ebuf(S * A_cap), em_s=ebuf(S * min(M_cap, 2048)), ea_h=ebuf(S * 24), em_h=ebuf(S * 128),
+            occ_off=ar.clone(), occ_cnt=torch.ones(S, device=dev, dtype=torch.int32), occ_src=ar.clone(),
+            active=i32(S), n_new=i32(S), inserted=i32(S), new_row=i32(S), new_cell=i32(S), new_shape=f(S, 3),
+            first_new=torch.full((S,), A_cap, device=dev, dtype=torch.int32), hv_ovr=f(S, 2), shape_all=torch.full((rows, 3), INVALID_SHAPE, device=dev),
+            scene_base=(ar * A_cap).contiguous(), inserted_rows=[[] for _ in range(S)])
+
+    def _ebuf_struct(self, e):
+        b = _lib.EdgeBuf()
+        P = _lib.ptr
+        b.off, b.cnt, b.src, b.raw, b.rhat, b.total, b.cap = P(e['off']), P(e['cnt']), P(e['src']), P(e['raw']), P(e['rhat']), P(e['total']), e['cap']
+        return b
+
+    def _edgeless(self, x, pack, has_pos=True):
+        I = self.ins
+        self.ops.attn_post(x, pack, I['AGG0'], I['Z0'], I['SIG0'], has_pos=has_pos)
+
+    def _insert_step(self, t: int):
+        """the insertion sub-loop of decode step t (reference agent_decoder.py:1773-2105).
+        Arithmetic runs in the HIP kernels; the data-dependent loop is sequenced here with one host
+        sync per iteration (did any scene insert?)."""
+        ops, w, cfg, lib, I = self.ops, self.w, self.cfg, self.lib, self.ins
+        S, rows, G = self.S, self.rows, self.G
+        c = 1 + t
+        ctx = C.byref(self._ctx)
+        st = ops.stream
+        I['first_new'].copy_(self.n_agents)
+        I['active'].fill_(1)
+        I['n_new'].zero_()
+        ea_s, em_s, ea_h, em_h = (self._ebuf_struct(I[k]) for k in ('ea_s', 'em_s', 'ea_h', 'em_h'))
+        H = w.heads
+        f_seed = w._tables['f_seed']
+        for it in range(10):
+            # occupancy embedding and its K/V for the three occ2sa layers
+            _lib.check(lib.infgen_occupancy(ctx, c, _lib.ptr(I['occ']), st), 'infgen_occupancy')
+            occ_emb = ops.mlp_layer(I['occ'], H['seed_agent_occ_embed'], G, 128)
+            for i in range(3):
+                ops.attn_pre(occ_emb, w.attn_occ2sa[i], use_src_ln=True, k=I['Kocc'][i], v=I['Vocc'][i])
+            # edges into the seed node (ego pose): agents every iteration, map tokens once per step
+            which = 3 if it == 0 else 1
+            _lib.check(lib.infgen_point_edges(ctx, c, _lib.ptr(self.av), _lib.ptr(I['active']), 0, which,
+                                              float(cfg.pl2seed_radius), 300, float(cfg.pl2seed_radius), 2048,
+                                              C.byref(ea_s), C.byref(em_s), st), 'infgen_point_edges')
+            ops.fourier(I['ea_s']['raw'], 3, w.four_a2sa, I['ea_s']['rhat'], count_dev=I['ea_s']['total'],
+                        rows=I['ea_s']['cap'], normalize=True)
+            if it == 0:
+                ops.fourier(I['em_s']['raw'], 3, w.four_pt2sa, I['em_s']['rhat'], count_dev=I['em_s']['total'],
+                            rows=I['em_s']['cap'], normalize=True)
+            # agents pass every layer edgelessly; their K/V feed the a2sa layers (A.6(a))
+            Xc = I['Xc']
+            Xc.copy_(self.X)
+            for i in range(3):
+                self._edgeless(Xc, w.attn_occ2sa[i], has_pos=False)
+                self._edgeless(Xc, w.attn_pt2sa[i])
+                ops.attn_pre(Xc, w.attn_a2sa[i], k=I['Ksa'][i], v=I['Vsa'][i])
+                self._edgeless(Xc, w.attn_a2sa[i])
+            # the seed node
+            XS = I['XS']
+            XS.copy_(f_seed.expand(S, D))
+            for i in range(3):
+                ops.attn_pre(XS, w.attn_occ2sa[i], q=I['QS'])
+                ops.edge_attn(S, I['QS'], None, I['Kocc'][i], I['Vocc'][i], I['occ_off'], I['occ_cnt'], I['occ_src'], None,
+                              I['AGGS'], None, I['SIGS'])
+                ops.attn_post(XS, w.attn_occ2sa[i], I['AGGS'], I['ZS'], I['SIGS'], has_pos=False)
+                ops.attn_pre(XS, w.attn_pt2sa[i], q=I['QS'], u=I['US'])
+                ops.edge_attn(S, I['QS'], I['US'], I['mapK'][i], I['mapV'][i], I['em_s']['off'], I['em_s']['cnt'],
+                              I['em_s']['src'], I['em_s']['rhat'], I['AGGS'], I['ZS'], I['SIGS'])
+                ops.attn_post(XS, w.attn_pt2sa[i], I['AGGS'], I['ZS'], I['SIGS'])
+                ops.attn_pre(XS, w.attn_a2sa[i], q=I['QS'], u=I['US'])
+                ops.edge_attn(S, I['QS'], I['US'], I['Ksa'][i], I['Vsa'][i], I['ea_s']['off'], I['ea_s']['cnt'],
+                              I['ea_s']['src'], I['ea_s']['rhat'], I['AGGS'], I['ZS'], I['SIGS'])
+                ops.attn_post(XS, w.attn_a2sa[i], I['AGGS'], I['ZS'], I['SIGS'])
+            lg_state = ops.mlp_layer(XS, H['seed_state_predict_head'], 128, 2)
+            lg_type = ops.mlp_layer(XS, H['seed_type_predict_head'], 128, 3)
+            shape = ops.mlp_layer(XS, H['seed_shape_predict_head'], 128, 3)
+            lg_pos = ops.mlp_layer(XS, H['seed_pos_rel_token_predict_head'], 128, G)
+            _lib.check(lib.infgen_insert_decide(ctx, t, int(self.force_enter), 10, _lib.ptr(lg_state), _lib.ptr(lg_type),
+                                                _lib.ptr(shape), _lib.ptr(lg_pos), _lib.ptr(I['occ']), _lib.ptr(I['active']),
+                                                _lib.ptr(I['n_new']), _lib.ptr(I['inserted']), _lib.ptr(I['new_row']),
+                                                _lib.ptr(I['new_shape']), _lib.ptr(I['new_cell']), st),
+                       'infgen_insert_decide')
+            ins = I['inserted'].bool()
+            ins_host = ins.cpu().numpy()                 # host sync: did any scene insert?
+            if not ins_host.any():
+                break
+            nr = I['new_row'][ins].long()
+            for s_i, r_i in zip(np.nonzero(ins_host)[0], nr.cpu().numpy()):
+                I['inserted_rows'][int(s_i)].append(int(r_i))
+            # categorical embedding / shape of the new rows (agent_decoder.py:1949-1950,1993)
+            shp = ops.mlp_embedding(I['new_shape'], w.shape_emb, 3)
+            self.cat_agent[nr] = w.type_a_emb[self.atype.reshape(-1)[nr].long()] + shp[ins]
+            I['shape_all'][nr] = I['new_shape'][ins]
+            _lib.check(lib.infgen_raw_feature(ctx, c, st), 'raw_feature')
+            # heading stage: the new row attends agents / map tokens within 10 m through the motion layers 0..2
+            new_local = (I['new_row'] - I['scene_base']).clamp_(0, self.A_cap - 1).contiguous()
+            _lib.check(lib.infgen_point_edges(ctx, c, _lib.ptr(new_local), _lib.ptr(I['inserted']), 1, 3,
+                                              float(cfg.a2sa_radius), 24, float(cfg.pl2sa_radius), 128,
+                                              C.byref(ea_h), C.byref(em_h), st), 'infgen_point_edges')
+            ops.fourier(I['ea_h']['raw'], 3, w.four_a, I['ea_h']['rhat'], count_dev=I['ea_h']['total'],
+                        rows=I['ea_h']['cap'], normalize=True)
+            ops.fourier(I['em_h']['raw'], 3, w.four_m, I['em_h']['rhat'], count_dev=I['em_h']['total'],
+                        rows=I['em_h']['cap'], normalize=True)
+            Xc.copy_(self.X)
+            for i in range(3):
+                self._edgeless(Xc, w.attn_m[i])
+                ops.attn_pre(Xc, w.attn_a[i], k=I['Kh'][i], v=I['Vh'][i])
+                self._edgeless(Xc, w.attn_a[i])
+            XN = self.X[I['new_row'].long().clamp(0, rows - 1)].contiguous()
+            for i in range(3):
+                ops.attn_pre(XN, w.attn_m[i], q=I['QS'], u=I['US'])
+                ops.edge_attn(S, I['QS'], I['US'], self.mapK[i], self.mapV[i], I['em_h']['off'], I['em_h']['cnt'],
+                              I['em_h']['src'], I['em_h']['rhat'], I['AGGS'], I['ZS'], I['SIGS'])
+                ops.attn_post(XN, w.attn_m[i], I['AGGS'], I['ZS'], I['SIGS'])
+                ops.attn_pre(XN, w.attn_a[i], q=I['QS'], u=I['US'])
+                ops.edge_attn(S, I['QS'], I['US'], I['Kh'][i], I['Vh'][i], I['ea_h']['off'], I['ea_h']['cnt'],
+                              I['ea_h']['src'], I['ea_h']['rhat'], I['AGGS'], I['ZS'], I['SIGS'])
+                ops.attn_post(XN, w.attn_a[i], I['AGGS'], I['ZS'], I['SIGS'])
+            n_head = int(360.0 / cfg.angle_interval)
+            lg_heading = ops.mlp_layer(XN, H['seed_heading_rel_token_predict_head'], 128, n_head)
+            offset = ops.mlp_layer(XN, H['seed_offset_xy_predict_head'], 128, 2)
+            _lib.check(lib.infgen_insert_finalize(ctx, c, float(cfg.angle_interval), _lib.ptr(I['inserted']),
+                                                  _lib.ptr(I['new_row']), _lib.ptr(lg_heading), n_head, _lib.ptr(offset),
+                                                  _lib.ptr(I['hv_ovr']), st), 'infgen_insert_finalize')
+            _lib.check(lib.infgen_raw_feature(ctx, c, st), 'raw_feature')
 
     def _build_ctx(self):
         cfg, w = self.cfg, self.w
@@ -478,6 +665,8 @@ class RolloutEngine:
         c.next_token, c.next_state, c.logits = P(self.next_token), P(self.next_state), P(self.logits)
         c.teacher_token, c.teacher_state = P(self.teacher_token), P(self.teacher_state)
         c.pred_traj, c.pred_head, c.pred_state = P(self.pred_traj), P(self.pred_head), P(self.pred_state)
+        if self.insertion:
+            c.first_new, c.hv_ovr = P(self.ins['first_new']), P(self.ins['hv_ovr'])
         self._ctx = c
 
     # ------------------------------------------------------------------ rollout
@@ -485,13 +674,21 @@ class RolloutEngine:
         if not self._prologue_done:
             self.prologue()
         t1 = self.cfg.num_decode_steps if t1 is None else t1
-        _lib.check(self.lib.infgen_rollout_run(C.byref(self._ctx), t0, t1, self.ops.stream), 'infgen_rollout_run')
+        if not self.insertion:
+            _lib.check(self.lib.infgen_rollout_run(C.byref(self._ctx), t0, t1, self.ops.stream), 'infgen_rollout_run')
+            return
+        for t in range(t0, t1):
+            if t > 0:
+                self._insert_step(t)
+            self.step(t)
 
     def step(self, t: int):
         _lib.check(self.lib.infgen_decode_step(C.byref(self._ctx), t, self.ops.stream), 'infgen_decode_step')
 
     # ------------------------------------------------------------------ outputs (reference :2303-2389)
     def outputs(self) -> List[Dict[str, np.ndarray]]:
+        """the reference's return dict per scene (agent_decoder.py:2303-2389); rows appended by the
+        insertion loop follow the initial ones like in the reference"""
         torch.cuda.synchronize(self.device)
         cfg, hc, H = self.cfg, self.hc, self.cfg.num_historical_steps
         pos, head = self.pos.cpu().numpy(), self.head.cpu().numpy()
@@ -500,9 +697,14 @@ class RolloutEngine:
         logits = self.logits.cpu().numpy() if self.logits is not None else None
         x_pt = self.x_pt.cpu().numpy() if self.x_pt is not None else None
         tabs = self.vocab.cpu().numpy()
+        n_fin = self.n_agents.cpu().numpy()
+        atype_dev = self.atype.cpu().numpy()
+        bos_dev = self.bos.cpu().numpy()
+        shape_all = self.ins['shape_all'].cpu().numpy().reshape(self.S, self.A_cap, 3) if self.ins is not None else None
         outs = []
         for s, h in enumerate(self.hosts):
-            A, M = h['A'], h['M']
+            A0, M = h['A'], h['M']
+            A = int(n_fin[s])
             sc = self.scenes[s]['agent']
             filt = h['filt']
             pos_a = pos[s, :, :A].transpose(1, 0, 2).copy()
@@ -510,34 +712,41 @@ class RolloutEngine:
             nstate = state[s, :, :A].T.astype(np.int64)
             ntok = token[s, :, :A].T.astype(np.int64)
             # history columns of next_token_idx / next_state_idx are the *input* tokens (:1733-1735)
-            ntok[:, :hc] = np.asarray(sc['token_idx'])[filt][:, :hc]
-            nstate[:, :hc] = np.asarray(sc['state_idx'])[filt][:, :hc]
-            R = self.R
+            ntok[:A0, :hc] = np.asarray(sc['token_idx'])[filt][:, :hc]
+            nstate[:A0, :hc] = np.asarray(sc['state_idx'])[filt][:, :hc]
+            for a in range(A0, A):                      # inserted rows: no token up to and including bos (:2303-2305)
+                ntok[a, :bos_dev[s, a] + 1] = -1
             pt = np.concatenate([np.zeros((A, H, 2), np.float32), ptraj[s, :A]], axis=1)
             ph = np.concatenate([np.zeros((A, H), np.float32), phead[s, :A]], axis=1)
             ps = np.concatenate([np.zeros((A, H), np.float32), pstate[s, :A]], axis=1)
-            pt[:, 0] = np.asarray(sc['position'])[filt][:, 0, :2]
-            ph[:, 0] = np.asarray(sc['heading'])[filt][:, 0]
-            ps[:, 1:H] = np.repeat(np.asarray(sc['state_idx'])[filt][:, :hc], cfg.shift, axis=1)
+            pt[:A0, 0] = np.asarray(sc['position'])[filt][:, 0, :2]
+            ph[:A0, 0] = np.asarray(sc['heading'])[filt][:, 0]
+            ps[:A0, 1:H] = np.repeat(np.asarray(sc['state_idx'])[filt][:, :hc], cfg.shift, axis=1)
             htok = np.asarray(sc['token_idx'])[filt][:, :hc].astype(np.int64).copy()
             htok[htok < 0] = 0
-            atype = h['type']
-            hcont = tabs[atype[:, None], htok]                      # (A, hc, 6, 4, 2)
-            th = head_a[:, 0].astype(np.float32)
+            atype0 = h['type']
+            hcont = tabs[atype0[:, None], htok]                      # (A0, hc, 6, 4, 2)
+            th = head_a[:A0, 0].astype(np.float32)
             cs, sn = np.cos(th)[:, None, None, None], np.sin(th)[:, None, None, None]
             x, y = hcont[..., 0], hcont[..., 1]
-            hx = x * cs - y * sn + pos_a[:, 0, 0][:, None, None, None]
-            hy = x * sn + y * cs + pos_a[:, 0, 1][:, None, None, None]
-            pt[:, 1:H, 0] = hx[:, :, 1:].mean(axis=3).reshape(A, -1)
-            pt[:, 1:H, 1] = hy[:, :, 1:].mean(axis=3).reshape(A, -1)
-            ph[:, 1:H] = np.arctan2(hy[:, :, 1:, 0] - hy[:, :, 1:, 3], hx[:, :, 1:, 0] - hx[:, :, 1:, 3]).reshape(A, -1)
+            hx = x * cs - y * sn + pos_a[:A0, 0, 0][:, None, None, None]
+            hy = x * sn + y * cs + pos_a[:A0, 0, 1][:, None, None, None]
+            pt[:A0, 1:H, 0] = hx[:, :, 1:].mean(axis=3).reshape(A0, -1)
+            pt[:A0, 1:H, 1] = hy[:, :, 1:].mean(axis=3).reshape(A0, -1)
+            ph[:A0, 1:H] = np.arctan2(hy[:, :, 1:, 0] - hy[:, :, 1:, 3], hx[:, :, 1:, 0] - hx[:, :, 1:, 3]).reshape(A0, -1)
+            atype = atype_dev[s, :A].astype(np.int64)
             eval_shape = np.asarray([[4.3, 1.8, 1.0], [0.5, 0.5, 1.0], [1.9, 0.5, 1.0]], np.float32)[atype]
-            o = dict(ego_index=h['av'], agent_id=np.asarray(sc['id'])[filt].copy(), valid_mask=h['valid'],
+            ids0 = np.asarray(sc['id'])[filt]
+            ids = np.concatenate([ids0, ids0.max() + 1 + np.arange(A - A0, dtype=ids0.dtype)])
+            pshape = np.asarray(sc['shape'])[filt][:, hc - 1].astype(np.float32)
+            if A > A0:
+                pshape = np.concatenate([pshape, shape_all[s, A0:A]])
+            o = dict(ego_index=h['av'], agent_id=ids, valid_mask=h['valid'],
                      pos_a=pos_a, head_a=head_a, pred_traj=pt, pred_head=ph, pred_state=ps,
-                     pred_valid=(ps != INVALID) & (ps != ENTER), pred_type=atype.copy(),
-                     pred_shape=np.asarray(sc['shape'])[filt][:, hc - 1].astype(np.float32), eval_shape=eval_shape,
+                     pred_valid=(ps != INVALID) & (ps != ENTER), pred_type=atype,
+                     pred_shape=pshape, eval_shape=eval_shape,
                      pred_z=np.zeros_like(ph), next_token_idx=ntok, next_state_idx=nstate,
-                     gt_traj=np.asarray(sc['position'])[filt][:, H:, :2].copy())
+                     gt_traj=np.asarray(sc['position'])[filt][:, H:, :2].copy(), num_inserted=A - A0)
             if logits is not None:
                 o['logits'] = logits[:, s * self.A_cap:s * self.A_cap + A].copy()
             if x_pt is not None:
@@ -546,5 +755,6 @@ class RolloutEngine:
         return outs
 
     def agent_steps(self) -> int:
-        """agent-steps (10 Hz) decoded by a full rollout of this batch."""
+        """agent-steps (10 Hz) decoded by a full rollout of this batch; rows inserted
+        during the rollout are not counted (lower bound)."""
         return int(sum(h['A'] for h in self.hosts)) * self.R

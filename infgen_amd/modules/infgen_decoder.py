@@ -110,9 +110,6 @@ class InfGenDecoder(nn.Module):
     # ------------------------------------------------------------------ driver
     def _run(self, data, x_pt=None, map_only=False, batch: Optional[Sequence] = None):
         ae = self.agent_encoder
-        if not map_only and not ae.disable_insertion:
-            raise NotImplementedError('scenario insertion (agent_decoder.py:1773-2105) is not implemented in the HIP '
-                                      'path yet: construct with disable_insertion=True')
         datas = list(batch) if batch is not None else [data]
         scenes = [scene_from_data(d) for d in datas]
         w = self._weights()
@@ -126,7 +123,10 @@ class InfGenDecoder(nn.Module):
         xo = None
         if x_pt is not None:
             xo = [x_pt] if batch is None else list(x_pt)
-        eng = RolloutEngine(w, scenes, vocab, map_vocab, grid, x_pt_override=xo)
+        import os
+        w.cfg.disable_insertion = bool(ae.disable_insertion)
+        eng = RolloutEngine(w, scenes, vocab, map_vocab, grid, x_pt_override=xo,
+                            force_enter=bool(int(os.getenv('DEBUG', 0))))    # DEBUG=1 forces 'enter' (agent_decoder.py:1888)
         if map_only:
             eng.prologue(map_only=True)
             return eng.x_pt[:eng.hosts[0]['M']].clone()
@@ -145,7 +145,8 @@ class InfGenDecoder(nn.Module):
                      grid_agent_occ_seed=z(11, steps, G), grid_pt_occ_seed=z(11, steps, G),
                      grid_agent_occ_gt_seed=z(11, steps, G),
                      agent_labels=[[None] * w.cfg.num_columns for _ in range(o['pos_a'].shape[0])],
-                     log_message='No agents inserted!')
+                     log_message=('No agents inserted!' if o['num_inserted'] == 0 else
+                                  f"Number of total inserted agents: {o['num_inserted']}"))
             # the callee mutates data['batch_size_a'] like the reference (agent_decoder.py:1649)
             try:
                 filt = eng.hosts[len(res)]['filt']

@@ -76,14 +76,22 @@ def test_inference_batch_equals_single():
     assert torch.equal(outs[1]['next_token_idx'], single['next_token_idx'])
 
 
-def test_insertion_not_silently_ignored():
-    c = load_case('c1_a8_m128')
+def test_infgen_decoder_inference_with_insertion(monkeypatch):
+    """disable_insertion=False through the module API; DEBUG=1 forces 'enter' like the reference"""
+    c = load_case('ins_forced_a16_m256')
+    z = c['z']
+    monkeypatch.setenv('DEBUG', '1')
     dev = torch.device('cuda:0')
-    dec = _decoder(c['cfg'])
+    cfg = c['cfg']
+    dec = _decoder(cfg)
     dec.agent_encoder.disable_insertion = False
-    dec = dec.to(dev)
-    with pytest.raises(NotImplementedError):
-        dec.inference(_to_data(c['scene'], dev))
+    _load(dec, c['sd'])
+    dec = dec.to(dev).eval()
+    out = dec.inference(_to_data(c['scene'], dev))
+    assert out['pos_a'].shape[0] == z['pos_a'].shape[0] == 36
+    assert np.array_equal(out['next_token_idx'].cpu().numpy(), z['next_token_idx'])
+    assert np.array_equal(out['agent_id'].cpu().numpy(), z['agent_id'])
+    assert 'inserted' in out['log_message']
 
 
 def test_operator_modules_match_oracle():

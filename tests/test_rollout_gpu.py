@@ -106,3 +106,38 @@ def test_rollout_vs_oracle_fresh_seed():
         assert np.array_equal(o['next_token_idx'], ref['next_token_idx'].numpy())
     assert np.abs(o['logits'][0] - lg[0]).max() <= tol
     assert np.array_equal(o['next_token_idx'][:, :3], ref['next_token_idx'].numpy()[:, :3])
+
+
+@pytest.mark.parametrize('name', ['ins_forced_a16_m256', 'ins_natural_a20_m256'])
+def test_insertion_rollout_matches_reference_fixture(name):
+    """scenario insertion (agent_decoder.py:1773-2105): same agents inserted at the same steps with the same
+    cells / types / headings as the reference, tokens bit-exact, logits within tolerance"""
+    from infgen_amd import engine
+    c = load_case(name)
+    z, m = c['z'], c['meta']
+    cfg = c['cfg']
+    cfg.disable_insertion = False
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], cfg, dev)
+    eng = engine.RolloutEngine(w, [c['scene']], c['vocab'], c['map_vocab'], c['grid'], store_logits=True,
+                               force_enter=(m['insertion'] == 'forced'))
+    eng.rollout()
+    o = eng.outputs()[0]
+    assert o['pos_a'].shape[0] == z['pos_a'].shape[0], (o['pos_a'].shape, z['pos_a'].shape)
+    assert np.array_equal(o['next_state_idx'], z['next_state_idx'])
+    assert np.array_equal(o['next_token_idx'], z['next_token_idx'])
+    assert np.array_equal(o['agent_id'], z['agent_id'])
+    assert np.array_equal(o['pred_type'], z['pred_type'])
+    assert np.abs(o['pred_shape'] - z['pred_shape']).max() <= 1e-4
+    tol = 1e-3 * max(1.0, m['head_gain'] / 16)
+    for i, n in enumerate(z['n_agents_step']):
+        assert np.abs(o['logits'][i, :n] - z['logits'][i, :n]).max() <= tol, i
+    assert np.abs(o['pos_a'] - z['pos_a']).max() <= 1e-3
+    assert np.abs(o['head_a'] - z['head_a']).max() <= 1e-4
+    assert np.abs(o['pred_traj'] - z['pred_traj']).max() <= 1e-3
+    assert np.abs(o['pred_head'] - z['pred_head']).max() <= 1e-4
+    assert np.array_equal(o['pred_state'], z['pred_state'])
+    # a second rollout of the same engine (state reset) reproduces the first
+    eng.rollout()
+    o2 = eng.outputs()[0]
+    assert np.array_equal(o2['next_token_idx'], o['next_token_idx'])
