@@ -54,6 +54,14 @@ def cpu_baseline(cfg, sd, scene, vocab, map_vocab, grid, budget_s=20.0):
     """The CPU oracle (a port of the reference algorithm, column-wise) timed on this host's cores
     on a bounded sample: whole rollouts of ONE scene of the same workload until ~budget_s."""
     from oracle import rollout_oracle as ro
+    if not cfg.disable_insertion:
+        from oracle import insertion_oracle as io
+
+        class _Shim:      # same call shape as rollout_oracle.run_scene
+            @staticmethod
+            def run_scene(tsd, scene, cfg_, vocab_, map_vocab_, grid_):
+                return io.run_scene_with_insertion(tsd, scene, cfg_, vocab_, map_vocab_, grid_)
+        ro = _Shim
     # torch's intra-op pool degrades badly beyond a few dozen threads on these small operators
     # (256 hardware threads on the GPU box): use 16 and say so in `cores`.
     ncores = min(os.cpu_count() or 1, 16)
@@ -87,6 +95,8 @@ def main():
     ap.add_argument('--scenes', type=int, default=256, help='scenes per GPU')
     ap.add_argument('--agents', type=int, default=64)
     ap.add_argument('--map-tokens', type=int, default=1024)
+    ap.add_argument('--insertion', action='store_true', help='scenario insertion on (configs/ours_long_term.yaml style)')
+    ap.add_argument('--rollout-steps', type=int, default=80, help='R = num_recurrent_steps_val (multiple of 5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
@@ -105,7 +115,7 @@ def main():
     dev = torch.device('cuda', local_rank)
 
     log(f'cpu_count={os.cpu_count()} device={torch.cuda.get_device_name(dev)}')
-    cfg = synth.standard_config(disable_insertion=True)
+    cfg = synth.standard_config(disable_insertion=not args.insertion, num_recurrent_steps_val=args.rollout_steps)
     sd = synth.fill_state_dict(load_shapes(), seed=1, rich=True)
     first = igdist.scenes_for_rank_weak(rank, args.scenes)[0]
     scenes, vocab, map_vocab, grid = build_scenes(cfg, args.scenes, args.agents, args.map_tokens, first)
@@ -156,6 +166,7 @@ def main():
                 'per_kernel_ms_one_rollout': {k: round(v['ms'], 3) for k, v in per_kernel.items()}}
 
     agent_steps = float(eng.agent_steps() * args.steps)
+    inserted = int((eng.n_agents.sum().item() - sum(h['A'] for h in eng.hosts))) if args.insertion else 0
     dt, agent_steps = igdist.reduce_run(dt, agent_steps, dev)
     if rank == 0:
         line = {
@@ -173,10 +184,11 @@ def main():
             'data': 'synthetic',
             'config': {
                 'workload': f'C3 shapes: configs/ours_standard.yaml, {args.agents} agents / {args.map_tokens} map tokens '
-                            f'per scene, R=80 (16 decode steps), greedy, insertion disabled, '
+                            f'per scene, R={args.rollout_steps} ({cfg.num_decode_steps} decode steps), greedy, '
+                            f'insertion {"on" if args.insertion else "disabled"}, '
                             f'{args.scenes} scenes per GPU, one step = reset + map encoder + full rollout',
                 'scenes_per_gpu': args.scenes, 'agents': args.agents, 'map_tokens': args.map_tokens,
-                'decode_steps': cfg.num_decode_steps, 'agent_token_steps_per_s': agent_steps / dt / cfg.shift,
+                'decode_steps': cfg.num_decode_steps, 'insertion': bool(args.insertion), 'agents_inserted_last_rollout': inserted, 'agent_token_steps_per_s': agent_steps / dt / cfg.shift,
                 'parallelism': f'scenes sharded over {world} rank(s), no data-path collective',
             },
             'roofline': roof,

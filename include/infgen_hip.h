@@ -127,6 +127,9 @@ int infgen_edge_attn(int rows, const float* Q, const float* U, const float* Ksrc
                      float* AGG, float* Z, float* SIG, void* stream);
 int infgen_attn_post(float* X, int rows, const float* pack, const float* AGG, const float* Z, const float* SIG,
                      int has_pos, void* stream);
+/* infgen_attn_post followed, on the same rows, by the NEXT layer's infgen_attn_pre (one launch) */
+int infgen_attn_post_pre(float* X, int rows, const float* pack, const float* AGG, const float* Z, const float* SIG,
+                         int has_pos, const float* next_pack, float* nQ, float* nU, float* nK, float* nV, void* stream);
 int infgen_heads(const float* X, int rows, const float* tok_pack, const float* st_pack, int token_size,
                  float* logits, int* next_token, int* next_state, void* stream);
 /* compacted CSR: `total` (device int) receives the edge count; rows whose edges would exceed `cap`

@@ -60,6 +60,7 @@ SYMBOLS = {
     'infgen_attn_pre': (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p]),
     'infgen_edge_attn': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'infgen_attn_post': (_i, [_p, _i, _p, _p, _p, _p, _i, _p]),
+    'infgen_attn_post_pre': (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
     'infgen_heads': (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _p]),
     'infgen_map_graph': (_i, [_i, _i, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _i, _p]),
     'infgen_build_edges': (_i, [C.POINTER(Rollout), _i, _i, _p]),

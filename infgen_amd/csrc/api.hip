@@ -192,11 +192,26 @@ extern "C" int infgen_edge_attn(int rows, const float* Q, const float* U, const 
   return check_launch("infgen_edge_attn");
 }
 
+static int attn_post_fused(float* X, int rows, const float* pack, const float* AGG, const float* Z, const float* SIG,
+                           int has_pos, const float* next_pack, float* nQ, float* nU, float* nK, float* nV, void* stream);
+
 extern "C" int infgen_attn_post(float* X, int rows, const float* pack, const float* AGG, const float* Z,
                                 const float* SIG, int has_pos, void* stream) {
+  return attn_post_fused(X, rows, pack, AGG, Z, SIG, has_pos, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int infgen_attn_post_pre(float* X, int rows, const float* pack, const float* AGG, const float* Z,
+                                    const float* SIG, int has_pos, const float* next_pack, float* nQ, float* nU,
+                                    float* nK, float* nV, void* stream) {
+  return attn_post_fused(X, rows, pack, AGG, Z, SIG, has_pos, next_pack, nQ, nU, nK, nV, stream);
+}
+
+static int attn_post_fused(float* X, int rows, const float* pack, const float* AGG, const float* Z, const float* SIG,
+                           int has_pos, const float* next_pack, float* nQ, float* nU, float* nK, float* nV, void* stream) {
   if (rows <= 0) return 0;
-  AttnPostArgs a{X, rows, pack, AGG, Z, SIG, has_pos};
-  { ProfScope _ps(INFGEN_KID_ATTN_POST, stream, (double)rows * (196608.0 + (has_pos ? 16384.0 : 0.0)));
+  AttnPostArgs a{X, rows, pack, AGG, Z, SIG, has_pos, next_pack, nQ, nU, nK, nV};
+  { ProfScope _ps(INFGEN_KID_ATTN_POST, stream, (double)rows * (196608.0 + (has_pos ? 16384.0 : 0.0) +
+        (next_pack ? 16384.0 * ((nQ || nU ? 1 : 0) + (nK ? 1 : 0) + (nV ? 1 : 0) + (nU ? 1 : 0)) : 0.0)));
     hipLaunchKernelGGL(k_attn_post, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_attn_post");
 }
@@ -311,22 +326,30 @@ extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless,
     RET_IF(infgen_fourier_embed(r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, stream));
   }
   const size_t slot = (size_t)(c % r->ring) * rows * D;
-  for (int i = 0; i < r->num_layers; ++i) {
-    // temporal: K/V of this column go to the ring (they are the cached layer inputs' projections)
-    RET_IF(infgen_attn_pre(r->X, rows, r->attn_t[i], 0, r->Q, r->U, r->ringK[i] + slot, r->ringV[i] + slot, stream));
+  const int L = r->num_layers;
+  // prologue of the first (temporal) layer; every later layer's prologue is fused into the previous
+  // layer's k_attn_post
+  RET_IF(infgen_attn_pre(r->X, rows, r->attn_t[0], 0, r->Q, r->U, r->ringK[0] + slot, r->ringV[0] + slot, stream));
+  for (int i = 0; i < L; ++i) {
+    // temporal: K/V of this column sit in the ring (they are the cached layer inputs' projections)
     RET_IF(infgen_edge_attn(rows, r->Q, r->U, r->ringK[i], r->ringV[i], r->et.off, r->et.cnt, r->et.src, r->et.rhat,
                             r->AGG, r->Z, r->SIG, stream));
-    RET_IF(infgen_attn_post(r->X, rows, r->attn_t[i], r->AGG, r->Z, r->SIG, 1, stream));
+    RET_IF(infgen_attn_post_pre(r->X, rows, r->attn_t[i], r->AGG, r->Z, r->SIG, 1, r->attn_m[i], r->Q, r->U,
+                                nullptr, nullptr, stream));
     // map -> agent (bipartite: K/V of the map tokens are per-scene constants)
-    RET_IF(infgen_attn_pre(r->X, rows, r->attn_m[i], 0, r->Q, r->U, nullptr, nullptr, stream));
     RET_IF(infgen_edge_attn(rows, r->Q, r->U, r->mapK[i], r->mapV[i], r->em.off, r->em.cnt, r->em.src, r->em.rhat,
                             r->AGG, r->Z, r->SIG, stream));
-    RET_IF(infgen_attn_post(r->X, rows, r->attn_m[i], r->AGG, r->Z, r->SIG, 1, stream));
+    RET_IF(infgen_attn_post_pre(r->X, rows, r->attn_m[i], r->AGG, r->Z, r->SIG, 1, r->attn_a[i], r->Q, r->U,
+                                r->Ka, r->Va, stream));
     // agent <-> agent
-    RET_IF(infgen_attn_pre(r->X, rows, r->attn_a[i], 0, r->Q, r->U, r->Ka, r->Va, stream));
     RET_IF(infgen_edge_attn(rows, r->Q, r->U, r->Ka, r->Va, r->ea.off, r->ea.cnt, r->ea.src, r->ea.rhat,
                             r->AGG, r->Z, r->SIG, stream));
-    RET_IF(infgen_attn_post(r->X, rows, r->attn_a[i], r->AGG, r->Z, r->SIG, 1, stream));
+    if (i + 1 < L) {
+      RET_IF(infgen_attn_post_pre(r->X, rows, r->attn_a[i], r->AGG, r->Z, r->SIG, 1, r->attn_t[i + 1], r->Q, r->U,
+                                  r->ringK[i + 1] + slot, r->ringV[i + 1] + slot, stream));
+    } else {
+      RET_IF(infgen_attn_post(r->X, rows, r->attn_a[i], r->AGG, r->Z, r->SIG, 1, stream));
+    }
   }
   return 0;
 }

@@ -58,6 +58,9 @@ struct AttnPostArgs {
   const float* pack;
   const float* AGG; const float* Z; const float* SIG;
   int has_pos;
+  // optional fused prologue of the NEXT layer on the freshly written rows (k_attn_pre's work)
+  const float* next_pack;            // null: none
+  float* nQ; float* nU; float* nK; float* nV;
 };
 
 struct HeadsArgs {

@@ -74,22 +74,75 @@ __global__ __launch_bounds__(NT, 2) void k_attn_pre(AttnPreArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // k_attn_post: agg = AGG + W'_vr z + b' sigma ; gate ; out-proj ; post-norm residual ; FFN residual
+// The residual stream of the tile lives in registers (RowSeg layout), three LDS tiles hold the GEMM
+// operands -> 50.7 KB of LDS, three workgroups per CU.  Optionally runs the next layer's
+// prenorm + q/k/v/u projections on the freshly computed rows (saves a launch and an X round trip).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT, 2) void k_attn_post(AttnPostArgs a) {
-  __shared__ __attribute__((aligned(16))) float B0[TR * LDT];   // x (raw) -> x1 -> x2
-  __shared__ __attribute__((aligned(16))) float B1[TR * LDT];   // LN_dst(x) -> LN_ffpre(x1)
+__device__ __forceinline__ void pre_from_lds(const float* Xn, float* Qs, const float* P, int row0, int nvalid,
+                                             float* Q, float* U, float* K, float* V) {
+  const int n0 = 32 * wave_id();
+  const int col = n0 + acc_col();
+  if (Q || U) {
+    f32x16 acc = zero16();
+    mfma_32x32<128>(acc, Xn, LDT, P + AL_WQ, 128, n0);
+    const float bq = P[AL_BQ + col];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int r = acc_row(reg);
+      const float q = acc[reg] + bq;
+      Qs[r * LDT + col] = q;
+      if (Q && r < nvalid) Q[(size_t)(row0 + r) * D + col] = q;
+    }
+  }
+  if (K) {
+    f32x16 acc = zero16();
+    mfma_32x32<128>(acc, Xn, LDT, P + AL_WK, 128, n0);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int r = acc_row(reg);
+      if (r < nvalid) K[(size_t)(row0 + r) * D + col] = acc[reg];
+    }
+  }
+  if (V) {
+    f32x16 acc = zero16();
+    mfma_32x32<128>(acc, Xn, LDT, P + AL_WV, 128, n0);
+    const float bv = P[AL_BV + col];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int r = acc_row(reg);
+      if (r < nvalid) V[(size_t)(row0 + r) * D + col] = acc[reg] + bv;
+    }
+  }
+  if (U) {
+    __syncthreads();
+    for (int h = 0; h < H; ++h) {
+      f32x16 acc = zero16();
+      mfma_32x32<16>(acc, Qs + DH * h, LDT, P + AL_WKR + h * (DH * D), 128, n0);
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = acc_row(reg);
+        if (r < nvalid) U[(size_t)(row0 + r) * (H * D) + h * D + col] = acc[reg];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT, 3) void k_attn_post(AttnPostArgs a) {
+  __shared__ __attribute__((aligned(16))) float B1[TR * LDT];   // LN_dst(x) -> LN_ffpre(x1) -> LN_next(x2)
   __shared__ __attribute__((aligned(16))) float B2[TR * LDT];   // agg -> to_out(...) -> ffn out
-  __shared__ __attribute__((aligned(16))) float B3[TR * LDT];   // upd -> relu(hidden chunk)
+  __shared__ __attribute__((aligned(16))) float B3[TR * LDT];   // upd -> relu(hidden chunk) -> q of the next layer
   const int row0 = blockIdx.x * TR;
   const int nvalid = min(TR, a.rows - row0);
   if (nvalid <= 0) return;
   const int w = wave_id(), n0 = 32 * w, lane = lane_id();
   const float* P = a.pack;
+  const int srow = seg_row();
+  float* xrow = srow < nvalid ? a.X + (size_t)(row0 + srow) * D : nullptr;
 
-  stage_rows_128(B0, [&](int r) { return a.X + (size_t)(row0 + r) * D; }, nvalid);
-  stage_rows_128(B2, [&](int r) { return a.AGG + (size_t)(row0 + r) * D; }, nvalid);
+  RowSeg x = seg_load(xrow);
+  seg_store(B1 + srow * LDT, seg_layernorm(x, P + AL_LN_DST_G, P + AL_LN_DST_B, false));
+  seg_store(B2 + srow * LDT, seg_load(srow < nvalid ? a.AGG + (size_t)(row0 + srow) * D : nullptr));
   __syncthreads();
-  ln_tile(B0, LDT, B1, LDT, P + AL_LN_DST_G, P + AL_LN_DST_B, false);
 
   if (a.has_pos) {
     // z-GEMM on v_mfma_f32_16x16x4_f32: per head h, out[row][16h + c] = sum_d Z[row][h][d] * B_h[d][c]
@@ -123,8 +176,8 @@ __global__ __launch_bounds__(NT, 2) void k_attn_post(AttnPostArgs a) {
         }
       }
     }
+    __syncthreads();
   }
-  __syncthreads();
 
   // gate / self projection / update (layers.py:94-99)
   {
@@ -149,9 +202,9 @@ __global__ __launch_bounds__(NT, 2) void k_attn_post(AttnPostArgs a) {
     acc_to_lds(acco, B2, LDT, n0, P + AL_BO);
   }
   __syncthreads();
-  ln_tile(B2, LDT, B0, LDT, P + AL_LN_POST_G, P + AL_LN_POST_B, false, B0, LDT);   // x1 = x + LN(out)
-  __syncthreads();
-  ln_tile(B0, LDT, B1, LDT, P + AL_LN_FFPRE_G, P + AL_LN_FFPRE_B, false);
+  // x1 = x + LN_post(out) stays in registers; LN_ffpre(x1) feeds the FFN
+  x = seg_add(x, seg_layernorm(seg_load(B2 + srow * LDT), P + AL_LN_POST_G, P + AL_LN_POST_B, false));
+  seg_store(B1 + srow * LDT, seg_layernorm(x, P + AL_LN_FFPRE_G, P + AL_LN_FFPRE_B, false));
   __syncthreads();
   f32x16 accf = zero16();
   for (int cc = 0; cc < 4; ++cc) {
@@ -169,9 +222,14 @@ __global__ __launch_bounds__(NT, 2) void k_attn_post(AttnPostArgs a) {
   }
   acc_to_lds(accf, B2, LDT, n0, P + AL_B2);
   __syncthreads();
-  ln_tile(B2, LDT, B0, LDT, P + AL_LN_FFPOST_G, P + AL_LN_FFPOST_B, false, B0, LDT);   // x2 = x1 + LN(ffn)
-  __syncthreads();
-  unstage_rows_128(B0, [&](int r) { return a.X + (size_t)(row0 + r) * D; }, nvalid);
+  x = seg_add(x, seg_layernorm(seg_load(B2 + srow * LDT), P + AL_LN_FFPOST_G, P + AL_LN_FFPOST_B, false));
+  seg_store(xrow, x);                                             // x2 = x1 + LN(ffn)
+  if (a.next_pack) {
+    const float* NP = a.next_pack;
+    seg_store(B1 + srow * LDT, seg_layernorm(x, NP + AL_LN_DST_G, NP + AL_LN_DST_B, false));
+    __syncthreads();
+    pre_from_lds(B1, B3, NP, row0, nvalid, a.nQ, a.nU, a.nK, a.nV);
+  }
 }
 
 // ------------------------------------------------------------------------------------------

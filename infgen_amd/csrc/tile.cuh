@@ -91,7 +91,7 @@ __device__ __forceinline__ void mfma_32x32(f32x16& acc, const float* __restrict_
   const int r = lane & 31, kh = lane >> 5;
   const float* ap = A + r * lda + 4 * kh;
   const float* bp = Wp + ((size_t)(n0 + r)) * 8 + 4 * kh;
-#pragma unroll 4
+#pragma unroll 8
   for (int g = 0; g < K / 8; ++g) {
     const float4 a = *reinterpret_cast<const float4*>(ap + g * 8);
     const float4 b = *reinterpret_cast<const float4*>(bp + (size_t)g * N * 8);
@@ -170,48 +170,80 @@ __device__ __forceinline__ void unstage_rows_128(const float* src, RowPtr rowptr
   }
 }
 
-// LayerNorm over the 128 columns of each row of a [32][128] LDS tile (biased variance, eps 1e-5,
-// like torch.nn.LayerNorm).  All 256 threads take part: thread t owns row t >> 3 and the four
-// 4-column groups {4*(t&7) + 32*j}; the row reductions are 3 DPP steps over the 8 lanes of the row.
-// gamma == nullptr -> no affine (plain normalisation).  res != nullptr -> dst = res + LN(src).
-// src == dst (in place) is allowed.
-__device__ __forceinline__ void ln_tile(const float* src, int lds_, float* dst, int ldd,
-                                        const float* __restrict__ gamma, const float* __restrict__ beta, bool relu,
-                                        const float* res = nullptr, int ldr = 0) {
-  const int t = threadIdx.x;
-  const int row = t >> 3, c0 = 4 * (t & 7);
-  float4 v[4];
+// ---- row segments: thread t of a 256-thread workgroup owns row t >> 3 of a 32-row tile and the four
+// 4-column groups {4*(t&7) + 32*j}; a LayerNorm reduction is 3 DPP steps over the 8 lanes of the row.
+struct RowSeg { float4 v[4]; };
+
+__device__ __forceinline__ int seg_row() { return threadIdx.x >> 3; }
+__device__ __forceinline__ int seg_col(int j) { return 4 * (threadIdx.x & 7) + 32 * j; }
+
+__device__ __forceinline__ RowSeg seg_zero() {
+  RowSeg r;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float4*>(src + row * lds_ + c0 + 32 * j);
+  for (int j = 0; j < 4; ++j) r.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  return r;
+}
+__device__ __forceinline__ RowSeg seg_load(const float* row /* this thread's row, may be null */) {
+  RowSeg r = seg_zero();
+  if (row) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.v[j] = *reinterpret_cast<const float4*>(row + seg_col(j));
+  }
+  return r;
+}
+__device__ __forceinline__ void seg_store(float* row, const RowSeg& r) {
+  if (row) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(row + seg_col(j)) = r.v[j];
+  }
+}
+__device__ __forceinline__ RowSeg seg_add(const RowSeg& a, const RowSeg& b) {
+  RowSeg r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    r.v[j] = make_float4(a.v[j].x + b.v[j].x, a.v[j].y + b.v[j].y, a.v[j].z + b.v[j].z, a.v[j].w + b.v[j].w);
+  return r;
+}
+// LayerNorm of the row this thread's segment belongs to (biased variance, eps 1e-5, torch.nn.LayerNorm);
+// gamma == nullptr -> affine-free
+__device__ __forceinline__ RowSeg seg_layernorm(RowSeg x, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, bool relu) {
   float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  for (int j = 0; j < 4; ++j) s += (x.v[j].x + x.v[j].y) + (x.v[j].z + x.v[j].w);
   const float mean = sum8(s) * (1.0f / 128.0f);
   float q = 0.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
-    q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+    x.v[j].x -= mean; x.v[j].y -= mean; x.v[j].z -= mean; x.v[j].w -= mean;
+    q += (x.v[j].x * x.v[j].x + x.v[j].y * x.v[j].y) + (x.v[j].z * x.v[j].z + x.v[j].w * x.v[j].w);
   }
   const float var = sum8(q) * (1.0f / 128.0f);
   const float rstd = 1.0f / sqrtf(var + LN_EPS);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int c = c0 + 32 * j;
     float4 g = make_float4(1.f, 1.f, 1.f, 1.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
     if (gamma) {
-      g = *reinterpret_cast<const float4*>(gamma + c);
-      b = *reinterpret_cast<const float4*>(beta + c);
+      g = *reinterpret_cast<const float4*>(gamma + seg_col(j));
+      b = *reinterpret_cast<const float4*>(beta + seg_col(j));
     }
-    float4 y = make_float4(v[j].x * rstd * g.x + b.x, v[j].y * rstd * g.y + b.y,
-                           v[j].z * rstd * g.z + b.z, v[j].w * rstd * g.w + b.w);
+    float4 y = make_float4(x.v[j].x * rstd * g.x + b.x, x.v[j].y * rstd * g.y + b.y,
+                           x.v[j].z * rstd * g.z + b.z, x.v[j].w * rstd * g.w + b.w);
     if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
-    if (res) {
-      const float4 rr = *reinterpret_cast<const float4*>(res + row * ldr + c);
-      y.x += rr.x; y.y += rr.y; y.z += rr.z; y.w += rr.w;
-    }
-    *reinterpret_cast<float4*>(dst + row * ldd + c) = y;
+    x.v[j] = y;
   }
+  return x;
+}
+
+// LayerNorm over the 128 columns of each row of a [32][128] LDS tile; all 256 threads take part.
+// res != nullptr -> dst = res + LN(src).  src == dst (in place) is allowed.
+__device__ __forceinline__ void ln_tile(const float* src, int lds_, float* dst, int ldd,
+                                        const float* __restrict__ gamma, const float* __restrict__ beta, bool relu,
+                                        const float* res = nullptr, int ldr = 0) {
+  const int row = seg_row();
+  RowSeg y = seg_layernorm(seg_load(src + row * lds_), gamma, beta, relu);
+  if (res) y = seg_add(y, seg_load(res + row * ldr));
+  seg_store(dst + row * ldd, y);
 }
 
 }  // namespace ig
