@@ -125,6 +125,11 @@ int infgen_attn_pre(const float* X, int rows, const float* pack, int use_src_ln,
 int infgen_edge_attn(int rows, const float* Q, const float* U, const float* Ksrc, const float* Vsrc,
                      const int* off, const int* cnt, const int* src, const float* rhat,
                      float* AGG, float* Z, float* SIG, void* stream);
+/* same with the kernel variant forced: wide = 1 -> one 8-wave workgroup per destination (long edge lists, few rows),
+ * wide = 0 -> one wave per destination; infgen_edge_attn picks wide when rows <= 256 */
+int infgen_edge_attn_mode(int rows, const float* Q, const float* U, const float* Ksrc, const float* Vsrc,
+                          const int* off, const int* cnt, const int* src, const float* rhat,
+                          float* AGG, float* Z, float* SIG, int wide, void* stream);
 int infgen_attn_post(float* X, int rows, const float* pack, const float* AGG, const float* Z, const float* SIG,
                      int has_pos, void* stream);
 /* infgen_attn_post followed, on the same rows, by the NEXT layer's infgen_attn_pre (one launch) */

@@ -59,6 +59,7 @@ SYMBOLS = {
     'infgen_fourier_embed': (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _p]),
     'infgen_attn_pre': (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p]),
     'infgen_edge_attn': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'infgen_edge_attn_mode': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     'infgen_attn_post': (_i, [_p, _i, _p, _p, _p, _p, _i, _p]),
     'infgen_attn_post_pre': (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
     'infgen_heads': (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _p]),

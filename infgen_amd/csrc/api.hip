@@ -182,14 +182,28 @@ extern "C" int infgen_attn_pre(const float* X, int rows, const float* pack, int 
   return check_launch("infgen_attn_pre");
 }
 
-extern "C" int infgen_edge_attn(int rows, const float* Q, const float* U, const float* Ksrc, const float* Vsrc,
-                                const int* off, const int* cnt, const int* src, const float* rhat,
-                                float* AGG, float* Z, float* SIG, void* stream) {
+static int edge_attn_impl(int rows, const float* Q, const float* U, const float* Ksrc, const float* Vsrc,
+                          const int* off, const int* cnt, const int* src, const float* rhat,
+                          float* AGG, float* Z, float* SIG, int wide, void* stream) {
   if (rows <= 0) return 0;
   EdgeAttnArgs a{rows, Q, U, Ksrc, Vsrc, EdgeSet{off, cnt, src, rhat}, AGG, Z, SIG};
   { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
-    hipLaunchKernelGGL(k_edge_attn, dim3(ceil_div(rows, 4)), dim3(NT), 0, (hipStream_t)stream, a); }
+    if (wide) hipLaunchKernelGGL(k_edge_attn_wide, dim3(rows), dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_edge_attn, dim3(ceil_div(rows, 4)), dim3(NT), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_edge_attn");
+}
+
+// one wave per destination; few destinations (<= 256 rows) get the 8-wave split so that the chip is not idle
+extern "C" int infgen_edge_attn(int rows, const float* Q, const float* U, const float* Ksrc, const float* Vsrc,
+                                const int* off, const int* cnt, const int* src, const float* rhat,
+                                float* AGG, float* Z, float* SIG, void* stream) {
+  return edge_attn_impl(rows, Q, U, Ksrc, Vsrc, off, cnt, src, rhat, AGG, Z, SIG, rows <= 256 ? 1 : 0, stream);
+}
+
+extern "C" int infgen_edge_attn_mode(int rows, const float* Q, const float* U, const float* Ksrc, const float* Vsrc,
+                                     const int* off, const int* cnt, const int* src, const float* rhat,
+                                     float* AGG, float* Z, float* SIG, int wide, void* stream) {
+  return edge_attn_impl(rows, Q, U, Ksrc, Vsrc, off, cnt, src, rhat, AGG, Z, SIG, wide, stream);
 }
 
 static int attn_post_fused(float* X, int rows, const float* pack, const float* AGG, const float* Z, const float* SIG,

@@ -25,43 +25,44 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-__global__ __launch_bounds__(NT) void k_edge_attn(EdgeAttnArgs a) {
-  const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave_id());
-  if (row >= a.rows) return;
-  const int lane = lane_id();
-  const int E = __builtin_amdgcn_readfirstlane(a.es.cnt[row]);
-  const int e_base = __builtin_amdgcn_readfirstlane(a.es.off[row]);
-  const bool has_r = a.es.rhat != nullptr && a.U != nullptr;
-  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+// running (un-normalised) attention state of one wavefront: lane l owns columns 2l, 2l+1 (head l >> 3)
+struct AttnState {
+  float2 z[H];      // sum_e p_e,h * rhat_e   (own columns, every head)
+  float2 ag;        // sum_e p_e,head(l) * v_src (own columns)
+  float m, lsum;    // running max / sum of exp for head (l >> 3)
+};
 
+// consume edges e = e_first, e_first + e_step, ... < E of destination `row`
+__device__ __forceinline__ void edge_attn_wave(const EdgeAttnArgs& a, int row, int E, int e_base, int e_first,
+                                               int e_step, bool has_r, AttnState& st) {
+  const int lane = lane_id();
+  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
   const float2 q = *reinterpret_cast<const float2*>(a.Q + (size_t)row * D + 2 * lane);
   float2 u[H];
 #pragma unroll
   for (int h = 0; h < H; ++h) {
     u[h] = has_r ? *reinterpret_cast<const float2*>(a.U + (size_t)row * (H * D) + h * D + 2 * lane)
                  : make_float2(0.f, 0.f);
+    st.z[h] = make_float2(0.f, 0.f);
   }
-  float2 z[H];
-#pragma unroll
-  for (int h = 0; h < H; ++h) z[h] = make_float2(0.f, 0.f);
-  float2 ag = make_float2(0.f, 0.f);
-  float m = -INFINITY, lsum = 0.f;
-
-  // software pipeline: operands of edge e+1 are requested before edge e is consumed
+  st.ag = make_float2(0.f, 0.f);
+  st.m = -INFINITY;
+  st.lsum = 0.f;
+  // software pipeline: operands of the next edge are requested before the current one is consumed
   float2 kn = make_float2(0.f, 0.f), vn = kn, rn = kn;
-  if (E > 0) {
-    const int s0 = __builtin_amdgcn_readfirstlane(a.es.src[e_base]);
+  if (e_first < E) {
+    const int s0 = __builtin_amdgcn_readfirstlane(a.es.src[e_base + e_first]);
     kn = *reinterpret_cast<const float2*>(a.Ksrc + (size_t)s0 * D + 2 * lane);
     vn = *reinterpret_cast<const float2*>(a.Vsrc + (size_t)s0 * D + 2 * lane);
-    if (has_r) rn = *reinterpret_cast<const float2*>(a.es.rhat + (size_t)e_base * D + 2 * lane);
+    if (has_r) rn = *reinterpret_cast<const float2*>(a.es.rhat + (size_t)(e_base + e_first) * D + 2 * lane);
   }
-  for (int e = 0; e < E; ++e) {
+  for (int e = e_first; e < E; e += e_step) {
     const float2 k2 = kn, v2 = vn, r2 = rn;
-    if (e + 1 < E) {
-      const int s1 = __builtin_amdgcn_readfirstlane(a.es.src[e_base + e + 1]);
+    if (e + e_step < E) {
+      const int s1 = __builtin_amdgcn_readfirstlane(a.es.src[e_base + e + e_step]);
       kn = *reinterpret_cast<const float2*>(a.Ksrc + (size_t)s1 * D + 2 * lane);
       vn = *reinterpret_cast<const float2*>(a.Vsrc + (size_t)s1 * D + 2 * lane);
-      if (has_r) rn = *reinterpret_cast<const float2*>(a.es.rhat + (size_t)(e_base + e + 1) * D + 2 * lane);
+      if (has_r) rn = *reinterpret_cast<const float2*>(a.es.rhat + (size_t)(e_base + e + e_step) * D + 2 * lane);
     }
     float val = fmaf(q.y, k2.y, q.x * k2.x);
     if (has_r) {
@@ -89,43 +90,111 @@ __global__ __launch_bounds__(NT) void k_edge_attn(EdgeAttnArgs a) {
       }
     }
     val = sum8(val);                          // score of head (lane >> 3), uniform over its 8 lanes
-    const float mn = fmaxf(m, val);
+    const float mn = fmaxf(st.m, val);
     const float pe = expf(val - mn);
-    if (__any(mn > m)) {                      // some head's running max grew: rescale the accumulators
-      const float sc = expf(m - mn);          // exp(-inf) = 0 on the first edge (accumulators are 0)
-      lsum *= sc;
-      ag.x *= sc; ag.y *= sc;
+    if (__any(mn > st.m)) {                   // some head's running max grew: rescale the accumulators
+      const float sc = expf(st.m - mn);       // exp(-inf) = 0 on the first edge (accumulators are 0)
+      st.lsum *= sc;
+      st.ag.x *= sc; st.ag.y *= sc;
       if (has_r) {
 #pragma unroll
         for (int h = 0; h < H; ++h) {
           const float sh = readlane_f(sc, 8 * h);
-          z[h].x *= sh; z[h].y *= sh;
+          st.z[h].x *= sh; st.z[h].y *= sh;
         }
       }
-      m = mn;
+      st.m = mn;
     }
-    lsum += pe;
-    ag.x = fmaf(pe, v2.x, ag.x);
-    ag.y = fmaf(pe, v2.y, ag.y);
+    st.lsum += pe;
+    st.ag.x = fmaf(pe, v2.x, st.ag.x);
+    st.ag.y = fmaf(pe, v2.y, st.ag.y);
     if (has_r) {
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         const float ph = readlane_f(pe, 8 * h);
-        z[h].x = fmaf(ph, r2.x, z[h].x);
-        z[h].y = fmaf(ph, r2.y, z[h].y);
+        st.z[h].x = fmaf(ph, r2.x, st.z[h].x);
+        st.z[h].y = fmaf(ph, r2.y, st.z[h].y);
       }
     }
   }
-  const float inv = 1.0f / (lsum + 1e-16f);
-  *reinterpret_cast<float2*>(a.AGG + (size_t)row * D + 2 * lane) = make_float2(ag.x * inv, ag.y * inv);
+}
+
+__device__ __forceinline__ void edge_attn_write(const EdgeAttnArgs& a, int row, const AttnState& st) {
+  const int lane = lane_id();
+  const float inv = 1.0f / (st.lsum + 1e-16f);
+  *reinterpret_cast<float2*>(a.AGG + (size_t)row * D + 2 * lane) = make_float2(st.ag.x * inv, st.ag.y * inv);
   if (a.Z) {
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       const float ih = readlane_f(inv, 8 * h);
-      *reinterpret_cast<float2*>(a.Z + (size_t)row * (H * D) + h * D + 2 * lane) = make_float2(z[h].x * ih, z[h].y * ih);
+      *reinterpret_cast<float2*>(a.Z + (size_t)row * (H * D) + h * D + 2 * lane) =
+          make_float2(st.z[h].x * ih, st.z[h].y * ih);
     }
   }
-  if ((lane & 7) == 0) a.SIG[(size_t)row * H + (lane >> 3)] = lsum * inv;
+  if ((lane & 7) == 0) a.SIG[(size_t)row * H + (lane >> 3)] = st.lsum * inv;
+}
+
+__global__ __launch_bounds__(NT) void k_edge_attn(EdgeAttnArgs a) {
+  const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave_id());
+  if (row >= a.rows) return;
+  const int E = __builtin_amdgcn_readfirstlane(a.es.cnt[row]);
+  const int e_base = __builtin_amdgcn_readfirstlane(a.es.off[row]);
+  const bool has_r = a.es.rhat != nullptr && a.U != nullptr;
+  AttnState st;
+  edge_attn_wave(a, row, E, e_base, 0, 1, has_r, st);
+  edge_attn_write(a, row, st);
+}
+
+// Few destinations with long edge lists (the insertion seed node: up to 300 agents + 2048 map tokens):
+// one 8-wave workgroup per destination, wave w takes edges w, w + 8, ...; the eight partial softmax
+// states are merged through LDS (flash-decoding style split over the edge list).
+constexpr int WIDE_WAVES = 8;
+__global__ __launch_bounds__(64 * WIDE_WAVES) void k_edge_attn_wide(EdgeAttnArgs a) {
+  __shared__ float sm[WIDE_WAVES][H];
+  __shared__ float sl[WIDE_WAVES][H];
+  __shared__ __attribute__((aligned(16))) float sag[WIDE_WAVES][D];
+  __shared__ __attribute__((aligned(16))) float sz[WIDE_WAVES][H * D];
+  const int row = blockIdx.x;
+  const int w = wave_id(), lane = lane_id();
+  const int E = a.es.cnt[row];
+  const int e_base = a.es.off[row];
+  const bool has_r = a.es.rhat != nullptr && a.U != nullptr;
+  AttnState st;
+  edge_attn_wave(a, row, E, e_base, w, WIDE_WAVES, has_r, st);
+  if ((lane & 7) == 0) { sm[w][lane >> 3] = st.m; sl[w][lane >> 3] = st.lsum; }
+  __syncthreads();
+  // rescale this wave's partial state to the global max of every head, publish, then wave 0 sums
+  const int myh = lane >> 3;
+  float mt = -INFINITY;
+#pragma unroll
+  for (int ww = 0; ww < WIDE_WAVES; ++ww) mt = fmaxf(mt, sm[ww][myh]);
+  const float sc = (st.m == -INFINITY) ? 0.f : expf(st.m - mt);   // waves that saw no edge contribute nothing
+  *reinterpret_cast<float2*>(&sag[w][2 * lane]) = make_float2(st.ag.x * sc, st.ag.y * sc);
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const float sh = readlane_f(sc, 8 * h);
+    *reinterpret_cast<float2*>(&sz[w][h * D + 2 * lane]) = make_float2(st.z[h].x * sh, st.z[h].y * sh);
+  }
+  if ((lane & 7) == 0) sl[w][myh] = st.lsum * sc;
+  __syncthreads();
+  if (w != 0) return;
+  AttnState tot;
+  tot.ag = make_float2(0.f, 0.f);
+  tot.lsum = 0.f;
+  tot.m = mt;
+#pragma unroll
+  for (int h = 0; h < H; ++h) tot.z[h] = make_float2(0.f, 0.f);
+  for (int ww = 0; ww < WIDE_WAVES; ++ww) {
+    const float2 g = *reinterpret_cast<const float2*>(&sag[ww][2 * lane]);
+    tot.ag.x += g.x; tot.ag.y += g.y;
+    tot.lsum += sl[ww][myh];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float2 zz = *reinterpret_cast<const float2*>(&sz[ww][h * D + 2 * lane]);
+      tot.z[h].x += zz.x; tot.z[h].y += zz.y;
+    }
+  }
+  edge_attn_write(a, row, tot);
 }
 
 // ------------------------------------------------------------------------------------------

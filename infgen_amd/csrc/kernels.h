@@ -199,6 +199,7 @@ __global__ void k_linear(LinearArgs a);
 __global__ void k_fourier(FourierArgs a);
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);
+__global__ void k_edge_attn_wide(EdgeAttnArgs a);
 __global__ void k_attn_post(AttnPostArgs a);
 __global__ void k_heads(HeadsArgs a);
 __global__ void k_build_edges(BuildEdgesArgs a);

@@ -171,18 +171,20 @@ class Ops:
         _lib.check(self.lib.infgen_attn_pre(_lib.ptr(x), rows, _lib.ptr(pack), int(use_src_ln), _lib.ptr(q),
                                             _lib.ptr(u), _lib.ptr(k), _lib.ptr(v), self.stream), 'infgen_attn_pre')
 
-    def edge_attn(self, rows, q, u, ksrc, vsrc, off, cnt, src, rhat, agg, z, sig):
-        _lib.check(self.lib.infgen_edge_attn(rows, _lib.ptr(q), _lib.ptr(u), _lib.ptr(ksrc), _lib.ptr(vsrc),
-                                             _lib.ptr(off), _lib.ptr(cnt), _lib.ptr(src), _lib.ptr(rhat),
-                                             _lib.ptr(agg), _lib.ptr(z), _lib.ptr(sig), self.stream),
-                   'infgen_edge_attn')
+    def edge_attn(self, rows, q, u, ksrc, vsrc, off, cnt, src, rhat, agg, z, sig, wide=None):
+        args = (rows, _lib.ptr(q), _lib.ptr(u), _lib.ptr(ksrc), _lib.ptr(vsrc), _lib.ptr(off), _lib.ptr(cnt),
+                _lib.ptr(src), _lib.ptr(rhat), _lib.ptr(agg), _lib.ptr(z), _lib.ptr(sig))
+        if wide is None:
+            _lib.check(self.lib.infgen_edge_attn(*args, self.stream), 'infgen_edge_attn')
+        else:
+            _lib.check(self.lib.infgen_edge_attn_mode(*args, int(wide), self.stream), 'infgen_edge_attn_mode')
 
     def attn_post(self, x, pack, agg, z, sig, has_pos=True, rows=None):
         rows = x.shape[0] if rows is None else rows
         _lib.check(self.lib.infgen_attn_post(_lib.ptr(x), rows, _lib.ptr(pack), _lib.ptr(agg), _lib.ptr(z),
                                              _lib.ptr(sig), int(has_pos), self.stream), 'infgen_attn_post')
 
-    def attention_layer(self, x, pack, off, cnt, src, rhat, x_src=None, scratch=None):
+    def attention_layer(self, x, pack, off, cnt, src, rhat, x_src=None, scratch=None, wide=None):
         """AttentionLayer.forward (layers.py:61-76) on CSR edges; in place on ``x``."""
         rows = x.shape[0]
         dev = self.device
@@ -201,7 +203,7 @@ class Ops:
             v = torch.empty(x_src.shape[0], D, device=dev)
             self.attn_pre(x_src, pack, use_src_ln=True, k=k, v=v)
             self.attn_pre(x, pack, q=q, u=u)
-        self.edge_attn(rows, q, u, k, v, off, cnt, src, rhat, agg, z, sig)
+        self.edge_attn(rows, q, u, k, v, off, cnt, src, rhat, agg, z, sig, wide=wide)
         self.attn_post(x, pack, agg, z, sig, has_pos=rhat is not None)
         return x
 
@@ -543,6 +545,7 @@ class RolloutEngine:
         ea_s, em_s, ea_h, em_h = (self._ebuf_struct(I[k]) for k in ('ea_s', 'em_s', 'ea_h', 'em_h'))
         H = w.heads
         f_seed = w._tables['f_seed']
+        prev_new, h_ready = None, False
         for it in range(10):
             # occupancy embedding and its K/V for the three occ2sa layers
             _lib.check(lib.infgen_occupancy(ctx, c, _lib.ptr(I['occ']), st), 'infgen_occupancy')
@@ -559,14 +562,34 @@ class RolloutEngine:
             if it == 0:
                 ops.fourier(I['em_s']['raw'], 3, w.four_pt2sa, I['em_s']['rhat'], count_dev=I['em_s']['total'],
                             rows=I['em_s']['cap'], normalize=True)
-            # agents pass every layer edgelessly; their K/V feed the a2sa layers (A.6(a))
+            # agents pass every layer edgelessly; their K/V feed the a2sa layers (A.6(a)).  The chain is
+            # row-local: all rows once per step, afterwards only the rows inserted in the previous iteration
             Xc = I['Xc']
-            Xc.copy_(self.X)
-            for i in range(3):
-                self._edgeless(Xc, w.attn_occ2sa[i], has_pos=False)
-                self._edgeless(Xc, w.attn_pt2sa[i])
-                ops.attn_pre(Xc, w.attn_a2sa[i], k=I['Ksa'][i], v=I['Vsa'][i])
-                self._edgeless(Xc, w.attn_a2sa[i])
+            if it == 0:
+                Xc.copy_(self.X)
+                for i in range(3):
+                    self._edgeless(Xc, w.attn_occ2sa[i], has_pos=False)
+                    self._edgeless(Xc, w.attn_pt2sa[i])
+                    ops.attn_pre(Xc, w.attn_a2sa[i], k=I['Ksa'][i], v=I['Vsa'][i])
+                    self._edgeless(Xc, w.attn_a2sa[i])
+            else:
+                xn = self.X[prev_new].contiguous()
+                kn, vn = torch.empty_like(xn), torch.empty_like(xn)
+                for i in range(3):
+                    self._edgeless(xn, w.attn_occ2sa[i], has_pos=False)
+                    self._edgeless(xn, w.attn_pt2sa[i])
+                    ops.attn_pre(xn, w.attn_a2sa[i], k=kn, v=vn)
+                    I['Ksa'][i][prev_new] = kn
+                    I['Vsa'][i][prev_new] = vn
+                    self._edgeless(xn, w.attn_a2sa[i])
+                if h_ready:
+                    xn = self.X[prev_new].contiguous()
+                    for i in range(3):
+                        self._edgeless(xn, w.attn_m[i])
+                        ops.attn_pre(xn, w.attn_a[i], k=kn, v=vn)
+                        I['Kh'][i][prev_new] = kn
+                        I['Vh'][i][prev_new] = vn
+                        self._edgeless(xn, w.attn_a[i])
             # the seed node
             XS = I['XS']
             XS.copy_(f_seed.expand(S, D))
@@ -577,11 +600,11 @@ class RolloutEngine:
                 ops.attn_post(XS, w.attn_occ2sa[i], I['AGGS'], I['ZS'], I['SIGS'], has_pos=False)
                 ops.attn_pre(XS, w.attn_pt2sa[i], q=I['QS'], u=I['US'])
                 ops.edge_attn(S, I['QS'], I['US'], I['mapK'][i], I['mapV'][i], I['em_s']['off'], I['em_s']['cnt'],
-                              I['em_s']['src'], I['em_s']['rhat'], I['AGGS'], I['ZS'], I['SIGS'])
+                              I['em_s']['src'], I['em_s']['rhat'], I['AGGS'], I['ZS'], I['SIGS'], wide=True)
                 ops.attn_post(XS, w.attn_pt2sa[i], I['AGGS'], I['ZS'], I['SIGS'])
                 ops.attn_pre(XS, w.attn_a2sa[i], q=I['QS'], u=I['US'])
                 ops.edge_attn(S, I['QS'], I['US'], I['Ksa'][i], I['Vsa'][i], I['ea_s']['off'], I['ea_s']['cnt'],
-                              I['ea_s']['src'], I['ea_s']['rhat'], I['AGGS'], I['ZS'], I['SIGS'])
+                              I['ea_s']['src'], I['ea_s']['rhat'], I['AGGS'], I['ZS'], I['SIGS'], wide=True)
                 ops.attn_post(XS, w.attn_a2sa[i], I['AGGS'], I['ZS'], I['SIGS'])
             lg_state = ops.mlp_layer(XS, H['seed_state_predict_head'], 128, 2)
             lg_type = ops.mlp_layer(XS, H['seed_type_predict_head'], 128, 3)
@@ -613,11 +636,13 @@ class RolloutEngine:
                         rows=I['ea_h']['cap'], normalize=True)
             ops.fourier(I['em_h']['raw'], 3, w.four_m, I['em_h']['rhat'], count_dev=I['em_h']['total'],
                         rows=I['em_h']['cap'], normalize=True)
-            Xc.copy_(self.X)
-            for i in range(3):
-                self._edgeless(Xc, w.attn_m[i])
-                ops.attn_pre(Xc, w.attn_a[i], k=I['Kh'][i], v=I['Vh'][i])
-                self._edgeless(Xc, w.attn_a[i])
+            if not h_ready:
+                Xc.copy_(self.X)
+                for i in range(3):
+                    self._edgeless(Xc, w.attn_m[i])
+                    ops.attn_pre(Xc, w.attn_a[i], k=I['Kh'][i], v=I['Vh'][i])
+                    self._edgeless(Xc, w.attn_a[i])
+                h_ready = True
             XN = self.X[I['new_row'].long().clamp(0, rows - 1)].contiguous()
             for i in range(3):
                 ops.attn_pre(XN, w.attn_m[i], q=I['QS'], u=I['US'])
@@ -635,6 +660,7 @@ class RolloutEngine:
                                                   _lib.ptr(I['new_row']), _lib.ptr(lg_heading), n_head, _lib.ptr(offset),
                                                   _lib.ptr(I['hv_ovr']), st), 'infgen_insert_finalize')
             _lib.check(lib.infgen_raw_feature(ctx, c, st), 'raw_feature')
+            prev_new = nr
 
     def _build_ctx(self):
         cfg, w = self.cfg, self.w

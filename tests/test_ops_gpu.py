@@ -94,10 +94,11 @@ def _random_graph(rng, n_dst, n_src, max_deg, empty_rows=()):
     return np.array(off, np.int32), np.array(cnt, np.int32), np.array(src, np.int32), np.array(dst, np.int64)
 
 
+@pytest.mark.parametrize('wide', [False, True])
 @pytest.mark.parametrize('prefix,bip', [('agent_encoder.a2a_attn_layers.2', False),
                                         ('agent_encoder.pt2a_attn_layers.1', True),
                                         ('agent_encoder.t_attn_layers.0', False)])
-def test_attention_layer(env, prefix, bip):
+def test_attention_layer(env, prefix, bip, wide):
     """pre + edge attention + post == AttentionLayer.forward (layers.py:61-113), incl. rows without
     incoming edges (exact-zero aggregate) and ragged degrees up to 70."""
     from oracle import rollout_oracle as ro
@@ -117,7 +118,7 @@ def test_attention_layer(env, prefix, bip):
     rhat = torch.nn.functional.layer_norm(torch.from_numpy(r), (128,)).to(dev).contiguous()
     xd = _dev(x, dev)
     env['ops'].attention_layer(xd, pack, torch.from_numpy(off).to(dev), torch.from_numpy(cnt).to(dev),
-                               torch.from_numpy(src).to(dev), rhat, x_src=_dev(xs, dev) if bip else None)
+                               torch.from_numpy(src).to(dev), rhat, x_src=_dev(xs, dev) if bip else None, wide=wide)
     err = np.abs(xd.cpu().numpy() - ref).max()
     assert err <= 1e-4, err
 
