@@ -13,64 +13,7 @@ namespace ig {
 // ------------------------------------------------------------------------------------------
 // k_attn_pre: Xn = LN(X); Q = scale*(Xn Wq^T + bq); K = Xn Wk^T; V = Xn Wv^T + bv; U_h = Q_h W'_kr,h
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT, 2) void k_attn_pre(AttnPreArgs a) {
-  __shared__ __attribute__((aligned(16))) float Xs[TR * LDT];
-  __shared__ __attribute__((aligned(16))) float Qs[TR * LDT];
-  const int row0 = blockIdx.x * TR;
-  const int nvalid = min(TR, a.rows - row0);
-  if (nvalid <= 0) return;
-  const int w = wave_id(), n0 = 32 * w;
-  stage_rows_128(Xs, [&](int r) { return a.X + (size_t)(row0 + r) * D; }, nvalid);
-  __syncthreads();
-  const float* g = a.pack + (a.use_src_ln ? AL_LN_SRC_G : AL_LN_DST_G);
-  const float* b = a.pack + (a.use_src_ln ? AL_LN_SRC_B : AL_LN_DST_B);
-  ln_tile(Xs, LDT, Xs, LDT, g, b, false);
-  __syncthreads();
-  const int col = n0 + acc_col();
-  if (a.Q || a.U) {
-    f32x16 acc = zero16();
-    mfma_32x32<128>(acc, Xs, LDT, a.pack + AL_WQ, 128, n0);
-    const float bq = a.pack[AL_BQ + col];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int r = acc_row(reg);
-      const float q = acc[reg] + bq;
-      Qs[r * LDT + col] = q;
-      if (a.Q && r < nvalid) a.Q[(size_t)(row0 + r) * D + col] = q;
-    }
-  }
-  if (a.K) {
-    f32x16 acc = zero16();
-    mfma_32x32<128>(acc, Xs, LDT, a.pack + AL_WK, 128, n0);
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int r = acc_row(reg);
-      if (r < nvalid) a.K[(size_t)(row0 + r) * D + col] = acc[reg];
-    }
-  }
-  if (a.V) {
-    f32x16 acc = zero16();
-    mfma_32x32<128>(acc, Xs, LDT, a.pack + AL_WV, 128, n0);
-    const float bv = a.pack[AL_BV + col];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int r = acc_row(reg);
-      if (r < nvalid) a.V[(size_t)(row0 + r) * D + col] = acc[reg] + bv;
-    }
-  }
-  if (a.U) {
-    __syncthreads();
-    for (int h = 0; h < H; ++h) {
-      f32x16 acc = zero16();
-      mfma_32x32<16>(acc, Qs + DH * h, LDT, a.pack + AL_WKR + h * (DH * D), 128, n0);
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int r = acc_row(reg);
-        if (r < nvalid) a.U[(size_t)(row0 + r) * (H * D) + h * D + col] = acc[reg];
-      }
-    }
-  }
-}
+__global__ __launch_bounds__(NT, 2) void k_attn_pre(AttnPreArgs a);
 
 // ------------------------------------------------------------------------------------------
 // k_attn_post: agg = AGG + W'_vr z + b' sigma ; gate ; out-proj ; post-norm residual ; FFN residual
@@ -78,13 +21,16 @@ __global__ __launch_bounds__(NT, 2) void k_attn_pre(AttnPreArgs a) {
 // operands -> 50.7 KB of LDS, three workgroups per CU.  Optionally runs the next layer's
 // prenorm + q/k/v/u projections on the freshly computed rows (saves a launch and an X round trip).
 // ------------------------------------------------------------------------------------------
+// q/k/v/u projections of one 32-row tile whose normalised input sits in LDS (Xn); `cur` carries the first
+// B half of to_q (requested by the caller before its barrier)
 __device__ __forceinline__ void pre_from_lds(const float* Xn, float* Qs, const float* P, int row0, int nvalid,
-                                             float* Q, float* U, float* K, float* V) {
+                                             float* Q, float* U, float* K, float* V, BHalf& cur) {
   const int n0 = 32 * wave_id();
   const int col = n0 + acc_col();
-  if (Q || U) {
+  const int lane = lane_id();
+  {
     f32x16 acc = zero16();
-    mfma_32x32<128>(acc, Xn, LDT, P + AL_WQ, 128, n0);
+    gemm128(acc, Xn, LDT, P + AL_WQ, 128, n0, cur, [&] { return b_load_half(P + AL_WK, 128, n0, 0); });
     const float bq = P[AL_BQ + col];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -96,28 +42,45 @@ __device__ __forceinline__ void pre_from_lds(const float* Xn, float* Qs, const f
   }
   if (K) {
     f32x16 acc = zero16();
-    mfma_32x32<128>(acc, Xn, LDT, P + AL_WK, 128, n0);
+    gemm128(acc, Xn, LDT, P + AL_WK, 128, n0, cur, [&] { return b_load_half(P + AL_WV, 128, n0, 0); });
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int r = acc_row(reg);
       if (r < nvalid) K[(size_t)(row0 + r) * D + col] = acc[reg];
     }
-  }
-  if (V) {
-    f32x16 acc = zero16();
-    mfma_32x32<128>(acc, Xn, LDT, P + AL_WV, 128, n0);
+    f32x16 accv = zero16();
+    gemm128(accv, Xn, LDT, P + AL_WV, 128, n0, cur, [&] { return cur; });
     const float bv = P[AL_BV + col];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int r = acc_row(reg);
-      if (r < nvalid) V[(size_t)(row0 + r) * D + col] = acc[reg] + bv;
+      if (r < nvalid) V[(size_t)(row0 + r) * D + col] = accv[reg] + bv;
     }
   }
   if (U) {
+    // u_h = q_h W'_kr,h : eight K = 16 GEMMs; the 16 B fragments of this wave's column slice are requested
+    // up front, the barrier publishes Qs meanwhile
+    const float* bp = P + AL_WKR + ((size_t)(n0 + (lane & 31))) * 8 + 4 * (lane >> 5);
+    float4 bu[H][2];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      bu[h][0] = *reinterpret_cast<const float4*>(bp + h * (DH * D));
+      bu[h][1] = *reinterpret_cast<const float4*>(bp + h * (DH * D) + 128 * 8);
+    }
     __syncthreads();
+    const float* ap = Qs + (lane & 31) * LDT + 4 * (lane >> 5);
+#pragma unroll
     for (int h = 0; h < H; ++h) {
       f32x16 acc = zero16();
-      mfma_32x32<16>(acc, Qs + DH * h, LDT, P + AL_WKR + h * (DH * D), 128, n0);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const float4 a = *reinterpret_cast<const float4*>(ap + DH * h + 8 * g);
+        const float4 b = bu[h][g];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      }
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int r = acc_row(reg);
@@ -127,10 +90,10 @@ __device__ __forceinline__ void pre_from_lds(const float* Xn, float* Qs, const f
   }
 }
 
-__global__ __launch_bounds__(NT, 3) void k_attn_post(AttnPostArgs a) {
-  __shared__ __attribute__((aligned(16))) float B1[TR * LDT];   // LN_dst(x) -> LN_ffpre(x1) -> LN_next(x2)
+__global__ __launch_bounds__(NT, 2) void k_attn_post(AttnPostArgs a) {
+  __shared__ __attribute__((aligned(16))) float B1[TR * LDT];   // Z head / LN_dst(x) -> LN_ffpre(x1) -> LN_next(x2)
   __shared__ __attribute__((aligned(16))) float B2[TR * LDT];   // agg -> to_out(...) -> ffn out
-  __shared__ __attribute__((aligned(16))) float B3[TR * LDT];   // upd -> relu(hidden chunk) -> q of the next layer
+  __shared__ __attribute__((aligned(16))) float B3[TR * LDT];   // Z head / upd -> relu(hidden chunk) -> q of the next layer
   const int row0 = blockIdx.x * TR;
   const int nvalid = min(TR, a.rows - row0);
   if (nvalid <= 0) return;
@@ -140,51 +103,59 @@ __global__ __launch_bounds__(NT, 3) void k_attn_post(AttnPostArgs a) {
   float* xrow = srow < nvalid ? a.X + (size_t)(row0 + srow) * D : nullptr;
 
   RowSeg x = seg_load(xrow);
-  seg_store(B1 + srow * LDT, seg_layernorm(x, P + AL_LN_DST_G, P + AL_LN_DST_B, false));
   seg_store(B2 + srow * LDT, seg_load(srow < nvalid ? a.AGG + (size_t)(row0 + srow) * D : nullptr));
-  __syncthreads();
 
   if (a.has_pos) {
-    // z-GEMM on v_mfma_f32_16x16x4_f32: per head h, out[row][16h + c] = sum_d Z[row][h][d] * B_h[d][c]
-    // lane l supplies A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; C: col = l&15, row = 4*(l>>4) + reg
+    // z-GEMM: out[row][16h + c] = sum_d Z[row][h][d] * B_h[d][c] on v_mfma_f32_16x16x4_f32
+    // (lane l supplies A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; C: col = l&15, row = 4*(l>>4) + reg).
+    // Z[:, h, :] is staged through LDS two heads per round (coalesced 512-B rows, next round's rows
+    // prefetched into registers): wave w handles head 2p + (w >> 1), row half w & 1.
     const int i16 = lane & 15, kq = lane >> 4;
-    for (int hh = 0; hh < 2; ++hh) {
-      const int h = 2 * w + hh;
-      const float* Bh = P + AL_WVR + h * (DH * D);
-      for (int mt = 0; mt < 2; ++mt) {
-        const int r = mt * 16 + i16;
-        const bool ok = r < nvalid;
-        const float* zrow = a.Z + (size_t)(row0 + (ok ? r : 0)) * (H * D) + h * D + 4 * kq;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (ok) av = *reinterpret_cast<const float4*>(zrow + 16 * s);
-          const float4 bv = *reinterpret_cast<const float4*>(Bh + ((s * 16 + i16) * 4 + kq) * 4);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
-        }
-        const int c = DH * h + i16;
-        const float bvr = P[AL_BVR + c];
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int rr = mt * 16 + 4 * kq + reg;
-          const float sg = rr < nvalid ? a.SIG[(size_t)(row0 + rr) * H + h] : 0.f;
-          B2[rr * LDT + c] += acc[reg] + bvr * sg;
-        }
+    const int mt = w & 1, hsel = w >> 1;
+    const float* zbase = srow < nvalid ? a.Z + (size_t)(row0 + srow) * (H * D) : nullptr;
+    RowSeg za = seg_load(zbase), zb = seg_load(zbase ? zbase + D : nullptr);
+    for (int p = 0; p < 4; ++p) {
+      seg_store(B1 + srow * LDT, za);
+      seg_store(B3 + srow * LDT, zb);
+      if (p + 1 < 4) {
+        za = seg_load(zbase ? zbase + (2 * p + 2) * D : nullptr);
+        zb = seg_load(zbase ? zbase + (2 * p + 3) * D : nullptr);
       }
+      __syncthreads();
+      const int h = 2 * p + hsel;
+      const float* Zs = (hsel ? B3 : B1) + (mt * 16 + i16) * LDT + 4 * kq;
+      const float* Bh = P + AL_WVR + h * (DH * D);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const float4 av = *reinterpret_cast<const float4*>(Zs + 16 * s);
+        const float4 bv = *reinterpret_cast<const float4*>(Bh + ((s * 16 + i16) * 4 + kq) * 4);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+      }
+      const int c = DH * h + i16;
+      const float bvr = P[AL_BVR + c];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int rr = mt * 16 + 4 * kq + reg;
+        const float sg = rr < nvalid ? a.SIG[(size_t)(row0 + rr) * H + h] : 0.f;
+        B2[rr * LDT + c] += acc[reg] + bvr * sg;
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
+  seg_store(B1 + srow * LDT, seg_layernorm(x, P + AL_LN_DST_G, P + AL_LN_DST_B, false));
+  BHalf cur = b_load_half(P + AL_WG, 128, n0, 0);
+  __syncthreads();
 
   // gate / self projection / update (layers.py:94-99)
   {
     f32x16 accg = zero16(), accs = zero16();
-    mfma_32x32<128>(accg, B2, LDT, P + AL_WG, 128, n0);
-    mfma_32x32<128>(accg, B1, LDT, P + AL_WG + 16384, 128, n0);
-    mfma_32x32<128>(accs, B1, LDT, P + AL_WS, 128, n0);
+    gemm128(accg, B2, LDT, P + AL_WG, 128, n0, cur, [&] { return b_load_half(P + AL_WG + 16384, 128, n0, 0); });
+    gemm128(accg, B1, LDT, P + AL_WG + 16384, 128, n0, cur, [&] { return b_load_half(P + AL_WS, 128, n0, 0); });
+    gemm128(accs, B1, LDT, P + AL_WS, 128, n0, cur, [&] { return b_load_half(P + AL_WO, 128, n0, 0); });
     const int col = n0 + acc_col();
     const float bg = P[AL_BG + col], bs = P[AL_BS + col];
 #pragma unroll
@@ -198,7 +169,7 @@ __global__ __launch_bounds__(NT, 3) void k_attn_post(AttnPostArgs a) {
   __syncthreads();
   {
     f32x16 acco = zero16();
-    mfma_32x32<128>(acco, B3, LDT, P + AL_WO, 128, n0);
+    gemm128(acco, B3, LDT, P + AL_WO, 128, n0, cur, [&] { return b_load_half(P + AL_W1, 512, n0, 0); });
     acc_to_lds(acco, B2, LDT, n0, P + AL_BO);
   }
   __syncthreads();
@@ -207,9 +178,12 @@ __global__ __launch_bounds__(NT, 3) void k_attn_post(AttnPostArgs a) {
   seg_store(B1 + srow * LDT, seg_layernorm(x, P + AL_LN_FFPRE_G, P + AL_LN_FFPRE_B, false));
   __syncthreads();
   f32x16 accf = zero16();
+  const float* NP = a.next_pack;
+#pragma unroll
   for (int cc = 0; cc < 4; ++cc) {
+    const float* Wd = P + AL_W2 + (size_t)(16 * cc) * 128 * 8;
     f32x16 acch = zero16();
-    mfma_32x32<128>(acch, B1, LDT, P + AL_W1, 512, 128 * cc + n0);
+    gemm128(acch, B1, LDT, P + AL_W1, 512, 128 * cc + n0, cur, [&] { return b_load_half(Wd, 128, n0, 0); });
     {
       const int col = n0 + acc_col();
       const float b1 = P[AL_B1 + 128 * cc + col];
@@ -217,18 +191,56 @@ __global__ __launch_bounds__(NT, 3) void k_attn_post(AttnPostArgs a) {
       for (int reg = 0; reg < 16; ++reg) B3[acc_row(reg) * LDT + col] = fmaxf(acch[reg] + b1, 0.f);
     }
     __syncthreads();
-    mfma_32x32<128>(accf, B3, LDT, P + AL_W2 + (size_t)(16 * cc) * 128 * 8, 128, n0);
+    gemm128(accf, B3, LDT, Wd, 128, n0, cur, [&] {
+      return cc + 1 < 4 ? b_load_half(P + AL_W1, 512, 128 * (cc + 1) + n0, 0)
+                        : (NP ? b_load_half(NP + AL_WQ, 128, n0, 0) : cur);
+    });
     __syncthreads();
   }
   acc_to_lds(accf, B2, LDT, n0, P + AL_B2);
   __syncthreads();
   x = seg_add(x, seg_layernorm(seg_load(B2 + srow * LDT), P + AL_LN_FFPOST_G, P + AL_LN_FFPOST_B, false));
   seg_store(xrow, x);                                             // x2 = x1 + LN(ffn)
-  if (a.next_pack) {
-    const float* NP = a.next_pack;
+  if (NP) {
     seg_store(B1 + srow * LDT, seg_layernorm(x, NP + AL_LN_DST_G, NP + AL_LN_DST_B, false));
     __syncthreads();
-    pre_from_lds(B1, B3, NP, row0, nvalid, a.nQ, a.nU, a.nK, a.nV);
+    pre_from_lds(B1, B3, NP, row0, nvalid, a.nQ, a.nU, a.nK, a.nV, cur);
+  }
+}
+
+__global__ __launch_bounds__(NT, 2) void k_attn_pre(AttnPreArgs a) {
+  __shared__ __attribute__((aligned(16))) float Xs[TR * LDT];
+  __shared__ __attribute__((aligned(16))) float Qs[TR * LDT];
+  const int row0 = blockIdx.x * TR;
+  const int nvalid = min(TR, a.rows - row0);
+  if (nvalid <= 0) return;
+  const int n0 = 32 * wave_id();
+  const int srow = seg_row();
+  const float* g = a.pack + (a.use_src_ln ? AL_LN_SRC_G : AL_LN_DST_G);
+  const float* b = a.pack + (a.use_src_ln ? AL_LN_SRC_B : AL_LN_DST_B);
+  BHalf cur = b_load_half(a.pack + ((a.Q || a.U) ? AL_WQ : AL_WK), 128, n0, 0);
+  seg_store(Xs + srow * LDT, seg_layernorm(seg_load(srow < nvalid ? a.X + (size_t)(row0 + srow) * D : nullptr), g, b, false));
+  __syncthreads();
+  if (a.Q || a.U) {
+    pre_from_lds(Xs, Qs, a.pack, row0, nvalid, a.Q, a.U, a.K, a.V, cur);
+  } else {
+    // K/V only (map tokens as a bipartite source)
+    const int col = n0 + acc_col();
+    f32x16 acc = zero16();
+    gemm128(acc, Xs, LDT, a.pack + AL_WK, 128, n0, cur, [&] { return b_load_half(a.pack + AL_WV, 128, n0, 0); });
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int r = acc_row(reg);
+      if (r < nvalid && a.K) a.K[(size_t)(row0 + r) * D + col] = acc[reg];
+    }
+    f32x16 accv = zero16();
+    gemm128(accv, Xs, LDT, a.pack + AL_WV, 128, n0, cur, [&] { return cur; });
+    const float bv = a.pack[AL_BV + col];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int r = acc_row(reg);
+      if (r < nvalid && a.V) a.V[(size_t)(row0 + r) * D + col] = accv[reg] + bv;
+    }
   }
 }
 

@@ -101,6 +101,86 @@ __device__ __forceinline__ void mfma_32x32(f32x16& acc, const float* __restrict_
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
   }
 }
+// ---- B-fragment prefetch across a barrier -------------------------------------------------------
+// The first two k-groups of a GEMM's B operand can be requested BEFORE the __syncthreads() that
+// publishes its A tile (plain global loads stay in flight across s_barrier), which hides the L2
+// latency that otherwise opens every short GEMM phase.
+struct BPre { float4 b0, b1; };
+__device__ __forceinline__ BPre b_prefetch(const float* __restrict__ Wp, int N, int n0) {
+  const int lane = lane_id();
+  const float* bp = Wp + ((size_t)(n0 + (lane & 31))) * 8 + 4 * (lane >> 5);
+  BPre p;
+  p.b0 = *reinterpret_cast<const float4*>(bp);
+  p.b1 = *reinterpret_cast<const float4*>(bp + (size_t)N * 8);
+  return p;
+}
+// same contraction as mfma_32x32<K> with the first two B groups already in registers and a
+// two-deep software pipeline on the rest (K/8 >= 2)
+template <int K>
+__device__ __forceinline__ void mfma_32x32_pf(f32x16& acc, const float* __restrict__ A, int lda,
+                                              const float* __restrict__ Wp, int N, int n0, const BPre& pre) {
+  const int lane = lane_id();
+  const int r = lane & 31, kh = lane >> 5;
+  const float* ap = A + r * lda + 4 * kh;
+  const float* bp = Wp + ((size_t)(n0 + r)) * 8 + 4 * kh;
+  constexpr int G = K / 8;
+  float4 bq[2] = {pre.b0, pre.b1};
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const float4 a = *reinterpret_cast<const float4*>(ap + g * 8);
+    const float4 b = bq[g & 1];
+    if (g + 2 < G) bq[g & 1] = *reinterpret_cast<const float4*>(bp + (size_t)(g + 2) * N * 8);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  }
+}
+
+// ---- explicit half-GEMM pipelining ---------------------------------------------------------------
+// hipcc keeps only ~2 B-operand loads in flight inside the unrolled K loop (each s_waitcnt then eats an
+// L2 round trip).  BHalf holds the B fragments of 8 k-groups (64 k-values x 32 columns, 32 VGPRs); the
+// kernels load the NEXT half (or the next GEMM's first half) before issuing the 32 MFMAs of the current
+// one and pin that order with sched_barrier, so ~2048 MFMA cycles cover every load.
+struct BHalf { float4 v[8]; };
+__device__ __forceinline__ BHalf b_load_half(const float* __restrict__ Wp, int N, int n0, int half) {
+  const int lane = lane_id();
+  const float* bp = Wp + ((size_t)(n0 + (lane & 31))) * 8 + 4 * (lane >> 5) + (size_t)(8 * half) * N * 8;
+  BHalf h;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) h.v[g] = *reinterpret_cast<const float4*>(bp + (size_t)g * N * 8);
+  return h;
+}
+// acc += A[32][64 k of `half`] * B-half ; A tile in LDS (row stride lda)
+__device__ __forceinline__ void mfma_half(f32x16& acc, const float* __restrict__ A, int lda, int half, const BHalf& b) {
+  const int lane = lane_id();
+  const float* ap = A + (lane & 31) * lda + 4 * (lane >> 5) + 64 * half;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const float4 a = *reinterpret_cast<const float4*>(ap + g * 8);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.v[g].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.v[g].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.v[g].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.v[g].w, acc, 0, 0, 0);
+  }
+}
+#define IG_PIN() __builtin_amdgcn_sched_barrier(0)
+
+// One K = 128 GEMM (32 rows x 32 columns per wave) in the pipelined form: `cur` holds the first B half on
+// entry (requested before the barrier that published A) and the NEXT GEMM's first half on exit.
+template <typename NextLoad>
+__device__ __forceinline__ void gemm128(f32x16& acc, const float* __restrict__ A, int lda,
+                                        const float* __restrict__ Wp, int N, int n0, BHalf& cur, NextLoad next) {
+  const BHalf h1 = b_load_half(Wp, N, n0, 1);
+  IG_PIN();
+  mfma_half(acc, A, lda, 0, cur);
+  IG_PIN();
+  cur = next();
+  IG_PIN();
+  mfma_half(acc, A, lda, 1, h1);
+  IG_PIN();
+}
+
 // runtime-K variant (K multiple of 8)
 __device__ __forceinline__ void mfma_32x32_rt(f32x16& acc, const float* __restrict__ A, int lda, int K,
                                               const float* __restrict__ Wp, int N, int n0) {
