@@ -259,12 +259,14 @@ __global__ __launch_bounds__(NT, 2) void k_heads(HeadsArgs a) {
   const int nvalid = min(TR, a.rows - row0);
   if (nvalid <= 0) return;
   const int w = wave_id(), n0 = 32 * w, lane = lane_id();
+  BHalf cur = b_load_half(a.tok_pack, 128, n0, 0);
   stage_rows_128(Xs, [&](int r) { return a.X + (size_t)(row0 + r) * D; }, nvalid);
   __syncthreads();
   {
     const float* P = a.tok_pack;
     f32x16 acc = zero16();
-    mfma_32x32<128>(acc, Xs, LDT, P, 128, n0);
+    const float* W3p = P + 16768;
+    gemm128(acc, Xs, LDT, P, 128, n0, cur, [&] { return b_load_half(W3p, a.token_size, n0, 0); });
     acc_to_lds(acc, Hs, LDT, n0, P + 16384);
     __syncthreads();
     ln_tile(Hs, LDT, Hs, LDT, P + 16512, P + 16640, true);
@@ -278,7 +280,10 @@ __global__ __launch_bounds__(NT, 2) void k_heads(HeadsArgs a) {
     for (int p = 0; p < a.token_size / 128; ++p) {
       const int c0 = 128 * p + n0;
       f32x16 acc2 = zero16();
-      mfma_32x32<128>(acc2, Hs, LDT, W3, a.token_size, c0);
+      const bool last = p + 1 >= a.token_size / 128;
+      gemm128(acc2, Hs, LDT, W3, a.token_size, c0, cur, [&] {
+        return last ? b_load_half(a.st_pack, 128, n0, 0) : b_load_half(W3, a.token_size, c0 + 128, 0);
+      });
       const int col = c0 + acc_col();
       const float bb = b3[col];
 #pragma unroll
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(NT, 2) void k_heads(HeadsArgs a) {
   {
     const float* P = a.st_pack;
     f32x16 acc = zero16();
-    mfma_32x32<128>(acc, Xs, LDT, P, 128, n0);
+    gemm128(acc, Xs, LDT, P, 128, n0, cur, [&] { return cur; });
     acc_to_lds(acc, Hs, LDT, n0, P + 16384);
     __syncthreads();
     ln_tile(Hs, LDT, Hs, LDT, P + 16512, P + 16640, true);
