@@ -97,6 +97,7 @@ def main():
     ap.add_argument('--map-tokens', type=int, default=1024)
     ap.add_argument('--insertion', action='store_true', help='scenario insertion on (configs/ours_long_term.yaml style)')
     ap.add_argument('--rollout-steps', type=int, default=80, help='R = num_recurrent_steps_val (multiple of 5)')
+    ap.add_argument('--streams', type=int, default=1, help='split the per-GPU batch over this many HIP streams')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
@@ -121,7 +122,38 @@ def main():
     scenes, vocab, map_vocab, grid = build_scenes(cfg, args.scenes, args.agents, args.map_tokens, first)
     log('scenes built')
     w = engine.PackedWeights(sd, cfg, dev)
-    eng = engine.RolloutEngine(w, scenes, vocab, map_vocab, grid, store_logits=False)
+    ns = max(1, args.streams)
+    per = (len(scenes) + ns - 1) // ns
+    engines = [engine.RolloutEngine(w, scenes[i * per:(i + 1) * per], vocab, map_vocab, grid, store_logits=False)
+               for i in range(ns) if scenes[i * per:(i + 1) * per]]
+    streams = [torch.cuda.Stream(device=dev) for _ in engines] if ns > 1 else [None]
+
+    class _Multi:
+        """the per-GPU batch split over several HIP streams (memory-bound edge attention of one group
+        overlaps the MFMA-bound kernels of another)"""
+        def rollout(self):
+            if ns == 1:
+                engines[0].rollout()
+                return
+            cur = torch.cuda.current_stream(dev)
+            for e, st in zip(engines, streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    e.rollout()
+            for st in streams:
+                cur.wait_stream(st)
+
+        def agent_steps(self):
+            return sum(e.agent_steps() for e in engines)
+
+        @property
+        def n_agents(self):
+            return torch.cat([e.n_agents for e in engines])
+
+        @property
+        def hosts(self):
+            return [h for e in engines for h in e.hosts]
+    eng = _Multi()
 
     log('engine built')
     cpu = None
@@ -187,7 +219,7 @@ def main():
                             f'per scene, R={args.rollout_steps} ({cfg.num_decode_steps} decode steps), greedy, '
                             f'insertion {"on" if args.insertion else "disabled"}, '
                             f'{args.scenes} scenes per GPU, one step = reset + map encoder + full rollout',
-                'scenes_per_gpu': args.scenes, 'agents': args.agents, 'map_tokens': args.map_tokens,
+                'scenes_per_gpu': args.scenes, 'streams': ns, 'agents': args.agents, 'map_tokens': args.map_tokens,
                 'decode_steps': cfg.num_decode_steps, 'insertion': bool(args.insertion), 'agents_inserted_last_rollout': inserted, 'agent_token_steps_per_s': agent_steps / dt / cfg.shift,
                 'parallelism': f'scenes sharded over {world} rank(s), no data-path collective',
             },

@@ -271,6 +271,7 @@ static int validate(const InfgenRollout* r, const char* where) {
   if (r->A_cap % 32) return fail(where, "A_cap must be a multiple of 32");
   if (r->num_layers <= 0 || r->num_layers > INFGEN_MAX_LAYERS) return fail(where, "bad num_layers");
   if (r->ring <= r->W) return fail(where, "ring must exceed the temporal window");
+  if (r->W > 16) return fail(where, "temporal window larger than 16 columns is not supported");
   return 0;
 }
 

@@ -231,6 +231,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh /*[NT+1]*/, int* t
 //   temporal: (j % ring) * rows + row ; map: s * M_cap + m ; agent: s * A_cap + j
 // ------------------------------------------------------------------------------------------
 constexpr int MAXA = 256;     // max agents per scene handled by one workgroup pass
+constexpr int MAP_LDS = 4096; // map-token positions staged in LDS by k_build_edges
 
 __global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
   __shared__ float px[MAXA], py[MAXA], hd[MAXA], hc[MAXA], hs[MAXA];
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
   __shared__ int mapidx[MAXA * 5];
   __shared__ int mapcnt[MAXA];
   __shared__ int base_t, base_m, base_a;
+  __shared__ __attribute__((aligned(8))) float2 mxy[MAP_LDS];
   const SceneState& st = a.st;
   const int s = blockIdx.x;
   const int t = threadIdx.x;
@@ -266,16 +268,30 @@ __global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
   }
   __syncthreads();
 
-  // ---------------- temporal
+  // ---------------- temporal (window <= 16 columns: every slot of the row is fetched up front, the
+  // loads are independent and overlap)
   {
+    constexpr int WMAX = 16;
     int cnt = 0;
     const int lo = max(c - st.W, 0);
     const bool dst_ok = (t < A) && (t < A - NUM_SEED_FEATURE);
-    int bos = 0;
+    unsigned ok_mask = 0;
+    float sx[WMAX], sy[WMAX], sh[WMAX];
+    int sst[WMAX];
     if (dst_ok) {
-      bos = st.bos[s * st.A_cap + t];
-      for (int j = lo; j < c; ++j)
-        if (j >= bos && st.tmask[sidx(st, s, j, t)]) ++cnt;
+      const int bos = st.bos[s * st.A_cap + t];
+#pragma unroll
+      for (int wq = 0; wq < WMAX; ++wq) {
+        const int j = lo + wq;
+        sx[wq] = 0.f; sy[wq] = 0.f; sh[wq] = 0.f; sst[wq] = 0;
+        if (j < c && wq < st.W) {
+          const size_t i = sidx(st, s, j, t);
+          const bool ok = j >= bos && st.tmask[i];
+          sx[wq] = st.pos[2 * i]; sy[wq] = st.pos[2 * i + 1]; sh[wq] = st.head[i]; sst[wq] = st.state[i];
+          if (ok) ok_mask |= 1u << wq;
+        }
+      }
+      cnt = __popc(ok_mask);
     }
     int tot;
     const int excl = block_excl_scan(cnt, scan, &tot);
@@ -287,12 +303,13 @@ __global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
       a.t.cnt[row] = cnt;
       if (cnt > 0) {
         const bool d_inv = stt[t] == INVALID;
-        for (int j = lo; j < c; ++j) {
-          const size_t i = sidx(st, s, j, t);
-          if (!(j >= bos && st.tmask[i])) continue;
-          float dx = st.pos[2 * i] - px[t], dy = st.pos[2 * i + 1] - py[t];
-          float dth = wrap_angle(st.head[i] - hd[t]);
-          const bool s_inv = st.state[i] == INVALID;
+#pragma unroll
+        for (int wq = 0; wq < WMAX; ++wq) {
+          if (!((ok_mask >> wq) & 1u)) continue;
+          const int j = lo + wq;
+          float dx = sx[wq] - px[t], dy = sy[wq] - py[t];
+          float dth = wrap_angle(sh[wq] - hd[t]);
+          const bool s_inv = sst[wq] == INVALID;
           if (s_inv && !d_inv) { dx = -MOTION_GAP; dy = -MOTION_GAP; dth = -HEADING_GAP; }
           if (!s_inv && d_inv) { dx = MOTION_GAP; dy = MOTION_GAP; }      // :598 is a no-op
           if (s_inv && d_inv) { dx = INVALID_MOTION; dy = INVALID_MOTION; dth = INVALID_HEAD; }
@@ -314,6 +331,11 @@ __global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
     const float r2 = a.r_map * a.r_map;
     const float* mp = st.map_pos + (size_t)s * st.M_cap * 2;
     const int lane = lane_id();
+    const bool map_in_lds = M <= MAP_LDS;
+    if (map_in_lds) {
+      for (int m = t; m < M; m += NT) mxy[m] = *reinterpret_cast<const float2*>(mp + 2 * m);
+      __syncthreads();
+    }
     for (int ag = wave_id(); ag < st.A_cap; ag += 4) {
       int found = 0;
       if (ag < A && im[ag]) {
@@ -322,7 +344,8 @@ __global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
           const int m = m0 + lane;
           bool in = false;
           if (m < M) {
-            const float dx = ax - mp[2 * m], dy = ay - mp[2 * m + 1];
+            const float2 mc = map_in_lds ? mxy[m] : *reinterpret_cast<const float2*>(mp + 2 * m);
+            const float dx = ax - mc.x, dy = ay - mc.y;
             in = (dx * dx + dy * dy) < r2;
           }
           const unsigned long long bal = __ballot(in);
@@ -487,9 +510,14 @@ __global__ __launch_bounds__(NT) void k_map_graph(MapGraphArgs a) {
 // tokenisation of the new position (attr_tokenizer.py:77-89), invalid handling.
 // One workgroup per scene.
 // ------------------------------------------------------------------------------------------
+constexpr int GRID_LDS = 2048;   // grid cells staged in LDS (1961 for the 150 m / 3 m / 75 m grid)
 __global__ __launch_bounds__(NT) void k_integrate(IntegrateArgs a) {
   __shared__ float npx[MAXA], npy[MAXA], nth[MAXA];
   __shared__ int nst[MAXA];
+  __shared__ __attribute__((aligned(8))) float2 gxy[GRID_LDS];
+  const bool grid_in_lds = a.grid_size <= GRID_LDS;
+  if (grid_in_lds)
+    for (int g = threadIdx.x; g < a.grid_size; g += NT) gxy[g] = *reinterpret_cast<const float2*>(a.grid_xy + 2 * g);
   const SceneState& st = a.st;
   const int s = blockIdx.x, t = threadIdx.x;
   const int A = st.n_agents[s];
@@ -544,8 +572,10 @@ __global__ __launch_bounds__(NT) void k_integrate(IntegrateArgs a) {
       const float ry = dx * sn + dy * cs;
       float best = INFINITY;
       int bi = 0x7fffffff;
+#pragma unroll 4
       for (int g = lane; g < a.grid_size; g += 64) {
-        const float ux = rx - a.grid_xy[2 * g], uy = ry - a.grid_xy[2 * g + 1];
+        const float2 gc = grid_in_lds ? gxy[g] : *reinterpret_cast<const float2*>(a.grid_xy + 2 * g);
+        const float ux = rx - gc.x, uy = ry - gc.y;
         const float d = sqrtf(ux * ux + uy * uy);
         if (d < best) { best = d; bi = g; }
       }
