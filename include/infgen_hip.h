@@ -110,6 +110,10 @@ typedef struct InfgenRollout {
   /* scenario insertion (optional, NULL when unused): rows >= first_new[s] inserted in the current step use
    * hv_ovr[s] as their head vector during the motion stage (agent_decoder.py:2083) */
   const int* first_new; const float* hv_ovr;
+  /* reproducible top-k sampling (optional): sample_k > 1 -> every step draws the motion token by inverse CDF over
+   * the sample_k most probable tokens with the uniforms sample_u[t][row]; needs logits_scratch [rows][token_size] */
+  int sample_k; int _pad1;
+  const float* sample_u; float* logits_scratch;
 } InfgenRollout;
 
 int infgen_linear(const float* X, int ldx, const int* gather, int rows, int K,
@@ -149,6 +153,10 @@ int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless, void* stre
 int infgen_decode_step(const InfgenRollout* r, int t, void* stream);
 /* steps t0 .. t1-1 back to back (one host call per rollout) */
 int infgen_rollout_run(const InfgenRollout* r, int t0, int t1, void* stream);
+
+/* reproducible stand-in for softmax -> topk(k) -> multinomial (agent_decoder.py:2162-2163,2194-2195): the k most
+ * probable tokens, inverse-CDF over their probabilities with a caller-supplied uniform per row */
+int infgen_sample_topk(const float* logits, int rows, int n, int k, const float* uniform, int* token, void* stream);
 
 /* ---- scenario insertion (reference agent_decoder.py:1773-2105); the sub-loop is sequenced by the host ----
  *   infgen_occupancy        one-hot sum of the grid tokens of column c (:1852-1854)

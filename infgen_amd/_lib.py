@@ -45,6 +45,7 @@ class Rollout(C.Structure):
         ('teacher_token', _p), ('teacher_state', _p),
         ('pred_traj', _p), ('pred_head', _p), ('pred_state', _p),
         ('first_new', _p), ('hv_ovr', _p),
+        ('sample_k', _i), ('_pad1', _i), ('sample_u', _p), ('logits_scratch', _p),
     ]
 
 
@@ -70,6 +71,7 @@ SYMBOLS = {
     'infgen_decode_layers': (_i, [C.POINTER(Rollout), _i, _i, _p]),
     'infgen_decode_step': (_i, [C.POINTER(Rollout), _i, _p]),
     'infgen_rollout_run': (_i, [C.POINTER(Rollout), _i, _i, _p]),
+    'infgen_sample_topk': (_i, [_p, _i, _i, _i, _p, _p, _p]),
     'infgen_occupancy': (_i, [C.POINTER(Rollout), _i, _p, _p]),
     'infgen_point_edges': (_i, [C.POINTER(Rollout), _i, _p, _p, _i, _i, _f, _i, _f, _i, C.POINTER(EdgeBuf), C.POINTER(EdgeBuf), _p]),
     'infgen_insert_decide': (_i, [C.POINTER(Rollout), _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

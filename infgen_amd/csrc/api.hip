@@ -331,6 +331,15 @@ extern "C" int infgen_raw_feature(const InfgenRollout* r, int col, void* stream)
   return 0;
 }
 
+extern "C" int infgen_sample_topk(const float* logits, int rows, int n, int k, const float* uniform, int* token,
+                                  void* stream) {
+  if (rows <= 0) return 0;
+  if (k < 1 || k > 16) return fail("infgen_sample_topk", "k must be in 1..16");
+  SampleArgs a{logits, rows, n, k, uniform, token};
+  hipLaunchKernelGGL(k_sample_topk, dim3(ceil_div(rows, 4)), dim3(NT), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_sample_topk");
+}
+
 extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless, void* stream) {
   RET_IF(validate(r, "infgen_decode_layers"));
   const int rows = r->S * r->A_cap;
@@ -376,8 +385,12 @@ extern "C" int infgen_decode_step(const InfgenRollout* r, int t, void* stream) {
   if (t < 0 || c + 1 > r->T - 1) return fail("infgen_decode_step", "step beyond the column range");
   RET_IF(infgen_decode_layers(r, c, 0, stream));
   float* lg = (r->store_logits && r->logits) ? r->logits + (size_t)t * rows * r->token_size : nullptr;
+  const bool sample = r->sample_k > 1 && r->sample_u && (lg || r->logits_scratch);
+  if (sample && !lg) lg = r->logits_scratch;
   RET_IF(infgen_heads(r->X, rows, r->tok_head_pack, r->st_head_pack, r->token_size, lg, r->next_token,
                       r->next_state, stream));
+  if (sample)
+    RET_IF(infgen_sample_topk(lg, rows, r->token_size, r->sample_k, r->sample_u + (size_t)t * rows, r->next_token, stream));
   RET_IF(infgen_integrate(r, t, stream));
   RET_IF(infgen_raw_feature(r, c + 1, stream));
   return 0;

@@ -828,4 +828,51 @@ __global__ __launch_bounds__(64) void k_insert_finalize(InsertFinalizeArgs a) {
   a.hv_ovr[2 * s + 1] = sinf(nh);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// k_sample_topk: reproducible stand-in for the reference's stochastic decode
+// (agent_decoder.py:2162-2163,2194-2195: softmax -> topk(motion_beam_size) -> torch.multinomial):
+// the k most probable tokens in descending order, then inverse-CDF sampling over their
+// (re-normalised) probabilities with a caller-supplied uniform.  One wave per row.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_sample_topk(SampleArgs a) {
+  const int row = blockIdx.x * 4 + wave_id();
+  if (row >= a.rows) return;
+  const int lane = lane_id();
+  const float* lg = a.logits + (size_t)row * a.n;
+  float topv[16];
+  int topi[16];
+  float prev_v = INFINITY;
+  int prev_i = -1;
+  for (int j = 0; j < a.k; ++j) {
+    // j-th largest: the largest element strictly after (prev_v, prev_i) in (value desc, index asc) order
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < a.n; c += 64) {
+      const float v = lg[c];
+      const bool after = (v < prev_v) || (v == prev_v && c > prev_i);
+      if (after && (v > best || (v == best && c < bi))) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    topv[j] = best; topi[j] = bi;
+    prev_v = best; prev_i = bi;
+  }
+  if (lane != 0) return;
+  float p[16], sum = 0.f;
+  for (int j = 0; j < a.k; ++j) { p[j] = expf(topv[j] - topv[0]); sum += p[j]; }
+  const float u = a.uniform[row] * sum;
+  float cdf = 0.f;
+  int pick = a.k - 1;
+  for (int j = 0; j < a.k; ++j) {
+    cdf += p[j];
+    if (u < cdf) { pick = j; break; }
+  }
+  a.token[row] = topi[pick];
+}
+
 }  // namespace ig

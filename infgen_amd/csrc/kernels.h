@@ -189,6 +189,13 @@ struct InsertFinalizeArgs {
   float* hv_ovr;                              // [S][2]
 };
 
+struct SampleArgs {
+  const float* logits; int rows; int n;      // [rows][n]
+  int k;                                     // beam size (<= 16)
+  const float* uniform;                      // [rows] caller-supplied U[0,1)
+  int* token;                                // [rows] out
+};
+
 struct MapGraphArgs {
   int S, M_cap; const int* n_map;
   const float* pos; const float* orient; float radius; int max_nbr;
@@ -210,6 +217,7 @@ __global__ void k_point_edges(PointEdgesArgs a);
 __global__ void k_occupancy(OccupancyArgs a);
 __global__ void k_insert_decide(InsertDecideArgs a);
 __global__ void k_insert_finalize(InsertFinalizeArgs a);
+__global__ void k_sample_topk(SampleArgs a);
 __global__ void k_layernorm(const float* X, int rows, const float* g, const float* b, float* Y);
 
 }  // namespace ig

@@ -215,7 +215,8 @@ class RolloutEngine:
                  map_vocab: np.ndarray, grid: np.ndarray, a_cap: Optional[int] = None, m_cap: Optional[int] = None,
                  store_logits: bool = False, live_state: bool = False,
                  teacher: Optional[Sequence] = None, x_pt_override: Optional[Sequence] = None,
-                 force_enter: bool = False, insert_headroom: Optional[int] = None):
+                 force_enter: bool = False, insert_headroom: Optional[int] = None,
+                 sample_k: int = 1, sample_uniforms: Optional[np.ndarray] = None):
         self.w = weights
         self.cfg = cfg = weights.cfg
         self.device = dev = weights.device
@@ -230,6 +231,8 @@ class RolloutEngine:
         self.W = cfg.window
         self.ring = self.W + 1
         self.store_logits = store_logits
+        self.sample_k = int(sample_k)
+        self._sample_uniforms = sample_uniforms      # [steps][S][A] float32 in [0,1) (top-k inverse-CDF sampling)
         self._x_pt_override = x_pt_override
         self.force_valid = bool(cfg.disable_insertion) and not live_state
         self.insertion = not cfg.disable_insertion
@@ -314,6 +317,15 @@ class RolloutEngine:
         steps = cfg.num_decode_steps
         self.logits = f(steps, rows, cfg.token_size) if store_logits else None
         self.pred_traj, self.pred_head, self.pred_state = f(S, A_cap, R, 2), f(S, A_cap, R), f(S, A_cap, R)
+        self.sample_u = self.logits_scratch = None
+        if self.sample_k > 1:
+            assert sample_uniforms is not None, 'top-k sampling needs caller-supplied uniforms'
+            u = np.zeros((steps, S, A_cap), np.float32)
+            su = np.asarray(sample_uniforms, dtype=np.float32)
+            u[:, :, :min(A_cap, su.shape[2])] = su[:, :, :A_cap]
+            self.sample_u = torch.from_numpy(u.reshape(steps, rows)).to(dev)
+            if self.logits is None:
+                self.logits_scratch = f(rows, cfg.token_size)
         self.tok_tab = self.grid_tab = self.cat_agent = self.cat_seed = None
         self.x_pt = None
         self._ctx = None
@@ -693,6 +705,7 @@ class RolloutEngine:
         c.pred_traj, c.pred_head, c.pred_state = P(self.pred_traj), P(self.pred_head), P(self.pred_state)
         if self.insertion:
             c.first_new, c.hv_ovr = P(self.ins['first_new']), P(self.ins['hv_ovr'])
+        c.sample_k, c.sample_u, c.logits_scratch = self.sample_k, P(self.sample_u), P(self.logits_scratch)
         self._ctx = c
 
     # ------------------------------------------------------------------ rollout

@@ -108,7 +108,7 @@ class InfGenDecoder(nn.Module):
         return self._packed
 
     # ------------------------------------------------------------------ driver
-    def _run(self, data, x_pt=None, map_only=False, batch: Optional[Sequence] = None):
+    def _run(self, data, x_pt=None, map_only=False, batch: Optional[Sequence] = None, sample_uniforms=None):
         ae = self.agent_encoder
         datas = list(batch) if batch is not None else [data]
         scenes = [scene_from_data(d) for d in datas]
@@ -125,8 +125,14 @@ class InfGenDecoder(nn.Module):
             xo = [x_pt] if batch is None else list(x_pt)
         import os
         w.cfg.disable_insertion = bool(ae.disable_insertion)
+        k = int(getattr(ae, 'motion_beam_size', 1))
+        if k > 1 and sample_uniforms is None and not map_only:
+            # stochastic decode like the reference's default (top-k multinomial), driven by torch's RNG
+            amax = max(int(np.asarray(s_['agent']['state_idx']).shape[0]) for s_ in scenes)
+            sample_uniforms = torch.rand(w.cfg.num_decode_steps, len(scenes), amax + 128).numpy()
         eng = RolloutEngine(w, scenes, vocab, map_vocab, grid, x_pt_override=xo,
-                            force_enter=bool(int(os.getenv('DEBUG', 0))))    # DEBUG=1 forces 'enter' (agent_decoder.py:1888)
+                            force_enter=bool(int(os.getenv('DEBUG', 0))),    # DEBUG=1 forces 'enter' (agent_decoder.py:1888)
+                            sample_k=k if not map_only else 1, sample_uniforms=sample_uniforms)
         if map_only:
             eng.prologue(map_only=True)
             return eng.x_pt[:eng.hosts[0]['M']].clone()
@@ -166,9 +172,11 @@ class InfGenDecoder(nn.Module):
                                   'hot path; use inference()')
 
     @torch.no_grad()
-    def inference(self, data) -> Dict[str, torch.Tensor]:
-        """map encoder + closed-loop rollout of one scene (reference infgen_decoder.py:123-130)"""
-        r = self._run(data)
+    def inference(self, data, sample_uniforms=None) -> Dict[str, torch.Tensor]:
+        """map encoder + closed-loop rollout of one scene (reference infgen_decoder.py:123-130).
+        Greedy unless ``agent_encoder.motion_beam_size > 1``; then tokens are drawn by inverse CDF over the
+        top-k probabilities with ``sample_uniforms`` ([steps][1][A]) or torch.rand when omitted."""
+        r = self._run(data, sample_uniforms=sample_uniforms)
         x_pt = r.pop('_x_pt')
         map_enc = {'x_pt': x_pt, 'map_next_token_idx': torch.zeros(0, 10, dtype=torch.long, device=x_pt.device),
                    'map_next_token_prob': torch.zeros(0, self.map_encoder.token_size, device=x_pt.device),

@@ -353,7 +353,8 @@ class RolloutOracle:
     # ---- full rollout
     @torch.no_grad()
     def rollout(self, scene, x_pt: torch.Tensor, vocab, teacher_tokens: Optional[np.ndarray] = None,
-                teacher_states: Optional[np.ndarray] = None):
+                teacher_states: Optional[np.ndarray] = None, sample_k: int = 1,
+                sample_uniforms: Optional[np.ndarray] = None):
         sd, p, cfg = self.sd, self.p, self.cfg
         ag = scene['agent']
         state0 = _t(ag['state_idx']).long()
@@ -444,6 +445,15 @@ class RolloutOracle:
             logits_all.append(logits)
             prob = torch.softmax(logits, dim=-1)
             next_tok = torch.topk(prob, k=1, dim=-1)[1][:, 0]
+            if sample_k > 1:
+                # agent_decoder.py:2163,2194-2195 with the multinomial replaced by an inverse CDF over the
+                # top-k probabilities driven by caller-supplied uniforms (torch RNG cannot be bit-matched)
+                pk, ik = torch.topk(prob, k=sample_k, dim=-1)
+                cdf = torch.cumsum(pk, dim=-1)
+                u = _t(sample_uniforms[t, :prob.shape[0]]).float() * cdf[:, -1]
+                pick = (u[:, None] >= cdf).sum(-1).clamp(max=sample_k - 1)
+                next_tok = ik.gather(1, pick[:, None])[:, 0]
+                self.sample_margin = getattr(self, 'sample_margin', []) + [((u[:, None] - cdf).abs().min(-1)[0] / cdf[:, -1]).numpy()]
             s_prob = mlp_layer(sd, p + '.state_predict_head', x)
             nstate = s_prob.softmax(dim=-1).argmax(dim=-1)
             nstate[nstate == 2] = EXIT
@@ -510,7 +520,8 @@ class RolloutOracle:
         )
 
 
-def run_scene(sd, scene, cfg, vocab, map_vocab, grid, live_state=False, teacher=None):
+def run_scene(sd, scene, cfg, vocab, map_vocab, grid, live_state=False, teacher=None, sample_k=1,
+              sample_uniforms=None):
     """map prologue + rollout; returns the rollout dict plus ``x_pt``."""
     with torch.no_grad():
         x_pt = map_encoder(sd, scene, cfg, map_vocab)
@@ -518,6 +529,8 @@ def run_scene(sd, scene, cfg, vocab, map_vocab, grid, live_state=False, teacher=
         tt = ts = None
         if teacher is not None:
             tt, ts = teacher
-        out = orc.rollout(scene, x_pt, vocab, teacher_tokens=tt, teacher_states=ts)
+        out = orc.rollout(scene, x_pt, vocab, teacher_tokens=tt, teacher_states=ts, sample_k=sample_k,
+                          sample_uniforms=sample_uniforms)
     out['x_pt'] = x_pt
+    out['sample_margin'] = getattr(orc, 'sample_margin', None)
     return out

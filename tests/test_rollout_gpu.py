@@ -194,3 +194,40 @@ def test_long_horizon_rollout_vs_oracle():
     part = np.partition(lg, -2, axis=-1)
     ok = (part[..., -1] - part[..., -2]) > 2e-2
     assert np.array_equal(o['logits'].argmax(-1)[ok], lg.argmax(-1)[ok])
+
+
+def test_topk_sampling_with_supplied_uniforms():
+    """the reference's default decode is top-5 multinomial (motion_beam_size = 5, agent_decoder.py:300,2163,2194);
+    torch RNG cannot be bit-matched, so the sampler is defined as inverse-CDF over the top-k probabilities with
+    caller-supplied uniforms — HIP vs oracle with the same uniforms"""
+    from infgen_amd import engine, synth
+    from oracle import rollout_oracle as ro
+    c = load_case('c1_a8_m128')
+    cfg = c['cfg']
+    rng = np.random.default_rng(99)
+    A = c['z']['pos_a'].shape[0]
+    u = rng.uniform(0, 1, size=(cfg.num_decode_steps, 1, A)).astype(np.float32)
+    tsd = {k: torch.from_numpy(v) for k, v in c['sd'].items()}
+    ref = ro.run_scene(tsd, c['scene'], cfg, c['vocab'], c['map_vocab'], c['grid'], sample_k=5, sample_uniforms=u[:, 0])
+    assert not np.array_equal(ref['next_token_idx'].numpy(), c['z']['next_token_idx'])      # it really samples
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], cfg, dev)
+    teacher = [(ref['next_token_idx'].numpy(), ref['next_state_idx'].numpy())]
+    # free-running sampled rollout
+    eng = engine.RolloutEngine(w, [c['scene']], c['vocab'], c['map_vocab'], c['grid'], store_logits=True, sample_k=5,
+                               sample_uniforms=u)
+    eng.rollout()
+    o = eng.outputs()[0]
+    margins = np.stack(ref['sample_margin'])            # distance of u to the nearest CDF edge, per (step, agent)
+    if margins.min() > 1e-4:
+        assert np.array_equal(o['next_token_idx'], ref['next_token_idx'].numpy())
+        assert np.abs(o['pos_a'] - ref['pos_a'].numpy()).max() <= 1e-3
+    else:
+        first_bad = int(np.argwhere(margins <= 1e-4)[0][0])
+        hc = cfg.hist_columns
+        assert np.array_equal(o['next_token_idx'][:, :hc + first_bad], ref['next_token_idx'].numpy()[:, :hc + first_bad])
+    # the sampler alone, without a stored logits buffer
+    eng2 = engine.RolloutEngine(w, [c['scene']], c['vocab'], c['map_vocab'], c['grid'], store_logits=False, sample_k=5,
+                                sample_uniforms=u)
+    eng2.rollout()
+    assert np.array_equal(eng2.outputs()[0]['next_token_idx'], o['next_token_idx'])
