@@ -231,3 +231,59 @@ def test_topk_sampling_with_supplied_uniforms():
                                 sample_uniforms=u)
     eng2.rollout()
     assert np.array_equal(eng2.outputs()[0]['next_token_idx'], o['next_token_idx'])
+
+
+def _oracle_vs_engine(cfg, scene, sd, c, tol=4e-3, min_margin=2e-2, **eng_kw):
+    from infgen_amd import engine
+    from oracle import rollout_oracle as ro
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    ref = ro.run_scene(tsd, scene, cfg, c['vocab'], c['map_vocab'], c['grid'])
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(sd, cfg, dev)
+    teacher = [(ref['next_token_idx'].numpy(), ref['next_state_idx'].numpy())]
+    eng = engine.RolloutEngine(w, [scene], c['vocab'], c['map_vocab'], c['grid'], store_logits=True, teacher=teacher,
+                               **eng_kw)
+    eng.rollout()
+    o = eng.outputs()[0]
+    lg = ref['logits'].numpy()
+    assert np.abs(o['logits'] - lg).max() <= tol
+    assert np.abs(o['pos_a'] - ref['pos_a'].numpy()).max() <= 2e-3
+    part = np.partition(lg, -2, axis=-1)
+    ok = (part[..., -1] - part[..., -2]) > min_margin
+    assert np.array_equal(o['logits'].argmax(-1)[ok], lg.argmax(-1)[ok])
+    if x_pt_ok := (ref['x_pt'].shape[0] > 0):
+        assert np.abs(o['x_pt'] - ref['x_pt'].numpy()).max() <= 1e-4
+    return o, ref
+
+
+def test_degenerate_scenes():
+    """empty / ragged inputs: a scene with the ego alone, a scene without any map token within reach, and a
+    scene whose other agents are all far outside every radius (no a2a / map edges at all)"""
+    from infgen_amd import synth
+    c = load_case('c1_a8_m128')
+    cfg = synth.standard_config(num_recurrent_steps_val=20)
+    sd = make_weights(seed=7, head_gain=64.0)
+    # ego alone
+    scene = synth.make_scene(31, 1, 64, cfg, vocab=c['vocab'], grid=c['grid'])
+    _oracle_vs_engine(cfg, scene, sd, c)
+    # map tokens all far away (no map->agent edge, map encoder still runs)
+    scene = synth.make_scene(32, 6, 40, cfg, vocab=c['vocab'], grid=c['grid'])
+    scene['pt_token']['position'][:, :2] += 5000.0
+    _oracle_vs_engine(cfg, scene, sd, c)
+    # agents spread over kilometres: no agent<->agent edges
+    scene = synth.make_scene(33, 12, 64, cfg, half_extent=5000.0, vocab=c['vocab'], grid=c['grid'])
+    o, ref = _oracle_vs_engine(cfg, scene, sd, c)
+    assert (ref['edge_count'][:, 1] == 0).all()
+
+
+def test_maximum_sizes_stress_shape():
+    """BASELINE config C5 shapes (256 agents, 4096 map tokens) in fp32, two decode steps: the per-scene
+    kernels at their agent cap (A_cap = 256), a2a degree > 64, map LDS staging at 4096 tokens"""
+    from infgen_amd import synth
+    c = load_case('c1_a8_m128')
+    cfg = synth.standard_config(num_recurrent_steps_val=10)
+    sd = make_weights(seed=8, head_gain=64.0)
+    scene = synth.make_scene(41, 256, 4096, cfg, half_extent=60.0, vocab=c['vocab'], grid=c['grid'])
+    o, ref = _oracle_vs_engine(cfg, scene, sd, c)
+    assert o['pos_a'].shape[0] == 256
+    assert ref['edge_count'][:, 1].max() > 256 * 64      # dense agent<->agent neighbourhoods
