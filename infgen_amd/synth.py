@@ -194,8 +194,15 @@ def scene_seed(config_id: int, scene_idx: int) -> int:
 def make_scene(seed: int, num_agents: int, num_map: int, cfg: RolloutConfig,
                half_extent: float = 60.0, ego_last: bool = True,
                edge_cases: bool = False, vocab: Optional[Dict[str, np.ndarray]] = None,
-               grid: Optional[np.ndarray] = None) -> Dict[str, Dict[str, np.ndarray]]:
+               grid: Optional[np.ndarray] = None, slip: float = 0.0) -> Dict[str, Dict[str, np.ndarray]]:
     """One synthetic scene in the reference's input schema (numpy).
+
+    ``slip`` (radians) turns each agent's velocity away from its heading by a per-agent angle drawn
+    from ±[slip/2, slip].  With ``slip == 0`` every agent moves exactly along its heading, so the
+    relative-position angle of its temporal edges (agent_decoder.py:600-604) is ±pi up to rounding
+    noise — the sign then depends on the last ulp of cos/sin(heading), which no two libm agree on
+    (DESIGN.md "parity caveats").  Parity tests at scale use slip > 0; the committed golden
+    fixtures were generated with slip == 0 and keep their seeds.
 
     ``edge_cases`` injects: an agent entering at column 1, an agent that exits at column 1,
     a row with ``valid_mask[:, 10] == False`` and (if ego_last) a row filtered out before
@@ -219,7 +226,11 @@ def make_scene(seed: int, num_agents: int, num_map: int, cfg: RolloutConfig,
     head0[av] = rng.uniform(-0.3, 0.3)
     atype[av] = 0
     speed[atype == 1] *= 0.2
-    vel = np.stack([np.cos(head0), np.sin(head0)], -1) * speed[:, None]
+    vdir = head0
+    if slip > 0.0:
+        srng = np.random.default_rng([seed, 977])
+        vdir = head0 + srng.uniform(0.5 * slip, slip, size=(A,)) * srng.choice([-1.0, 1.0], size=(A,))
+    vel = np.stack([np.cos(vdir), np.sin(vdir)], -1) * speed[:, None]
 
     col = np.arange(T0)
     token_pos = (pos0[:, None, :] + vel[:, None, :] * (0.5 * col)[None, :, None]).astype(np.float32)

@@ -283,7 +283,7 @@ def test_maximum_sizes_stress_shape():
     c = load_case('c1_a8_m128')
     cfg = synth.standard_config(num_recurrent_steps_val=10)
     sd = make_weights(seed=8, head_gain=64.0)
-    scene = synth.make_scene(41, 256, 4096, cfg, half_extent=60.0, vocab=c['vocab'], grid=c['grid'])
+    scene = synth.make_scene(41, 256, 4096, cfg, half_extent=60.0, vocab=c['vocab'], grid=c['grid'], slip=0.2)
     o, ref = _oracle_vs_engine(cfg, scene, sd, c)
     assert o['pos_a'].shape[0] == 256
     assert ref['edge_count'][:, 1].max() > 256 * 64      # dense agent<->agent neighbourhoods
