@@ -2,6 +2,7 @@
 // launch sequence.  No host synchronisation, no allocation: graph-capturable.
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "kernels.h"
@@ -132,6 +133,14 @@ extern "C" int infgen_fourier_pack_offset(const char* f, int n, int dim) {
   F("w1", d0 + FD_W1) F("w1x", d0 + FD_W1X) F("b1", d0 + FD_B1) F("ln_g", d0 + FD_LN_G) F("ln_b", d0 + FD_LN_B)
   F("w2", d0 + FD_W2)
   F("b2sum", t0 + FT_B2SUM) F("lno_g", t0 + FT_LN_G) F("lno_b", t0 + FT_LN_B) F("w3", t0 + FT_W3) F("b3", t0 + FT_B3)
+  // fp16-split section (FourierHLayout)
+  const int h0 = fourier_pack_size_f32(n);
+  const int hd = h0 + FH_DIM0 + dim * FHD_SIZE;
+  F("h_hdr", h0 + FH_HDR) F("h_freq", h0 + FH_FREQ + dim * 64)
+  F("h_wx", hd + FHD_WX) F("h_b1", hd + FHD_B1) F("h_g1", hd + FHD_G1) F("h_be1", hd + FHD_BE1)
+  F("h_b2sum", h0 + FH_TAIL + FHT_B2SUM) F("h_g2", h0 + FH_TAIL + FHT_G2) F("h_be2", h0 + FH_TAIL + FHT_BE2)
+  F("h_b3", h0 + FH_TAIL + FHT_B3)
+  F("h_mat", h0 + FH_VEC_SIZE + dim * FH_HALF_MAT_FLOATS)      /* dim = half-matrix index here */
 #undef F
   return -1;
 }
@@ -160,16 +169,30 @@ extern "C" int infgen_layernorm(const float* X, int rows, const float* gamma, co
   return check_launch("infgen_layernorm");
 }
 
+static int g_fourier_mode = 1;   // 1: fp16 three-term split (k_fourier_h), 0: fp32-input MFMA (k_fourier)
+extern "C" int infgen_set_fourier_mode(int mode) {
+  if (mode != 0 && mode != 1) return fail("infgen_set_fourier_mode", "mode must be 0 (fp32 MFMA) or 1 (fp16 split)");
+  g_fourier_mode = mode;
+  return 0;
+}
+
 extern "C" int infgen_fourier_embed(const float* raw, int n, const int* count_dev, int e_cap, const float* pack,
                                     const float* cat, int ldcat, float* out, int ldo, int normalize, void* stream) {
   if (e_cap <= 0) return 0;
   if (n < 1 || n > 4) return fail("infgen_fourier_embed", "n_dims must be in 1..4");
   FourierArgs a{raw, n, count_dev, e_cap, pack, cat, ldcat, out, ldo, normalize,
                 (g_prof.mask >> INFGEN_KID_FOURIER) & 1u ? g_prof.rows_dev : nullptr};
-  int grid = ceil_div(e_cap, TR);
-  if (grid > 2048) grid = 2048;
-  { ProfScope _ps(INFGEN_KID_FOURIER, stream);
-    hipLaunchKernelGGL(k_fourier, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a); }
+  if (g_fourier_mode == 0) {
+    int grid = ceil_div(e_cap, TR);
+    if (grid > 2048) grid = 2048;
+    ProfScope _ps(INFGEN_KID_FOURIER, stream);
+    hipLaunchKernelGGL(k_fourier, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a);
+  } else {
+    int grid = ceil_div(e_cap, 128);     // 128-row tiles (8 waves x 16 rows), persistent
+    if (grid > 256) grid = 256;          // one workgroup per CU (fourier_h.hip explains why)
+    ProfScope _ps(INFGEN_KID_FOURIER, stream);
+    hipLaunchKernelGGL(k_fourier_h, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+  }
   return check_launch("infgen_fourier_embed");
 }
 

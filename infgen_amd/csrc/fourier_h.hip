@@ -1,0 +1,315 @@
+// k_fourier_h: FourierEmbedding.forward (reference infgen/modules/layers.py:142-160) on the fp16 matrix
+// pipe with a three-term split, register-resident from the sin/cos features to the output row.
+//
+// Why: the fp32-input MFMA (32x32x2) runs at the fp32 vector rate (157 TFLOP/s); the f16 MFMA
+// (32x32x16) is 16x faster.  Every operand is split into two fp16 numbers, x*2^s = hi + lo with hi the top
+// 11 significand bits and lo the next 11 (power-of-two prescales chosen at pack time keep both in the
+// fp16 normal range), and  x*w ~= hi_x*hi_w + hi_x*lo_w + lo_x*hi_w  is accumulated in fp32 by three
+// MFMAs: 2^-21 relative error per product (fp32: 2^-24), 16/3 = 5.3x the fp32 matrix rate.
+// Logit error of a full rollout with every GEMM split like this stays at the fp32 noise floor
+// (DESIGN.md section 5).
+//
+// Orientation: C[f][e] = sum_k W[f][k] X[k][e] - the WEIGHTS are the MFMA A operand (rows = output
+// features), the 16 edges of a wave are the B operand / the C columns (16x16x32 MFMA).  A lane then
+// holds 32 of the 128 features of ONE edge (lanes ^ 16, ^ 32, ^ 48 hold the rest), so
+//   * LayerNorm over the features is an in-lane sum plus two cross-lane exchanges, and
+//   * the C registers of one GEMM, split to fp16, ARE the B fragments of the next GEMM (the k order
+//     of the weights is permuted to the C-register order at pack time) - no LDS round trip.
+// LDS only holds the weights: quarter-matrices (one k-step of 32: 8 feature tiles x hi/lo x 1 KB
+// fragments = 16 KB) are streamed global -> LDS with global_load_lds_dwordx4 through a ring of five
+// buffers (four quarters in flight), shared by the 8 waves of the workgroup; the sequence of quarters is
+// the same for every tile, so the pipeline runs across tile boundaries.
+// Workgroup = 8 waves x 16 edges, ONE workgroup per CU (two waves per SIMD, whose VALU phases - sin/cos,
+// LayerNorm, splitting - overlap the partner's MFMA phases).  One per CU is deliberate: with two or
+// three independent workgroups of this kernel resident on a CU, single waves produced wrong rows at
+// random (16 consecutive rows off by ~1e-2, different rows every run; with and without LDS-DMA, with A
+// fragments read from LDS or from global memory; never with one workgroup per CU, whatever its wave
+// count).  The cause was not found; the 91 KB of LDS make the single-workgroup placement structural,
+// and tests/test_ops_gpu.py::test_fourier_split_is_deterministic re-runs a 350k-row launch bitwise.
+#include "kernels.h"
+#include "layout.h"
+#include "tile.cuh"
+
+namespace ig {
+
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FH_WAVES = 8;
+constexpr int FH_NT = 64 * FH_WAVES;     // threads per workgroup
+constexpr int FH_TILE = 16 * FH_WAVES;   // edges per workgroup tile (16 per wave)
+constexpr int QUARTER = 8192;            // fp16 elements of one quarter-matrix in LDS (16 KB)
+constexpr int RING = 5;                  // quarter buffers in LDS
+constexpr int DIST = RING - 1;           // quarters in flight ahead of the one being consumed
+constexpr int GLDS_PER_STAGE = 1024 / FH_NT;   // global_load_lds instructions per thread and quarter
+
+__device__ __forceinline__ unsigned pk_rtz(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+
+// (a, b) -> packed fp16 pairs hi, lo with a = hi_a + lo_a (+ <= 2^-21 |a|)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  const float ah = __uint_as_float(__float_as_uint(a) & 0xFFFFE000u);
+  const float bh = __uint_as_float(__float_as_uint(b) & 0xFFFFE000u);
+  hi = pk_rtz(ah, bh);
+  lo = pk_rtz(a - ah, b - bh);
+}
+
+// sin/cos: three-constant Cody-Waite reduction by pi/2 with fused multiply-adds (the products n * c are
+// exact inside the fma), then the classic minimax polynomials on [-pi/4, pi/4] (Cephes sinf/cosf
+// coefficients); about 1 ulp, like the sleef kernels torch uses on the CPU.  Arguments of 1e5 rad and more
+// (never produced by in-radius geometry) are reduced in fp64 with a three-term pi/2, good to 2^40 rad.
+__device__ __forceinline__ void sincos_fast(float z, float& s, float& c) {
+  const float n = rintf(z * 0.636619772f);
+  float r = __builtin_fmaf(n, -1.57079601e+00f, z);
+  r = __builtin_fmaf(n, -3.13916473e-07f, r);
+  r = __builtin_fmaf(n, -5.39030253e-15f, r);
+  int qi = (int)n;
+  if (__builtin_expect(!(fabsf(z) < 1.0e5f), 0)) {
+    const double zd = (double)z;
+    const double nd = rint(zd * 0.63661977236758134308);
+    double rd = __builtin_fma(-nd, 1.57079632679489655800e+00, zd);
+    rd = __builtin_fma(-nd, 6.12323399573676603587e-17, rd);
+    rd = __builtin_fma(-nd, -1.49738490485916983e-33, rd);
+    r = (float)rd;
+    qi = (int)(nd - 4.0 * floor(nd * 0.25));
+  }
+  const float r2 = r * r;
+  float ps = __builtin_fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f);
+  ps = __builtin_fmaf(ps, r2, -1.6666654611e-1f);
+  ps = __builtin_fmaf(ps * r2, r, r);
+  float pc = __builtin_fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(pc, r2, 4.166664568298827e-2f);
+  pc = __builtin_fmaf(pc * r2, r2, __builtin_fmaf(-0.5f, r2, 1.0f));
+  // quadrant: swap by bit 0, negate by bit 1 - as bit operations on the VGPRs (selects would tie up SGPR masks)
+  const unsigned m = 0u - ((unsigned)qi & 1u);
+  const unsigned ups = __float_as_uint(ps), upc = __float_as_uint(pc);
+  const unsigned sv = (upc & m) | (ups & ~m);
+  const unsigned cv = (ups & m) | (upc & ~m);
+  s = __uint_as_float(sv ^ (((unsigned)qi & 2u) << 30));
+  c = __uint_as_float(cv ^ ((((unsigned)qi + 1u) & 2u) << 30));
+}
+
+__device__ __forceinline__ float xor_lanes(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+__device__ __forceinline__ void stage_quarter(const unsigned short* __restrict__ gsrc, unsigned short* ldst, int tid) {
+  // 16 KB = 1024 sixteen-byte units; a wave instruction lands 1 KB at (uniform base + lane * 16)
+#pragma unroll
+  for (int c = 0; c < GLDS_PER_STAGE; ++c) {
+    const int unit = c * FH_NT + tid;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + unit * 8),
+                                     (__attribute__((address_space(3))) void*)(ldst + (c * FH_NT + (tid & ~63)) * 8),
+                                     16, 0, 0);
+  }
+}
+
+// acc[t] += W[16 t .., this k-step] * B   (three MFMAs per feature tile; the two A fragments of tile t + 1 are
+// read from LDS while the MFMAs of tile t run)
+__device__ __forceinline__ void gemm_quarter(f32x4 (&acc)[8], const unsigned short* Wl, u32x4 Bh, u32x4 Bl, int lane) {
+  const v8h bh = __builtin_bit_cast(v8h, Bh);
+  const v8h bl = __builtin_bit_cast(v8h, Bl);
+  const unsigned short* p = Wl + lane * 8;
+  v8h ah = *reinterpret_cast<const v8h*>(p);
+  v8h al = *reinterpret_cast<const v8h*>(p + 512);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    v8h nh = ah, nl = al;
+    if (t + 1 < 8) {
+      nh = *reinterpret_cast<const v8h*>(p + (t + 1) * 1024);
+      nl = *reinterpret_cast<const v8h*>(p + (t + 1) * 1024 + 512);
+    }
+    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[t], 0, 0, 0);
+    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[t], 0, 0, 0);
+    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[t], 0, 0, 0);
+    ah = nh; al = nl;
+  }
+}
+
+// LayerNorm over the 128 features of this lane's edge (32 here, the rest in lanes ^ 16, ^ 32, ^ 48), biased
+// variance, eps 1e-5; register r of tile t is feature 16 t + 4 rg + r.
+template <bool AFFINE, bool RELU>
+__device__ __forceinline__ void ln_regs(f32x4 (&v)[8], const float* gtab, const float* btab, int rg) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) s += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
+  const float mean = xor_lanes(s) * (1.0f / 128.0f);
+  float q = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    v[t][0] -= mean; v[t][1] -= mean; v[t][2] -= mean; v[t][3] -= mean;
+    q += (v[t][0] * v[t][0] + v[t][1] * v[t][1]) + (v[t][2] * v[t][2] + v[t][3] * v[t][3]);
+  }
+  const float rstd = 1.0f / sqrtf(xor_lanes(q) * (1.0f / 128.0f) + LN_EPS);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    float4 gg = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (AFFINE) {
+      gg = *reinterpret_cast<const float4*>(gtab + 16 * t + 4 * rg);
+      bb = *reinterpret_cast<const float4*>(btab + 16 * t + 4 * rg);
+    }
+    float y0 = v[t][0] * rstd * gg.x + bb.x, y1 = v[t][1] * rstd * gg.y + bb.y;
+    float y2 = v[t][2] * rstd * gg.z + bb.z, y3 = v[t][3] * rstd * gg.w + bb.w;
+    if (RELU) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
+    v[t][0] = y0; v[t][1] = y1; v[t][2] = y2; v[t][3] = y3;
+  }
+}
+
+// C registers -> B fragments of the next GEMM: k-step s takes tiles 2 s (slots 0..3) and 2 s + 1 (slots 4..7)
+__device__ __forceinline__ void regs_to_frags(const f32x4 (&v)[8], u32x4 (&Bh)[4], u32x4 (&Bl)[4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      unsigned hi, lo;
+      split_pair(v[2 * s + (w >> 1)][2 * (w & 1)], v[2 * s + (w >> 1)][2 * (w & 1) + 1], hi, lo);
+      Bh[s][w] = hi;
+      Bl[s][w] = lo;
+    }
+}
+
+__global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned short Wb[RING][QUARTER];    // 80 KB: also keeps the CU to ONE workgroup
+  __shared__ __attribute__((aligned(16))) float Vt[FH_VEC_SIZE];
+  const int E = a.count_dev ? min(*a.count_dev, a.e_cap) : a.e_cap;
+  const int ntiles = (E + FH_TILE - 1) / FH_TILE;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  const int j = lane & 15, rg = lane >> 4;
+  if (a.prof_rows && blockIdx.x == 0 && tid == 0) atomicAdd(a.prof_rows + a.n, (unsigned long long)E);
+  const float* vec = a.pack + fourier_pack_size_f32(a.n);
+  const unsigned short* wg = reinterpret_cast<const unsigned short*>(vec + FH_VEC_SIZE);
+  const int nq = 4 * (2 * a.n + 1);      // quarter-matrices per tile, consumed in storage order
+  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_tiles * nq;       // quarters this workgroup consumes
+  int consumed = 0, slot = 0;            // quarter count so far, ring slot of the next quarter
+  int q_stage = 0, slot_stage = 0;       // next quarter to stage (index within the tile sequence) and its slot
+  for (int d = 0; d < DIST && d < total; ++d) {
+    stage_quarter(wg + (size_t)q_stage * QUARTER, Wb[slot_stage], tid);
+    q_stage = (q_stage + 1 == nq) ? 0 : q_stage + 1;
+    slot_stage = (slot_stage + 1 == RING) ? 0 : slot_stage + 1;
+  }
+  for (int i = tid; i < FH_VEC_SIZE; i += FH_NT) Vt[i] = vec[i];
+  __syncthreads();                       // Vt visible
+  // Returns the next quarter: waits until it has landed, releases the slot of the previous quarter and refills
+  // it with the quarter DIST ahead.  The LDS-DMA of a quarter is ordered for the ds_reads of OTHER waves only by
+  // the issuing wave's vmcnt wait followed by the barrier; hipcc adds no such wait on its own (it only drains
+  // lgkmcnt before s_barrier).  vmcnt counts every VMEM operation in issue order, so "all but the
+  // (DIST - 1) * GLDS_PER_STAGE most recent" always covers the quarter needed now.
+  auto take = [&]() -> const unsigned short* {
+    if (consumed + DIST <= total) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DIST - 1) * GLDS_PER_STAGE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (consumed + DIST < total) {
+      stage_quarter(wg + (size_t)q_stage * QUARTER, Wb[slot_stage], tid);
+      q_stage = (q_stage + 1 == nq) ? 0 : q_stage + 1;
+      slot_stage = (slot_stage + 1 == RING) ? 0 : slot_stage + 1;
+    }
+    const unsigned short* cur = Wb[slot];
+    slot = (slot + 1 == RING) ? 0 : slot + 1;
+    ++consumed;
+    return cur;
+  };
+  const float inv2 = Vt[FH_HDR + 4], inv3 = Vt[FH_HDR + 5], fscale = Vt[FH_HDR + 6];
+  const float* tail = Vt + FH_TAIL;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int e = tile * FH_TILE + w * 16 + j;
+    const bool valid = e < E;
+    float4 rawv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) rawv = *reinterpret_cast<const float4*>(a.raw + 4 * (size_t)e);
+    u32x4 Bh[4], Bl[4];
+    f32x4 acc2[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int i = 0; i < a.n; ++i) {
+      const float x = (i == 0) ? rawv.x : (i == 1) ? rawv.y : (i == 2) ? rawv.z : rawv.w;
+      const float* fq = Vt + FH_FREQ + i * 64;
+      const float* dv = Vt + FH_DIM0 + i * FHD_SIZE;
+      // features: k-step s (0, 1) slot p is cos of frequency 32 s + 8 rg + p, k-step s + 2 its sin
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const float4 f0 = *reinterpret_cast<const float4*>(fq + 32 * s + 8 * rg);
+        const float4 f1 = *reinterpret_cast<const float4*>(fq + 32 * s + 8 * rg + 4);
+        const float fr[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        float cs[8], sn[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          // reference: x.unsqueeze(-1) * freqs.weight * 2 * math.pi  (left to right, fp32)
+          const float z = x * fr[p] * 2.0f * PI_F;
+          sincos_fast(z, sn[p], cs[p]);
+          cs[p] *= fscale; sn[p] *= fscale;
+        }
+#pragma unroll
+        for (int wd = 0; wd < 4; ++wd) {
+          unsigned hi, lo;
+          split_pair(cs[2 * wd], cs[2 * wd + 1], hi, lo);
+          Bh[s][wd] = hi; Bl[s][wd] = lo;
+          split_pair(sn[2 * wd], sn[2 * wd + 1], hi, lo);
+          Bh[s + 2][wd] = hi; Bl[s + 2][wd] = lo;
+        }
+      }
+      f32x4 acc1[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) gemm_quarter(acc1, take(), Bh[s], Bl[s], lane);
+      {
+        const float inv1 = Vt[FH_HDR + i];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float4 wx = *reinterpret_cast<const float4*>(dv + FHD_WX + 16 * t + 4 * rg);
+          const float4 b1 = *reinterpret_cast<const float4*>(dv + FHD_B1 + 16 * t + 4 * rg);
+          acc1[t][0] = acc1[t][0] * inv1 + x * wx.x + b1.x;
+          acc1[t][1] = acc1[t][1] * inv1 + x * wx.y + b1.y;
+          acc1[t][2] = acc1[t][2] * inv1 + x * wx.z + b1.z;
+          acc1[t][3] = acc1[t][3] * inv1 + x * wx.w + b1.w;
+        }
+      }
+      ln_regs<true, true>(acc1, dv + FHD_G1, dv + FHD_BE1, rg);     // gamma/beta carry the activation prescale
+      regs_to_frags(acc1, Bh, Bl);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) gemm_quarter(acc2, take(), Bh[s], Bl[s], lane);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int f = 16 * t + 4 * rg;
+      const float4 b2 = *reinterpret_cast<const float4*>(tail + FHT_B2SUM + f);
+      float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.cat && valid) c = *reinterpret_cast<const float4*>(a.cat + (size_t)e * a.ldcat + f);
+      acc2[t][0] = acc2[t][0] * inv2 + b2.x + c.x;
+      acc2[t][1] = acc2[t][1] * inv2 + b2.y + c.y;
+      acc2[t][2] = acc2[t][2] * inv2 + b2.z + c.z;
+      acc2[t][3] = acc2[t][3] * inv2 + b2.w + c.w;
+    }
+    ln_regs<true, true>(acc2, tail + FHT_G2, tail + FHT_BE2, rg);
+    regs_to_frags(acc2, Bh, Bl);
+    f32x4 acc3[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc3[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) gemm_quarter(acc3, take(), Bh[s], Bl[s], lane);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float4 b3 = *reinterpret_cast<const float4*>(tail + FHT_B3 + 16 * t + 4 * rg);
+      acc3[t][0] = acc3[t][0] * inv3 + b3.x;
+      acc3[t][1] = acc3[t][1] * inv3 + b3.y;
+      acc3[t][2] = acc3[t][2] * inv3 + b3.z;
+      acc3[t][3] = acc3[t][3] * inv3 + b3.w;
+    }
+    if (a.normalize) ln_regs<false, false>(acc3, nullptr, nullptr, rg);
+    if (valid) {
+      float* o = a.out + (size_t)e * a.ldo;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        *reinterpret_cast<float4*>(o + 16 * t + 4 * rg) = make_float4(acc3[t][0], acc3[t][1], acc3[t][2], acc3[t][3]);
+    }
+  }
+}
+
+}  // namespace ig

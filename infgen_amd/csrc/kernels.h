@@ -204,6 +204,7 @@ struct MapGraphArgs {
 
 __global__ void k_linear(LinearArgs a);
 __global__ void k_fourier(FourierArgs a);
+__global__ void k_fourier_h(FourierArgs a);     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);
 __global__ void k_edge_attn_wide(EdgeAttnArgs a);

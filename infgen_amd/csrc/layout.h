@@ -58,6 +58,34 @@ enum FourierLayout : int {
   FT_B3 = FT_W3 + 16384,
   FT_SIZE = FT_B3 + 128,
 };
-__host__ __device__ inline int fourier_pack_size(int n) { return FE_DIM0 + n * FD_SIZE + FT_SIZE; }
+__host__ __device__ inline int fourier_pack_size_f32(int n) { return FE_DIM0 + n * FD_SIZE + FT_SIZE; }
+
+// ---- fp16-split section appended to the Fourier pack (k_fourier_h, fourier_h.hip) ---------------
+// a table of fp32 per-feature vectors (copied to LDS), then 2 (2 n + 1) half-matrices of fp16
+// MFMA A-fragments in consumption order  W1_0 W2_0 W1_1 W2_1 ... W3 :
+//   half-matrix = [k-step 4][feature tile 4][hi, lo][lane 64][8 fp16]       (16384 fp16 = 8192 floats)
+//   element (ks = 4 half + k-step, ft, lane = (i, g), s) = W[32 ft + i][k] * 2^sw with
+//     k = 16 ks + 8 g + s                                   for W1 (input = [cos 64 | sin 64])
+//     k = 32 (ks >> 1) + 16 (ks & 1) + (s & 3) + 8 (s >> 2) + 4 g    for W2 / W3 (input = C registers of the previous GEMM)
+enum FourierHLayout : int {
+  FH_HDR = 0,                  // [0..3] 1 / (sw1_i * sf)   [4] 1 / (sw2 * sa1)   [5] 1 / (sw3 * sa2)   [6] sf (feature prescale)
+  FH_FREQ = 16,                // [4][64] freqs.weight
+  FH_DIM0 = FH_FREQ + 256,     // four per-dim blocks
+  FHD_WX = 0,                  // mlps.i.0.weight[:, 128]
+  FHD_B1 = 128,
+  FHD_G1 = 256,                // mlps.i.1.weight * sa1
+  FHD_BE1 = 384,               // mlps.i.1.bias * sa1
+  FHD_SIZE = 512,
+  FH_TAIL = FH_DIM0 + 4 * FHD_SIZE,
+  FHT_B2SUM = 0,
+  FHT_G2 = 128,                // to_out.0.weight * sa2
+  FHT_BE2 = 256,
+  FHT_B3 = 384,
+  FH_VEC_SIZE = FH_TAIL + 512,
+  FH_HALF_MAT_FLOATS = 8192,
+};
+__host__ __device__ inline int fourier_pack_size(int n) {
+  return fourier_pack_size_f32(n) + FH_VEC_SIZE + 2 * (2 * n + 1) * FH_HALF_MAT_FLOATS;
+}
 
 }  // namespace ig

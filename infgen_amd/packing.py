@@ -102,7 +102,72 @@ def pack_fourier(sd, prefix: str, n: int) -> np.ndarray:
     put('b2sum', 0, b2sum)
     put('lno_g', 0, g('to_out.0.weight')); put('lno_b', 0, g('to_out.0.bias'))
     put('w3', 0, pack_matrix(g('to_out.2.weight'))); put('b3', 0, g('to_out.2.bias'))
+
+    # ---- fp16-split section for k_fourier_h (FourierHLayout in csrc/layout.h) ----
+    pow2 = lambda bound: float(2.0 ** np.floor(np.log2(H_TARGET / max(float(bound), 1e-30))))
+    ln_bound = lambda gam, bet: LN_MAX * float(np.abs(gam).max()) + float(np.abs(bet).max())
+    sf = 1024.0                                                     # |cos|, |sin| <= 1
+    sa1 = min(min(pow2(ln_bound(g(f'mlps.{i}.1.weight'), g(f'mlps.{i}.1.bias'))) for i in range(n)), 4096.0)
+    sa2 = min(pow2(ln_bound(g('to_out.0.weight'), g('to_out.0.bias'))), 4096.0)
+    sw1 = [min(pow2(np.abs(g(f'mlps.{i}.0.weight')[:, :128]).max()), 2.0 ** 14) for i in range(n)]
+    sw2 = min(min(pow2(np.abs(g(f'mlps.{i}.3.weight')).max()) for i in range(n)), 2.0 ** 14)
+    sw3 = min(pow2(np.abs(g('to_out.2.weight')).max()), 2.0 ** 14)
+    hdr = np.zeros(16, np.float32)
+    for i in range(n):
+        hdr[i] = 1.0 / (sw1[i] * sf)
+    hdr[4], hdr[5], hdr[6] = 1.0 / (sw2 * sa1), 1.0 / (sw3 * sa2), sf
+    put('h_hdr', 0, hdr)
+    mats = []
+    for i in range(n):
+        w1 = g(f'mlps.{i}.0.weight')
+        put('h_freq', i, freqs[i])
+        put('h_wx', i, w1[:, 128]); put('h_b1', i, g(f'mlps.{i}.0.bias'))
+        put('h_g1', i, g(f'mlps.{i}.1.weight') * sa1); put('h_be1', i, g(f'mlps.{i}.1.bias') * sa1)
+        mats.append(pack_matrix_h(w1[:, :128] * sw1[i], natural_k=True))
+        mats.append(pack_matrix_h(g(f'mlps.{i}.3.weight') * sw2, natural_k=False))
+    put('h_b2sum', 0, b2sum)
+    put('h_g2', 0, g('to_out.0.weight') * sa2); put('h_be2', 0, g('to_out.0.bias') * sa2)
+    put('h_b3', 0, g('to_out.2.bias'))
+    mats.append(pack_matrix_h(g('to_out.2.weight') * sw3, natural_k=False))
+    halfs = np.concatenate(mats)                                   # uint16
+    o = lib.infgen_fourier_pack_offset(b'h_mat', n, 0)
+    out[o:o + halfs.size // 2] = halfs.view(np.float32)            # raw bits; never touched as floats
     return out
+
+
+H_TARGET = 32000.0      # |scaled operand| bound: fp16 max is 65504
+LN_MAX = 11.3           # max |(x - mean) / std| over 128 values is sqrt(127)
+
+
+def split_f16(x: np.ndarray):
+    """x -> (hi, lo) fp16 bit patterns with x ~= hi + lo: hi = x truncated to 11 significand bits, lo = the
+    remainder rounded toward zero - the same split the kernel applies to activations."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    hi32 = (x.view(np.uint32) & np.uint32(0xFFFFE000)).view(np.float32)
+    hi = hi32.astype(np.float16)
+    assert np.all(np.isfinite(hi)), 'fp16 overflow in the weight split'
+    rem = x - hi.astype(np.float32)
+    lo = rem.astype(np.float16)
+    # round toward zero like v_cvt_pkrtz
+    over = np.abs(lo.astype(np.float32)) > np.abs(rem)
+    lo = np.where(over, np.nextafter(lo, np.float16(0)), lo).astype(np.float16)
+    return hi.view(np.uint16), lo.view(np.uint16)
+
+
+def pack_matrix_h(w: np.ndarray, natural_k: bool) -> np.ndarray:
+    """nn.Linear weight [128 out][128 in] (already prescaled) -> 4 quarter-matrices (one k-step of 32 each) of
+    16x16x32 MFMA A fragments: [k-step 4][feature tile 8][hi, lo][lane 64][slot 8] fp16.
+    lane = (i = lane & 15, kg = lane >> 4) holds W[16 t + i][k(s, kg, p)] with
+      natural_k:  k = 32 s + 8 kg + p                      (input = [cos 64 | sin 64] features)
+      otherwise:  k = 32 s + 16 (p >> 2) + 4 kg + (p & 3)  (input = C registers of the previous GEMM)"""
+    w = np.asarray(w, dtype=np.float32)
+    assert w.shape == (128, 128)
+    s_, t_, l_, p_ = np.meshgrid(np.arange(4), np.arange(8), np.arange(64), np.arange(8), indexing='ij')
+    i_, kg_ = l_ & 15, l_ >> 4
+    k_ = 32 * s_ + 8 * kg_ + p_ if natural_k else 32 * s_ + 16 * (p_ >> 2) + 4 * kg_ + (p_ & 3)
+    vals = w[16 * t_ + i_, k_]                                    # [4][8][64][8]
+    hi, lo = split_f16(vals)
+    return np.stack([hi, lo], axis=2).reshape(-1)                 # [4][8][2][64][8]
 
 
 def pack_mlp_embedding(sd, prefix: str) -> np.ndarray:

@@ -54,17 +54,33 @@ def test_linear_layernorm_relu_epilogue(env):
     assert np.abs(y.cpu().numpy() - ref.numpy()).max() <= 2e-5
 
 
-@pytest.mark.parametrize('n,prefix', [(2, 'agent_encoder.x_a_emb'), (3, 'agent_encoder.r_a2a_emb'),
-                                      (4, 'agent_encoder.r_t_emb'), (3, 'map_encoder.r_pt2pt_emb')])
-def test_fourier_embedding(env, n, prefix):
+@pytest.mark.parametrize('mode', [1, 0])
+@pytest.mark.parametrize('n,prefix,E', [(2, 'agent_encoder.x_a_emb', 77), (3, 'agent_encoder.r_a2a_emb', 77),
+                                        (4, 'agent_encoder.r_t_emb', 77), (3, 'map_encoder.r_pt2pt_emb', 1),
+                                        (3, 'agent_encoder.r_pt2a_emb', 70001)])
+def test_fourier_embedding(env, n, prefix, E, mode):
+    """mode 1: fp16 MFMA with the three-term hi/lo split (k_fourier_h); mode 0: fp32-input MFMA (k_fourier).
+    Same tolerances for both: the split keeps 21 bits per product."""
+    from oracle import rollout_oracle as ro
+    from infgen_amd import _lib
+    _lib.check(env['lib'].infgen_set_fourier_mode(mode))
+    try:
+        _fourier_case(env, n, prefix, E)
+    finally:
+        _lib.check(env['lib'].infgen_set_fourier_mode(1))
+
+
+def _fourier_case(env, n, prefix, E):
     from oracle import rollout_oracle as ro
     rng = np.random.default_rng(n)
-    E = 77
     raw = np.zeros((E, 4), np.float32)
     raw[:, 0] = rng.uniform(0, 60, E)
     raw[:, 1:n] = rng.uniform(-np.pi, np.pi, (E, n - 1))
     if n == 4:
         raw[:, 3] = -rng.integers(1, 13, E)
+    if E > 1000:
+        raw[7, 0] = 4.0e5            # |z| >= 1e5 rad: the fp64 range-reduction path
+        raw[8, 0] = 0.0
     cat = rng.standard_normal((E, 128)).astype(np.float32) * 0.1 if n == 2 else None
     pack = _dev(env['packing'].pack_fourier(env['sd'], prefix, n), env['dev'])
     out = torch.empty(E, 128, device=env['dev'])
@@ -80,6 +96,35 @@ def test_fourier_embedding(env, n, prefix):
                        normalize=True)
     ref2 = torch.nn.functional.layer_norm(ref, (128,))
     assert np.abs(out2.cpu().numpy() - ref2.numpy()).max() <= 2e-4
+
+
+def test_fourier_split_is_deterministic(env):
+    """350k rows (every CU busy for ~10 tiles), four launches: bitwise identical, and equal to the fp32-MFMA kernel
+    within the split's accuracy.  Guards the one-workgroup-per-CU placement of k_fourier_h (csrc/fourier_h.hip)."""
+    from infgen_amd import _lib
+    E, n, prefix = 350000, 3, 'agent_encoder.r_a2a_emb'
+    rng = np.random.default_rng(0)
+    raw = np.zeros((E, 4), np.float32)
+    raw[:, 0] = rng.uniform(0, 60, E)
+    raw[:, 1:n] = rng.uniform(-np.pi, np.pi, (E, n - 1))
+    rawd = _dev(raw, env['dev'])
+    pack = _dev(env['packing'].pack_fourier(env['sd'], prefix, n), env['dev'])
+    outs = []
+    for _ in range(4):
+        out = torch.empty(E, 128, device=env['dev'])
+        env['ops'].fourier(rawd, n, pack, out, normalize=True)
+        outs.append(out)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o.view(torch.int32), outs[0].view(torch.int32))
+    _lib.check(env['lib'].infgen_set_fourier_mode(0))
+    try:
+        ref = torch.empty(E, 128, device=env['dev'])
+        env['ops'].fourier(rawd, n, pack, ref, normalize=True)
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(env['lib'].infgen_set_fourier_mode(1))
+    assert float((outs[0] - ref).abs().max()) <= 5e-5
 
 
 def _random_graph(rng, n_dst, n_src, max_deg, empty_rows=()):
