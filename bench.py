@@ -92,7 +92,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--scenes', type=int, default=256, help='scenes per GPU')
+    ap.add_argument('--scenes', type=int, default=512, help='scenes per GPU')
     ap.add_argument('--agents', type=int, default=64)
     ap.add_argument('--map-tokens', type=int, default=1024)
     ap.add_argument('--insertion', action='store_true', help='scenario insertion on (configs/ours_long_term.yaml style)')

@@ -121,6 +121,7 @@ extern "C" int infgen_attn_pack_offset(const char* f) {
   F("ln_ffpre_g", AL_LN_FFPRE_G) F("ln_ffpre_b", AL_LN_FFPRE_B)
   F("w1", AL_W1) F("b1", AL_B1) F("w2", AL_W2) F("b2", AL_B2)
   F("ln_ffpost_g", AL_LN_FFPOST_G) F("ln_ffpost_b", AL_LN_FFPOST_B)
+  F("h_hdr", AH_HDR) F("h_pre", AH_PRE) F("h_post", AH_POST)
 #undef F
   return -1;
 }
@@ -196,9 +197,33 @@ extern "C" int infgen_fourier_embed(const float* raw, int n, const int* count_de
   return check_launch("infgen_fourier_embed");
 }
 
+static int g_attn_mode = 1;      // 1: fp16 three-term split (k_attn_h), 0: fp32-input MFMA (k_attn_pre / k_attn_post)
+extern "C" int infgen_set_attn_mode(int mode) {
+  if (mode != 0 && mode != 1) return fail("infgen_set_attn_mode", "mode must be 0 (fp32 MFMA) or 1 (fp16 split)");
+  g_attn_mode = mode;
+  return 0;
+}
+
+// one workgroup per CU: 64-row tiles (4 waves) while they fill the chip at most once, 128-row tiles (8 waves) beyond
+static void launch_attn_h(const AttnHArgs& a, void* stream) {
+  if (a.rows <= 256 * 64) {
+    hipLaunchKernelGGL(k_attn_h<4>, dim3(ceil_div(a.rows, 64)), dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    int grid = ceil_div(a.rows, 128);
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL(k_attn_h<8>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+  }
+}
+
 extern "C" int infgen_attn_pre(const float* X, int rows, const float* pack, int use_src_ln,
                                float* Q, float* U, float* K, float* V, void* stream) {
   if (rows <= 0) return 0;
+  if (g_attn_mode == 1) {
+    AttnHArgs h{const_cast<float*>(X), rows, nullptr, nullptr, nullptr, nullptr, 0, pack, use_src_ln, Q, U, K, V};
+    { ProfScope _ps(INFGEN_KID_ATTN_PRE, stream, (double)rows * 16384.0 * ((Q || U ? 1 : 0) + (K ? 1 : 0) + (V ? 1 : 0) + (U ? 1 : 0)));
+      launch_attn_h(h, stream); }
+    return check_launch("infgen_attn_pre");
+  }
   AttnPreArgs a{X, rows, pack, use_src_ln, Q, U, K, V};
   { ProfScope _ps(INFGEN_KID_ATTN_PRE, stream, (double)rows * 16384.0 * ((Q || U ? 1 : 0) + (K ? 1 : 0) + (V ? 1 : 0) + (U ? 1 : 0)));
     hipLaunchKernelGGL(k_attn_pre, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a); }
@@ -246,6 +271,13 @@ extern "C" int infgen_attn_post_pre(float* X, int rows, const float* pack, const
 static int attn_post_fused(float* X, int rows, const float* pack, const float* AGG, const float* Z, const float* SIG,
                            int has_pos, const float* next_pack, float* nQ, float* nU, float* nK, float* nV, void* stream) {
   if (rows <= 0) return 0;
+  if (g_attn_mode == 1) {
+    AttnHArgs h{X, rows, pack, AGG, Z, SIG, has_pos, next_pack, 0, nQ, nU, nK, nV};
+    { ProfScope _ps(INFGEN_KID_ATTN_POST, stream, (double)rows * (196608.0 + (has_pos ? 16384.0 : 0.0) +
+          (next_pack ? 16384.0 * ((nQ || nU ? 1 : 0) + (nK ? 1 : 0) + (nV ? 1 : 0) + (nU ? 1 : 0)) : 0.0)));
+      launch_attn_h(h, stream); }
+    return check_launch("infgen_attn_post");
+  }
   AttnPostArgs a{X, rows, pack, AGG, Z, SIG, has_pos, next_pack, nQ, nU, nK, nV};
   { ProfScope _ps(INFGEN_KID_ATTN_POST, stream, (double)rows * (196608.0 + (has_pos ? 16384.0 : 0.0) +
         (next_pack ? 16384.0 * ((nQ || nU ? 1 : 0) + (nK ? 1 : 0) + (nV ? 1 : 0) + (nU ? 1 : 0)) : 0.0)));

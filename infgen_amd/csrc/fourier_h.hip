@@ -29,31 +29,14 @@
 #include "kernels.h"
 #include "layout.h"
 #include "tile.cuh"
+#include "split.cuh"
 
 namespace ig {
-
-typedef _Float16 v8h __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FH_WAVES = 8;
 constexpr int FH_NT = 64 * FH_WAVES;     // threads per workgroup
 constexpr int FH_TILE = 16 * FH_WAVES;   // edges per workgroup tile (16 per wave)
-constexpr int QUARTER = 8192;            // fp16 elements of one quarter-matrix in LDS (16 KB)
-constexpr int RING = 5;                  // quarter buffers in LDS
-constexpr int DIST = RING - 1;           // quarters in flight ahead of the one being consumed
 constexpr int GLDS_PER_STAGE = 1024 / FH_NT;   // global_load_lds instructions per thread and quarter
-
-__device__ __forceinline__ unsigned pk_rtz(float a, float b) {
-  return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-}
-
-// (a, b) -> packed fp16 pairs hi, lo with a = hi_a + lo_a (+ <= 2^-21 |a|)
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
-  const float ah = __uint_as_float(__float_as_uint(a) & 0xFFFFE000u);
-  const float bh = __uint_as_float(__float_as_uint(b) & 0xFFFFE000u);
-  hi = pk_rtz(ah, bh);
-  lo = pk_rtz(a - ah, b - bh);
-}
 
 // sin/cos: three-constant Cody-Waite reduction by pi/2 with fused multiply-adds (the products n * c are
 // exact inside the fma), then the classic minimax polynomials on [-pi/4, pi/4] (Cephes sinf/cosf
@@ -90,87 +73,6 @@ __device__ __forceinline__ void sincos_fast(float z, float& s, float& c) {
   c = __uint_as_float(cv ^ ((((unsigned)qi + 1u) & 2u) << 30));
 }
 
-__device__ __forceinline__ float xor_lanes(float v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
-}
-
-__device__ __forceinline__ void stage_quarter(const unsigned short* __restrict__ gsrc, unsigned short* ldst, int tid) {
-  // 16 KB = 1024 sixteen-byte units; a wave instruction lands 1 KB at (uniform base + lane * 16)
-#pragma unroll
-  for (int c = 0; c < GLDS_PER_STAGE; ++c) {
-    const int unit = c * FH_NT + tid;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + unit * 8),
-                                     (__attribute__((address_space(3))) void*)(ldst + (c * FH_NT + (tid & ~63)) * 8),
-                                     16, 0, 0);
-  }
-}
-
-// acc[t] += W[16 t .., this k-step] * B   (three MFMAs per feature tile; the two A fragments of tile t + 1 are
-// read from LDS while the MFMAs of tile t run)
-__device__ __forceinline__ void gemm_quarter(f32x4 (&acc)[8], const unsigned short* Wl, u32x4 Bh, u32x4 Bl, int lane) {
-  const v8h bh = __builtin_bit_cast(v8h, Bh);
-  const v8h bl = __builtin_bit_cast(v8h, Bl);
-  const unsigned short* p = Wl + lane * 8;
-  v8h ah = *reinterpret_cast<const v8h*>(p);
-  v8h al = *reinterpret_cast<const v8h*>(p + 512);
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    v8h nh = ah, nl = al;
-    if (t + 1 < 8) {
-      nh = *reinterpret_cast<const v8h*>(p + (t + 1) * 1024);
-      nl = *reinterpret_cast<const v8h*>(p + (t + 1) * 1024 + 512);
-    }
-    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[t], 0, 0, 0);
-    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[t], 0, 0, 0);
-    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[t], 0, 0, 0);
-    ah = nh; al = nl;
-  }
-}
-
-// LayerNorm over the 128 features of this lane's edge (32 here, the rest in lanes ^ 16, ^ 32, ^ 48), biased
-// variance, eps 1e-5; register r of tile t is feature 16 t + 4 rg + r.
-template <bool AFFINE, bool RELU>
-__device__ __forceinline__ void ln_regs(f32x4 (&v)[8], const float* gtab, const float* btab, int rg) {
-  float s = 0.f;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) s += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
-  const float mean = xor_lanes(s) * (1.0f / 128.0f);
-  float q = 0.f;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    v[t][0] -= mean; v[t][1] -= mean; v[t][2] -= mean; v[t][3] -= mean;
-    q += (v[t][0] * v[t][0] + v[t][1] * v[t][1]) + (v[t][2] * v[t][2] + v[t][3] * v[t][3]);
-  }
-  const float rstd = 1.0f / sqrtf(xor_lanes(q) * (1.0f / 128.0f) + LN_EPS);
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    float4 gg = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (AFFINE) {
-      gg = *reinterpret_cast<const float4*>(gtab + 16 * t + 4 * rg);
-      bb = *reinterpret_cast<const float4*>(btab + 16 * t + 4 * rg);
-    }
-    float y0 = v[t][0] * rstd * gg.x + bb.x, y1 = v[t][1] * rstd * gg.y + bb.y;
-    float y2 = v[t][2] * rstd * gg.z + bb.z, y3 = v[t][3] * rstd * gg.w + bb.w;
-    if (RELU) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
-    v[t][0] = y0; v[t][1] = y1; v[t][2] = y2; v[t][3] = y3;
-  }
-}
-
-// C registers -> B fragments of the next GEMM: k-step s takes tiles 2 s (slots 0..3) and 2 s + 1 (slots 4..7)
-__device__ __forceinline__ void regs_to_frags(const f32x4 (&v)[8], u32x4 (&Bh)[4], u32x4 (&Bl)[4]) {
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      unsigned hi, lo;
-      split_pair(v[2 * s + (w >> 1)][2 * (w & 1)], v[2 * s + (w >> 1)][2 * (w & 1) + 1], hi, lo);
-      Bh[s][w] = hi;
-      Bl[s][w] = lo;
-    }
-}
-
 __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned short Wb[RING][QUARTER];    // 80 KB: also keeps the CU to ONE workgroup
   __shared__ __attribute__((aligned(16))) float Vt[FH_VEC_SIZE];
@@ -189,7 +91,7 @@ __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
   int consumed = 0, slot = 0;            // quarter count so far, ring slot of the next quarter
   int q_stage = 0, slot_stage = 0;       // next quarter to stage (index within the tile sequence) and its slot
   for (int d = 0; d < DIST && d < total; ++d) {
-    stage_quarter(wg + (size_t)q_stage * QUARTER, Wb[slot_stage], tid);
+    stage_quarter<FH_NT>(wg + (size_t)q_stage * QUARTER, Wb[slot_stage], tid);
     q_stage = (q_stage + 1 == nq) ? 0 : q_stage + 1;
     slot_stage = (slot_stage + 1 == RING) ? 0 : slot_stage + 1;
   }
@@ -205,7 +107,7 @@ __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (consumed + DIST < total) {
-      stage_quarter(wg + (size_t)q_stage * QUARTER, Wb[slot_stage], tid);
+      stage_quarter<FH_NT>(wg + (size_t)q_stage * QUARTER, Wb[slot_stage], tid);
       q_stage = (q_stage + 1 == nq) ? 0 : q_stage + 1;
       slot_stage = (slot_stage + 1 == RING) ? 0 : slot_stage + 1;
     }

@@ -63,6 +63,19 @@ struct AttnPostArgs {
   float* nQ; float* nU; float* nK; float* nV;
 };
 
+// k_attn_h (attn_h.hip): the node side of one AttentionLayer on the fp16 matrix pipe - any of
+//   post:  everything after the edge aggregation of layer `pack` (k_attn_post's work), in place on X
+//   pre:   LayerNorm + q / u / k / v projections of layer `next_pack` on the (updated) rows (k_attn_pre's work)
+struct AttnHArgs {
+  float* X; int rows;
+  const float* pack;                 // layer whose post part runs (null: none)
+  const float* AGG; const float* Z; const float* SIG;
+  int has_pos;
+  const float* next_pack;            // layer whose pre part runs (null: none)
+  int next_src_ln;                   // 1: LayerNorm with the *_src parameters (K/V of a bipartite source)
+  float* nQ; float* nU; float* nK; float* nV;
+};
+
 struct HeadsArgs {
   const float* X; int rows;
   const float* tok_pack;    // MLPLayer pack: P(128,128) W0, b0, ln g/b, P(128,2048) W3, b3
@@ -204,7 +217,8 @@ struct MapGraphArgs {
 
 __global__ void k_linear(LinearArgs a);
 __global__ void k_fourier(FourierArgs a);
-__global__ void k_fourier_h(FourierArgs a);     // fourier_h.hip: fp16 three-term split, register resident
+__global__ void k_fourier_h(FourierArgs a);
+template <int WAVES> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);
 __global__ void k_edge_attn_wide(EdgeAttnArgs a);

@@ -72,6 +72,34 @@ def pack_attention_layer(sd, prefix: str, has_pos_emb: bool = True) -> np.ndarra
     put('w1', pack_matrix(g('ff_mlp.0.weight'))); put('b1', g('ff_mlp.0.bias'))
     put('w2', pack_matrix(g('ff_mlp.3.weight'))); put('b2', g('ff_mlp.3.bias'))
     put('ln_ffpost_g', g('ff_postnorm.weight')); put('ln_ffpost_b', g('ff_postnorm.bias'))
+
+    # ---- fp16-split section for k_attn_h (AH_* in csrc/layout.h): every matrix prescaled by a power of two ----
+    pow2 = lambda w: float(min(2.0 ** np.floor(np.log2(H_TARGET / max(float(np.abs(w).max()), 1e-30))), 2.0 ** 14))
+    hdr = np.zeros(16, np.float32)
+    wq = g('to_q.weight') * scale
+    wk, wv = g('to_k.weight'), g('to_v.weight')
+    ws, wg, wo = g('to_s.weight'), g('to_g.weight'), g('to_out.weight')
+    w1, w2 = g('ff_mlp.0.weight'), g('ff_mlp.3.weight')
+    zero = np.zeros((128, 128), np.float32)
+    wkr_ = wkr if has_pos_emb else zero
+    wvr_ = wvr if has_pos_emb else zero
+    sc = [pow2(wq), pow2(wkr_) if has_pos_emb else 1.0, pow2(wk), pow2(wv), pow2(wvr_) if has_pos_emb else 1.0,
+          pow2(wg), pow2(ws), pow2(wo), pow2(w1), pow2(w2)]
+    hdr[:10] = [1.0 / v for v in sc]
+    pre = [pack_matrix_h(wq * sc[0], natural_k=False), pack_wkr_h(wkr_ * sc[1]),
+           pack_matrix_h(wk * sc[2], natural_k=False), pack_matrix_h(wv * sc[3], natural_k=False)]
+    post = [pack_wvr_h(wvr_ * sc[4]), pack_matrix_h(wg[:, :128] * sc[5], natural_k=False),
+            pack_matrix_h(wg[:, 128:] * sc[5], natural_k=False), pack_matrix_h(ws * sc[6], natural_k=False),
+            pack_matrix_h(wo * sc[7], natural_k=False)]
+    for c in range(4):
+        post.append(pack_matrix_h(w1[128 * c:128 * (c + 1), :] * sc[8], natural_k=False))
+        post.append(pack_matrix_h(w2[:, 128 * c:128 * (c + 1)] * sc[9], natural_k=False))
+    o = lib.infgen_attn_pack_offset(b'h_hdr')
+    out[o:o + 16] = hdr
+    halfs = np.concatenate(pre + post)
+    assert halfs.size == 68 * 8192
+    o = lib.infgen_attn_pack_offset(b'h_pre')
+    out[o:o + halfs.size // 2] = halfs.view(np.float32)
     return out
 
 
@@ -152,6 +180,24 @@ def split_f16(x: np.ndarray):
     over = np.abs(lo.astype(np.float32)) > np.abs(rem)
     lo = np.where(over, np.nextafter(lo, np.float16(0)), lo).astype(np.float16)
     return hi.view(np.uint16), lo.view(np.uint16)
+
+
+def pack_wvr_h(wvr: np.ndarray) -> np.ndarray:
+    """W'_vr [128 = 16 h + c][128 d] -> 4 quarters of two heads: [head 2][k-step 4][hi, lo][lane 64][slot 8];
+    lane (i, kg) slot p of head h, k-step s = wvr[16 h + i][32 s + 8 kg + p]  (B fragments come from Z in natural order)"""
+    h_, s_, l_, p_ = np.meshgrid(np.arange(8), np.arange(4), np.arange(64), np.arange(8), indexing='ij')
+    vals = np.asarray(wvr, np.float32)[16 * h_ + (l_ & 15), 32 * s_ + 8 * (l_ >> 4) + p_]       # [8][4][64][8]
+    hi, lo = split_f16(vals)
+    return np.stack([hi, lo], axis=2).reshape(-1)                                                # [8][4][2][64][8]
+
+
+def pack_wkr_h(wkr: np.ndarray) -> np.ndarray:
+    """W'_kr [128 = 16 h + d][128 c] -> 4 quarters of two heads for the K = 16 MFMA (16x16x16):
+    [head 2][column tile 8][hi, lo][lane 64][slot 4]; lane (i, kg) slot p = wkr[16 h + 4 kg + p][16 ct + i]"""
+    h_, c_, l_, p_ = np.meshgrid(np.arange(8), np.arange(8), np.arange(64), np.arange(4), indexing='ij')
+    vals = np.asarray(wkr, np.float32)[16 * h_ + 4 * (l_ >> 4) + p_, 16 * c_ + (l_ & 15)]       # [8][8][64][4]
+    hi, lo = split_f16(vals)
+    return np.stack([hi, lo], axis=2).reshape(-1)                                                # [8][8][2][64][4]
 
 
 def pack_matrix_h(w: np.ndarray, natural_k: bool) -> np.ndarray:

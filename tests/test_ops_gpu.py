@@ -139,11 +139,20 @@ def _random_graph(rng, n_dst, n_src, max_deg, empty_rows=()):
     return np.array(off, np.int32), np.array(cnt, np.int32), np.array(src, np.int32), np.array(dst, np.int64)
 
 
+@pytest.fixture(params=[1, 0], ids=['split16', 'fp32mfma'])
+def attn_mode(request, env):
+    """1: node-side GEMMs on the fp16 matrix pipe with the three-term split (k_attn_h); 0: fp32-input MFMA kernels"""
+    from infgen_amd import _lib
+    _lib.check(env['lib'].infgen_set_attn_mode(request.param))
+    yield request.param
+    _lib.check(env['lib'].infgen_set_attn_mode(1))
+
+
 @pytest.mark.parametrize('wide', [False, True])
 @pytest.mark.parametrize('prefix,bip', [('agent_encoder.a2a_attn_layers.2', False),
                                         ('agent_encoder.pt2a_attn_layers.1', True),
                                         ('agent_encoder.t_attn_layers.0', False)])
-def test_attention_layer(env, prefix, bip, wide):
+def test_attention_layer(env, prefix, bip, wide, attn_mode):
     """pre + edge attention + post == AttentionLayer.forward (layers.py:61-113), incl. rows without
     incoming edges (exact-zero aggregate) and ragged degrees up to 70."""
     from oracle import rollout_oracle as ro
@@ -168,7 +177,7 @@ def test_attention_layer(env, prefix, bip, wide):
     assert err <= 1e-4, err
 
 
-def test_attention_layer_edgeless(env):
+def test_attention_layer_edgeless(env, attn_mode):
     from oracle import rollout_oracle as ro
     rng = np.random.default_rng(12)
     x = rng.standard_normal((20, 128)).astype(np.float32)
