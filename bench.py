@@ -34,6 +34,11 @@ from infgen_amd import engine, synth, _lib  # noqa: E402
 from infgen_amd import dist as igdist  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+# kernels that run on the fp16 matrix pipe with the three-term split: one algorithmic multiply-add costs three
+# f16 MFMA multiply-adds, so the ceiling for ALGORITHMIC flops is the dense f16 peak (2.5 PFLOP/s) / 3
+F16_SPLIT_PEAK_TFLOPS = 2500.0 / 3.0
+SPLIT_KERNELS = ('k_fourier', 'k_attn_pre', 'k_attn_post')
+HBM_PEAK_GBS = 8000.0                # HBM3E peak of the same guide
 
 
 def load_shapes():
@@ -187,15 +192,38 @@ def main():
     dom = _lib.prof_collect()[dominant]
     _lib.prof_enable(0)
     roof = None
-    if dom['calls'] > 0 and dom['macs'] > 0:
+    common = {'launches': dom['calls'],
+              'share_of_gpu_time': per_kernel[dominant]['ms'] / max(1e-9, sum(v['ms'] for v in per_kernel.values())),
+              'per_kernel_ms_one_rollout': {k: round(v['ms'], 3) for k, v in per_kernel.items()}}
+    if dom['calls'] > 0 and dominant == 'k_edge_attn':
+        # HBM-bound gather kernel: compulsory bytes (DESIGN.md "Measurement"): 512 B of rhat per edge; per destination
+        # row q 512 + u 4096 in, agg 512 + z 4096 + sigma 32 out; K and V (1 KB) once per DISTINCT source row of a
+        # launch: every temporal edge has its own source, the agent set re-reads the rows of its own launch, the map
+        # set at most the map tokens of the batch.
+        L = cfg.num_agent_layers
+        ed = {k: v * L for k, v in dom['edges_built'].items()}      # each set feeds one launch per layer
+        rows = args.scenes * eng.A_cap
+        rows_total = float(dom['calls']) * rows
+        launches_per_kind = dom['calls'] / 3.0
+        e_all = sum(ed.values())
+        kv = 1024.0 * (ed['temporal'] + launches_per_kind * rows
+                       + min(ed['map'], launches_per_kind * args.scenes * args.map_tokens))
+        nbytes = 512.0 * e_all + 9248.0 * rows_total + kv
+        avg_s = dom['ms'] * 1e-3 / dom['calls']
+        ach = nbytes / (dom['ms'] * 1e-3) / 1e9
+        roof = {'bound': 'hbm', 'kernel': dominant, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': ach / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_us': avg_s * 1e6,
+                'bytes_per_launch': nbytes / dom['calls'], 'edges_per_launch': e_all / dom['calls'], **common}
+    elif dom['calls'] > 0 and dom['macs'] > 0:
         avg_s = dom['ms'] * 1e-3 / dom['calls']
         flops_per_launch = 2.0 * dom['macs'] / dom['calls']
         ach = flops_per_launch / avg_s / 1e12
-        roof = {'bound': 'mfma', 'kernel': dominant, 'achieved': ach, 'peak': FP32_MATRIX_PEAK_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': ach / FP32_MATRIX_PEAK_TFLOPS, 'traffic': None,
-                'launches': dom['calls'], 'avg_launch_us': avg_s * 1e6, 'flops_per_launch': flops_per_launch,
-                'share_of_gpu_time': per_kernel[dominant]['ms'] / max(1e-9, sum(v['ms'] for v in per_kernel.values())),
-                'per_kernel_ms_one_rollout': {k: round(v['ms'], 3) for k, v in per_kernel.items()}}
+        split = dominant in SPLIT_KERNELS
+        peak = F16_SPLIT_PEAK_TFLOPS if split else FP32_MATRIX_PEAK_TFLOPS
+        roof = {'bound': 'mfma', 'kernel': dominant, 'achieved': ach, 'peak': peak,
+                'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+                'arithmetic': 'fp16 MFMA, three-term hi/lo split (peak = 2500 / 3)' if split else 'fp32-input MFMA',
+                'avg_launch_us': avg_s * 1e6, 'flops_per_launch': flops_per_launch, **common}
 
     agent_steps = float(eng.agent_steps() * args.steps)
     inserted = int((eng.n_agents.sum().item() - sum(h['A'] for h in eng.hosts))) if args.insertion else 0

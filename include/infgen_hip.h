@@ -184,15 +184,17 @@ int infgen_insert_finalize(const InfgenRollout* r, int c, float angle_interval, 
 /* ---- optional profiling (bench.py roofline leg; process-global, off by default) ----
  * HIP events are recorded on the launch stream around every launch of the kernels selected by
  * `mask` (bit = INFGEN_KID_*).  infgen_prof_collect synchronises the device, returns the summed
- * duration (ms), launch count and algorithmic multiply-accumulates per kernel id and the rows processed by the Fourier kernel per
- * number of input dims, then clears the event log. */
+ * duration (ms), launch count and algorithmic multiply-accumulates per kernel id and 16 device-side counters, then clears
+ * the event log.  counters[n] (n < 8): rows processed by the Fourier kernel with n input dims; counters[8 + k]: edges
+ * built by infgen_build_edges (k = 0 temporal, 1 map, 2 agent set; counted when INFGEN_KID_EDGE_ATTN or
+ * INFGEN_KID_BUILD_EDGES is selected) - each is consumed by one edge-attention launch per layer. */
 enum {
   INFGEN_KID_LINEAR = 0, INFGEN_KID_FOURIER, INFGEN_KID_ATTN_PRE, INFGEN_KID_EDGE_ATTN, INFGEN_KID_ATTN_POST,
   INFGEN_KID_HEADS, INFGEN_KID_BUILD_EDGES, INFGEN_KID_INTEGRATE, INFGEN_KID_RAWFEAT, INFGEN_KID_MAP_GRAPH,
   INFGEN_KID_COUNT
 };
 int infgen_prof_enable(unsigned mask, int max_launches);
-int infgen_prof_collect(double* total_ms, int* calls, double* total_macs, unsigned long long* fourier_rows);
+int infgen_prof_collect(double* total_ms, int* calls, double* total_macs, unsigned long long* counters);
 
 #ifdef __cplusplus
 }

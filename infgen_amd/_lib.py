@@ -140,9 +140,11 @@ def prof_collect():
     ms = (C.c_double * n)()
     calls = (_i * n)()
     macs = (C.c_double * n)()
-    rows = (C.c_ulonglong * 8)()
+    rows = (C.c_ulonglong * 16)()
     check(load().infgen_prof_collect(ms, calls, macs, rows), 'infgen_prof_collect')
     out = {k: dict(ms=ms[i], calls=calls[i], macs=macs[i]) for i, k in enumerate(KERNEL_IDS)}
+    # edges built per set; every decode step's sets are consumed by one edge-attention launch per layer
+    out['k_edge_attn']['edges_built'] = dict(temporal=int(rows[8]), map=int(rows[9]), agent=int(rows[10]))
     # FourierEmbedding: n x (129x128 + 128x128) + 128x128 MACs per row (reference layers.py:126-141)
     out['k_fourier']['macs'] = float(sum(rows[nd] * (nd * 32896 + 16384) for nd in range(8)))
     out['k_fourier']['rows'] = {nd: int(rows[nd]) for nd in range(8) if rows[nd]}

@@ -35,7 +35,8 @@ struct Prof {
   std::vector<int> kid;
   std::vector<double> macs;                 // algorithmic multiply-accumulates of the launch (0: not a GEMM kernel)
   size_t used = 0;
-  unsigned long long* rows_dev = nullptr;   // [8] rows processed by k_fourier, indexed by n_dims
+  unsigned long long* rows_dev = nullptr;   // [16] device counters: [n] rows processed by k_fourier with n input dims (n < 8);
+                                            // [8 + kind] edges built by k_build_edges (kind 0 temporal, 1 map, 2 agent)
 } g_prof;
 
 struct ProfScope {
@@ -66,16 +67,16 @@ extern "C" int infgen_prof_enable(unsigned mask, int max_launches) {
     }
   }
   if (mask && !g_prof.rows_dev) {
-    if (hipMalloc(&g_prof.rows_dev, 8 * sizeof(unsigned long long)) != hipSuccess)
+    if (hipMalloc(&g_prof.rows_dev, 16 * sizeof(unsigned long long)) != hipSuccess)
       return fail("infgen_prof_enable", "hipMalloc failed");
   }
-  if (g_prof.rows_dev) (void)hipMemset(g_prof.rows_dev, 0, 8 * sizeof(unsigned long long));
+  if (g_prof.rows_dev) (void)hipMemset(g_prof.rows_dev, 0, 16 * sizeof(unsigned long long));
   g_prof.mask = mask;
   g_prof.used = 0;
   return 0;
 }
 
-// total_ms / calls: [INFGEN_KID_COUNT]; fourier_rows: [8] rows processed per n_dims.  Synchronises.
+// total_ms / calls: [INFGEN_KID_COUNT]; counters: [16] device-side row / edge counts (see Prof::rows_dev).  Synchronises.
 extern "C" int infgen_prof_collect(double* total_ms, int* calls, double* total_macs, unsigned long long* fourier_rows) {
   for (int k = 0; k < INFGEN_KID_COUNT; ++k) { total_ms[k] = 0.0; calls[k] = 0; total_macs[k] = 0.0; }
   if (hipDeviceSynchronize() != hipSuccess) return fail("infgen_prof_collect", "sync failed");
@@ -88,8 +89,8 @@ extern "C" int infgen_prof_collect(double* total_ms, int* calls, double* total_m
     total_macs[g_prof.kid[i]] += g_prof.macs[i];
   }
   if (fourier_rows) {
-    for (int i = 0; i < 8; ++i) fourier_rows[i] = 0;
-    if (g_prof.rows_dev) (void)hipMemcpy(fourier_rows, g_prof.rows_dev, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    for (int i = 0; i < 16; ++i) fourier_rows[i] = 0;
+    if (g_prof.rows_dev) (void)hipMemcpy(fourier_rows, g_prof.rows_dev, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   }
   const int dropped = 0;
   g_prof.used = 0;
@@ -342,6 +343,7 @@ extern "C" int infgen_build_edges(const InfgenRollout* r, int c, int edgeless, v
   BuildEdgesArgs a;
   a.st = scene_of(r); a.c = c; a.edgeless = edgeless; a.r_map = r->r_map; a.r_agent = r->r_agent;
   a.rows = r->S * r->A_cap; a.t = ebuf(r->et); a.m = ebuf(r->em); a.a = ebuf(r->ea);
+  a.prof = (g_prof.mask & ((1u << INFGEN_KID_EDGE_ATTN) | (1u << INFGEN_KID_BUILD_EDGES))) ? g_prof.rows_dev : nullptr;
   { ProfScope _ps(INFGEN_KID_BUILD_EDGES, stream);
     hipLaunchKernelGGL(k_build_edges, dim3(r->S), dim3(NT), 0, s, a); }
   return check_launch("infgen_build_edges");

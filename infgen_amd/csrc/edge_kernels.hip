@@ -295,7 +295,7 @@ __global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
     }
     int tot;
     const int excl = block_excl_scan(cnt, scan, &tot);
-    if (t == 0) base_t = atomicAdd(a.t.total, tot);
+    if (t == 0) { base_t = atomicAdd(a.t.total, tot); if (a.prof) atomicAdd(a.prof + 8, (unsigned long long)tot); }
     __syncthreads();
     if (t < st.A_cap) {
       int e = base_t + excl;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
     const int cnt = (t < st.A_cap) ? mapcnt[t] : 0;
     int tot;
     const int excl = block_excl_scan(cnt, scan, &tot);
-    if (t == 0) base_m = atomicAdd(a.m.total, tot);
+    if (t == 0) { base_m = atomicAdd(a.m.total, tot); if (a.prof) atomicAdd(a.prof + 9, (unsigned long long)tot); }
     __syncthreads();
     if (t < st.A_cap) {
       int e = base_m + excl;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
     }
     int tot;
     const int excl = block_excl_scan(cnt, scan, &tot);
-    if (t == 0) base_a = atomicAdd(a.a.total, tot);
+    if (t == 0) { base_a = atomicAdd(a.a.total, tot); if (a.prof) atomicAdd(a.prof + 10, (unsigned long long)tot); }
     __syncthreads();
     if (t < st.A_cap) {
       int e = base_a + excl;

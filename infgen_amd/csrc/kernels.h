@@ -122,6 +122,7 @@ struct BuildEdgesArgs {
   float r_map, r_agent;             // pl2a_radius, a2a_radius
   int rows;                         // S * A_cap
   EdgeBuf t, m, a;
+  unsigned long long* prof;         // optional profiling counters (api.hip Prof::rows_dev): [8 + kind] += edges of the scene
 };
 
 struct IntegrateArgs {
