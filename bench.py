@@ -41,6 +41,20 @@ SPLIT_KERNELS = ('k_fourier', 'k_attn_pre', 'k_attn_post')
 HBM_PEAK_GBS = 8000.0                # HBM3E peak of the same guide
 
 
+def pmc_traffic(kernel, args):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json, written
+    from tools/prof_round.sh output), if they were taken on this workload; None otherwise."""
+    try:
+        with open(os.path.join(REPO, 'profiles', 'traffic.json')) as f:
+            t = json.load(f)
+    except OSError:
+        return None
+    same = (t.get('scenes_per_gpu') == args.scenes and t.get('agents') == args.agents and
+            t.get('map_tokens') == args.map_tokens and t.get('insertion') == bool(args.insertion))
+    k = t.get('kernels', {}).get(kernel)
+    return float(k['fetch_bytes_per_launch'] + k['write_bytes_per_launch']) if same and k else None
+
+
 def load_shapes():
     with open(os.path.join(REPO, 'tests', 'golden', 'state_dict_shapes.json')) as f:
         return {k: tuple(v) for k, v in json.load(f).items()}
@@ -98,6 +112,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--scenes', type=int, default=512, help='scenes per GPU')
+    ap.add_argument('--roofline-kernel', default='', help='report the roofline of this kernel instead of the dominant one')
     ap.add_argument('--agents', type=int, default=64)
     ap.add_argument('--map-tokens', type=int, default=1024)
     ap.add_argument('--insertion', action='store_true', help='scenario insertion on (configs/ours_long_term.yaml style)')
@@ -175,7 +190,7 @@ def main():
     _lib.prof_enable((1 << len(_lib.KERNEL_IDS)) - 1)
     eng.rollout()
     per_kernel = _lib.prof_collect()
-    dominant = max(per_kernel, key=lambda k: per_kernel[k]['ms'])
+    dominant = args.roofline_kernel or max(per_kernel, key=lambda k: per_kernel[k]['ms'])
     log('per-kernel ms of one rollout: ' + ', '.join(f'{k}={v["ms"]:.2f}' for k, v in per_kernel.items()))
     # roofline leg 2: events only around the dominant kernel's launches, inside the timed region
     _lib.prof_enable(1 << _lib.KERNEL_IDS.index(dominant))
@@ -202,7 +217,7 @@ def main():
         # set at most the map tokens of the batch.
         L = cfg.num_agent_layers
         ed = {k: v * L for k, v in dom['edges_built'].items()}      # each set feeds one launch per layer
-        rows = args.scenes * eng.A_cap
+        rows = args.scenes * engines[0].A_cap
         rows_total = float(dom['calls']) * rows
         launches_per_kind = dom['calls'] / 3.0
         e_all = sum(ed.values())
@@ -224,6 +239,9 @@ def main():
                 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
                 'arithmetic': 'fp16 MFMA, three-term hi/lo split (peak = 2500 / 3)' if split else 'fp32-input MFMA',
                 'avg_launch_us': avg_s * 1e6, 'flops_per_launch': flops_per_launch, **common}
+
+    if roof is not None:
+        roof['traffic'] = pmc_traffic(dominant, args)
 
     agent_steps = float(eng.agent_steps() * args.steps)
     inserted = int((eng.n_agents.sum().item() - sum(h['A'] for h in eng.hosts))) if args.insertion else 0
