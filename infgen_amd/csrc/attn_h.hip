@@ -47,12 +47,9 @@ __device__ __forceinline__ void zero_acc(f32x4 (&v)[8]) {
 }
 // v = v * s + bias (bias: per-feature vector in LDS, may be null)
 __device__ __forceinline__ void scale_bias(f32x4 (&v)[8], float s, const float* bias, int rg) {
+  const f32x4 s4 = splat4(s);
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias) b = *reinterpret_cast<const float4*>(bias + 16 * t + 4 * rg);
-    v[t][0] = v[t][0] * s + b.x; v[t][1] = v[t][1] * s + b.y; v[t][2] = v[t][2] * s + b.z; v[t][3] = v[t][3] * s + b.w;
-  }
+  for (int t = 0; t < 8; ++t) v[t] = bias ? fma4(v[t], s4, lds4(bias + 16 * t + 4 * rg)) : v[t] * s4;
 }
 
 template <int WAVES>
@@ -240,19 +237,14 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_attn_h(AttnHArgs a) {
           gemm_unit(hdn, Fh, Fl);
           scale_bias(hdn, inv_f * hdr[8], Vt + VT_B1 + 128 * cc, rg);
 #pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            hdn[t][0] = fmaxf(hdn[t][0], 0.f); hdn[t][1] = fmaxf(hdn[t][1], 0.f);
-            hdn[t][2] = fmaxf(hdn[t][2], 0.f); hdn[t][3] = fmaxf(hdn[t][3], 0.f);
-          }
+          for (int t = 0; t < 8; ++t) hdn[t] = __builtin_elementwise_max(hdn[t], splat4(0.f));
           const float inv_h = frags_scaled(hdn, Bh, Bl);
           f32x4 part[8];
           zero_acc(part);
           gemm_unit(part, Bh, Bl);
           const float ch = inv_h * hdr[9];
 #pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            f[t][0] += part[t][0] * ch; f[t][1] += part[t][1] * ch; f[t][2] += part[t][2] * ch; f[t][3] += part[t][3] * ch;
-          }
+          for (int t = 0; t < 8; ++t) f[t] = fma4(part[t], splat4(ch), f[t]);
         }
         scale_bias(f, 1.0f, Vt + VT_B2, rg);
         ln_regs<true, false>(f, Vt + VT_LNO_G, Vt + VT_LNO_B, rg);

@@ -165,12 +165,7 @@ __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
         const float inv1 = Vt[FH_HDR + i];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          const float4 wx = *reinterpret_cast<const float4*>(dv + FHD_WX + 16 * t + 4 * rg);
-          const float4 b1 = *reinterpret_cast<const float4*>(dv + FHD_B1 + 16 * t + 4 * rg);
-          acc1[t][0] = acc1[t][0] * inv1 + x * wx.x + b1.x;
-          acc1[t][1] = acc1[t][1] * inv1 + x * wx.y + b1.y;
-          acc1[t][2] = acc1[t][2] * inv1 + x * wx.z + b1.z;
-          acc1[t][3] = acc1[t][3] * inv1 + x * wx.w + b1.w;
+          acc1[t] = fma4(acc1[t], splat4(inv1), fma4(splat4(x), lds4(dv + FHD_WX + 16 * t + 4 * rg), lds4(dv + FHD_B1 + 16 * t + 4 * rg)));
         }
       }
       ln_regs<true, true>(acc1, dv + FHD_G1, dv + FHD_BE1, rg);     // gamma/beta carry the activation prescale
@@ -181,13 +176,9 @@ __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int f = 16 * t + 4 * rg;
-      const float4 b2 = *reinterpret_cast<const float4*>(tail + FHT_B2SUM + f);
-      float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.cat && valid) c = *reinterpret_cast<const float4*>(a.cat + (size_t)e * a.ldcat + f);
-      acc2[t][0] = acc2[t][0] * inv2 + b2.x + c.x;
-      acc2[t][1] = acc2[t][1] * inv2 + b2.y + c.y;
-      acc2[t][2] = acc2[t][2] * inv2 + b2.z + c.z;
-      acc2[t][3] = acc2[t][3] * inv2 + b2.w + c.w;
+      f32x4 c = lds4(tail + FHT_B2SUM + f);
+      if (a.cat && valid) c += lds4(a.cat + (size_t)e * a.ldcat + f);
+      acc2[t] = fma4(acc2[t], splat4(inv2), c);
     }
     ln_regs<true, true>(acc2, tail + FHT_G2, tail + FHT_BE2, rg);
     regs_to_frags(acc2, Bh, Bl);
@@ -198,11 +189,7 @@ __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
     for (int s = 0; s < 4; ++s) gemm_quarter(acc3, take(), Bh[s], Bl[s], lane);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const float4 b3 = *reinterpret_cast<const float4*>(tail + FHT_B3 + 16 * t + 4 * rg);
-      acc3[t][0] = acc3[t][0] * inv3 + b3.x;
-      acc3[t][1] = acc3[t][1] * inv3 + b3.y;
-      acc3[t][2] = acc3[t][2] * inv3 + b3.z;
-      acc3[t][3] = acc3[t][3] * inv3 + b3.w;
+      acc3[t] = fma4(acc3[t], splat4(inv3), lds4(tail + FHT_B3 + 16 * t + 4 * rg));
     }
     if (a.normalize) ln_regs<false, false>(acc3, nullptr, nullptr, rg);
     if (valid) {

@@ -20,12 +20,14 @@ __device__ __forceinline__ unsigned pk_rtz(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
 
-// (a, b) -> packed fp16 pairs hi, lo with a = hi_a + lo_a (+ <= 2^-21 |a|)
+// (a, b) -> packed fp16 pairs hi, lo with a = hi_a + lo_a (+ <= 2^-21 |a|): hi = a truncated to 11 significand bits
+// (the round-toward-zero conversion IS that truncation), lo = the remainder, again rounded toward zero
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
-  const float ah = __uint_as_float(__float_as_uint(a) & 0xFFFFE000u);
-  const float bh = __uint_as_float(__float_as_uint(b) & 0xFFFFE000u);
-  hi = pk_rtz(ah, bh);
-  lo = pk_rtz(a - ah, b - bh);
+  hi = pk_rtz(a, b);
+  const f32x2 t = {__uint_as_float(__float_as_uint(a) & 0xFFFFE000u), __uint_as_float(__float_as_uint(b) & 0xFFFFE000u)};
+  const f32x2 r = f32x2{a, b} - t;
+  lo = pk_rtz(r[0], r[1]);
 }
 
 __device__ __forceinline__ float xor_lanes(float v) {
@@ -70,30 +72,37 @@ __device__ __forceinline__ void gemm_quarter(f32x4 (&acc)[8], const unsigned sho
 
 // LayerNorm over the 128 features of this lane's edge (32 here, the rest in lanes ^ 16, ^ 32, ^ 48), biased
 // variance, eps 1e-5; register r of tile t is feature 16 t + 4 rg + r.
+// Packed-math helpers: whole-f32x4 expressions lower to v_pk_* (two floats per instruction); fused multiply-adds
+// are written explicitly because the library is built with -ffp-contract=off.
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x4 splat4(float x) { return f32x4{x, x, x, x}; }
+__device__ __forceinline__ f32x4 lds4(const float* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  return f32x4{v.x, v.y, v.z, v.w};
+}
+
 template <bool AFFINE, bool RELU>
 __device__ __forceinline__ void ln_regs(f32x4 (&v)[8], const float* gtab, const float* btab, int rg) {
-  float s = 0.f;
+  f32x4 s4 = (v[0] + v[1]) + (v[2] + v[3]);
+  s4 += (v[4] + v[5]) + (v[6] + v[7]);
+  const float mean = xor_lanes((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 128.0f);
+  const f32x4 m4 = splat4(mean);
+  f32x4 q4 = splat4(0.f), q5 = splat4(0.f);
 #pragma unroll
-  for (int t = 0; t < 8; ++t) s += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
-  const float mean = xor_lanes(s) * (1.0f / 128.0f);
-  float q = 0.f;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    v[t][0] -= mean; v[t][1] -= mean; v[t][2] -= mean; v[t][3] -= mean;
-    q += (v[t][0] * v[t][0] + v[t][1] * v[t][1]) + (v[t][2] * v[t][2] + v[t][3] * v[t][3]);
+  for (int t = 0; t < 8; t += 2) {
+    v[t] -= m4; v[t + 1] -= m4;
+    q4 = fma4(v[t], v[t], q4);
+    q5 = fma4(v[t + 1], v[t + 1], q5);
   }
-  const float rstd = 1.0f / sqrtf(xor_lanes(q) * (1.0f / 128.0f) + LN_EPS);
+  q4 += q5;
+  const float rstd = 1.0f / sqrtf(xor_lanes((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 128.0f) + LN_EPS);
+  const f32x4 r4 = splat4(rstd);
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    float4 gg = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (AFFINE) {
-      gg = *reinterpret_cast<const float4*>(gtab + 16 * t + 4 * rg);
-      bb = *reinterpret_cast<const float4*>(btab + 16 * t + 4 * rg);
-    }
-    float y0 = v[t][0] * rstd * gg.x + bb.x, y1 = v[t][1] * rstd * gg.y + bb.y;
-    float y2 = v[t][2] * rstd * gg.z + bb.z, y3 = v[t][3] * rstd * gg.w + bb.w;
-    if (RELU) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
-    v[t][0] = y0; v[t][1] = y1; v[t][2] = y2; v[t][3] = y3;
+    f32x4 y = v[t] * r4;
+    if (AFFINE) y = fma4(y, lds4(gtab + 16 * t + 4 * rg), lds4(btab + 16 * t + 4 * rg));
+    if (RELU) y = __builtin_elementwise_max(y, splat4(0.f));
+    v[t] = y;
   }
 }
 
