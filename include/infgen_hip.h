@@ -181,6 +181,15 @@ int infgen_insert_finalize(const InfgenRollout* r, int c, float angle_interval, 
                            const int* new_row, const float* lg_heading, int n_heading, const float* offset,
                            float* hv_ovr, void* stream);
 
+/* ---- agent tokenisation on the device ----
+ * TokenProcessor._match_agent_token (infgen/datasets/preprocess.py:552-653; cal_polygon_contour :24-54), noise off:
+ * valid [A][T] bytes, pos [A][T][2], heading [A][T], shape [A][2] = (width, length); tok = last contour of every token,
+ * [n_type][n_token][4][2] indexed by type[a], or per agent (type == NULL, tables tok_agent_stride floats apart).
+ * Writes token_index [A][T / shift] (int32) and token_contour [A][T / shift][4][2]. */
+int infgen_match_agent_tokens(const unsigned char* valid, const float* pos, const float* heading, const float* shape,
+                              const int* type, const float* tok, long long tok_agent_stride, int A, int T, int shift,
+                              int n_token, int* token_index, float* token_contour, void* stream);
+
 /* ---- optional profiling (bench.py roofline leg; process-global, off by default) ----
  * HIP events are recorded on the launch stream around every launch of the kernels selected by
  * `mask` (bit = INFGEN_KID_*).  infgen_prof_collect synchronises the device, returns the summed

@@ -286,6 +286,17 @@ static int attn_post_fused(float* X, int rows, const float* pack, const float* A
   return check_launch("infgen_attn_post");
 }
 
+extern "C" int infgen_match_agent_tokens(const unsigned char* valid, const float* pos, const float* heading, const float* shape,
+                                        const int* type, const float* tok, long long tok_agent_stride, int A, int T, int shift,
+                                        int n_token, int* token_index, float* token_contour, void* stream) {
+  if (A <= 0) return 0;
+  if (shift <= 0 || T <= shift) return fail("infgen_match_agent_tokens", "need 0 < shift < T");
+  if (n_token <= 0 || n_token > 2048) return fail("infgen_match_agent_tokens", "n_token must be in 1..2048");
+  MatchTokensArgs a{valid, pos, heading, shape, type, tok, tok_agent_stride, A, T, shift, n_token, token_index, token_contour};
+  hipLaunchKernelGGL(k_match_tokens, dim3(A), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_match_agent_tokens");
+}
+
 extern "C" int infgen_heads(const float* X, int rows, const float* tok_pack, const float* st_pack, int token_size,
                             float* logits, int* next_token, int* next_state, void* stream) {
   if (rows <= 0) return 0;

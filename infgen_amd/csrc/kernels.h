@@ -76,6 +76,20 @@ struct AttnHArgs {
   float* nQ; float* nU; float* nK; float* nV;
 };
 
+// k_match_tokens (token_kernels.hip): TokenProcessor._match_agent_token, one workgroup per agent
+struct MatchTokensArgs {
+  const unsigned char* valid;        // [A][T]
+  const float* pos;                  // [A][T][2]
+  const float* heading;              // [A][T]
+  const float* shape;                // [A][2] = (width, length)
+  const int* type;                   // [A] index into tok (null: per-agent tables, tok_agent_stride floats apart)
+  const float* tok;                  // [3 or A][n_token][4][2] last contour of every token
+  long long tok_agent_stride;
+  int A, T, shift, n_token;
+  int* token_index;                  // [A][T / shift]
+  float* token_contour;              // [A][T / shift][4][2]
+};
+
 struct HeadsArgs {
   const float* X; int rows;
   const float* tok_pack;    // MLPLayer pack: P(128,128) W0, b0, ln g/b, P(128,2048) W3, b3
@@ -219,6 +233,7 @@ struct MapGraphArgs {
 __global__ void k_linear(LinearArgs a);
 __global__ void k_fourier(FourierArgs a);
 __global__ void k_fourier_h(FourierArgs a);
+__global__ void k_match_tokens(MatchTokensArgs a);   // token_kernels.hip
 template <int WAVES> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);

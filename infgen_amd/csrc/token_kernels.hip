@@ -1,0 +1,135 @@
+// k_match_tokens: TokenProcessor._match_agent_token (reference infgen/datasets/preprocess.py:552-653, with
+// cal_polygon_contour :24-54) - per agent, for every 0.5 s step: rotate / translate the last contour of all
+// n_token motion tokens of the agent's type by the previous matched pose, pick the token whose four corners are
+// closest (sum of corner distances, first minimum) to the agent's box at this step, then continue from the
+// matched contour's pose (or from the logged pose where the step pair is not valid).
+// One workgroup per agent: the 18 steps are sequential, the 2048 tokens of a step are spread over 256 threads
+// (8 tokens each, held in registers for all steps - the vocabulary is read once).
+// fp32 arithmetic restated from what torch executes on the CPU (checked bit for bit against torch ops):
+//   bmm with K = 2:          w.x = fma(t.y, -sin, t.x * cos),  w.y = fma(t.y, cos, t.x * sin)
+//   torch.norm(dim=-1):      sqrt(fma(dy, dy, dx * dx))
+//   sum / mean over corners: sequential, mean = sum * 0.25
+// cos / sin / atan2 are evaluated in fp64 and rounded once (correctly rounded fp32 results): the reference's sleef
+// kernels are within 1 ulp of that and usually equal to it, so poses agree bit for bit on most steps and drift by
+// ulps otherwise; a token can differ from the reference only where two tokens tie to within rounding.
+#include "kernels.h"
+
+namespace ig {
+
+constexpr int MT_THREADS = 256;
+constexpr int MT_MAX_PER_THREAD = 8;     // n_token <= 2048
+
+struct Contour { float x[4], y[4]; };
+
+__device__ __forceinline__ float cos_cr(float x) { return (float)cos((double)x); }
+__device__ __forceinline__ float sin_cr(float x) { return (float)sin((double)x); }
+
+__device__ __forceinline__ Contour box_contour(float x, float y, float head, float width, float length) {
+  const float hc = 0.5f * cos_cr(head), hs = 0.5f * sin_cr(head);
+  const float lc = length * hc, ls = length * hs, wc = width * hc, ws = width * hs;
+  Contour c;
+  c.x[0] = (x + lc) - ws; c.y[0] = (y + ls) + wc;      // left front
+  c.x[1] = (x + lc) + ws; c.y[1] = (y + ls) - wc;      // right front
+  c.x[2] = (x - lc) + ws; c.y[2] = (y - ls) - wc;      // right back
+  c.x[3] = (x - lc) - ws; c.y[3] = (y - ls) + wc;      // left back
+  return c;
+}
+
+__global__ __launch_bounds__(MT_THREADS) void k_match_tokens(MatchTokensArgs a) {
+  __shared__ float s_val[MT_THREADS];
+  __shared__ int s_idx[MT_THREADS];
+  __shared__ float s_pose[3];
+  __shared__ float s_step[10];           // cos, sin of the previous pose and the four corners of the current box
+  const int ag = blockIdx.x, t = threadIdx.x;
+  const float* V = a.tok + (a.type ? (size_t)a.type[ag] * a.n_token * 8 : (size_t)ag * a.tok_agent_stride);
+  const int per = (a.n_token + MT_THREADS - 1) / MT_THREADS;
+  float4 tk[MT_MAX_PER_THREAD][2];
+#pragma unroll
+  for (int j = 0; j < MT_MAX_PER_THREAD; ++j) {
+    const int k = t + j * MT_THREADS;
+    tk[j][0] = tk[j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < per && k < a.n_token) {
+      tk[j][0] = *reinterpret_cast<const float4*>(V + (size_t)k * 8);
+      tk[j][1] = *reinterpret_cast<const float4*>(V + (size_t)k * 8 + 4);
+    }
+  }
+  const float width = a.shape[2 * ag], length = a.shape[2 * ag + 1];
+  const size_t row = (size_t)ag * a.T;
+  if (t == 0) { s_pose[0] = a.heading[row]; s_pose[1] = a.pos[2 * row]; s_pose[2] = a.pos[2 * row + 1]; }
+  __syncthreads();
+  const int n_out = a.T / a.shift;
+  for (int i = a.shift, o = 0; i < a.T; i += a.shift, ++o) {
+    const float px = s_pose[1], py = s_pose[2];
+    if (t == 0) {                        // fp64 trigonometry once per step, not once per thread
+      const float ph = s_pose[0];
+      s_step[0] = cos_cr(ph); s_step[1] = sin_cr(ph);
+      const Contour c0 = box_contour(a.pos[2 * (row + i)], a.pos[2 * (row + i) + 1], a.heading[row + i], width, length);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { s_step[2 + 2 * c] = c0.x[c]; s_step[3 + 2 * c] = c0.y[c]; }
+    }
+    __syncthreads();
+    const float cs = s_step[0], sn = s_step[1];
+    Contour cur;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { cur.x[c] = s_step[2 + 2 * c]; cur.y[c] = s_step[3 + 2 * c]; }
+    float best = INFINITY;
+    int bidx = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < MT_MAX_PER_THREAD; ++j) {
+      const int k = t + j * MT_THREADS;
+      if (j < per && k < a.n_token) {
+        const float tx[4] = {tk[j][0].x, tk[j][0].z, tk[j][1].x, tk[j][1].z};
+        const float ty[4] = {tk[j][0].y, tk[j][0].w, tk[j][1].y, tk[j][1].w};
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float wx = __builtin_fmaf(ty[c], -sn, tx[c] * cs) + px;
+          const float wy = __builtin_fmaf(ty[c], cs, tx[c] * sn) + py;
+          const float dx = wx - cur.x[c], dy = wy - cur.y[c];
+          const float n = sqrtf(__builtin_fmaf(dy, dy, dx * dx));
+          sum = (c == 0) ? n : sum + n;
+        }
+        if (sum < best) { best = sum; bidx = k; }      // ascending k per thread: the first minimum stays
+      }
+    }
+    s_val[t] = best; s_idx[t] = bidx;
+    __syncthreads();
+    for (int off = MT_THREADS / 2; off > 0; off >>= 1) {
+      if (t < off) {
+        const float v2 = s_val[t + off];
+        const int i2 = s_idx[t + off];
+        if (v2 < s_val[t] || (v2 == s_val[t] && i2 < s_idx[t])) { s_val[t] = v2; s_idx[t] = i2; }
+      }
+      __syncthreads();
+    }
+    if (t == 0) {
+      const int k = s_idx[0];
+      const float4 p0 = *reinterpret_cast<const float4*>(V + (size_t)k * 8);
+      const float4 p1 = *reinterpret_cast<const float4*>(V + (size_t)k * 8 + 4);
+      const float tx[4] = {p0.x, p0.z, p1.x, p1.z}, ty[4] = {p0.y, p0.w, p1.y, p1.w};
+      float wx[4], wy[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        wx[c] = __builtin_fmaf(ty[c], -sn, tx[c] * cs) + px;
+        wy[c] = __builtin_fmaf(ty[c], cs, tx[c] * sn) + py;
+      }
+      a.token_index[(size_t)ag * n_out + o] = k;
+      float* oc = a.token_contour + ((size_t)ag * n_out + o) * 8;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { oc[2 * c] = wx[c]; oc[2 * c + 1] = wy[c]; }
+      const bool ok = a.valid[row + i - a.shift] && a.valid[row + i];
+      if (ok) {
+        s_pose[0] = (float)atan2((double)(wy[0] - wy[3]), (double)(wx[0] - wx[3]));
+        s_pose[1] = (((wx[0] + wx[1]) + wx[2]) + wx[3]) * 0.25f;
+        s_pose[2] = (((wy[0] + wy[1]) + wy[2]) + wy[3]) * 0.25f;
+      } else {
+        s_pose[0] = a.heading[row + i];
+        s_pose[1] = a.pos[2 * (row + i)];
+        s_pose[2] = a.pos[2 * (row + i) + 1];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace ig

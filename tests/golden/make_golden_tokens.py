@@ -1,0 +1,71 @@
+"""Golden vectors for the agent tokeniser: runs the REFERENCE's own
+`TokenProcessor._match_agent_token` (infgen/datasets/preprocess.py:552-653, with cal_polygon_contour :24-54)
+on seeded synthetic trajectories and stores inputs + outputs.  Build container only (imports /root/reference).
+
+    python tests/golden/make_golden_tokens.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+import _standins  # noqa: E402
+
+_standins.install()
+sys.path.insert(0, '/root/reference')
+from infgen.datasets.preprocess import TokenProcessor  # noqa: E402
+
+from infgen_amd import synth  # noqa: E402
+
+
+def make_tracks(seed, A, n_step=91):
+    """agents on noisy unicycle tracks at 10 Hz, with dropouts in the validity mask"""
+    rng = np.random.default_rng(seed)
+    atype = rng.integers(0, 3, size=A)
+    speed = rng.uniform(0.0, 14.0, size=A) * np.where(atype == 1, 0.15, 1.0)
+    yaw_rate = rng.uniform(-0.5, 0.5, size=A)
+    head0 = rng.uniform(-np.pi, np.pi, size=A)
+    pos0 = rng.uniform(-80, 80, size=(A, 2))
+    t = np.arange(n_step) * 0.1
+    head = head0[:, None] + yaw_rate[:, None] * t[None, :] + rng.normal(0, 0.01, size=(A, n_step))
+    vel = speed[:, None, None] * np.stack([np.cos(head), np.sin(head)], -1)
+    pos = pos0[:, None, :] + np.cumsum(vel, 1) * 0.1 + rng.normal(0, 0.02, size=(A, n_step, 2))
+    pos3 = np.concatenate([pos, np.zeros((A, n_step, 1))], -1).astype(np.float32)
+    valid = np.ones((A, n_step), bool)
+    for a in range(A):
+        if rng.random() < 0.4:
+            s = rng.integers(0, n_step - 10)
+            valid[a, s:s + rng.integers(1, 30)] = False
+        if rng.random() < 0.2:
+            valid[a, :rng.integers(1, 40)] = False
+    # (width, length) per type exactly as the caller builds it (preprocess.py:346-354: veh 2 x 4.8, ped 1 x 2, cyc 1 x 1)
+    shape = np.array([[2.0, 4.8], [1.0, 2.0], [1.0, 1.0]], np.float32)[atype]
+    return dict(valid=valid, pos=pos3, heading=head.astype(np.float32), shape=shape, type=atype.astype(np.int64))
+
+
+def main():
+    cfg = synth.standard_config()
+    vocab = synth.make_agent_vocab(cfg.token_size)
+    tp = object.__new__(TokenProcessor)
+    torch.nn.Module.__init__(tp)
+    tp.shift, tp.noise, tp.training = 5, False, False
+    names = ['veh', 'ped', 'cyc']
+    for case, (seed, A) in {'tok_a48': (7001, 48), 'tok_a7': (7002, 7)}.items():
+        tr = make_tracks(seed, A)
+        token_traj = torch.stack([torch.from_numpy(vocab[names[k]][:, -1]) for k in tr['type']])   # (A, 2048, 4, 2)
+        with torch.no_grad():
+            idx, contour, _ = tp._match_agent_token(torch.from_numpy(tr['valid']), torch.from_numpy(tr['pos'][..., :2].copy()),
+                                                    torch.from_numpy(tr['heading']), torch.from_numpy(tr['shape']),
+                                                    token_traj, None)
+        np.savez_compressed(os.path.join(HERE, case + '.npz'), seed=seed, token_index=idx.numpy(),
+                            token_contour=contour.numpy(), **tr)
+        print(case, idx.shape, contour.shape, 'unique tokens', len(np.unique(idx.numpy())))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,108 @@
+"""GPU: device-side agent tokenisation through the C ABI against the golden vectors of the
+reference's own TokenProcessor._match_agent_token and against the oracle on fresh seeded tracks."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _vocab_last(dev):
+    from infgen_amd import synth
+    v = synth.make_agent_vocab(synth.standard_config().token_size)
+    return torch.stack([torch.from_numpy(v[k][:, -1]) for k in ('veh', 'ped', 'cyc')]).to(dev)     # (3, 2048, 4, 2)
+
+
+def _check(idx, con, ref_idx, ref_con, cost_fn):
+    """indices equal; where they are not, the two candidates must tie to within rounding in the reference's own cost
+    (cos / sin / atan2 differ by an ulp between ocml and sleef) and only the first such step of an agent is judged"""
+    idx, con = idx.cpu().numpy(), con.cpu().numpy()
+    eq = idx == ref_idx
+    first_bad = np.where(~eq.all(1), (~eq).argmax(1), idx.shape[1])
+    n_bad = 0
+    for a in np.nonzero(first_bad < idx.shape[1])[0]:
+        o = first_bad[a]
+        c_ref, c_dev = cost_fn(a, o, ref_idx[a, o]), cost_fn(a, o, idx[a, o])
+        assert abs(c_ref - c_dev) <= 2e-6 * max(1.0, abs(c_ref)), (a, o, c_ref, c_dev)
+        n_bad += 1
+    assert n_bad <= max(1, idx.shape[0] // 50), f'{n_bad} agents diverge'
+    for a in range(idx.shape[0]):
+        o = first_bad[a]
+        # matched contours up to the first divergence: positions of ~100 m in fp32; ulp-level pose differences
+        # (libm) can drift over the 18 chained steps
+        assert np.abs(con[a, :o] - ref_con[a, :o]).max(initial=0.0) <= 1e-3
+    return n_bad
+
+
+@pytest.mark.parametrize('case', ['tok_a48', 'tok_a7'])
+@pytest.mark.parametrize('per_agent_tables', [False, True])
+def test_match_agent_token_golden(case, per_agent_tables):
+    from infgen_amd.modules import TokenProcessor
+    from oracle import token_match_oracle as tm
+    dev = torch.device('cuda:0')
+    z = np.load(os.path.join(GOLDEN, case + '.npz'))
+    tp = TokenProcessor()
+    tok3 = _vocab_last(dev)
+    ty = torch.from_numpy(z['type']).to(dev)
+    args = (torch.from_numpy(z['valid']).to(dev), torch.from_numpy(z['pos'][..., :2].copy()).to(dev),
+            torch.from_numpy(z['heading']).to(dev), torch.from_numpy(z['shape']).to(dev))
+    if per_agent_tables:          # the reference's calling convention: one (n_token, 4, 2) table per agent
+        idx, con, extra = tp._match_agent_token(*args, tok3[ty])
+    else:
+        idx, con, extra = tp._match_agent_token(*args, tok3, agent_type=ty)
+    assert extra == [] and idx.dtype == torch.int64 and tuple(idx.shape) == (len(z['type']), 18)
+
+    def cost(a, o, k):            # the reference's matching cost of token k for agent a at output step o, from ITS poses
+        i = 5 * (o + 1)
+        if o == 0:
+            ph, pp = torch.tensor(z['heading'][a, 0]), torch.from_numpy(z['pos'][a, 0, :2].copy())
+        else:
+            ok = z['valid'][a, i - 5 - 5] and z['valid'][a, i - 5]
+            c = torch.from_numpy(z['token_contour'][a, o - 1])
+            d = c[0] - c[3]
+            ph = torch.arctan2(d[1], d[0]) if ok else torch.tensor(z['heading'][a, i - 5])
+            pp = c.mean(0) if ok else torch.from_numpy(z['pos'][a, i - 5, :2].copy())
+        t = tok3[int(z['type'][a]), int(k)].cpu()
+        rot = torch.tensor([[ph.cos(), ph.sin()], [-ph.sin(), ph.cos()]])
+        world = t @ rot + pp
+        cur = tm.cal_polygon_contour(torch.from_numpy(z['pos'][a, i, :2].copy()), torch.tensor(z['heading'][a, i]),
+                                     torch.from_numpy(z['shape'][a]))
+        return float(torch.norm(world - cur, dim=-1).sum())
+
+    _check(idx, con, z['token_index'], z['token_contour'], cost)
+
+
+def test_match_agent_token_many_agents_vs_oracle():
+    """4096 fresh agents (64 scenes x 64): exact agreement with the oracle except rounding-level ties"""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from infgen_amd.modules import TokenProcessor
+    from oracle import token_match_oracle as tm
+    rng = np.random.default_rng(99)
+    A, T = 4096, 91
+    atype = rng.integers(0, 3, size=A)
+    speed = rng.uniform(0.0, 14.0, size=A) * np.where(atype == 1, 0.15, 1.0)
+    yaw = rng.uniform(-0.5, 0.5, size=A)
+    t = np.arange(T) * 0.1
+    head = rng.uniform(-np.pi, np.pi, size=A)[:, None] + yaw[:, None] * t[None] + rng.normal(0, 0.01, size=(A, T))
+    vel = speed[:, None, None] * np.stack([np.cos(head), np.sin(head)], -1)
+    pos = rng.uniform(-80, 80, size=(A, 1, 2)) + np.cumsum(vel, 1) * 0.1 + rng.normal(0, 0.02, size=(A, T, 2))
+    valid = rng.random((A, T)) > 0.05
+    shape = np.array([[2.0, 4.8], [1.0, 2.0], [1.0, 1.0]], np.float32)[atype]
+    dev = torch.device('cuda:0')
+    tok3 = _vocab_last(dev)
+    pos_t, head_t = torch.from_numpy(pos.astype(np.float32)), torch.from_numpy(head.astype(np.float32))
+    ref_idx, ref_con = tm.match_agent_token(torch.from_numpy(valid), pos_t, head_t, torch.from_numpy(shape),
+                                            tok3.cpu()[torch.from_numpy(atype)])
+    idx, con, _ = TokenProcessor()._match_agent_token(torch.from_numpy(valid).to(dev), pos_t.to(dev), head_t.to(dev),
+                                                      torch.from_numpy(shape).to(dev), tok3,
+                                                      agent_type=torch.from_numpy(atype).to(dev))
+    same = (idx.cpu() == ref_idx).all(1)
+    assert same.float().mean() >= 0.99, float(same.float().mean())
+    assert float((con.cpu()[same] - ref_con[same]).abs().max()) <= 1e-3
+    exact = (con.cpu() == ref_con).flatten(1).all(1).float().mean()
+    print('agents with bit-identical contours over all 18 steps:', float(exact))
