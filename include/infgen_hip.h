@@ -190,6 +190,11 @@ int infgen_match_agent_tokens(const unsigned char* valid, const float* pos, cons
                               const int* type, const float* tok, long long tok_agent_stride, int A, int T, int shift,
                               int n_token, int* token_index, float* token_contour, void* stream);
 
+/* InfGen.match_token_map, the matching core (infgen/model/infgen.py:918-936), noise off: traj_pos [P][3][2], theta [P],
+ * sample_pt [n_token][3][2] -> token_idx [P] (int32) */
+int infgen_match_map_tokens(const float* traj_pos, const float* theta, const float* sample_pt, int P, int n_token,
+                            int* token_idx, void* stream);
+
 /* ---- optional profiling (bench.py roofline leg; process-global, off by default) ----
  * HIP events are recorded on the launch stream around every launch of the kernels selected by
  * `mask` (bit = INFGEN_KID_*).  infgen_prof_collect synchronises the device, returns the summed

@@ -297,6 +297,15 @@ extern "C" int infgen_match_agent_tokens(const unsigned char* valid, const float
   return check_launch("infgen_match_agent_tokens");
 }
 
+extern "C" int infgen_match_map_tokens(const float* traj_pos, const float* theta, const float* sample_pt, int P, int n_token,
+                                      int* token_idx, void* stream) {
+  if (P <= 0) return 0;
+  if (n_token <= 0) return fail("infgen_match_map_tokens", "n_token must be positive");
+  MatchMapArgs a{traj_pos, theta, sample_pt, P, n_token, token_idx};
+  hipLaunchKernelGGL(k_match_map_tokens, dim3(ceil_div(P, 4)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_match_map_tokens");
+}
+
 extern "C" int infgen_heads(const float* X, int rows, const float* tok_pack, const float* st_pack, int token_size,
                             float* logits, int* next_token, int* next_state, void* stream) {
   if (rows <= 0) return 0;

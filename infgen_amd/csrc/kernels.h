@@ -90,6 +90,15 @@ struct MatchTokensArgs {
   float* token_contour;              // [A][T / shift][4][2]
 };
 
+// k_match_map_tokens (token_kernels.hip): InfGen.match_token_map, one wave per polyline piece
+struct MatchMapArgs {
+  const float* traj_pos;             // [P][3][2]
+  const float* theta;                // [P]
+  const float* sample_pt;            // [n_token][3][2]
+  int P, n_token;
+  int* token_idx;                    // [P]
+};
+
 struct HeadsArgs {
   const float* X; int rows;
   const float* tok_pack;    // MLPLayer pack: P(128,128) W0, b0, ln g/b, P(128,2048) W3, b3
@@ -234,6 +243,7 @@ __global__ void k_linear(LinearArgs a);
 __global__ void k_fourier(FourierArgs a);
 __global__ void k_fourier_h(FourierArgs a);
 __global__ void k_match_tokens(MatchTokensArgs a);   // token_kernels.hip
+__global__ void k_match_map_tokens(MatchMapArgs a);
 template <int WAVES> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);

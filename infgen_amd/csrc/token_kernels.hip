@@ -132,4 +132,47 @@ __global__ __launch_bounds__(MT_THREADS) void k_match_tokens(MatchTokensArgs a) 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_match_map_tokens: InfGen.match_token_map's matching core (reference infgen/model/infgen.py:918-936): a
+// three-point polyline piece, moved to its own frame, against the sample points of the n_token map tokens; sum of
+// squared distances, first minimum.  One wave per piece, tokens spread over the lanes.
+// Arithmetic as torch executes it on the CPU for these shapes (checked bit for bit): the (P,3,2) x (P,2,2) bmm is
+// (dx * r00) + (dy * r10) WITHOUT fma; the six squared differences e0..e5 are summed as ((((e0+e4)+e5)+e1)+e2)+e3.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MT_THREADS) void k_match_map_tokens(MatchMapArgs a) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (p >= a.P) return;
+  const float th = a.theta[p];
+  const float cs = cos_cr(th), sn = sin_cr(th);
+  const float* tp = a.traj_pos + (size_t)p * 6;
+  float lx[3], ly[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float dx = tp[2 * i] - tp[0], dy = tp[2 * i + 1] - tp[1];
+    lx[i] = (dx * cs) + (dy * sn);
+    ly[i] = (dx * -sn) + (dy * cs);
+  }
+  float best = INFINITY;
+  int bidx = 0x7fffffff;
+  for (int k = lane; k < a.n_token; k += 64) {
+    const float* sp = a.sample_pt + (size_t)k * 6;
+    float e[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float ex = sp[2 * i] - lx[i], ey = sp[2 * i + 1] - ly[i];
+      e[2 * i] = ex * ex; e[2 * i + 1] = ey * ey;
+    }
+    const float d = ((((e[0] + e[4]) + e[5]) + e[1]) + e[2]) + e[3];
+    if (d < best) { best = d; bidx = k; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float v2 = __shfl_xor(best, off, 64);
+    const int i2 = __shfl_xor(bidx, off, 64);
+    if (v2 < best || (v2 == best && i2 < bidx)) { best = v2; bidx = i2; }
+  }
+  if (lane == 0) a.token_idx[p] = bidx;
+}
+
 }  // namespace ig

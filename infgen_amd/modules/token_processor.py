@@ -50,3 +50,21 @@ class TokenProcessor(torch.nn.Module):
                                                  _lib.ptr(contour), torch.cuda.current_stream(dev).cuda_stream),
                    'infgen_match_agent_tokens')
         return idx.long(), contour, []
+
+
+@torch.no_grad()
+def match_token_map(traj_pos: torch.Tensor, traj_theta: torch.Tensor, token_sample_pt: torch.Tensor) -> torch.Tensor:
+    """The matching core of the reference's ``InfGen.match_token_map`` (infgen/model/infgen.py:918-936, noise off) on the
+    GPU: traj_pos (P, 3, 2), traj_theta (P,), token_sample_pt (n_token, 3, 2) -> pt_token_id (P,) int64."""
+    dev = traj_pos.device
+    if dev.type != 'cuda':
+        raise RuntimeError('match_token_map runs on the GPU only (no CPU fallback)')
+    lib = _lib.load()
+    P, n_token = traj_pos.shape[0], token_sample_pt.shape[0]
+    tp = traj_pos.to(torch.float32).contiguous()
+    th = traj_theta.to(torch.float32).contiguous()
+    sp = token_sample_pt.to(device=dev, dtype=torch.float32).contiguous()
+    out = torch.empty(P, dtype=torch.int32, device=dev)
+    _lib.check(lib.infgen_match_map_tokens(_lib.ptr(tp), _lib.ptr(th), _lib.ptr(sp), P, n_token, _lib.ptr(out),
+                                           torch.cuda.current_stream(dev).cuda_stream), 'infgen_match_map_tokens')
+    return out.long()

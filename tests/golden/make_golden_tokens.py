@@ -2,7 +2,7 @@
 `TokenProcessor._match_agent_token` (infgen/datasets/preprocess.py:552-653, with cal_polygon_contour :24-54)
 on seeded synthetic trajectories and stores inputs + outputs.  Build container only (imports /root/reference).
 
-    python tests/golden/make_golden_tokens.py
+    PROTOCOL_BUFFERS_PYTHON_IMPLEMENTATION=python python tests/golden/make_golden_tokens.py
 """
 import os
 import sys
@@ -67,5 +67,45 @@ def main():
         print(case, idx.shape, contour.shape, 'unique tokens', len(np.unique(idx.numpy())))
 
 
+def make_polylines(seed, P):
+    """P three-point polyline pieces (start, middle, end) as `map_save.traj_pos`, with the direction of the piece"""
+    rng = np.random.default_rng(seed)
+    theta = rng.uniform(-np.pi, np.pi, size=P)
+    start = rng.uniform(-100, 100, size=(P, 2))
+    length = rng.uniform(1.0, 6.0, size=P)
+    curv = rng.uniform(-0.2, 0.2, size=P)
+    s = np.linspace(0, 1, 3)[None, :] * length[:, None]
+    th = curv[:, None] * s
+    lx = np.where(np.abs(curv[:, None]) < 1e-9, s, np.sin(th) / np.where(curv[:, None] == 0, 1, curv[:, None]))
+    ly = np.where(np.abs(curv[:, None]) < 1e-9, 0 * s, (1 - np.cos(th)) / np.where(curv[:, None] == 0, 1, curv[:, None]))
+    c, sn = np.cos(theta)[:, None], np.sin(theta)[:, None]
+    pos = np.stack([start[:, :1] + lx * c - ly * sn, start[:, 1:] + lx * sn + ly * c], -1)
+    pos += rng.normal(0, 0.05, size=pos.shape)
+    return dict(traj_pos=pos.astype(np.float32), traj_theta=theta.astype(np.float32),
+                pl_idx_list=np.sort(rng.integers(0, max(1, P // 6), size=P)).astype(np.int64),
+                side=rng.integers(0, 3, size=P).astype(np.int64))
+
+
+def main_map():
+    """InfGen.match_token_map (infgen/model/infgen.py:918-936: polyline piece -> nearest of the 1024 map tokens)"""
+    import types
+    from infgen.model.infgen import InfGen
+    mv = synth.make_map_vocab()                        # (1024, 11, 2) like map_traj_token5.pkl['traj_src']
+    sample_pt = np.ascontiguousarray(mv[:, ::5]).astype(np.float32)     # (1024, 3, 2) like ['sample_pt']
+    fake = types.SimpleNamespace(map_token={'sample_pt': torch.from_numpy(sample_pt), 'traj_src': torch.from_numpy(mv)},
+                                 noise=False)
+    for case, (seed, P) in {'maptok_p500': (7101, 500), 'maptok_p3': (7102, 3)}.items():
+        pl = make_polylines(seed, P)
+        data = {'map_save': {'traj_pos': torch.from_numpy(pl['traj_pos']), 'traj_theta': torch.from_numpy(pl['traj_theta']),
+                             'pl_idx_list': torch.from_numpy(pl['pl_idx_list'])},
+                'pt_token': {'side': torch.from_numpy(pl['side']), 'num_nodes': P}}
+        with torch.no_grad():
+            out = InfGen.match_token_map(fake, data)
+        np.savez_compressed(os.path.join(HERE, case + '.npz'), seed=seed, token_idx=out['pt_token']['token_idx'].numpy(),
+                            position=out['pt_token']['position'].numpy(), **pl)
+        print(case, out['pt_token']['token_idx'].shape, 'unique', len(np.unique(out['pt_token']['token_idx'].numpy())))
+
+
 if __name__ == '__main__':
     main()
+    main_map()

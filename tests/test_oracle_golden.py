@@ -80,3 +80,18 @@ def test_token_match_oracle_reproduces_the_reference(case):
                                     torch.from_numpy(z['heading']), torch.from_numpy(z['shape']), tt)
     assert np.array_equal(idx.numpy(), z['token_index'])
     assert np.array_equal(con.numpy(), z['token_contour'])
+
+
+@pytest.mark.parametrize('case', ['maptok_p500', 'maptok_p3'])
+def test_map_token_match_oracle_reproduces_the_reference(case):
+    """oracle match_token_map vs InfGen.match_token_map (tests/golden/make_golden_tokens.py): identical token ids"""
+    import os
+    import torch
+    from conftest import GOLDEN
+    from infgen_amd import synth
+    from oracle import token_match_oracle as tm
+    z = np.load(os.path.join(GOLDEN, case + '.npz'))
+    sample_pt = torch.from_numpy(np.ascontiguousarray(synth.make_map_vocab()[:, ::5]).astype(np.float32))
+    idx = tm.match_token_map(torch.from_numpy(z['traj_pos']), torch.from_numpy(z['traj_theta']), sample_pt)
+    assert np.array_equal(idx.numpy(), z['token_idx'])
+    assert np.array_equal(z['position'][:, :2], z['traj_pos'][:, 0])

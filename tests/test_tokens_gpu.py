@@ -106,3 +106,37 @@ def test_match_agent_token_many_agents_vs_oracle():
     assert float((con.cpu()[same] - ref_con[same]).abs().max()) <= 1e-3
     exact = (con.cpu() == ref_con).flatten(1).all(1).float().mean()
     print('agents with bit-identical contours over all 18 steps:', float(exact))
+
+
+@pytest.mark.parametrize('case', ['maptok_p500', 'maptok_p3'])
+def test_match_token_map_golden(case):
+    """device map-token matching vs the reference's own output; a different id is only accepted for a rounding-level tie"""
+    from infgen_amd import synth
+    from infgen_amd.modules import match_token_map
+    dev = torch.device('cuda:0')
+    z = np.load(os.path.join(GOLDEN, case + '.npz'))
+    sample_pt = torch.from_numpy(np.ascontiguousarray(synth.make_map_vocab()[:, ::5]).astype(np.float32))
+    idx = match_token_map(torch.from_numpy(z['traj_pos']).to(dev), torch.from_numpy(z['traj_theta']).to(dev), sample_pt).cpu().numpy()
+    bad = np.nonzero(idx != z['token_idx'])[0]
+    assert len(bad) <= max(1, len(idx) // 100)
+    for p in bad:
+        th = torch.tensor(z['traj_theta'][p])
+        rot = torch.tensor([[th.cos(), -th.sin()], [th.sin(), th.cos()]])
+        loc = (torch.from_numpy(z['traj_pos'][p]) - torch.from_numpy(z['traj_pos'][p, 0])) @ rot
+        d = ((sample_pt - loc[None]) ** 2).sum((-2, -1))
+        assert abs(float(d[idx[p]] - d[z['token_idx'][p]])) <= 1e-6 * max(1.0, float(d[z['token_idx'][p]]))
+
+
+def test_match_token_map_large_vs_oracle():
+    from infgen_amd import synth
+    from infgen_amd.modules import match_token_map
+    from oracle import token_match_oracle as tm
+    rng = np.random.default_rng(3)
+    P = 200000
+    pos = (rng.uniform(-100, 100, size=(P, 1, 2)) + np.cumsum(rng.normal(0, 1.5, size=(P, 3, 2)), 1)).astype(np.float32)
+    theta = rng.uniform(-np.pi, np.pi, size=P).astype(np.float32)
+    sample_pt = torch.from_numpy(np.ascontiguousarray(synth.make_map_vocab()[:, ::5]).astype(np.float32))
+    ref = tm.match_token_map(torch.from_numpy(pos), torch.from_numpy(theta), sample_pt).numpy()
+    dev = torch.device('cuda:0')
+    idx = match_token_map(torch.from_numpy(pos).to(dev), torch.from_numpy(theta).to(dev), sample_pt).cpu().numpy()
+    assert (idx == ref).mean() >= 0.999, float((idx == ref).mean())
