@@ -134,6 +134,12 @@ int infgen_attn_pre(const float* X, int rows, const float* pack, int use_src_ln,
 int infgen_edge_attn(int rows, const float* Q, const float* U, const float* Ksrc, const float* Vsrc,
                      const int* off, const int* cnt, const int* src, const float* rhat,
                      float* AGG, float* Z, float* SIG, void* stream);
+/* the same with the absorbed query u_h = q_h W'_kr,h computed inside the kernel (wkr = W'_kr [128][128] fp32, the
+ * "h_wkr_plain" field of the layer pack): no U array.  infgen_decode_layers uses it unless infgen_set_edge_fuse(0). */
+int infgen_edge_attn_fused(int rows, const float* Q, const float* wkr, const float* Ksrc, const float* Vsrc,
+                           const int* off, const int* cnt, const int* src, const float* rhat,
+                           float* AGG, float* Z, float* SIG, void* stream);
+int infgen_set_edge_fuse(int mode);
 /* same with the kernel variant forced: wide = 1 -> one 8-wave workgroup per destination (long edge lists, few rows),
  * wide = 0 -> one wave per destination; infgen_edge_attn picks wide when rows <= 256 */
 int infgen_edge_attn_mode(int rows, const float* Q, const float* U, const float* Ksrc, const float* Vsrc,

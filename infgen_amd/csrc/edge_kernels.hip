@@ -33,17 +33,39 @@ struct AttnState {
 };
 
 // consume edges e = e_first, e_first + e_step, ... < E of destination `row`
+// wk_lds / q_lds != null: the absorbed query u_h = q_h W'_kr,h is computed here from q (W'_kr [128][128] fp32 resident
+// in LDS, q parked in this wave's 128 floats of LDS for broadcast reads) instead of being read from a.U
 __device__ __forceinline__ void edge_attn_wave(const EdgeAttnArgs& a, int row, int E, int e_base, int e_first,
-                                               int e_step, bool has_r, AttnState& st) {
+                                               int e_step, bool has_r, AttnState& st,
+                                               const float* wk_lds = nullptr, float* q_lds = nullptr) {
   const int lane = lane_id();
   const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
   const float2 q = *reinterpret_cast<const float2*>(a.Q + (size_t)row * D + 2 * lane);
   float2 u[H];
+  if (wk_lds && has_r) {
+    *reinterpret_cast<float2*>(q_lds + 2 * lane) = q;
 #pragma unroll
-  for (int h = 0; h < H; ++h) {
-    u[h] = has_r ? *reinterpret_cast<const float2*>(a.U + (size_t)row * (H * D) + h * D + 2 * lane)
-                 : make_float2(0.f, 0.f);
-    st.z[h] = make_float2(0.f, 0.f);
+    for (int h = 0; h < H; ++h) {
+      float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int d4 = 0; d4 < 4; ++d4) {
+        const float4 qv = *reinterpret_cast<const float4*>(q_lds + DH * h + 4 * d4);        // broadcast
+        const float* wp = wk_lds + (size_t)(DH * h + 4 * d4) * D + 2 * lane;
+        const float2 w0 = *reinterpret_cast<const float2*>(wp), w1 = *reinterpret_cast<const float2*>(wp + D);
+        const float2 w2 = *reinterpret_cast<const float2*>(wp + 2 * D), w3 = *reinterpret_cast<const float2*>(wp + 3 * D);
+        acc.x = fmaf(qv.w, w3.x, fmaf(qv.z, w2.x, fmaf(qv.y, w1.x, fmaf(qv.x, w0.x, acc.x))));
+        acc.y = fmaf(qv.w, w3.y, fmaf(qv.z, w2.y, fmaf(qv.y, w1.y, fmaf(qv.x, w0.y, acc.y))));
+      }
+      u[h] = acc;
+      st.z[h] = make_float2(0.f, 0.f);
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      u[h] = has_r ? *reinterpret_cast<const float2*>(a.U + (size_t)row * (H * D) + h * D + 2 * lane)
+                   : make_float2(0.f, 0.f);
+      st.z[h] = make_float2(0.f, 0.f);
+    }
   }
   st.ag = make_float2(0.f, 0.f);
   st.m = -INFINITY;
@@ -143,6 +165,28 @@ __global__ __launch_bounds__(NT) void k_edge_attn(EdgeAttnArgs a) {
   AttnState st;
   edge_attn_wave(a, row, E, e_base, 0, 1, has_r, st);
   edge_attn_write(a, row, st);
+}
+
+// k_edge_attn_fu: the same with the absorbed query computed on the fly (a.wkr = W'_kr [128][128] fp32 of the layer, a.U
+// unused): saves the 4 KB per row of U written by the node-side kernel and read here.  12 waves per workgroup share
+// one LDS copy of W'_kr (64 KB; two workgroups per CU), rows are dealt to the waves in a persistent loop.
+constexpr int FU_WAVES = 12;
+__global__ __launch_bounds__(64 * FU_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_edge_attn_fu(EdgeAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float Wk[D * D];
+  __shared__ __attribute__((aligned(16))) float qs[FU_WAVES][D];
+  for (int i = threadIdx.x; i < D * D / 4; i += 64 * FU_WAVES)
+    reinterpret_cast<float4*>(Wk)[i] = reinterpret_cast<const float4*>(a.wkr)[i];
+  __syncthreads();
+  const int w = wave_id();
+  for (int r0 = blockIdx.x * FU_WAVES; r0 < a.rows; r0 += gridDim.x * FU_WAVES) {
+    const int row = __builtin_amdgcn_readfirstlane(r0 + w);
+    if (row >= a.rows) continue;
+    const int E = __builtin_amdgcn_readfirstlane(a.es.cnt[row]);
+    const int e_base = __builtin_amdgcn_readfirstlane(a.es.off[row]);
+    AttnState st;
+    edge_attn_wave(a, row, E, e_base, 0, 1, true, st, Wk, qs[w]);
+    edge_attn_write(a, row, st);
+  }
 }
 
 // Few destinations with long edge lists (the insertion seed node: up to 300 agents + 2048 map tokens):

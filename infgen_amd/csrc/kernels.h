@@ -51,6 +51,7 @@ struct EdgeAttnArgs {
   float* AGG;                        // [rows][128]  sum_e attn * v_src
   float* Z;                          // [rows][8][128] sum_e attn * rhat   (pos-emb layers only)
   float* SIG;                        // [rows][8]    sum_e attn
+  const float* wkr;                  // k_edge_attn_fu: W'_kr [128][128] fp32 (row 16 h + d', column = rhat dim); U unused
 };
 
 struct AttnPostArgs {
@@ -247,6 +248,7 @@ __global__ void k_match_map_tokens(MatchMapArgs a);
 template <int WAVES> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);
+__global__ void k_edge_attn_fu(EdgeAttnArgs a);
 __global__ void k_edge_attn_wide(EdgeAttnArgs a);
 __global__ void k_attn_post(AttnPostArgs a);
 __global__ void k_heads(HeadsArgs a);

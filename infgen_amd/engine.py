@@ -174,7 +174,11 @@ class Ops:
     def edge_attn(self, rows, q, u, ksrc, vsrc, off, cnt, src, rhat, agg, z, sig, wide=None):
         args = (rows, _lib.ptr(q), _lib.ptr(u), _lib.ptr(ksrc), _lib.ptr(vsrc), _lib.ptr(off), _lib.ptr(cnt),
                 _lib.ptr(src), _lib.ptr(rhat), _lib.ptr(agg), _lib.ptr(z), _lib.ptr(sig))
-        if wide is None:
+        if wide == 'fused':         # u is the layer pack: the absorbed query is computed inside the kernel
+            wkr = u[self.lib.infgen_attn_pack_offset(b'h_wkr_plain'):]
+            _lib.check(self.lib.infgen_edge_attn_fused(rows, _lib.ptr(q), _lib.ptr(wkr), *args[3:], self.stream),
+                       'infgen_edge_attn_fused')
+        elif wide is None:
             _lib.check(self.lib.infgen_edge_attn(*args, self.stream), 'infgen_edge_attn')
         else:
             _lib.check(self.lib.infgen_edge_attn_mode(*args, int(wide), self.stream), 'infgen_edge_attn_mode')
@@ -203,7 +207,7 @@ class Ops:
             v = torch.empty(x_src.shape[0], D, device=dev)
             self.attn_pre(x_src, pack, use_src_ln=True, k=k, v=v)
             self.attn_pre(x, pack, q=q, u=u)
-        self.edge_attn(rows, q, u, k, v, off, cnt, src, rhat, agg, z, sig, wide=wide)
+        self.edge_attn(rows, q, pack if wide == 'fused' else u, k, v, off, cnt, src, rhat, agg, z, sig, wide=wide)
         self.attn_post(x, pack, agg, z, sig, has_pos=rhat is not None)
         return x
 

@@ -148,7 +148,7 @@ def attn_mode(request, env):
     _lib.check(env['lib'].infgen_set_attn_mode(1))
 
 
-@pytest.mark.parametrize('wide', [False, True])
+@pytest.mark.parametrize('wide', [False, True, 'fused'])
 @pytest.mark.parametrize('prefix,bip', [('agent_encoder.a2a_attn_layers.2', False),
                                         ('agent_encoder.pt2a_attn_layers.1', True),
                                         ('agent_encoder.t_attn_layers.0', False)])
