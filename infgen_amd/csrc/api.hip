@@ -242,7 +242,8 @@ static int edge_attn_impl(int rows, const float* Q, const float* U, const float*
   return check_launch("infgen_edge_attn");
 }
 
-static int g_edge_fuse = 1;      // 1: infgen_decode_layers computes the absorbed query inside the edge kernel (no U round trip)
+static int g_edge_fuse = 0;      // 1: infgen_decode_layers computes the absorbed query inside the edge kernel (no U round trip);
+                                 // measured neutral (edge kernel +7 ms, node kernel -7 ms per 512-scene rollout), so off by default
 extern "C" int infgen_set_edge_fuse(int mode) {
   if (mode != 0 && mode != 1) return fail("infgen_set_edge_fuse", "mode must be 0 or 1");
   g_edge_fuse = mode;

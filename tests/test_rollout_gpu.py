@@ -287,3 +287,26 @@ def test_maximum_sizes_stress_shape():
     o, ref = _oracle_vs_engine(cfg, scene, sd, c)
     assert o['pos_a'].shape[0] == 256
     assert ref['edge_count'][:, 1].max() > 256 * 64      # dense agent<->agent neighbourhoods
+
+
+def test_fused_edge_attention_rollout_matches_default():
+    """infgen_set_edge_fuse(1): the absorbed query is computed inside the edge kernel (no U array); tokens identical,
+    logits within fp32 noise of the default path"""
+    from infgen_amd import engine, synth, _lib
+    c = load_case('c2_a32_m512')
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], c['cfg'], dev)
+    scenes = [synth.make_scene(600 + i, 24 + i, 300, c['cfg'], vocab=c['vocab'], grid=c['grid'], slip=0.2) for i in range(12)]
+    outs = []
+    lib = _lib.load()
+    try:
+        for mode in (0, 1):
+            _lib.check(lib.infgen_set_edge_fuse(mode))
+            eng = engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=True)
+            eng.rollout()
+            outs.append(eng.outputs())
+    finally:
+        _lib.check(lib.infgen_set_edge_fuse(0))
+    for a, b in zip(*outs):
+        assert np.array_equal(a['next_token_idx'], b['next_token_idx'])
+        assert np.abs(a['logits'] - b['logits']).max() <= 2e-4
