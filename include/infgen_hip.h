@@ -127,7 +127,8 @@ int infgen_fourier_embed(const float* raw, int n_dims, const int* count_dev, int
 /* arithmetic of infgen_fourier_embed: 1 (default) = fp16 MFMA with a three-term hi/lo split of both operands and fp32
  * accumulation (2^-21 relative error per product, 5.3x the fp32 matrix rate), 0 = fp32-input MFMA.  Process-wide. */
 int infgen_set_fourier_mode(int mode);
-/* same switch for infgen_attn_pre / infgen_attn_post / infgen_attn_post_pre */
+/* the switch for infgen_attn_pre / infgen_attn_post / infgen_attn_post_pre: 0 fp32 MFMA, 1 fp16 split, 2 (default) by
+ * row count (split from ~10 k rows, where its one-workgroup-per-CU tiles fill the chip) */
 int infgen_set_attn_mode(int mode);
 int infgen_attn_pre(const float* X, int rows, const float* pack, int use_src_ln,
                     float* Q, float* U, float* K, float* V, void* stream);

@@ -198,12 +198,16 @@ extern "C" int infgen_fourier_embed(const float* raw, int n, const int* count_de
   return check_launch("infgen_fourier_embed");
 }
 
-static int g_attn_mode = 1;      // 1: fp16 three-term split (k_attn_h), 0: fp32-input MFMA (k_attn_pre / k_attn_post)
+// 0: fp32-input MFMA (k_attn_pre / k_attn_post), 1: fp16 three-term split (k_attn_h), 2 (default): by size - the split
+// kernel runs one workgroup per CU on 64/128-row tiles and wins from ~10 k rows (16 k rows: 99 vs 121 us, 64 k: 337 vs
+// 479 us); below, the 32-row tiles of the fp32 kernels fill the chip better (8 k rows: 73 vs 95 us, 64 rows: 54 vs 77 us)
+static int g_attn_mode = 2;
 extern "C" int infgen_set_attn_mode(int mode) {
-  if (mode != 0 && mode != 1) return fail("infgen_set_attn_mode", "mode must be 0 (fp32 MFMA) or 1 (fp16 split)");
+  if (mode < 0 || mode > 2) return fail("infgen_set_attn_mode", "mode must be 0 (fp32 MFMA), 1 (fp16 split) or 2 (by size)");
   g_attn_mode = mode;
   return 0;
 }
+static inline bool attn_split(int rows) { return g_attn_mode == 1 || (g_attn_mode == 2 && rows > 10240); }
 
 // one workgroup per CU: 64-row tiles (4 waves) while they fill the chip at most once, 128-row tiles (8 waves) beyond
 static void launch_attn_h(const AttnHArgs& a, void* stream) {
@@ -219,7 +223,7 @@ static void launch_attn_h(const AttnHArgs& a, void* stream) {
 extern "C" int infgen_attn_pre(const float* X, int rows, const float* pack, int use_src_ln,
                                float* Q, float* U, float* K, float* V, void* stream) {
   if (rows <= 0) return 0;
-  if (g_attn_mode == 1) {
+  if (attn_split(rows)) {
     AttnHArgs h{const_cast<float*>(X), rows, nullptr, nullptr, nullptr, nullptr, 0, pack, use_src_ln, Q, U, K, V};
     { ProfScope _ps(INFGEN_KID_ATTN_PRE, stream, (double)rows * 16384.0 * ((Q || U ? 1 : 0) + (K ? 1 : 0) + (V ? 1 : 0) + (U ? 1 : 0)));
       launch_attn_h(h, stream); }
@@ -293,7 +297,7 @@ extern "C" int infgen_attn_post_pre(float* X, int rows, const float* pack, const
 static int attn_post_fused(float* X, int rows, const float* pack, const float* AGG, const float* Z, const float* SIG,
                            int has_pos, const float* next_pack, float* nQ, float* nU, float* nK, float* nV, void* stream) {
   if (rows <= 0) return 0;
-  if (g_attn_mode == 1) {
+  if (attn_split(rows)) {
     AttnHArgs h{X, rows, pack, AGG, Z, SIG, has_pos, next_pack, 0, nQ, nU, nK, nV};
     { ProfScope _ps(INFGEN_KID_ATTN_POST, stream, (double)rows * (196608.0 + (has_pos ? 16384.0 : 0.0) +
           (next_pack ? 16384.0 * ((nQ || nU ? 1 : 0) + (nK ? 1 : 0) + (nV ? 1 : 0) + (nU ? 1 : 0)) : 0.0)));

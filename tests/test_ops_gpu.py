@@ -145,7 +145,7 @@ def attn_mode(request, env):
     from infgen_amd import _lib
     _lib.check(env['lib'].infgen_set_attn_mode(request.param))
     yield request.param
-    _lib.check(env['lib'].infgen_set_attn_mode(1))
+    _lib.check(env['lib'].infgen_set_attn_mode(2))
 
 
 @pytest.mark.parametrize('wide', [False, True, 'fused'])

@@ -24,8 +24,18 @@ def _engine(case, teacher=None, scenes=None, **kw):
     return eng, eng.outputs()
 
 
+@pytest.fixture(params=[2, 1, 0], ids=['by-size', 'split16', 'fp32mfma'])
+def attn_mode(request):
+    """node-side attention kernels: chosen by row count (default), forced fp16 three-term split, forced fp32 MFMA"""
+    from infgen_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.infgen_set_attn_mode(request.param))
+    yield request.param
+    _lib.check(lib.infgen_set_attn_mode(2))
+
+
 @pytest.mark.parametrize('name', GOLDEN_CASES)
-def test_free_running_rollout_matches_reference_fixture(name):
+def test_free_running_rollout_matches_reference_fixture(name, attn_mode):
     c = load_case(name)
     z, m = c['z'], c['meta']
     eng, outs = _engine(c)

@@ -30,4 +30,4 @@ for mode in (0, 1):
     print(f'rows={rows} mode={mode}: {dt*1e6:.1f} us  {fl/dt/1e12:.1f} TFLOP/s (algorithmic)')
 for n, a, b in zip('XQUKV', res[0], res[1]):
     print('  max |split - fp32mfma|', n, float((a - b).abs().max()))
-_lib.check(lib.infgen_set_attn_mode(1))
+_lib.check(lib.infgen_set_attn_mode(2))
