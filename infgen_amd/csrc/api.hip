@@ -209,9 +209,10 @@ extern "C" int infgen_set_attn_mode(int mode) {
 }
 static inline bool attn_split(int rows) { return g_attn_mode == 1 || (g_attn_mode == 2 && rows > 10240); }
 
-// one workgroup per CU: 64-row tiles (4 waves) while they fill the chip at most once, 128-row tiles (8 waves) beyond
+// 64-row tiles, 4 waves, two workgroups per CU (attn_h.hip); INFGEN_ATTN_WAVES=8 selects the 128-row variant
 static void launch_attn_h(const AttnHArgs& a, void* stream) {
-  if (a.rows <= 256 * 64) {
+  static const int waves = getenv("INFGEN_ATTN_WAVES") ? atoi(getenv("INFGEN_ATTN_WAVES")) : 4;
+  if (waves != 8) {
     hipLaunchKernelGGL(k_attn_h<4>, dim3(ceil_div(a.rows, 64)), dim3(256), 0, (hipStream_t)stream, a);
   } else {
     int grid = ceil_div(a.rows, 128);

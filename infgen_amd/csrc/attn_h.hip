@@ -11,7 +11,10 @@
 // 16 t + 4 rg + r (tile t, register r) of row j; weights are the MFMA A operand and stream through the
 // five-buffer LDS ring as quarter-matrices (16 KB); activations are split to fp16 hi/lo B fragments with a
 // per-row power-of-two scale (frags_scaled), so no bound on their magnitude is assumed.
-// One workgroup per CU (see fourier_h.hip): WAVES = 4 -> 64-row tiles, WAVES = 8 -> 128-row tiles.
+// WAVES = 4: 64-row tiles, two workgroups per CU (measured 5-11 % faster than one 8-wave workgroup from 32 k rows up,
+// and - unlike k_fourier_h, see fourier_h.hip - bitwise reproducible with several workgroups per CU: 40 re-runs each of
+// 16 k / 32 k / 64 k / 100 k rows; tests/test_ops_gpu.py::test_attn_split_is_deterministic keeps watching it).
+// WAVES = 8 (128-row tiles, one workgroup per CU) is kept for comparison.
 #include "kernels.h"
 #include "layout.h"
 #include "tile.cuh"
@@ -53,9 +56,12 @@ __device__ __forceinline__ void scale_bias(f32x4 (&v)[8], float s, const float* 
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 1) void k_attn_h(AttnHArgs a) {
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnHArgs a) {
   constexpr int NTH = 64 * WAVES, TILE = 16 * WAVES, GLDS = 1024 / NTH;
-  __shared__ __attribute__((aligned(16))) unsigned short Wb[RING][QUARTER];    // 80 KB: also keeps the CU to ONE workgroup
+  // 4 waves: three quarter buffers (59 KB with the vectors) and <= 256 registers -> two workgroups per CU;
+  // 8 waves: the five-buffer ring of split.cuh, one workgroup per CU
+  constexpr int XRING = WAVES == 4 ? 3 : RING, XDIST = XRING - 1;
+  __shared__ __attribute__((aligned(16))) unsigned short Wb[XRING][QUARTER];
   __shared__ __attribute__((aligned(16))) float Vt[VT_SIZE];
   __shared__ const unsigned short* seg_ptr[5];
   __shared__ int seg_n[5];
@@ -107,18 +113,18 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_attn_h(AttnHArgs a) {
     while (soff >= seg_n[sseg]) { soff = 0; sseg = (sseg + 1 == 5) ? 0 : sseg + 1; }
     stage_quarter<NTH>(seg_ptr[sseg] + (size_t)soff * QUARTER, Wb[slot_stage], tid);
     ++soff;
-    slot_stage = (slot_stage + 1 == RING) ? 0 : slot_stage + 1;
+    slot_stage = (slot_stage + 1 == XRING) ? 0 : slot_stage + 1;
   };
-  for (int d = 0; d < DIST && d < total; ++d) stage_next();
+  for (int d = 0; d < XDIST && d < total; ++d) stage_next();
   // next quarter: wait until it has landed (vmcnt counts every VMEM operation in issue order, so "all but the
   // (DIST - 1) * GLDS most recent" always covers it), barrier, refill the slot released by the previous quarter
   auto take = [&]() -> const unsigned short* {
-    if (consumed + DIST <= total) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DIST - 1) * GLDS) : "memory");
+    if (consumed + XDIST <= total) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((XDIST - 1) * GLDS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (consumed + DIST < total) stage_next();
+    if (consumed + XDIST < total) stage_next();
     const unsigned short* cur = Wb[slot];
-    slot = (slot + 1 == RING) ? 0 : slot + 1;
+    slot = (slot + 1 == XRING) ? 0 : slot + 1;
     ++consumed;
     return cur;
   };

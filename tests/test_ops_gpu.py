@@ -127,6 +127,38 @@ def test_fourier_split_is_deterministic(env):
     assert float((outs[0] - ref).abs().max()) <= 5e-5
 
 
+def test_attn_split_is_deterministic(env):
+    """k_attn_h runs two workgroups per CU; 64 k rows, six launches, bitwise identical (the Fourier kernel of the same
+    family is NOT reproducible with several workgroups per CU - csrc/fourier_h.hip - so this one is watched)"""
+    from infgen_amd import _lib
+    dev, lib = env['dev'], env['lib']
+    rows = 65536
+    p1 = _dev(env['packing'].pack_attention_layer(env['sd'], 'agent_encoder.t_attn_layers.0'), dev)
+    p2 = _dev(env['packing'].pack_attention_layer(env['sd'], 'agent_encoder.pt2a_attn_layers.0'), dev)
+    g = torch.Generator(device='cpu').manual_seed(0)
+    X0 = torch.randn(rows, 128, generator=g).to(dev)
+    AGG = (torch.randn(rows, 128, generator=g) * 0.5).to(dev)
+    Z = (torch.randn(rows, 8, 128, generator=g) * 0.3).to(dev)
+    SIG = torch.rand(rows, 8, generator=g).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.infgen_set_attn_mode(1))
+    try:
+        outs = []
+        for _ in range(6):
+            X = X0.clone()
+            Q, K, V = (torch.empty(rows, 128, device=dev) for _ in range(3))
+            U = torch.empty(rows, 8, 128, device=dev)
+            _lib.check(lib.infgen_attn_post_pre(X.data_ptr(), rows, p1.data_ptr(), AGG.data_ptr(), Z.data_ptr(), SIG.data_ptr(), 1,
+                                                p2.data_ptr(), Q.data_ptr(), U.data_ptr(), K.data_ptr(), V.data_ptr(), st))
+            outs.append((X, Q, U, K, V))
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(lib.infgen_set_attn_mode(2))
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 def _random_graph(rng, n_dst, n_src, max_deg, empty_rows=()):
     off, cnt, src, dst = [], [], [], []
     e = 0

@@ -1,0 +1,33 @@
+import sys, numpy as np, torch
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+from infgen_amd import _lib
+if os.environ.get('EXP_LIB'):
+    _lib.LIB_PATH = os.environ['EXP_LIB']
+from conftest import make_weights
+from infgen_amd import packing, engine
+dev = torch.device('cuda:0'); lib = _lib.load(); ops = engine.Ops(dev)
+sd = make_weights(seed=3)
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+p1 = torch.from_numpy(packing.pack_attention_layer(sd, 'agent_encoder.t_attn_layers.0')).to(dev)
+p2 = torch.from_numpy(packing.pack_attention_layer(sd, 'agent_encoder.pt2a_attn_layers.0')).to(dev)
+g = torch.Generator(device='cpu').manual_seed(0)
+f = lambda *s: torch.randn(*s, generator=g).to(dev)
+X0 = f(rows, 128); AGG = f(rows, 128) * 0.5; Z = f(rows, 8, 128) * 0.3; SIG = torch.rand(rows, 8, generator=g).to(dev)
+st = torch.cuda.current_stream().cuda_stream
+_lib.check(lib.infgen_set_attn_mode(1))
+outs = []
+import time
+for it in range(int(os.environ.get("REPS", "8"))):
+    X = X0.clone(); Q = torch.empty(rows, 128, device=dev); U = torch.empty(rows, 8, 128, device=dev)
+    K = torch.empty(rows, 128, device=dev); V = torch.empty(rows, 128, device=dev)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    _lib.check(lib.infgen_attn_post_pre(X.data_ptr(), rows, p1.data_ptr(), AGG.data_ptr(), Z.data_ptr(), SIG.data_ptr(), 1,
+                                        p2.data_ptr(), Q.data_ptr(), U.data_ptr(), K.data_ptr(), V.data_ptr(), st))
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    outs.append((X, Q, U, K, V, dt))
+bad = 0
+for o in outs[1:]:
+    for a, b in zip(o[:5], outs[0][:5]):
+        bad += int((a.view(torch.int32) != b.view(torch.int32)).any(-1).sum()) if a.dim() == 2 else int((a.view(torch.int32) != b.view(torch.int32)).flatten(1).any(-1).sum())
+print('rows', rows, 'rows differing bitwise over the reruns:', bad, ' time us', [round(o[5] * 1e6) for o in outs[2:6]])

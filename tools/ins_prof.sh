@@ -1,9 +1,9 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-python $R/bench.py --insertion --scenes 64 --no-cpu-baseline --steps 2 --warmup 1 2>/dev/null | cut -c1-400
-timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --insertion --scenes 64 --no-cpu-baseline --steps 2 --warmup 1 > /tmp/kt.log 2>&1
+S=${1:-512}
+timeout -s KILL 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --insertion --scenes $S --no-cpu-baseline --steps 1 --warmup 1 > /tmp/kt.log 2>&1
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1)
-head -16 $f | cut -c1-150
+head -14 $f | cut -c1-140
 python - $(find /tmp/kt -name "*kernel_trace.csv" | head -1) <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
