@@ -19,13 +19,15 @@
 // fragments = 16 KB) are streamed global -> LDS with global_load_lds_dwordx4 through a ring of five
 // buffers (four quarters in flight), shared by the 8 waves of the workgroup; the sequence of quarters is
 // the same for every tile, so the pipeline runs across tile boundaries.
-// Workgroup = 8 waves x 16 edges, ONE workgroup per CU (two waves per SIMD, whose VALU phases - sin/cos,
-// LayerNorm, splitting - overlap the partner's MFMA phases).  One per CU is deliberate: with two or
-// three independent workgroups of this kernel resident on a CU, single waves produced wrong rows at
-// random (16 consecutive rows off by ~1e-2, different rows every run; with and without LDS-DMA, with A
-// fragments read from LDS or from global memory; never with one workgroup per CU, whatever its wave
-// count).  The cause was not found; the 91 KB of LDS make the single-workgroup placement structural,
-// and tests/test_ops_gpu.py::test_fourier_split_is_deterministic re-runs a 350k-row launch bitwise.
+// Workgroup = 8 waves x 16 edges, one workgroup per CU (two waves per SIMD, whose VALU phases - sin/cos,
+// LayerNorm, splitting - overlap the partner's MFMA phases).
+// Bring-up note: early 4-wave versions with two or three workgroups per CU produced wrong rows at random (16
+// consecutive rows off by ~1e-2, ~1 wave-tile in 3000, different rows every run; independent of LDS-DMA, of where the
+// A fragments came from, of spills, of the fp64 slow path; never with one workgroup per CU).  The cause was never
+// pinned down, and the final code no longer shows it: a 4-wave / three-buffer / two-workgroups-per-CU build of this
+// file was bitwise reproducible over 160 re-runs (100 k .. 1 M rows, n = 3 and 4) and only 3 % faster, so the
+// one-workgroup configuration stays; tests/test_ops_gpu.py::test_fourier_split_is_deterministic re-runs a 350 k-row
+// launch bitwise, test_attn_split_is_deterministic does the same for k_attn_h (which does run two per CU).
 #include "kernels.h"
 #include "layout.h"
 #include "tile.cuh"
