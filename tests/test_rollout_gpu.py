@@ -280,6 +280,10 @@ def test_degenerate_scenes():
     scene = synth.make_scene(32, 6, 40, cfg, vocab=c['vocab'], grid=c['grid'])
     scene['pt_token']['position'][:, :2] += 5000.0
     _oracle_vs_engine(cfg, scene, sd, c)
+    # no map tokens at all / a single one (empty map encoder input, empty map edge set)
+    for m in (0, 1):
+        scene = synth.make_scene(35, 5, m, cfg, vocab=c['vocab'], grid=c['grid'])
+        _oracle_vs_engine(cfg, scene, sd, c)
     # agents spread over kilometres: no agent<->agent edges
     scene = synth.make_scene(33, 12, 64, cfg, half_extent=5000.0, vocab=c['vocab'], grid=c['grid'])
     o, ref = _oracle_vs_engine(cfg, scene, sd, c)
