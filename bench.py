@@ -112,6 +112,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--scenes', type=int, default=512, help='scenes per GPU')
+    ap.add_argument('--overlap', type=int, default=-1, help='infgen_set_overlap (default: library default)')
     ap.add_argument('--roofline-kernel', default='', help='report the roofline of this kernel instead of the dominant one')
     ap.add_argument('--agents', type=int, default=64)
     ap.add_argument('--map-tokens', type=int, default=1024)
@@ -182,6 +183,8 @@ def main():
 
     log(f'cpu baseline done: {cpu}')
     lib = _lib.load()
+    if args.overlap >= 0:
+        _lib.check(lib.infgen_set_overlap(args.overlap))
     for _ in range(args.warmup):
         eng.rollout()
         torch.cuda.synchronize(dev)

@@ -142,6 +142,9 @@ int infgen_edge_attn_fused(int rows, const float* Q, const float* wkr, const flo
                            const int* off, const int* cnt, const int* src, const float* rhat,
                            float* AGG, float* Z, float* SIG, void* stream);
 int infgen_set_edge_fuse(int mode);
+/* 1: infgen_decode_layers runs the Fourier embeddings of the map and agent edge sets on an internal side stream, overlapped
+ * with the first temporal / map sublayers on the caller's stream (joined with events before their first use) */
+int infgen_set_overlap(int mode);
 /* same with the kernel variant forced: wide = 1 -> one 8-wave workgroup per destination (long edge lists, few rows),
  * wide = 0 -> one wave per destination; infgen_edge_attn picks wide when rows <= 256 */
 int infgen_edge_attn_mode(int rows, const float* Q, const float* U, const float* Ksrc, const float* Vsrc,

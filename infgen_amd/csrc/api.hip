@@ -443,11 +443,39 @@ extern "C" int infgen_sample_topk(const float* logits, int rows, int n, int k, c
   return check_launch("infgen_sample_topk");
 }
 
+// Optional: the Fourier embeddings of the map and agent edge sets (matrix-pipe / VALU work) run on a side stream while
+// the temporal and map sublayers of the first layer (memory-bound) run on the caller's stream.
+static int g_overlap = 0;
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_ev_fork = nullptr, g_ev_m = nullptr, g_ev_a = nullptr;
+extern "C" int infgen_set_overlap(int mode) {
+  if (mode != 0 && mode != 1) return fail("infgen_set_overlap", "mode must be 0 or 1");
+  if (mode && !g_side) {
+    if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_ev_m, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_ev_a, hipEventDisableTiming) != hipSuccess)
+      return fail("infgen_set_overlap", "stream / event creation failed");
+  }
+  g_overlap = mode;
+  return 0;
+}
+
 extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless, void* stream) {
   RET_IF(validate(r, "infgen_decode_layers"));
   const int rows = r->S * r->A_cap;
   RET_IF(infgen_build_edges(r, c, edgeless, stream));
-  if (!edgeless) {
+  const bool overlap = g_overlap && !edgeless;
+  if (overlap) {
+    hipStream_t ms = (hipStream_t)stream;
+    if (hipEventRecord(g_ev_fork, ms) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork, 0) != hipSuccess)
+      return fail("infgen_decode_layers", "fork failed");
+    RET_IF(infgen_fourier_embed(r->em.raw, 3, r->em.total, r->em.cap, r->four_m, nullptr, 0, r->em.rhat, 128, 1, g_side));
+    if (hipEventRecord(g_ev_m, g_side) != hipSuccess) return fail("infgen_decode_layers", "event failed");
+    RET_IF(infgen_fourier_embed(r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, g_side));
+    if (hipEventRecord(g_ev_a, g_side) != hipSuccess) return fail("infgen_decode_layers", "event failed");
+    RET_IF(infgen_fourier_embed(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, stream));
+  } else if (!edgeless) {
     RET_IF(infgen_fourier_embed(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, stream));
     RET_IF(infgen_fourier_embed(r->em.raw, 3, r->em.total, r->em.cap, r->four_m, nullptr, 0, r->em.rhat, 128, 1, stream));
     RET_IF(infgen_fourier_embed(r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, stream));
@@ -469,10 +497,14 @@ extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless,
     RET_IF(infgen_attn_post_pre(r->X, rows, r->attn_t[i], r->AGG, r->Z, r->SIG, 1, r->attn_m[i], r->Q, U,
                                 nullptr, nullptr, stream));
     // map -> agent (bipartite: K/V of the map tokens are per-scene constants)
+    if (overlap && i == 0 && hipStreamWaitEvent((hipStream_t)stream, g_ev_m, 0) != hipSuccess)
+      return fail("infgen_decode_layers", "join failed");
     RET_IF(edge(r->attn_m[i], r->mapK[i], r->mapV[i], r->em));
     RET_IF(infgen_attn_post_pre(r->X, rows, r->attn_m[i], r->AGG, r->Z, r->SIG, 1, r->attn_a[i], r->Q, U,
                                 r->Ka, r->Va, stream));
     // agent <-> agent
+    if (overlap && i == 0 && hipStreamWaitEvent((hipStream_t)stream, g_ev_a, 0) != hipSuccess)
+      return fail("infgen_decode_layers", "join failed");
     RET_IF(edge(r->attn_a[i], r->Ka, r->Va, r->ea));
     if (i + 1 < L) {
       RET_IF(infgen_attn_post_pre(r->X, rows, r->attn_a[i], r->AGG, r->Z, r->SIG, 1, r->attn_t[i + 1], r->Q, U,

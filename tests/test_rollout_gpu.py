@@ -303,6 +303,27 @@ def test_maximum_sizes_stress_shape():
     assert ref['edge_count'][:, 1].max() > 256 * 64      # dense agent<->agent neighbourhoods
 
 
+def test_side_stream_overlap_is_bitwise_neutral():
+    """infgen_set_overlap(1): Fourier embeddings of the map / agent sets on a side stream; same kernels, same results"""
+    from infgen_amd import engine, synth, _lib
+    c = load_case('c2_a32_m512')
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], c['cfg'], dev)
+    scenes = [synth.make_scene(700 + i, 20 + i, 256, c['cfg'], vocab=c['vocab'], grid=c['grid'], slip=0.2) for i in range(8)]
+    lib = _lib.load()
+    outs = []
+    try:
+        for mode in (0, 1):
+            _lib.check(lib.infgen_set_overlap(mode))
+            eng = engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=True)
+            eng.rollout()
+            outs.append(eng.outputs())
+    finally:
+        _lib.check(lib.infgen_set_overlap(0))
+    for a, b in zip(*outs):
+        assert np.array_equal(a['logits'], b['logits']) and np.array_equal(a['pos_a'], b['pos_a'])
+
+
 def test_fused_edge_attention_rollout_matches_default():
     """infgen_set_edge_fuse(1): the absorbed query is computed inside the edge kernel (no U array); tokens identical,
     logits within fp32 noise of the default path"""
