@@ -4,7 +4,8 @@
 // closest (sum of corner distances, first minimum) to the agent's box at this step, then continue from the
 // matched contour's pose (or from the logged pose where the step pair is not valid).
 // One workgroup per agent: the 18 steps are sequential, the 2048 tokens of a step are spread over 256 threads
-// (8 tokens each, held in registers for all steps - the vocabulary is read once).
+// (8 tokens each, held in registers for all steps - the vocabulary is read once); every thread carries the pose and
+// repeats the uniform scalar work of a step, so a step costs one barrier.
 // fp32 arithmetic restated from what torch executes on the CPU (checked bit for bit against torch ops):
 //   bmm with K = 2:          w.x = fma(t.y, -sin, t.x * cos),  w.y = fma(t.y, cos, t.x * sin)
 //   torch.norm(dim=-1):      sqrt(fma(dy, dy, dx * dx))
@@ -36,10 +37,8 @@ __device__ __forceinline__ Contour box_contour(float x, float y, float head, flo
 }
 
 __global__ __launch_bounds__(MT_THREADS) void k_match_tokens(MatchTokensArgs a) {
-  __shared__ float s_val[MT_THREADS];
-  __shared__ int s_idx[MT_THREADS];
-  __shared__ float s_pose[3];
-  __shared__ float s_step[10];           // cos, sin of the previous pose and the four corners of the current box
+  __shared__ float s_val[2][MT_THREADS / 64];
+  __shared__ int s_idx[2][MT_THREADS / 64];
   const int ag = blockIdx.x, t = threadIdx.x;
   const float* V = a.tok + (a.type ? (size_t)a.type[ag] * a.n_token * 8 : (size_t)ag * a.tok_agent_stride);
   const int per = (a.n_token + MT_THREADS - 1) / MT_THREADS;
@@ -55,23 +54,13 @@ __global__ __launch_bounds__(MT_THREADS) void k_match_tokens(MatchTokensArgs a) 
   }
   const float width = a.shape[2 * ag], length = a.shape[2 * ag + 1];
   const size_t row = (size_t)ag * a.T;
-  if (t == 0) { s_pose[0] = a.heading[row]; s_pose[1] = a.pos[2 * row]; s_pose[2] = a.pos[2 * row + 1]; }
-  __syncthreads();
+  // every thread carries the pose and repeats the (cheap, uniform) per-step scalar work: one barrier per step
+  float ph = a.heading[row], px = a.pos[2 * row], py = a.pos[2 * row + 1];
   const int n_out = a.T / a.shift;
   for (int i = a.shift, o = 0; i < a.T; i += a.shift, ++o) {
-    const float px = s_pose[1], py = s_pose[2];
-    if (t == 0) {                        // fp64 trigonometry once per step, not once per thread
-      const float ph = s_pose[0];
-      s_step[0] = cos_cr(ph); s_step[1] = sin_cr(ph);
-      const Contour c0 = box_contour(a.pos[2 * (row + i)], a.pos[2 * (row + i) + 1], a.heading[row + i], width, length);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { s_step[2 + 2 * c] = c0.x[c]; s_step[3 + 2 * c] = c0.y[c]; }
-    }
-    __syncthreads();
-    const float cs = s_step[0], sn = s_step[1];
-    Contour cur;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { cur.x[c] = s_step[2 + 2 * c]; cur.y[c] = s_step[3 + 2 * c]; }
+    const float cs = cos_cr(ph), sn = sin_cr(ph);
+    const float cxi = a.pos[2 * (row + i)], cyi = a.pos[2 * (row + i) + 1], chi = a.heading[row + i];
+    const Contour cur = box_contour(cxi, cyi, chi, width, length);
     float best = INFINITY;
     int bidx = 0x7fffffff;
 #pragma unroll
@@ -92,43 +81,47 @@ __global__ __launch_bounds__(MT_THREADS) void k_match_tokens(MatchTokensArgs a) 
         if (sum < best) { best = sum; bidx = k; }      // ascending k per thread: the first minimum stays
       }
     }
-    s_val[t] = best; s_idx[t] = bidx;
+    // arg-min with the first-index tie rule: inside the wave by shuffles, across the four waves through LDS
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float v2 = __shfl_xor(best, off, 64);
+      const int i2 = __shfl_xor(bidx, off, 64);
+      if (v2 < best || (v2 == best && i2 < bidx)) { best = v2; bidx = i2; }
+    }
+    const int buf = o & 1;                               // double buffered: one barrier per step is enough
+    if ((t & 63) == 0) { s_val[buf][t >> 6] = best; s_idx[buf][t >> 6] = bidx; }
     __syncthreads();
-    for (int off = MT_THREADS / 2; off > 0; off >>= 1) {
-      if (t < off) {
-        const float v2 = s_val[t + off];
-        const int i2 = s_idx[t + off];
-        if (v2 < s_val[t] || (v2 == s_val[t] && i2 < s_idx[t])) { s_val[t] = v2; s_idx[t] = i2; }
-      }
-      __syncthreads();
+    best = s_val[buf][0]; bidx = s_idx[buf][0];
+#pragma unroll
+    for (int w = 1; w < MT_THREADS / 64; ++w) {
+      const float v2 = s_val[buf][w];
+      const int i2 = s_idx[buf][w];
+      if (v2 < best || (v2 == best && i2 < bidx)) { best = v2; bidx = i2; }
+    }
+    const int k = bidx;
+    const float4 p0 = *reinterpret_cast<const float4*>(V + (size_t)k * 8);
+    const float4 p1 = *reinterpret_cast<const float4*>(V + (size_t)k * 8 + 4);
+    const float tx[4] = {p0.x, p0.z, p1.x, p1.z}, ty[4] = {p0.y, p0.w, p1.y, p1.w};
+    float wx[4], wy[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      wx[c] = __builtin_fmaf(ty[c], -sn, tx[c] * cs) + px;
+      wy[c] = __builtin_fmaf(ty[c], cs, tx[c] * sn) + py;
     }
     if (t == 0) {
-      const int k = s_idx[0];
-      const float4 p0 = *reinterpret_cast<const float4*>(V + (size_t)k * 8);
-      const float4 p1 = *reinterpret_cast<const float4*>(V + (size_t)k * 8 + 4);
-      const float tx[4] = {p0.x, p0.z, p1.x, p1.z}, ty[4] = {p0.y, p0.w, p1.y, p1.w};
-      float wx[4], wy[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        wx[c] = __builtin_fmaf(ty[c], -sn, tx[c] * cs) + px;
-        wy[c] = __builtin_fmaf(ty[c], cs, tx[c] * sn) + py;
-      }
       a.token_index[(size_t)ag * n_out + o] = k;
       float* oc = a.token_contour + ((size_t)ag * n_out + o) * 8;
 #pragma unroll
       for (int c = 0; c < 4; ++c) { oc[2 * c] = wx[c]; oc[2 * c + 1] = wy[c]; }
-      const bool ok = a.valid[row + i - a.shift] && a.valid[row + i];
-      if (ok) {
-        s_pose[0] = (float)atan2((double)(wy[0] - wy[3]), (double)(wx[0] - wx[3]));
-        s_pose[1] = (((wx[0] + wx[1]) + wx[2]) + wx[3]) * 0.25f;
-        s_pose[2] = (((wy[0] + wy[1]) + wy[2]) + wy[3]) * 0.25f;
-      } else {
-        s_pose[0] = a.heading[row + i];
-        s_pose[1] = a.pos[2 * (row + i)];
-        s_pose[2] = a.pos[2 * (row + i) + 1];
-      }
     }
-    __syncthreads();
+    const bool ok = a.valid[row + i - a.shift] && a.valid[row + i];
+    if (ok) {
+      ph = (float)atan2((double)(wy[0] - wy[3]), (double)(wx[0] - wx[3]));
+      px = (((wx[0] + wx[1]) + wx[2]) + wx[3]) * 0.25f;
+      py = (((wy[0] + wy[1]) + wy[2]) + wy[3]) * 0.25f;
+    } else {
+      ph = chi; px = cxi; py = cyi;
+    }
   }
 }
 
