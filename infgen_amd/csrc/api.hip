@@ -213,7 +213,9 @@ static inline bool attn_split(int rows) { return g_attn_mode == 1 || (g_attn_mod
 static void launch_attn_h(const AttnHArgs& a, void* stream) {
   static const int waves = getenv("INFGEN_ATTN_WAVES") ? atoi(getenv("INFGEN_ATTN_WAVES")) : 4;
   if (waves != 8) {
-    hipLaunchKernelGGL(k_attn_h<4>, dim3(ceil_div(a.rows, 64)), dim3(256), 0, (hipStream_t)stream, a);
+    int grid = ceil_div(a.rows, 64);
+    if (grid > 512) grid = 512;          // two workgroups per CU, persistent over the 64-row tiles beyond that
+    hipLaunchKernelGGL(k_attn_h<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   } else {
     int grid = ceil_div(a.rows, 128);
     if (grid > 256) grid = 256;
