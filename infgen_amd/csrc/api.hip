@@ -340,7 +340,13 @@ extern "C" int infgen_heads(const float* X, int rows, const float* tok_pack, con
   if (token_size % 128) return fail("infgen_heads", "token_size must be a multiple of 128");
   HeadsArgs a{X, rows, tok_pack, st_pack, token_size, logits, next_token, next_state};
   { ProfScope _ps(INFGEN_KID_HEADS, stream, (double)rows * (2 * 16384.0 + 128.0 * token_size + 384.0));
-    hipLaunchKernelGGL(k_heads, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a); }
+    if (attn_split(rows)) {
+      int grid = ceil_div(rows, 64);
+      if (grid > 512) grid = 512;
+      hipLaunchKernelGGL(k_heads_h, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+      hipLaunchKernelGGL(k_heads, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a);
+    } }
   return check_launch("infgen_heads");
 }
 
@@ -426,6 +432,14 @@ extern "C" int infgen_raw_feature(const InfgenRollout* r, int col, void* stream)
   RET_IF(check_launch("infgen_raw_feature/prep"));
   RET_IF(infgen_fourier_embed(r->raw2, 2, nullptr, rows, r->four_xa, r->cat, 128, r->fus_in + 128, 512, 0, stream));
   const float* P = r->fusion_pack;
+  if (attn_split(rows)) {      // the three Linear stages of fusion_emb in one launch on the fp16 split
+    MlpEmbHArgs m{r->fus_in, 512, rows, 512, P, r->X, 128};
+    int grid = ceil_div(rows, 64);
+    if (grid > 512) grid = 512;
+    { ProfScope _ps(INFGEN_KID_LINEAR, stream, (double)rows * (512 + 128 + 128) * 128.0);
+      hipLaunchKernelGGL(k_mlpemb_h, dim3(grid), dim3(256), 0, (hipStream_t)stream, m); }
+    return check_launch("infgen_raw_feature/fusion");
+  }
   const int o2 = mlpemb_off2(512), o3 = mlpemb_off3(512);
   RET_IF(infgen_linear(r->fus_in, 512, nullptr, rows, 512, P, 128, P + 512 * 128, 128, nullptr, nullptr,
                        P + 512 * 128 + 128, P + 512 * 128 + 256, 1, r->tmp1, 128, stream));

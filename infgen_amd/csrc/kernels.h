@@ -77,6 +77,13 @@ struct AttnHArgs {
   float* nQ; float* nU; float* nK; float* nV;
 };
 
+// k_mlpemb_h (mlp_h.hip): MLPEmbedding with K0 = 128 j on the fp16 split
+struct MlpEmbHArgs {
+  const float* X; int ldx; int rows; int K0;
+  const float* pack;                 // packing.pack_mlp_embedding incl. its split section
+  float* Y; int ldy;
+};
+
 // k_match_tokens (token_kernels.hip): TokenProcessor._match_agent_token, one workgroup per agent
 struct MatchTokensArgs {
   const unsigned char* valid;        // [A][T]
@@ -244,6 +251,8 @@ __global__ void k_linear(LinearArgs a);
 __global__ void k_fourier(FourierArgs a);
 __global__ void k_fourier_h(FourierArgs a);
 __global__ void k_match_tokens(MatchTokensArgs a);   // token_kernels.hip
+__global__ void k_mlpemb_h(MlpEmbHArgs a);           // mlp_h.hip
+__global__ void k_heads_h(HeadsArgs a);
 __global__ void k_match_map_tokens(MatchMapArgs a);
 template <int WAVES> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);

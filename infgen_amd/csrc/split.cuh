@@ -119,6 +119,44 @@ __device__ __forceinline__ void regs_to_frags(const f32x4 (&v)[8], u32x4 (&Bh)[4
     }
 }
 
+// The weight stream of a workgroup: up to four runs of consecutive quarter-matrices (tables in LDS, filled by thread
+// 0 before init), cycled once per tile through a ring of NR quarter buffers.  take() returns the next quarter after
+// waiting for its LDS-DMA (counted vmcnt: "all but the (NR - 2) * GLDS most recent VMEM operations" always covers it;
+// hipcc does not order LDS-DMA against ds_read on its own), a barrier, and a refill of the slot just released.
+template <int NTH, int NR>
+struct QuarterStream {
+  static constexpr int GLDS = 1024 / NTH, ND = NR - 1;
+  const unsigned short* const* seg_ptr;
+  const int* seg_n;
+  unsigned short (*Wb)[QUARTER];
+  int nseg, total, consumed, slot, slot_stage, sseg, soff, tid;
+  __device__ __forceinline__ void stage_next() {
+    while (soff >= seg_n[sseg]) { soff = 0; sseg = (sseg + 1 == nseg) ? 0 : sseg + 1; }
+    stage_quarter<NTH>(seg_ptr[sseg] + (size_t)soff * QUARTER, Wb[slot_stage], tid);
+    ++soff;
+    slot_stage = (slot_stage + 1 == NR) ? 0 : slot_stage + 1;
+  }
+  __device__ __forceinline__ void init(const unsigned short* const* sp, const int* sn, int nseg_, int my_tiles,
+                                       unsigned short (*wb)[QUARTER], int tid_) {
+    seg_ptr = sp; seg_n = sn; nseg = nseg_; Wb = wb; tid = tid_;
+    int nq = 0;
+    for (int i = 0; i < nseg; ++i) nq += sn[i];
+    total = my_tiles * nq;
+    consumed = slot = slot_stage = sseg = soff = 0;
+    for (int d = 0; d < ND && d < total; ++d) stage_next();
+  }
+  __device__ __forceinline__ const unsigned short* take() {
+    if (consumed + ND <= total) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((ND - 1) * GLDS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (consumed + ND < total) stage_next();
+    const unsigned short* cur = Wb[slot];
+    slot = (slot + 1 == NR) ? 0 : slot + 1;
+    ++consumed;
+    return cur;
+  }
+};
+
 // Row-scaled fragments: the 128-vector of this lane's row is multiplied by the power of two that brings its
 // largest magnitude into [2^14, 2^15) (exact), split into fp16 hi/lo B fragments, and the inverse factor is
 // returned - scaling a column of B scales the same column of C, so the caller multiplies its GEMM result by it.

@@ -221,10 +221,26 @@ def pack_matrix_h(w: np.ndarray, natural_k: bool) -> np.ndarray:
 def pack_mlp_embedding(sd, prefix: str) -> np.ndarray:
     """MLPEmbedding (layers.py:163-179): P(K0p,128) b ln_g ln_b | P(128,128) b ln_g ln_b | P(128,128) b"""
     g = lambda k: _get(sd, f'{prefix}.{k}')
-    return np.concatenate([
+    out = np.concatenate([
         pack_matrix(g('mlp.0.weight')), g('mlp.0.bias'), g('mlp.1.weight'), g('mlp.1.bias'),
         pack_matrix(g('mlp.3.weight')), g('mlp.3.bias'), g('mlp.4.weight'), g('mlp.4.bias'),
         pack_matrix(g('mlp.6.weight')), g('mlp.6.bias')]).astype(np.float32)
+    w0 = g('mlp.0.weight')
+    if w0.shape[1] % 128 == 0:
+        # split section for k_mlpemb_h: [16] inverse weight scales, then quarter-matrices W0 (one unit per 128 inputs), W1, W2
+        ws = [w0, g('mlp.3.weight'), g('mlp.6.weight')]
+        sc = [_pow2_scale(w) for w in ws]
+        hdr = np.zeros(16, np.float32)
+        hdr[:3] = [1.0 / v for v in sc]
+        mats = [pack_matrix_h(w0[:, 128 * j:128 * (j + 1)] * sc[0], natural_k=False) for j in range(w0.shape[1] // 128)]
+        mats += [pack_matrix_h(ws[1] * sc[1], natural_k=False), pack_matrix_h(ws[2] * sc[2], natural_k=False)]
+        assert out.size % 4 == 0
+        out = np.concatenate([out, hdr, np.concatenate(mats).view(np.float32)])
+    return out
+
+
+def _pow2_scale(w) -> float:
+    return float(min(2.0 ** np.floor(np.log2(H_TARGET / max(float(np.abs(w).max()), 1e-30))), 2.0 ** 14))
 
 
 def mlp_embedding_offsets(k0: int):
@@ -246,8 +262,23 @@ def pack_mlp_layer(sd, prefix: str, row_major_out: bool = False) -> np.ndarray:
     if not row_major_out:
         npad = (w3.shape[0] + 31) // 32 * 32
         b3 = np.concatenate([b3, np.zeros(npad - b3.size, dtype=np.float32)])
-    return np.concatenate([pack_matrix(g('mlp.0.weight')), g('mlp.0.bias'), g('mlp.1.weight'), g('mlp.1.bias'),
-                           w3p, b3]).astype(np.float32)
+    out = np.concatenate([pack_matrix(g('mlp.0.weight')), g('mlp.0.bias'), g('mlp.1.weight'), g('mlp.1.bias'),
+                          w3p, b3]).astype(np.float32)
+    # split section for k_heads_h (16-byte aligned): [16] inverse weight scales, W0 quarters, and for the wide head the
+    # quarters of every 128-output chunk of W3
+    w0 = g('mlp.0.weight')
+    if w0.shape == (128, 128) and (row_major_out or w3.shape[0] % 128 == 0):
+        out = np.concatenate([out, np.zeros((-out.size) % 4, np.float32)])
+        s0 = _pow2_scale(w0)
+        hdr = np.zeros(16, np.float32)
+        hdr[0] = 1.0 / s0
+        mats = [pack_matrix_h(w0 * s0, natural_k=False)]
+        if not row_major_out:
+            s3 = _pow2_scale(w3)
+            hdr[1] = 1.0 / s3
+            mats += [pack_matrix_h(w3[128 * c:128 * (c + 1), :] * s3, natural_k=False) for c in range(w3.shape[0] // 128)]
+        out = np.concatenate([out, hdr, np.concatenate(mats).view(np.float32)])
+    return out
 
 
 MLP_LAYER_W3_OFFSET = 16384 + 3 * 128

@@ -226,7 +226,7 @@ def test_attention_layer_edgeless(env, attn_mode):
     assert np.abs(xd.cpu().numpy() - ref).max() <= 5e-5
 
 
-def test_heads_argmax_and_logits(env):
+def test_heads_argmax_and_logits(env, attn_mode):
     from oracle import rollout_oracle as ro
     rng = np.random.default_rng(13)
     rows = 50

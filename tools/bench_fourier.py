@@ -2,7 +2,11 @@
 import sys, time, numpy as np, torch
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 from conftest import make_weights
-from infgen_amd import _lib, packing, engine
+import os
+from infgen_amd import _lib
+if os.environ.get('EXP_LIB'):
+    _lib.LIB_PATH = os.environ['EXP_LIB']
+from infgen_amd import packing, engine
 dev = torch.device('cuda:0')
 lib = _lib.load()
 ops = engine.Ops(dev)
