@@ -57,10 +57,10 @@ __device__ __forceinline__ void scale_bias(f32x4 (&v)[8], float s, const float* 
 
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnHArgs a) {
-  constexpr int NTH = 64 * WAVES, TILE = 16 * WAVES, GLDS = 1024 / NTH;
+  constexpr int NTH = 64 * WAVES, TILE = 16 * WAVES;
   // 4 waves: three quarter buffers (59 KB with the vectors) and <= 256 registers -> two workgroups per CU;
   // 8 waves: the five-buffer ring of split.cuh, one workgroup per CU
-  constexpr int XRING = WAVES == 4 ? 3 : RING, XDIST = XRING - 1;
+  constexpr int XRING = WAVES == 4 ? 3 : RING;
   __shared__ __attribute__((aligned(16))) unsigned short Wb[XRING][QUARTER];
   __shared__ __attribute__((aligned(16))) float Vt[VT_SIZE];
   __shared__ const unsigned short* seg_ptr[5];
@@ -105,29 +105,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnH
     if (tid < 16) Vt[VT_N_HDR + tid] = NP[AH_HDR + tid];
   }
   __syncthreads();
-  const int nq = seg_n[0] + seg_n[1] + seg_n[2] + seg_n[3] + seg_n[4];
-  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int total = my_tiles * nq;
-  int consumed = 0, slot = 0, slot_stage = 0, sseg = 0, soff = 0;
-  auto stage_next = [&]() {
-    while (soff >= seg_n[sseg]) { soff = 0; sseg = (sseg + 1 == 5) ? 0 : sseg + 1; }
-    stage_quarter<NTH>(seg_ptr[sseg] + (size_t)soff * QUARTER, Wb[slot_stage], tid);
-    ++soff;
-    slot_stage = (slot_stage + 1 == XRING) ? 0 : slot_stage + 1;
-  };
-  for (int d = 0; d < XDIST && d < total; ++d) stage_next();
-  // next quarter: wait until it has landed (vmcnt counts every VMEM operation in issue order, so "all but the
-  // (DIST - 1) * GLDS most recent" always covers it), barrier, refill the slot released by the previous quarter
-  auto take = [&]() -> const unsigned short* {
-    if (consumed + XDIST <= total) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((XDIST - 1) * GLDS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (consumed + XDIST < total) stage_next();
-    const unsigned short* cur = Wb[slot];
-    slot = (slot + 1 == XRING) ? 0 : slot + 1;
-    ++consumed;
-    return cur;
-  };
+  QuarterStream<NTH, XRING> qs;
+  qs.init(seg_ptr, seg_n, 5, (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x, Wb, tid);
+  auto take = [&]() { return qs.take(); };
   auto gemm_unit = [&](f32x4 (&acc)[8], const u32x4 (&Bh)[4], const u32x4 (&Bl)[4]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) gemm_quarter(acc, take(), Bh[s], Bl[s], lane);

@@ -38,7 +38,6 @@ namespace ig {
 constexpr int FH_WAVES = 8;
 constexpr int FH_NT = 64 * FH_WAVES;     // threads per workgroup
 constexpr int FH_TILE = 16 * FH_WAVES;   // edges per workgroup tile (16 per wave)
-constexpr int GLDS_PER_STAGE = 1024 / FH_NT;   // global_load_lds instructions per thread and quarter
 
 // sin/cos: three-constant Cody-Waite reduction by pi/2 with fused multiply-adds (the products n * c are
 // exact inside the fma), then the classic minimax polynomials on [-pi/4, pi/4] (Cephes sinf/cosf
@@ -87,37 +86,14 @@ __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
   if (a.prof_rows && blockIdx.x == 0 && tid == 0) atomicAdd(a.prof_rows + a.n, (unsigned long long)E);
   const float* vec = a.pack + fourier_pack_size_f32(a.n);
   const unsigned short* wg = reinterpret_cast<const unsigned short*>(vec + FH_VEC_SIZE);
-  const int nq = 4 * (2 * a.n + 1);      // quarter-matrices per tile, consumed in storage order
-  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int total = my_tiles * nq;       // quarters this workgroup consumes
-  int consumed = 0, slot = 0;            // quarter count so far, ring slot of the next quarter
-  int q_stage = 0, slot_stage = 0;       // next quarter to stage (index within the tile sequence) and its slot
-  for (int d = 0; d < DIST && d < total; ++d) {
-    stage_quarter<FH_NT>(wg + (size_t)q_stage * QUARTER, Wb[slot_stage], tid);
-    q_stage = (q_stage + 1 == nq) ? 0 : q_stage + 1;
-    slot_stage = (slot_stage + 1 == RING) ? 0 : slot_stage + 1;
-  }
+  __shared__ const unsigned short* seg_ptr[1];
+  __shared__ int seg_n[1];
+  if (tid == 0) { seg_ptr[0] = wg; seg_n[0] = 4 * (2 * a.n + 1); }   // quarter-matrices per tile, consumed in storage order
   for (int i = tid; i < FH_VEC_SIZE; i += FH_NT) Vt[i] = vec[i];
-  __syncthreads();                       // Vt visible
-  // Returns the next quarter: waits until it has landed, releases the slot of the previous quarter and refills
-  // it with the quarter DIST ahead.  The LDS-DMA of a quarter is ordered for the ds_reads of OTHER waves only by
-  // the issuing wave's vmcnt wait followed by the barrier; hipcc adds no such wait on its own (it only drains
-  // lgkmcnt before s_barrier).  vmcnt counts every VMEM operation in issue order, so "all but the
-  // (DIST - 1) * GLDS_PER_STAGE most recent" always covers the quarter needed now.
-  auto take = [&]() -> const unsigned short* {
-    if (consumed + DIST <= total) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DIST - 1) * GLDS_PER_STAGE) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (consumed + DIST < total) {
-      stage_quarter<FH_NT>(wg + (size_t)q_stage * QUARTER, Wb[slot_stage], tid);
-      q_stage = (q_stage + 1 == nq) ? 0 : q_stage + 1;
-      slot_stage = (slot_stage + 1 == RING) ? 0 : slot_stage + 1;
-    }
-    const unsigned short* cur = Wb[slot];
-    slot = (slot + 1 == RING) ? 0 : slot + 1;
-    ++consumed;
-    return cur;
-  };
+  __syncthreads();
+  QuarterStream<FH_NT, RING> qs;
+  qs.init(seg_ptr, seg_n, 1, (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x, Wb, tid);
+  auto take = [&]() { return qs.take(); };
   const float inv2 = Vt[FH_HDR + 4], inv3 = Vt[FH_HDR + 5], fscale = Vt[FH_HDR + 6];
   const float* tail = Vt + FH_TAIL;
 
