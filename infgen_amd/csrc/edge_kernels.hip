@@ -21,6 +21,7 @@ constexpr float MOTION_GAP = 1.0f, HEADING_GAP = 1.0f, INVALID_MOTION = -2.0f, I
 //   outputs   AGG = sum_e a_e v_src (own columns), Z_h = sum_e a_e,h rhat_e (all heads), SIG_h = sum_e a_e,h
 // Rows without incoming edges produce exact zeros (0 / (0 + 1e-16)).
 // ------------------------------------------------------------------------------------------
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float readlane_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
@@ -91,19 +92,19 @@ __device__ __forceinline__ void edge_attn_wave(const EdgeAttnArgs& a, int row, i
       float p[H];
 #pragma unroll
       for (int h = 0; h < H; ++h) p[h] = fmaf(u[h].y, r2.y, u[h].x * r2.x);
+      // halving exchange over lane bits 5 and 4 with the gfx950 half / row swaps: after swapping the upper half of X
+      // with the lower half of Y, X + Y holds the X sum in the lower lanes and the Y sum in the upper ones
       float k4[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float send = b5 ? p[i] : p[4 + i];
-        const float keep = b5 ? p[4 + i] : p[i];
-        k4[i] = keep + __shfl_xor(send, 32, 64);
+        const u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[i]), __float_as_uint(p[4 + i]), false, false);
+        k4[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
       }
       float k2v[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const float send = b4 ? k4[i] : k4[2 + i];
-        const float keep = b4 ? k4[2 + i] : k4[i];
-        k2v[i] = keep + __shfl_xor(send, 16, 64);
+        const u32x2_t sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(k4[i]), __float_as_uint(k4[2 + i]), false, false);
+        k2v[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
       }
       {
         const float send = b3 ? k2v[0] : k2v[1];
@@ -131,11 +132,13 @@ __device__ __forceinline__ void edge_attn_wave(const EdgeAttnArgs& a, int row, i
     st.ag.x = fmaf(pe, v2.x, st.ag.x);
     st.ag.y = fmaf(pe, v2.y, st.ag.y);
     if (has_r) {
+      float ph[H];                     // all eight broadcasts first: their SGPR results are not needed back to back
+#pragma unroll
+      for (int h = 0; h < H; ++h) ph[h] = readlane_f(pe, 8 * h);
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        const float ph = readlane_f(pe, 8 * h);
-        st.z[h].x = fmaf(ph, r2.x, st.z[h].x);
-        st.z[h].y = fmaf(ph, r2.y, st.z[h].y);
+        st.z[h].x = fmaf(ph[h], r2.x, st.z[h].x);
+        st.z[h].y = fmaf(ph[h], r2.y, st.z[h].y);
       }
     }
   }
