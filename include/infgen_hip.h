@@ -206,6 +206,14 @@ int infgen_match_agent_tokens(const unsigned char* valid, const float* pos, cons
 int infgen_match_map_tokens(const float* traj_pos, const float* theta, const float* sample_pt, int P, int n_token,
                             int* token_idx, void* stream);
 
+/* ---- a rollout-metric feature on the device ----
+ * compute_distance_to_nearest_object (infgen/metrics/interact_features.py:19-95): every array [B][N][T] with the evaluated
+ * objects in the first n_eval rows of a scene (the order the reference builds, :48-50); work = B*N*T*9 floats of scratch;
+ * out [B][n_eval][T]: signed distance to the nearest other valid object (negative = overlap), 1e10 where there is none. */
+int infgen_distance_to_nearest_object(const float* cx, const float* cy, const float* length, const float* width,
+                                      const float* heading, const unsigned char* valid, int B, int N, int T, int n_eval,
+                                      float corner_rounding_factor, float* work, float* out, void* stream);
+
 /* ---- optional profiling (bench.py roofline leg; process-global, off by default) ----
  * HIP events are recorded on the launch stream around every launch of the kernels selected by
  * `mask` (bit = INFGEN_KID_*).  infgen_prof_collect synchronises the device, returns the summed

@@ -325,6 +325,19 @@ extern "C" int infgen_match_agent_tokens(const unsigned char* valid, const float
   return check_launch("infgen_match_agent_tokens");
 }
 
+extern "C" int infgen_distance_to_nearest_object(const float* cx, const float* cy, const float* length, const float* width,
+                                                const float* heading, const unsigned char* valid, int B, int N, int T,
+                                                int n_eval, float corner_rounding_factor, float* work, float* out,
+                                                void* stream) {
+  if (B <= 0 || N <= 0 || T <= 0 || n_eval <= 0) return 0;
+  if (n_eval > N) return fail("infgen_distance_to_nearest_object", "n_eval > N");
+  NearestArgs a{cx, cy, length, width, heading, valid, B, N, T, n_eval, corner_rounding_factor, work, out};
+  const long long nbox = (long long)B * N * T, nout = (long long)B * n_eval * T;
+  hipLaunchKernelGGL(k_box_corners, dim3((unsigned)((nbox + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_nearest_distance, dim3((unsigned)((nout + 127) / 128)), dim3(128), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_distance_to_nearest_object");
+}
+
 extern "C" int infgen_match_map_tokens(const float* traj_pos, const float* theta, const float* sample_pt, int P, int n_token,
                                       int* token_idx, void* stream) {
   if (P <= 0) return 0;

@@ -77,6 +77,16 @@ struct AttnHArgs {
   float* nQ; float* nU; float* nK; float* nV;
 };
 
+// metric_kernels.hip: compute_distance_to_nearest_object; all arrays [B][N][T], evaluated objects first
+struct NearestArgs {
+  const float* cx; const float* cy; const float* length; const float* width; const float* heading;
+  const unsigned char* valid;
+  int B, N, T, n_eval;
+  float rounding;                    // corner_rounding_factor (0.7)
+  float* work;                       // [B][N][T][9] scratch: shrunk corners + shrink radius
+  float* out;                        // [B][n_eval][T]
+};
+
 // k_mlpemb_h (mlp_h.hip): MLPEmbedding with K0 = 128 j on the fp16 split
 struct MlpEmbHArgs {
   const float* X; int ldx; int rows; int K0;
@@ -252,6 +262,8 @@ __global__ void k_fourier(FourierArgs a);
 __global__ void k_fourier_h(FourierArgs a);
 __global__ void k_match_tokens(MatchTokensArgs a);   // token_kernels.hip
 __global__ void k_mlpemb_h(MlpEmbHArgs a);           // mlp_h.hip
+__global__ void k_box_corners(NearestArgs a);        // metric_kernels.hip
+__global__ void k_nearest_distance(NearestArgs a);
 __global__ void k_heads_h(HeadsArgs a);
 __global__ void k_match_map_tokens(MatchMapArgs a);
 template <int WAVES> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident

@@ -1,0 +1,104 @@
+// Rollout-metric feature on the device: compute_distance_to_nearest_object
+// (reference infgen/metrics/interact_features.py:19-95 with box_utils.py:77-113 and geometry_utils.py:10-129):
+// signed distance of every evaluated object to the nearest other valid object at every step, boxes with rounded
+// corners (shrink by 0.7 * min(l, w) / 2, measure, subtract both shrink radii).  Distance between two convex boxes =
+// signed distance of the origin to the Minkowski sum of box 1 and the negated box 2 (8 vertices, merged by edge angle).
+//   k_box_corners        one thread per (object, step): shrunk corners (+l,+w) (-l,+w) (-l,-w) (+l,-w) rotated, + shrink
+//   k_nearest_distance   one thread per (evaluated object, step): loop over all objects of the scene
+// Objects are expected "evaluated first" (the reference concatenates them in that order, :48-50); the self pair is the
+// one with equal index.
+#include "kernels.h"
+
+namespace ig {
+
+constexpr float MT_BIG = 1e10f;
+
+__global__ __launch_bounds__(256) void k_box_corners(NearestArgs a) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)a.B * a.N * a.T) return;
+  const float l = a.length[i], w = a.width[i], h = a.heading[i];
+  const float sh = fminf(l, w) * a.rounding / 2.0f;
+  const float l2 = (l - 2.0f * sh) * 0.5f, w2 = (w - 2.0f * sh) * 0.5f;
+  const float c = cosf(h), s = sinf(h);
+  const float lx[4] = {l2, -l2, -l2, l2}, ly[4] = {w2, w2, -w2, -w2};
+  float* o = a.work + i * 9;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    o[2 * k] = (c * lx[k] - s * ly[k]) + a.cx[i];
+    o[2 * k + 1] = (s * lx[k] + c * ly[k]) + a.cy[i];
+  }
+  o[8] = sh;
+}
+
+struct Box { float x[4], y[4]; };
+
+__device__ __forceinline__ int downmost(const Box& b, float& dx, float& dy) {
+  int i0 = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k) if (b.y[k] < b.y[i0]) i0 = k;          // first minimum
+  const int i1 = (i0 + 1) & 3;
+  const float ex = b.x[i1] - b.x[i0], ey = b.y[i1] - b.y[i0];
+  const float len = sqrtf(ex * ex + ey * ey);
+  dx = ex / len; dy = ey / len;
+  return i0;
+}
+
+__device__ __forceinline__ float pair_distance(const Box& b1, const Box& b2n) {
+  float d1x, d1y, d2x, d2y;
+  const int s1 = downmost(b1, d1x, d1y), s2 = downmost(b2n, d2x, d2y);
+  const bool cond = (d1x * d2y - d1y * d2x) >= 0.0f;
+  float px[8], py[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int oa = k >> 1, ob = ((k + 1) >> 1) & 3;                   // orders [0,0,1,1,2,2,3,3] and [0,1,1,2,2,3,3,0]
+    const int i1 = ((cond ? ob : oa) + s1) & 3, i2 = ((cond ? oa : ob) + s2) & 3;
+    px[k] = b1.x[i1] + b2n.x[i2];
+    py[k] = b1.y[i1] + b2n.y[i2];
+  }
+  // signed distance of the origin to the convex polygon p[0..7]
+  float best = INFINITY;
+  bool inside = true;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int kn = (k + 1) & 7;
+    const float ex = px[kn] - px[k], ey = py[kn] - py[k];
+    const float len = sqrtf(ex * ex + ey * ey);
+    const float tx = ex / (len + 1.1920929e-07f), ty = ey / (len + 1.1920929e-07f);
+    const float vx = -px[k], vy = -py[k];
+    const float perp = (ty * vx) + (-tx * vy);                        // sum(-normal * v), normal = (-ty, tx)
+    inside = inside && (perp <= 0.0f);
+    const float prop = (tx * vx + ty * vy) / len;
+    if (prop >= 0.0f && prop <= 1.0f) best = fminf(best, fabsf(perp));
+    best = fminf(best, sqrtf(vx * vx + vy * vy));
+  }
+  return inside ? -best : best;
+}
+
+__global__ __launch_bounds__(128) void k_nearest_distance(NearestArgs a) {
+  const int idx = blockIdx.x * 128 + threadIdx.x;
+  if (idx >= a.B * a.n_eval * a.T) return;
+  const int t = idx % a.T, e = (idx / a.T) % a.n_eval, b = idx / (a.T * a.n_eval);
+  const size_t base = (size_t)b * a.N * a.T;
+  const size_t ie = base + (size_t)e * a.T + t;
+  float out = MT_BIG;
+  if (a.valid[ie]) {
+    Box b1;
+    const float* w1 = a.work + ie * 9;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { b1.x[k] = w1[2 * k]; b1.y[k] = w1[2 * k + 1]; }
+    const float sh1 = w1[8];
+    for (int j = 0; j < a.N; ++j) {
+      const size_t ij = base + (size_t)j * a.T + t;
+      if (j == e || !a.valid[ij]) continue;
+      const float* w2 = a.work + ij * 9;
+      Box b2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { b2.x[k] = -1.0f * w2[2 * k]; b2.y[k] = -1.0f * w2[2 * k + 1]; }
+      const float d = (pair_distance(b1, b2) - sh1) - w2[8];
+      out = fminf(out, d);
+    }
+  }
+  a.out[((size_t)b * a.n_eval + e) * a.T + t] = out;
+}
+
+}  // namespace ig

@@ -95,3 +95,16 @@ def test_map_token_match_oracle_reproduces_the_reference(case):
     idx = tm.match_token_map(torch.from_numpy(z['traj_pos']), torch.from_numpy(z['traj_theta']), sample_pt)
     assert np.array_equal(idx.numpy(), z['token_idx'])
     assert np.array_equal(z['position'][:, :2], z['traj_pos'][:, 0])
+
+
+@pytest.mark.parametrize('case', ['dist_n24_t30', 'dist_n5_t4'])
+def test_nearest_object_distance_oracle_reproduces_the_reference(case):
+    """oracle/metrics_oracle.py vs compute_distance_to_nearest_object run by tests/golden/make_golden_metrics.py: bit-identical"""
+    import os
+    import torch
+    from conftest import GOLDEN
+    from oracle import metrics_oracle as mo
+    z = np.load(os.path.join(GOLDEN, case + '.npz'))
+    t = {k: torch.from_numpy(z[k]) for k in ('cx', 'cy', 'length', 'width', 'heading', 'valid', 'eval_mask')}
+    d = mo.distance_to_nearest_object(t['cx'], t['cy'], t['length'], t['width'], t['heading'], t['valid'], t['eval_mask'])
+    assert np.array_equal(d.numpy(), z['distance'])
