@@ -214,6 +214,17 @@ int infgen_distance_to_nearest_object(const float* cx, const float* cy, const fl
                                       const float* heading, const unsigned char* valid, int B, int N, int T, int n_eval,
                                       float corner_rounding_factor, float* work, float* out, void* stream);
 
+/* compute_kinematic_features (infgen/metrics/trajectory_features.py:37-51): x, y, z (NULL = 0), heading [n][T] -> linear
+ * speed, linear acceleration, yaw rate, yaw acceleration [n][T] (NaN at both ends; accel / yaw outputs may be NULL) */
+int infgen_kinematic_features(const float* x, const float* y, const float* z, const float* heading, int n, int T,
+                              float seconds_per_step, float* speed, float* accel, float* yaw_rate, float* yaw_accel,
+                              void* stream);
+/* compute_time_to_collision_with_object_in_front (infgen/metrics/interact_features.py:96-219): arrays [B][N][T] in the
+ * original object order, speed from infgen_kinematic_features, eval_idx [n_eval] ascending -> out [B][n_eval][T] seconds */
+int infgen_time_to_collision(const float* cx, const float* cy, const float* length, const float* width, const float* heading,
+                             const float* speed, const unsigned char* valid, const int* eval_idx, int B, int N, int T,
+                             int n_eval, float* out, void* stream);
+
 /* ---- optional profiling (bench.py roofline leg; process-global, off by default) ----
  * HIP events are recorded on the launch stream around every launch of the kernels selected by
  * `mask` (bit = INFGEN_KID_*).  infgen_prof_collect synchronises the device, returns the summed

@@ -338,6 +338,27 @@ extern "C" int infgen_distance_to_nearest_object(const float* cx, const float* c
   return check_launch("infgen_distance_to_nearest_object");
 }
 
+extern "C" int infgen_kinematic_features(const float* x, const float* y, const float* z, const float* heading, int n, int T,
+                                        float seconds_per_step, float* speed, float* accel, float* yaw_rate,
+                                        float* yaw_accel, void* stream) {
+  if (n <= 0 || T <= 0) return 0;
+  if (!speed) return fail("infgen_kinematic_features", "speed output is required");
+  KinematicArgs a{x, y, z, heading, n, T, seconds_per_step, speed, accel, yaw_rate, yaw_accel};
+  const long long tot = (long long)n * T;
+  hipLaunchKernelGGL(k_kinematic, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_kinematic_features");
+}
+
+extern "C" int infgen_time_to_collision(const float* cx, const float* cy, const float* length, const float* width,
+                                       const float* heading, const float* speed, const unsigned char* valid,
+                                       const int* eval_idx, int B, int N, int T, int n_eval, float* out, void* stream) {
+  if (B <= 0 || N <= 0 || T <= 0 || n_eval <= 0) return 0;
+  TtcArgs a{cx, cy, length, width, heading, speed, valid, eval_idx, B, N, T, n_eval, out};
+  const long long tot = (long long)B * n_eval * T;
+  hipLaunchKernelGGL(k_ttc, dim3((unsigned)((tot + 127) / 128)), dim3(128), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_time_to_collision");
+}
+
 extern "C" int infgen_match_map_tokens(const float* traj_pos, const float* theta, const float* sample_pt, int P, int n_token,
                                       int* token_idx, void* stream) {
   if (P <= 0) return 0;

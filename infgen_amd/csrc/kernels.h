@@ -87,6 +87,19 @@ struct NearestArgs {
   float* out;                        // [B][n_eval][T]
 };
 
+struct KinematicArgs {               // compute_kinematic_features; x, y, z (may be null), heading: [n][T]
+  const float* x; const float* y; const float* z; const float* heading;
+  int n, T; float dt;
+  float* speed; float* accel; float* yaw_rate; float* yaw_accel;      // [n][T]; all but speed may be null
+};
+struct TtcArgs {                     // compute_time_to_collision_with_object_in_front; arrays [B][N][T] in ORIGINAL object order
+  const float* cx; const float* cy; const float* length; const float* width; const float* heading; const float* speed;
+  const unsigned char* valid;
+  const int* eval_idx;               // [n_eval] evaluated objects, ascending
+  int B, N, T, n_eval;
+  float* out;                        // [B][n_eval][T]
+};
+
 // k_mlpemb_h (mlp_h.hip): MLPEmbedding with K0 = 128 j on the fp16 split
 struct MlpEmbHArgs {
   const float* X; int ldx; int rows; int K0;
@@ -264,6 +277,8 @@ __global__ void k_match_tokens(MatchTokensArgs a);   // token_kernels.hip
 __global__ void k_mlpemb_h(MlpEmbHArgs a);           // mlp_h.hip
 __global__ void k_box_corners(NearestArgs a);        // metric_kernels.hip
 __global__ void k_nearest_distance(NearestArgs a);
+__global__ void k_kinematic(KinematicArgs a);
+__global__ void k_ttc(TtcArgs a);
 __global__ void k_heads_h(HeadsArgs a);
 __global__ void k_match_map_tokens(MatchMapArgs a);
 template <int WAVES> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident

@@ -101,4 +101,74 @@ __global__ __launch_bounds__(128) void k_nearest_distance(NearestArgs a) {
   a.out[((size_t)b * a.n_eval + e) * a.T + t] = out;
 }
 
+// ------------------------------------------------------------------------------------------
+// k_kinematic: compute_kinematic_features (reference infgen/metrics/trajectory_features.py:37-51): central differences
+// over steps, NaN at both ends; one thread per (object, step).  out: speed, accel, yaw rate, yaw accel, each [n][T].
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wrap_pm_pi(float a) {
+  const float two_pi = 6.283185307179586f, pi = 3.141592653589793f;
+  float m = fmodf(a + pi, two_pi);                 // python '%': result takes the sign of the divisor
+  if (m < 0.f) m += two_pi;
+  return m - pi;
+}
+__device__ __forceinline__ float speed_at(const KinematicArgs& a, size_t row, int t) {
+  if (t < 1 || t > a.T - 2) return NAN;
+  const float dx = (a.x[row + t + 1] - a.x[row + t - 1]) / 2.f, dy = (a.y[row + t + 1] - a.y[row + t - 1]) / 2.f;
+  const float dz = a.z ? (a.z[row + t + 1] - a.z[row + t - 1]) / 2.f : 0.f;
+  return sqrtf(dx * dx + dy * dy + dz * dz) / a.dt;
+}
+__device__ __forceinline__ float dh_step_at(const KinematicArgs& a, size_t row, int t) {
+  if (t < 1 || t > a.T - 2) return NAN;
+  return wrap_pm_pi((a.heading[row + t + 1] - a.heading[row + t - 1]) / 2.f * 2.f) / 2.f;
+}
+__global__ __launch_bounds__(256) void k_kinematic(KinematicArgs a) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)a.n * a.T) return;
+  const int t = (int)(i % a.T);
+  const size_t row = i - t;
+  const bool inner = t >= 1 && t <= a.T - 2;
+  a.speed[i] = speed_at(a, row, t);
+  if (a.accel) a.accel[i] = inner ? (speed_at(a, row, t + 1) - speed_at(a, row, t - 1)) / 2.f / a.dt : NAN;
+  if (a.yaw_rate) a.yaw_rate[i] = dh_step_at(a, row, t) / a.dt;
+  if (a.yaw_accel)
+    a.yaw_accel[i] = inner ? wrap_pm_pi((dh_step_at(a, row, t + 1) - dh_step_at(a, row, t - 1)) / 2.f * 2.f) / 2.f / (a.dt * a.dt) : NAN;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_ttc: compute_time_to_collision_with_object_in_front (reference infgen/metrics/interact_features.py:96-219): per
+// (evaluated object, step) the nearest valid object it follows (ahead, laterally overlapping its trail, aligned) and
+// distance / closing speed, capped at 5 s.  eval_idx lists the evaluated objects in their original order.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_ttc(TtcArgs a) {
+  const int idx = blockIdx.x * 128 + threadIdx.x;
+  if (idx >= a.B * a.n_eval * a.T) return;
+  const int t = idx % a.T, e = (idx / a.T) % a.n_eval, b = idx / (a.T * a.n_eval);
+  const size_t base = (size_t)b * a.N * a.T;
+  const size_t ie = base + (size_t)a.eval_idx[e] * a.T + t;
+  const float ex = a.cx[ie], ey = a.cy[ie], el = a.length[ie], ew = a.width[ie], eh = a.heading[ie], es = a.speed[ie];
+  const float ce = cosf(-eh), se = sinf(-eh);
+  const float max_diff = 1.3089969389957472f, max_diff_small = 0.17453292519943295f;     // 75 and 10 degrees
+  float best = INFINITY, best_speed = 0.f;
+  for (int j = 0; j < a.N; ++j) {
+    const size_t ij = base + (size_t)j * a.T + t;
+    if (!a.valid[ij]) continue;
+    const float yd = fabsf(a.heading[ij] - eh);
+    const float c = fabsf(cosf(yd)), s = fabsf(sinf(yd));
+    const float hl = a.length[ij] / 2.0f, hw = a.width[ij] / 2.0f;
+    const float long_off = hl * c + hw * s, lat_off = hl * s + hw * c;
+    const float dx = a.cx[ij] - ex, dy = a.cy[ij] - ey;
+    const float rx = ce * dx - se * dy, ry = se * dx + ce * dy;
+    const float long_d = rx - el / 2.0f - long_off;
+    const float lat_o = fabsf(ry) - ew / 2.0f - lat_off;
+    const bool follow = long_d > 0.0f && yd <= max_diff && lat_o < 0.0f && (lat_o < -0.5f || yd <= max_diff_small);
+    if (follow && long_d < best) { best = long_d; best_speed = a.speed[ij]; }      // first minimum
+  }
+  float ttc = 5.0f;
+  if (best < INFINITY) {
+    const float rel = es - best_speed;
+    if (rel > 0.0f) ttc = fminf(best / rel, 5.0f);
+  }
+  a.out[((size_t)b * a.n_eval + e) * a.T + t] = ttc;
+}
+
 }  // namespace ig

@@ -6,6 +6,8 @@ Pinned against a fixture produced by the reference's own function (tests/golden/
       Minkowski sum            infgen/metrics/geometry_utils.py:10-37, 69-83
       signed distance          infgen/metrics/geometry_utils.py:40-66, 94-129
 """
+import math
+
 import torch
 
 BIG = 1e10
@@ -76,3 +78,53 @@ def distance_to_nearest_object(cx, cy, length, width, heading, valid, eval_mask,
     ok = valid[order[:ne]][:, None, :] & valid[order][None, :, :]
     d = torch.where(ok, d, torch.tensor(BIG))
     return torch.min(d, dim=1).values
+
+
+def _central_diff(t, pad):
+    p = torch.full((*t.shape[:-1], 1), pad, dtype=t.dtype)
+    return torch.cat([p, (t[..., 2:] - t[..., :-2]) / 2, p], dim=-1)
+
+
+def _wrap(a):
+    return (a + math.pi) % (2 * math.pi) - math.pi
+
+
+@torch.no_grad()
+def kinematic_features(x, y, z, heading, seconds_per_step):
+    """infgen/metrics/trajectory_features.py:37-51 (central differences, NaN at both ends) ->
+    linear speed, linear acceleration, yaw rate, yaw acceleration, each (..., T)"""
+    dpos = _central_diff(torch.stack([x, y, z], dim=0), float('nan'))
+    speed = torch.norm(dpos, p=2, dim=0) / seconds_per_step
+    accel = _central_diff(speed, float('nan')) / seconds_per_step
+    dh_step = _wrap(_central_diff(heading, float('nan')) * 2) / 2
+    d2h_step = _wrap(_central_diff(dh_step, float('nan')) * 2) / 2
+    return speed, accel, dh_step / seconds_per_step, d2h_step / (seconds_per_step ** 2)
+
+
+@torch.no_grad()
+def time_to_collision(cx, cy, length, width, heading, valid, eval_mask, seconds_per_step):
+    """infgen/metrics/interact_features.py:96-219: for every evaluated object and step the closest valid object it is
+    "following" (ahead, laterally overlapping its trail, yaw within 75 deg - 10 deg if the overlap is below 0.5 m) and
+    distance / closing speed, capped at 5 s.  (N, T) inputs -> (n_eval, T)"""
+    speed = kinematic_features(cx, cy, torch.zeros_like(cx), heading, seconds_per_step)[0]
+    P = lambda a: a.permute(1, 0)                                  # (T, N)
+    ex, ey, el, ew, eh, es = (P(a)[:, eval_mask] for a in (cx, cy, length, width, heading, speed))
+    ox, oy, ol, ow, oh = (P(a) for a in (cx, cy, length, width, heading))
+    yd = torch.abs(oh[:, None, :] - eh[:, :, None])                # (T, E, N)
+    c, s = torch.cos(yd).abs(), torch.sin(yd).abs()
+    long_off = ol[:, None] / 2.0 * c + ow[:, None] / 2.0 * s
+    lat_off = ol[:, None] / 2.0 * s + ow[:, None] / 2.0 * c
+    dx, dy = ox[:, None] - ex[:, :, None], oy[:, None] - ey[:, :, None]
+    ce, se = torch.cos(-eh)[:, :, None], torch.sin(-eh)[:, :, None]
+    rx, ry = ce * dx - se * dy, se * dx + ce * dy
+    long_d = rx - el[:, :, None] / 2.0 - long_off
+    lat_o = ry.abs() - ew[:, :, None] / 2.0 - lat_off
+    follow = (long_d > 0.0) & (yd <= math.radians(75.0)) & (lat_o < 0.0) & ((lat_o < -0.5) | (yd <= math.radians(10.0)))
+    ok = P(valid)[:, None] & follow
+    masked = long_d + (1.0 - ok.float()) * BIG
+    idx = masked.argmin(dim=-1)
+    dist = torch.gather(masked, -1, idx[..., None])[..., 0]
+    ahead_speed = torch.gather(P(speed)[:, None, :].expand_as(masked), -1, idx[..., None])[..., 0]
+    rel = es - ahead_speed
+    ttc = torch.where(rel > 0.0, torch.minimum(dist / rel, torch.tensor(5.0)), torch.tensor(5.0))
+    return ttc.T

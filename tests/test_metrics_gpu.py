@@ -10,7 +10,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('case', ['dist_n24_t30', 'dist_n5_t4'])
+@pytest.mark.parametrize('case', ['dist_n24_t30', 'dist_n5_t4', 'ttc_platoon_n20_t30'])
 def test_distance_to_nearest_object_golden(case):
     from infgen_amd.metrics import compute_distance_to_nearest_object
     dev = torch.device('cuda:0')
@@ -50,3 +50,21 @@ def test_distance_to_nearest_object_batched_vs_oracle():
         fin = ref < 1e9
         assert np.array_equal(d[b] > 1e9, ~fin)
         assert np.abs(d[b][fin] - ref[fin]).max() <= 5e-5
+
+
+@pytest.mark.parametrize('case', ['dist_n24_t30', 'dist_n5_t4', 'ttc_platoon_n20_t30'])
+def test_kinematics_and_time_to_collision_golden(case):
+    from infgen_amd.metrics import compute_kinematic_features, compute_time_to_collision_with_object_in_front
+    dev = torch.device('cuda:0')
+    z = np.load(os.path.join(GOLDEN, case + '.npz'))
+    t = {k: torch.from_numpy(z[k]).to(dev) for k in ('cx', 'cy', 'length', 'width', 'heading', 'valid', 'eval_mask')}
+    kin = compute_kinematic_features(t['cx'], t['cy'], torch.zeros_like(t['cx']), t['heading'], 0.1)
+    for a, n, tol in zip(kin, ('speed', 'accel', 'yaw_rate', 'yaw_accel'), (1e-4, 2e-3, 1e-5, 2e-4)):
+        a = a.cpu().numpy()
+        assert np.array_equal(np.isnan(a), np.isnan(z[n]))
+        assert np.nanmax(np.abs(a - z[n]), initial=0.0) <= tol, n          # differences of fp32 positions / 0.1 s (/ 0.01 s^2)
+    ttc = compute_time_to_collision_with_object_in_front(center_x=t['cx'], center_y=t['cy'], length=t['length'], width=t['width'],
+                                                         heading=t['heading'], valid=t['valid'],
+                                                         evaluated_object_mask=t['eval_mask'], seconds_per_step=0.1).cpu().numpy()
+    assert np.array_equal(ttc < 5.0, z['ttc'] < 5.0)
+    assert np.abs(ttc - z['ttc']).max() <= 1e-3

@@ -97,7 +97,7 @@ def test_map_token_match_oracle_reproduces_the_reference(case):
     assert np.array_equal(z['position'][:, :2], z['traj_pos'][:, 0])
 
 
-@pytest.mark.parametrize('case', ['dist_n24_t30', 'dist_n5_t4'])
+@pytest.mark.parametrize('case', ['dist_n24_t30', 'dist_n5_t4', 'ttc_platoon_n20_t30'])
 def test_nearest_object_distance_oracle_reproduces_the_reference(case):
     """oracle/metrics_oracle.py vs compute_distance_to_nearest_object run by tests/golden/make_golden_metrics.py: bit-identical"""
     import os
@@ -108,3 +108,8 @@ def test_nearest_object_distance_oracle_reproduces_the_reference(case):
     t = {k: torch.from_numpy(z[k]) for k in ('cx', 'cy', 'length', 'width', 'heading', 'valid', 'eval_mask')}
     d = mo.distance_to_nearest_object(t['cx'], t['cy'], t['length'], t['width'], t['heading'], t['valid'], t['eval_mask'])
     assert np.array_equal(d.numpy(), z['distance'])
+    ttc = mo.time_to_collision(t['cx'], t['cy'], t['length'], t['width'], t['heading'], t['valid'], t['eval_mask'], 0.1)
+    assert np.array_equal(ttc.numpy(), z['ttc'])
+    kin = mo.kinematic_features(t['cx'], t['cy'], torch.zeros_like(t['cx']), t['heading'], 0.1)
+    for a, n in zip(kin, ('speed', 'accel', 'yaw_rate', 'yaw_accel')):
+        assert np.array_equal(a.numpy(), z[n], equal_nan=True)
