@@ -225,6 +225,12 @@ int infgen_time_to_collision(const float* cx, const float* cy, const float* leng
                              const float* speed, const unsigned char* valid, const int* eval_idx, int B, int N, int T,
                              int n_eval, float* out, void* stream);
 
+/* compute_num_placement + compute_distance_placement (infgen/metrics/placement_features.py:6-48): x, y, z (NULL = 0) and
+ * state [B][N][T], av_index [B] (row of the ego, excluded) -> num_bos / num_eos [B][T], bos / eos distance [B][N][T] */
+int infgen_placement_features(const float* x, const float* y, const float* z, const int* state, const int* av_index,
+                              int B, int N, int T, int enter_state, int exit_state, int* num_bos, int* num_eos,
+                              float* bos_distance, float* eos_distance, void* stream);
+
 /* ---- optional profiling (bench.py roofline leg; process-global, off by default) ----
  * HIP events are recorded on the launch stream around every launch of the kernels selected by
  * `mask` (bit = INFGEN_KID_*).  infgen_prof_collect synchronises the device, returns the summed

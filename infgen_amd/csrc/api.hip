@@ -359,6 +359,15 @@ extern "C" int infgen_time_to_collision(const float* cx, const float* cy, const 
   return check_launch("infgen_time_to_collision");
 }
 
+extern "C" int infgen_placement_features(const float* x, const float* y, const float* z, const int* state, const int* av_index,
+                                        int B, int N, int T, int enter_state, int exit_state, int* num_bos, int* num_eos,
+                                        float* bos_distance, float* eos_distance, void* stream) {
+  if (B <= 0 || N <= 0 || T <= 0) return 0;
+  PlacementArgs a{x, y, z, state, av_index, B, N, T, enter_state, exit_state, num_bos, num_eos, bos_distance, eos_distance};
+  hipLaunchKernelGGL(k_placement, dim3(B * T), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_placement_features");
+}
+
 extern "C" int infgen_match_map_tokens(const float* traj_pos, const float* theta, const float* sample_pt, int P, int n_token,
                                       int* token_idx, void* stream) {
   if (P <= 0) return 0;

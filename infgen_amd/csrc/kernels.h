@@ -100,6 +100,14 @@ struct TtcArgs {                     // compute_time_to_collision_with_object_in
   float* out;                        // [B][n_eval][T]
 };
 
+struct PlacementArgs {               // placement_features; arrays [B][N][T]
+  const float* x; const float* y; const float* z;      // z may be null
+  const int* state; const int* av_index;               // [B][N][T], [B]
+  int B, N, T, enter_state, exit_state;
+  int* num_bos; int* num_eos;                          // [B][T]
+  float* bos_distance; float* eos_distance;            // [B][N][T]
+};
+
 // k_mlpemb_h (mlp_h.hip): MLPEmbedding with K0 = 128 j on the fp16 split
 struct MlpEmbHArgs {
   const float* X; int ldx; int rows; int K0;
@@ -279,6 +287,7 @@ __global__ void k_box_corners(NearestArgs a);        // metric_kernels.hip
 __global__ void k_nearest_distance(NearestArgs a);
 __global__ void k_kinematic(KinematicArgs a);
 __global__ void k_ttc(TtcArgs a);
+__global__ void k_placement(PlacementArgs a);
 __global__ void k_heads_h(HeadsArgs a);
 __global__ void k_match_map_tokens(MatchMapArgs a);
 template <int WAVES> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident

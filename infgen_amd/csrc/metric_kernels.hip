@@ -171,4 +171,40 @@ __global__ __launch_bounds__(128) void k_ttc(TtcArgs a) {
   a.out[((size_t)b * a.n_eval + e) * a.T + t] = ttc;
 }
 
+// ------------------------------------------------------------------------------------------
+// k_placement: compute_num_placement + compute_distance_placement (reference infgen/metrics/placement_features.py:6-48):
+// per step the number of agents entering / leaving (ego excluded) and per agent its distance to the ego where it does.
+// One workgroup per (scene, step): threads over agents, counts reduced with wave ballots.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_placement(PlacementArgs a) {
+  __shared__ int s_b[4], s_e[4];
+  const int t = blockIdx.x % a.T, b = blockIdx.x / a.T;
+  const size_t base = (size_t)b * a.N * a.T;
+  const int av = a.av_index[b];
+  const size_t iav = base + (size_t)av * a.T + t;
+  const float ax = a.x[iav], ay = a.y[iav], az = a.z ? a.z[iav] : 0.f;
+  int nb = 0, ne = 0;
+  for (int n0 = 0; n0 < a.N; n0 += 256) {
+    const int n = n0 + threadIdx.x;
+    bool bos = false, eos = false;
+    if (n < a.N) {
+      const size_t i = base + (size_t)n * a.T + t;
+      const int st = (n == av) ? -1 : a.state[i];
+      bos = st == a.enter_state; eos = st == a.exit_state;
+      const float dx = a.x[i] - ax, dy = a.y[i] - ay, dz = a.z ? a.z[i] - az : 0.f;
+      const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+      a.bos_distance[i] = bos ? d : 0.f * d;                 // the reference multiplies by the mask (NaN stays NaN)
+      a.eos_distance[i] = eos ? d : 0.f * d;
+    }
+    nb += __popcll(__ballot(bos));
+    ne += __popcll(__ballot(eos));
+  }
+  if ((threadIdx.x & 63) == 0) { s_b[threadIdx.x >> 6] = nb; s_e[threadIdx.x >> 6] = ne; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.num_bos[(size_t)b * a.T + t] = s_b[0] + s_b[1] + s_b[2] + s_b[3];
+    a.num_eos[(size_t)b * a.T + t] = s_e[0] + s_e[1] + s_e[2] + s_e[3];
+  }
+}
+
 }  // namespace ig

@@ -128,3 +128,15 @@ def time_to_collision(cx, cy, length, width, heading, valid, eval_mask, seconds_
     rel = es - ahead_speed
     ttc = torch.where(rel > 0.0, torch.minimum(dist / rel, torch.tensor(5.0)), torch.tensor(5.0))
     return ttc.T
+
+
+@torch.no_grad()
+def placement_features(position, state, av_index, enter_state=2, exit_state=3):
+    """infgen/metrics/placement_features.py:6-48 (compute_num_placement + compute_distance_placement; the ego row is
+    excluded by setting its state to -1 as there).  position (N, T, 2|3), state (N, T) ->
+    num_bos (T,), num_eos (T,), bos_distance (N, T), eos_distance (N, T)"""
+    st = state.clone()
+    st[av_index] = -1
+    is_bos, is_eos = st == enter_state, st == exit_state
+    dist = torch.norm(position - position[av_index:av_index + 1], p=2, dim=-1)
+    return torch.sum(is_bos, dim=0), torch.sum(is_eos, dim=0), dist * is_bos, dist * is_eos

@@ -19,6 +19,7 @@ sys.path.insert(0, '/root/reference')
 from infgen.metrics.interact_features import (compute_distance_to_nearest_object,  # noqa: E402
                                                compute_time_to_collision_with_object_in_front)
 from infgen.metrics.trajectory_features import compute_kinematic_features  # noqa: E402
+from infgen.metrics.placement_features import compute_num_placement, compute_distance_placement  # noqa: E402
 
 
 def make_boxes(seed, N, T, extent):
@@ -76,6 +77,14 @@ def main():
                 center_x=tt['cx'], center_y=tt['cy'], length=tt['length'], width=tt['width'], heading=tt['heading'],
                 valid=tt['valid'], evaluated_object_mask=tt['eval_mask'], seconds_per_step=0.1)
             kin = compute_kinematic_features(tt['cx'], tt['cy'], z, tt['heading'], 0.1)
+            rs = np.random.default_rng(seed + 1)
+            state = torch.from_numpy(rs.choice([0, 1, 1, 1, 2, 3], size=tt['cx'].shape).astype(np.int64))
+            pos3 = torch.stack([tt['cx'], tt['cy'], z], -1)
+            oid = torch.arange(100, 100 + N)
+            names = ['invalid', 'valid', 'enter', 'exit']
+            nb, ne = compute_num_placement(tt['valid'], state.clone(), 100 + N - 1, oid, names)
+            db, de = compute_distance_placement(pos3, state.clone(), tt['valid'], 100 + N - 1, oid, names)
+        b = dict(b, state=state.numpy(), num_bos=nb.numpy(), num_eos=ne.numpy(), bos_distance=db.numpy(), eos_distance=de.numpy())
         np.savez_compressed(os.path.join(HERE, case + '.npz'), seed=seed, distance=out.numpy(), ttc=ttc.numpy(),
                             speed=kin[0].numpy(), accel=kin[1].numpy(), yaw_rate=kin[2].numpy(), yaw_accel=kin[3].numpy(), **b)
         print('   ttc < 5 s cells', int((ttc.numpy() < 5).sum()))

@@ -68,3 +68,21 @@ def test_kinematics_and_time_to_collision_golden(case):
                                                          evaluated_object_mask=t['eval_mask'], seconds_per_step=0.1).cpu().numpy()
     assert np.array_equal(ttc < 5.0, z['ttc'] < 5.0)
     assert np.abs(ttc - z['ttc']).max() <= 1e-3
+
+
+@pytest.mark.parametrize('case', ['dist_n24_t30', 'dist_n5_t4', 'ttc_platoon_n20_t30'])
+def test_placement_features_golden(case):
+    from infgen_amd.metrics import compute_num_placement, compute_distance_placement
+    dev = torch.device('cuda:0')
+    z = np.load(os.path.join(GOLDEN, case + '.npz'))
+    N = z['cx'].shape[0]
+    pos = torch.stack([torch.from_numpy(z['cx']), torch.from_numpy(z['cy']), torch.zeros(z['cx'].shape)], -1).to(dev)
+    state = torch.from_numpy(z['state']).to(dev)
+    oid = torch.arange(100, 100 + N)
+    names = ['invalid', 'valid', 'enter', 'exit']
+    nb, ne = compute_num_placement(torch.from_numpy(z['valid']).to(dev), state, 100 + N - 1, oid, names)
+    db, de = compute_distance_placement(pos, state, torch.from_numpy(z['valid']).to(dev), 100 + N - 1, oid, names)
+    assert np.array_equal(nb.cpu().numpy(), z['num_bos']) and np.array_equal(ne.cpu().numpy(), z['num_eos'])
+    assert np.abs(db.cpu().numpy() - z['bos_distance']).max() <= 1e-4
+    assert np.abs(de.cpu().numpy() - z['eos_distance']).max() <= 1e-4
+    assert np.array_equal(db.cpu().numpy() > 0, z['bos_distance'] > 0)

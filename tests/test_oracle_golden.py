@@ -113,3 +113,7 @@ def test_nearest_object_distance_oracle_reproduces_the_reference(case):
     kin = mo.kinematic_features(t['cx'], t['cy'], torch.zeros_like(t['cx']), t['heading'], 0.1)
     for a, n in zip(kin, ('speed', 'accel', 'yaw_rate', 'yaw_accel')):
         assert np.array_equal(a.numpy(), z[n], equal_nan=True)
+    pos = torch.stack([t['cx'], t['cy'], torch.zeros_like(t['cx'])], -1)
+    pl = mo.placement_features(pos, torch.from_numpy(z['state']), z['cx'].shape[0] - 1)
+    for a, n in zip(pl, ('num_bos', 'num_eos', 'bos_distance', 'eos_distance')):
+        assert np.array_equal(a.numpy(), z[n])
