@@ -225,6 +225,15 @@ int infgen_time_to_collision(const float* cx, const float* cy, const float* leng
                              const float* speed, const unsigned char* valid, const int* eval_idx, int B, int N, int T,
                              int n_eval, float* out, void* stream);
 
+/* compute_distance_to_road_edge (infgen/metrics/map_features.py:27-79; signed distance :139-349, z stretch 3): boxes
+ * [B][N][T] (cz / height may be NULL = 0), eval_idx [B][n_eval] rows of the evaluated objects, road edges of all scenes
+ * as padded polylines [P][L][4] = x, y, z, valid with cyclic [P] (:82-136) and poly_off [B+1] = polyline range per scene
+ * -> out [B][n_eval][T], -1e10 where the box is invalid; > 0 = off road */
+int infgen_distance_to_road_edge(const float* cx, const float* cy, const float* cz, const float* length, const float* width,
+                                 const float* height, const float* heading, const unsigned char* valid, const int* eval_idx,
+                                 int B, int N, int T, int n_eval, const float* polylines, const unsigned char* cyclic,
+                                 const int* poly_off, int L, float z_stretch, float* out, void* stream);
+
 /* compute_num_placement + compute_distance_placement (infgen/metrics/placement_features.py:6-48): x, y, z (NULL = 0) and
  * state [B][N][T], av_index [B] (row of the ego, excluded) -> num_bos / num_eos [B][T], bos / eos distance [B][N][T] */
 int infgen_placement_features(const float* x, const float* y, const float* z, const int* state, const int* av_index,

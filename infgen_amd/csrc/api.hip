@@ -359,6 +359,20 @@ extern "C" int infgen_time_to_collision(const float* cx, const float* cy, const 
   return check_launch("infgen_time_to_collision");
 }
 
+extern "C" int infgen_distance_to_road_edge(const float* cx, const float* cy, const float* cz, const float* length,
+                                          const float* width, const float* height, const float* heading,
+                                          const unsigned char* valid, const int* eval_idx, int B, int N, int T, int n_eval,
+                                          const float* polylines, const unsigned char* cyclic, const int* poly_off, int L,
+                                          float z_stretch, float* out, void* stream) {
+  if (B <= 0 || N <= 0 || T <= 0 || n_eval <= 0) return 0;
+  if (L < 2) return fail("infgen_distance_to_road_edge", "polylines need at least two points");
+  RoadEdgeArgs a{cx, cy, cz, length, width, height, heading, valid, eval_idx, polylines, cyclic, poly_off,
+                 B, N, T, n_eval, L, z_stretch, out};
+  const long long boxes = (long long)B * n_eval * T;
+  hipLaunchKernelGGL(k_road_edge, dim3((unsigned)((boxes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_distance_to_road_edge");
+}
+
 extern "C" int infgen_placement_features(const float* x, const float* y, const float* z, const int* state, const int* av_index,
                                         int B, int N, int T, int enter_state, int exit_state, int* num_bos, int* num_eos,
                                         float* bos_distance, float* eos_distance, void* stream) {

@@ -100,6 +100,14 @@ struct TtcArgs {                     // compute_time_to_collision_with_object_in
   float* out;                        // [B][n_eval][T]
 };
 
+struct RoadEdgeArgs {                // compute_distance_to_road_edge; boxes [B][N][T]
+  const float* cx; const float* cy; const float* cz; const float* length; const float* width; const float* height;
+  const float* heading; const unsigned char* valid; const int* eval_idx;     // eval_idx [B][n_eval]
+  const float* poly; const unsigned char* cyclic; const int* poly_off;       // [P][L][4], [P], [B+1]
+  int B, N, T, n_eval, L; float z_stretch;
+  float* out;                                                                // [B][n_eval][T]
+};
+
 struct PlacementArgs {               // placement_features; arrays [B][N][T]
   const float* x; const float* y; const float* z;      // z may be null
   const int* state; const int* av_index;               // [B][N][T], [B]
@@ -288,6 +296,7 @@ __global__ void k_nearest_distance(NearestArgs a);
 __global__ void k_kinematic(KinematicArgs a);
 __global__ void k_ttc(TtcArgs a);
 __global__ void k_placement(PlacementArgs a);
+__global__ void k_road_edge(RoadEdgeArgs a);
 __global__ void k_heads_h(HeadsArgs a);
 __global__ void k_match_map_tokens(MatchMapArgs a);
 template <int WAVES> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident

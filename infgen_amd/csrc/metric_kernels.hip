@@ -207,4 +207,96 @@ __global__ __launch_bounds__(256) void k_placement(PlacementArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_road_edge: compute_distance_to_road_edge (reference infgen/metrics/map_features.py:27-79, :139-349): per evaluated box
+// and step the largest signed distance of its four bottom corners to the road edges; each corner takes the segment that
+// is nearest in the z-stretched 3-D metric (first minimum over the flattened padded segment list) and signs the planar
+// distance by the side of that segment, corrected at the ends by the neighbouring segment and the local convexity.
+// One wave per box: lanes stride over the segments of the scene, wave arg-min, lanes 0..3 finish one corner each.
+// ------------------------------------------------------------------------------------------
+struct SegEval { float t, side, d2, d3; bool ok; float dx, dy; };
+
+__device__ __forceinline__ SegEval seg_eval(const float4* __restrict__ poly, int p, int j, int L, float qx, float qy, float qz,
+                                            float zs) {
+  const float4 A = poly[(size_t)p * L + j], B = poly[(size_t)p * L + j + 1];
+  SegEval r;
+  r.ok = A.w != 0.f && B.w != 0.f;
+  const float dx = B.x - A.x, dy = B.y - A.y, dz = B.z - A.z;
+  const float wx = qx - A.x, wy = qy - A.y, wz = qz - A.z;
+  const float den = dx * dx + dy * dy, num = wx * dx + wy * dy;
+  r.t = den != 0.f ? num / den : 0.f;
+  const float cr = wx * dy - wy * dx;
+  r.side = (float)((cr > 0.f) - (cr < 0.f));
+  const float tc = fminf(fmaxf(r.t, 0.f), 1.f);
+  const float fx = wx - dx * tc, fy = wy - dy * tc, fz = (wz - dz * tc) * zs;
+  const float pl = fx * fx + fy * fy;
+  r.d2 = r.ok ? sqrtf(pl) : 1e10f;
+  r.d3 = r.ok ? sqrtf(pl + fz * fz) : 1e10f;
+  r.dx = dx; r.dy = dy;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_road_edge(RoadEdgeArgs a) {
+  const int box = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (box >= a.B * a.n_eval * a.T) return;
+  const int t = box % a.T, e = (box / a.T) % a.n_eval, b = box / (a.T * a.n_eval);
+  const size_t i = ((size_t)b * a.N + a.eval_idx[b * a.n_eval + e]) * a.T + t;
+  if (!a.valid[i]) { if (lane == 0) a.out[box] = -1e10f; return; }
+  const float c = cosf(a.heading[i]), s = sinf(a.heading[i]);
+  const float hl = 0.5f * a.length[i], hw = 0.5f * a.width[i];
+  const float qz = (a.cz ? a.cz[i] : 0.f) - 0.5f * (a.height ? a.height[i] : 0.f);
+  float qx[4], qy[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {                               // (+l,+w) (-l,+w) (-l,-w) (+l,-w)
+    const float sl = (k == 0 || k == 3) ? hl : -hl, sw = (k < 2) ? hw : -hw;
+    qx[k] = a.cx[i] + (c * sl - s * sw);
+    qy[k] = a.cy[i] + (s * sl + c * sw);
+  }
+  const float4* poly = reinterpret_cast<const float4*>(a.poly);
+  const int p0 = a.poly_off[b], S = a.L - 1, nseg = (a.poly_off[b + 1] - p0) * S;
+  float best[4]; int bi[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { best[k] = INFINITY; bi[k] = 0x7fffffff; }
+  for (int k = lane; k < nseg; k += 64) {
+    const int p = p0 + k / S, j = k % S;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const SegEval r = seg_eval(poly, p, j, a.L, qx[q], qy[q], qz, a.z_stretch);
+      if (r.d3 < best[q]) { best[q] = r.d3; bi[q] = k; }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+      const float ob = __shfl_xor(best[q], off);
+      const int oi = __shfl_xor(bi[q], off);
+      if (ob < best[q] || (ob == best[q] && oi < bi[q])) { best[q] = ob; bi[q] = oi; }
+    }
+  float res = -INFINITY;
+  if (lane < 4 && nseg > 0) {
+    const int q = lane;
+    const float x = q == 0 ? qx[0] : q == 1 ? qx[1] : q == 2 ? qx[2] : qx[3];
+    const float y = q == 0 ? qy[0] : q == 1 ? qy[1] : q == 2 ? qy[2] : qy[3];
+    const int k = q == 0 ? bi[0] : q == 1 ? bi[1] : q == 2 ? bi[2] : bi[3];
+    const int p = p0 + k / S, j = k % S;
+    const bool cyc = a.cyclic[p] != 0;
+    const int jw_prev = (j + S - 1) % S, jw_next = (j + 1) % S;               // convexity always wraps (padded list)
+    const int jp = j > 0 ? j - 1 : (cyc ? S - 1 : 0), jn = j < S - 1 ? j + 1 : (cyc ? 0 : S - 1);
+    const SegEval r = seg_eval(poly, p, j, a.L, x, y, qz, a.z_stretch);
+    const SegEval rp = seg_eval(poly, p, jp, a.L, x, y, qz, a.z_stretch);
+    const SegEval rn = seg_eval(poly, p, jn, a.L, x, y, qz, a.z_stretch);
+    const SegEval wp = seg_eval(poly, p, jw_prev, a.L, x, y, qz, a.z_stretch);
+    const SegEval wn = seg_eval(poly, p, jw_next, a.L, x, y, qz, a.z_stretch);
+    const bool convex_in = wp.dx * r.dy - wp.dy * r.dx > 0.f, convex_out = r.dx * wn.dy - r.dy * wn.dx > 0.f;
+    float sg = r.side;
+    if (r.t < 0.f && rp.ok) sg = convex_in ? fmaxf(r.side, rp.side) : fminf(r.side, rp.side);
+    else if (r.t > 1.f && rn.ok) sg = convex_out ? fmaxf(r.side, rn.side) : fminf(r.side, rn.side);
+    res = sg * r.d2;
+  }
+  res = fmaxf(res, __shfl_xor(res, 1));
+  res = fmaxf(res, __shfl_xor(res, 2));
+  if (lane == 0) a.out[box] = res;
+}
+
 }  // namespace ig

@@ -1,7 +1,9 @@
 """Device-side rollout-metric features - mirrors of infgen/metrics/*_features.py."""
 from .interact_features import compute_distance_to_nearest_object, compute_time_to_collision_with_object_in_front
 from .trajectory_features import compute_kinematic_features
+from .map_features import compute_distance_to_road_edge, tensorize_polylines
 from .placement_features import compute_num_placement, compute_distance_placement
 
 __all__ = ['compute_distance_to_nearest_object', 'compute_time_to_collision_with_object_in_front',
-           'compute_kinematic_features', 'compute_num_placement', 'compute_distance_placement']
+           'compute_kinematic_features', 'compute_num_placement', 'compute_distance_placement',
+           'compute_distance_to_road_edge', 'tensorize_polylines']

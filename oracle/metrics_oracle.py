@@ -140,3 +140,73 @@ def placement_features(position, state, av_index, enter_state=2, exit_state=3):
     is_bos, is_eos = st == enter_state, st == exit_state
     dist = torch.norm(position - position[av_index:av_index + 1], p=2, dim=-1)
     return torch.sum(is_bos, dim=0), torch.sum(is_eos, dim=0), dist * is_bos, dist * is_eos
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# compute_distance_to_road_edge (reference infgen/metrics/map_features.py:27-79 with :82-136 tensorisation and
+# :139-349 signed distance to polylines)
+# ---------------------------------------------------------------------------------------------------------------
+def tensorize_polylines(polylines):
+    """list of (n_i, 3) arrays -> padded (P, L, 4) float32 [x, y, z, valid] and cyclic (P,) bool; polylines with fewer
+    than two points are dropped (map_features.py:82-136; cyclic = squared end gap below 1 m^2)."""
+    keep = [torch.as_tensor(p, dtype=torch.float32).reshape(-1, 3) for p in polylines if len(p) >= 2]
+    L = max(p.shape[0] for p in keep)
+    out = torch.zeros(len(keep), L, 4)
+    for i, p in enumerate(keep):
+        out[i, :p.shape[0], :3] = p
+        out[i, :p.shape[0], 3] = 1.0
+    cyc = torch.stack([((p[0] - p[-1]) ** 2).sum() < 1.0 for p in keep])
+    return out, cyc
+
+
+def signed_distance_to_polylines(pts, poly, cyclic, z_stretch=3.0):
+    """pts (Q, 3), poly (P, L, 4), cyclic (P,) -> (Q,) signed planar distance to the segment that is nearest in the
+    z-stretched 3-D metric (first minimum); negative = port side (map_features.py:139-349).  Neighbour lookups wrap for
+    cyclic polylines over the PADDED segment list, like the reference."""
+    P, L, _ = poly.shape
+    S = L - 1
+    ok_pt = poly[..., 3] != 0
+    ok = ok_pt[:, :-1] & ok_pt[:, 1:]                                   # (P, S)
+    a, b = poly[:, :-1, :3], poly[:, 1:, :3]
+    d = (b - a)[None]                                                   # (1, P, S, 3)
+    w = pts[:, None, None, :] - a[None]                                 # (Q, P, S, 3)
+    num = w[..., 0] * d[..., 0] + w[..., 1] * d[..., 1]
+    den = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]
+    t = torch.where(den != 0, num / den, torch.zeros_like(num))
+    side = torch.sign(w[..., 0] * d[..., 1] - w[..., 1] * d[..., 0])
+    foot = w - d * t.clamp(0.0, 1.0)[..., None]
+    d3 = torch.sqrt(foot[..., 0] ** 2 + foot[..., 1] ** 2 + (foot[..., 2] * z_stretch) ** 2)
+    d2 = torch.sqrt(foot[..., 0] ** 2 + foot[..., 1] ** 2)
+    dxy = d[0, :, :, :2]                                                # (P, S, 2)
+    prev_d = torch.roll(dxy, 1, dims=1)                                 # d[i-1], wrapping (also for open polylines)
+    turn_in = (prev_d[..., 0] * dxy[..., 1] - prev_d[..., 1] * dxy[..., 0]) > 0      # convex at the start vertex of i
+    turn_out = torch.roll(turn_in, -1, dims=1)                                     # convex at its end vertex
+    idx = torch.arange(S)
+    cyc = cyclic[:, None]
+    i_prev = torch.where(cyc, (idx - 1) % S, (idx - 1).clamp(min=0))    # (P, S)
+    i_next = torch.where(cyc, (idx + 1) % S, (idx + 1).clamp(max=S - 1))
+    side_prev = torch.gather(side, 2, i_prev[None].expand_as(side))
+    side_next = torch.gather(side, 2, i_next[None].expand_as(side))
+    ok_prev = torch.gather(ok, 1, i_prev)
+    ok_next = torch.gather(ok, 1, i_next)
+    before = torch.where(turn_in[None], torch.maximum(side, side_prev), torch.minimum(side, side_prev))
+    after = torch.where(turn_out[None], torch.maximum(side, side_next), torch.minimum(side, side_next))
+    sgn = torch.where((t < 0) & ok_prev[None], before, torch.where((t > 1) & ok_next[None], after, side))
+    big = torch.tensor(1e10)
+    d3 = torch.where(ok[None], d3, big).reshape(pts.shape[0], -1)
+    d2 = torch.where(ok[None], d2, big).reshape(pts.shape[0], -1)
+    k = d3.argmin(-1, keepdim=True)
+    return (sgn.reshape(pts.shape[0], -1).gather(1, k) * d2.gather(1, k))[:, 0]
+
+
+def distance_to_road_edge(cx, cy, cz, length, width, height, heading, valid, eval_mask, poly, cyclic):
+    """(N, T) boxes -> (n_eval, T): the most off-road bottom corner's signed distance; -1e10 where the box is invalid"""
+    c, s = torch.cos(heading), torch.sin(heading)
+    hl, hw = length * 0.5, width * 0.5
+    zb = cz - height * 0.5
+    cor = []
+    for sl, sw in ((1, 1), (-1, 1), (-1, -1), (1, -1)):
+        cor.append(torch.stack([cx + (c * (sl * hl) - s * (sw * hw)), cy + (s * (sl * hl) + c * (sw * hw)), zb], -1))
+    cor = torch.stack(cor, -2)[eval_mask]                               # (n_eval, T, 4, 3)
+    dist = signed_distance_to_polylines(cor.reshape(-1, 3), poly, cyclic).reshape(cor.shape[:3])
+    return torch.where(valid[eval_mask], dist.max(-1)[0], torch.tensor(-1e10))

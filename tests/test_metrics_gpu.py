@@ -86,3 +86,58 @@ def test_placement_features_golden(case):
     assert np.abs(db.cpu().numpy() - z['bos_distance']).max() <= 1e-4
     assert np.abs(de.cpu().numpy() - z['eos_distance']).max() <= 1e-4
     assert np.array_equal(db.cpu().numpy() > 0, z['bos_distance'] > 0)
+
+
+@pytest.mark.parametrize('case', ['road_n24_t30', 'road_n5_t4'])
+def test_distance_to_road_edge_golden(case):
+    """device vs the reference's own output: 1e-4 m (device cos/sin and fused multiply-adds), same off-road set"""
+    from infgen_amd.metrics import compute_distance_to_road_edge, tensorize_polylines
+    dev = torch.device('cuda:0')
+    z = np.load(os.path.join(GOLDEN, case + '.npz'))
+    t = {k: torch.from_numpy(z[k]).to(dev) for k in z.files if z[k].ndim > 0}
+    roads = np.split(z['road_points'], np.cumsum(z['road_lengths'])[:-1])
+    kw = dict(center_x=t['cx'], center_y=t['cy'], center_z=t['cz'], length=t['length'], width=t['width'], height=t['height'],
+              heading=t['heading'], valid=t['valid'], evaluated_object_mask=t['eval_mask'])
+    out = compute_distance_to_road_edge(road_edge_polylines=roads, **kw)
+    ref = t['distance']
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() <= 1e-4
+    assert torch.equal(out > 0, ref > 0)
+    again = compute_distance_to_road_edge(road_edge_polylines=tensorize_polylines(roads, dev), **kw)
+    assert torch.equal(out, again)
+    with pytest.raises(ValueError):
+        compute_distance_to_road_edge(road_edge_polylines=[], **kw)
+
+
+def test_distance_to_road_edge_vs_oracle_large():
+    """a bigger seeded scene against the oracle (64 boxes x 80 steps, 60 road edges of up to 120 points)"""
+    from oracle import metrics_oracle as mo
+    from infgen_amd.metrics import compute_distance_to_road_edge
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(77)
+    N, T = 64, 80
+    r = lambda *s: torch.rand(*s, generator=g)
+    head = (r(N, 1) * 2 - 1) * 3.14159 + 0.02 * torch.arange(T)[None]
+    cx = (r(N, 1) * 2 - 1) * 80 + torch.cos(head) * torch.arange(T)[None] * 0.5
+    cy = (r(N, 1) * 2 - 1) * 80 + torch.sin(head) * torch.arange(T)[None] * 0.5
+    cz = r(N, 1).expand(N, T).contiguous()
+    ln, wd, ht = 4 + r(N, 1).expand(N, T), 1.8 + 0.4 * r(N, 1).expand(N, T), 1.5 + r(N, 1).expand(N, T)
+    valid = r(N, T) > 0.1
+    mask = r(N) > 0.5
+    roads = []
+    for k in range(60):
+        n = int(torch.randint(2, 120, (1,), generator=g))
+        h = (r(1) * 6.28 + torch.cumsum((r(n) - 0.5) * 0.3, 0))
+        xy = (r(1, 2) * 2 - 1) * 90 + torch.cumsum(torch.stack([torch.cos(h), torch.sin(h)], -1) * (0.5 + 2 * r(n, 1)), 0)
+        roads.append(torch.cat([xy, torch.full((n, 1), 6.0 if k % 7 == 0 else 0.0)], -1).numpy())
+    loop = torch.linspace(0, 6.2831853, 90)
+    roads.append(torch.stack([100 * torch.cos(loop), 100 * torch.sin(loop), torch.zeros(90)], -1).numpy())
+    poly, cyc = mo.tensorize_polylines(roads)
+    want = mo.distance_to_road_edge(cx, cy, cz, ln, wd, ht, head, valid, mask, poly, cyc)
+    d = lambda a: a.to(dev)
+    got = compute_distance_to_road_edge(center_x=d(cx), center_y=d(cy), center_z=d(cz), length=d(ln), width=d(wd),
+                                        height=d(ht), heading=d(head), valid=d(valid), evaluated_object_mask=d(mask),
+                                        road_edge_polylines=(poly, cyc.to(torch.uint8))).cpu()
+    err = (got - want).abs()
+    # a corner equidistant (to rounding) from two segments of different polylines may pick the other one: allow 0.1 %
+    assert (err > 1e-3).float().mean().item() <= 1e-3, err.max()
