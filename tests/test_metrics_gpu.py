@@ -141,3 +141,77 @@ def test_distance_to_road_edge_vs_oracle_large():
     err = (got - want).abs()
     # a corner equidistant (to rounding) from two segments of different polylines may pick the other one: allow 0.1 %
     assert (err > 1e-3).float().mean().item() <= 1e-3, err.max()
+
+
+def test_rollout_sink_features_golden():
+    """rollouts dict -> output_to_rollouts -> compute_metric_features, all arrays on the GPU, against the REFERENCE's
+    MetricFeatures of the same dict (tests/golden/make_golden_features.py)"""
+    from infgen_amd.metrics import compute_metric_features, output_to_rollouts
+    from test_oracle_golden import _features_fixture
+    dev = torch.device('cuda:0')
+    z, scen, roads = _features_fixture()
+    scen = {k: v.to(dev) if torch.is_tensor(v) else v for k, v in scen.items()}
+
+    class _F:
+        def __init__(self, pts, edge=True):
+            from types import SimpleNamespace as NS
+            self.road_edge, self._e = NS(polyline=[NS(x=p[0], y=p[1], z=p[2]) for p in pts.tolist()]), edge
+
+        def HasField(self, name):
+            return self._e and name == 'road_edge'
+
+    from types import SimpleNamespace
+    log = SimpleNamespace(map_features=[_F(r) for r in roads] + [_F(roads[0] + 5, False)])
+    sim = output_to_rollouts(scen)[0].joint_scenes[0]
+    f = compute_metric_features(sim, evaluate_agent_ids=None, scenario_log=log)
+    tol = dict(linear_speed=1e-4, linear_acceleration=2e-3, angular_speed=1e-4, angular_acceleration=2e-3,
+               distance_to_nearest_object=1e-4, time_to_collision=1e-3, distance_to_road_edge=1e-4,
+               distance_placement=1e-4, distance_removement=1e-4)
+    for name, t in tol.items():
+        got, want = getattr(f, name).cpu().numpy(), z['f_' + name]
+        assert got.shape == want.shape, name
+        assert np.array_equal(np.isnan(got), np.isnan(want)), name
+        assert np.nanmax(np.abs(got - want)) <= t, (name, np.nanmax(np.abs(got - want)))
+    for name in ('object_id', 'valid', 'collision_per_step', 'offroad_per_step', 'num_placement', 'num_removement'):
+        assert np.array_equal(getattr(f, name).cpu().numpy(), z['f_' + name]), name
+    sub = compute_metric_features(sim, evaluate_agent_ids=torch.from_numpy(z['eval_ids']), road_edge_polylines=None)
+    assert sub.distance_to_road_edge is None and sub.linear_speed.shape == (4, 80)
+    assert np.array_equal(sub.valid.cpu().numpy(), z['s_valid'])
+    assert np.nanmax(np.abs(sub.linear_speed.cpu().numpy() - z['s_linear_speed'])) <= 1e-4
+
+
+def test_rollout_to_features_end_to_end():
+    """InfGenDecoder.inference -> format_rollouts -> output_to_rollouts -> compute_metric_features without leaving the
+    GPU; checked against the oracle functions on the same rollout"""
+    from conftest import load_case
+    from oracle import metrics_oracle as mo
+    from test_boundary_cpu import _decoder
+    from test_modules_gpu import _load, _to_data
+    from infgen_amd.metrics import compute_metric_features, format_rollouts, output_to_rollouts
+    c = load_case('a24_m256_edge')
+    dev = torch.device('cuda:0')
+    dec = _decoder(c['cfg'])
+    _load(dec, c['sd'])
+    dec = dec.to(dev).eval()
+    data = _to_data(c['scene'], dev)
+    if 'tfrecord_path' not in data:
+        data['tfrecord_path'] = ['none']
+    out = dec.inference(data)
+    roll = format_rollouts(data, [out])
+    assert roll['pred_traj'].is_cuda and roll['pred_traj'].shape[1] == 1 and roll['scenario_id'].shape == (1, 16)
+    assert roll['av_id'] == int(out['agent_id'][int(out['ego_index'])])
+    sr = output_to_rollouts(roll)
+    sim = sr[0].joint_scenes[0]
+    f = compute_metric_features(sim)
+    A, T = sim.x.shape
+    assert f.linear_speed.shape == (A, T - 11) and f.num_placement.shape[0] == 1
+    cpu = lambda a: a.detach().cpu()
+    every = torch.ones(A, dtype=torch.bool)
+    d = mo.distance_to_nearest_object(cpu(sim.x), cpu(sim.y), cpu(sim.length), cpu(sim.width), cpu(sim.heading),
+                                      cpu(sim.valid), every)[:, 11:]
+    assert (cpu(f.distance_to_nearest_object) - d).abs().max() <= 1e-3
+    nb, ne, db, de = mo.placement_features(torch.cat([cpu(sim.token_pos), torch.zeros(A, sim.state.shape[1], 1)], -1),
+                                           cpu(sim.state), int(out['ego_index']))
+    assert torch.equal(cpu(f.num_placement)[0], nb[2:]) and torch.equal(cpu(f.num_removement)[0], ne[2:])
+    pickled = format_rollouts(data, [out], to_cpu=True)
+    assert not pickled['pred_traj'].is_cuda

@@ -135,3 +135,51 @@ def test_road_edge_oracle_matches_reference(case):
                                    t['eval_mask'], poly, cyc)
     assert (out - t['distance']).abs().max() <= 1e-5
     assert torch.equal(out > 0, t['distance'] > 0)
+
+
+def _features_fixture():
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'features_platoon_n20.npz'))
+    scen = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('in_')}
+    scen['av_id'] = int(z['av_id'])
+    roads = np.split(z['road_points'], np.cumsum(z['road_lengths'])[:-1])
+    return z, scen, roads
+
+
+def test_rollout_sink_layout_and_oracle_features():
+    """host side of the rollout sink (output_to_rollouts, infgen/metrics/compute_metrics.py:360-463) on the fixture's
+    rollouts dict, and the oracle functions composed like compute_metric_features (:560-707) against the REFERENCE's
+    features of the same dict (tests/golden/make_golden_features.py)"""
+    from infgen_amd.metrics import compute_metrics as cmx
+    from oracle import metrics_oracle as mo
+    z, scen, roads = _features_fixture()
+    assert torch.equal(cmx.get_scenario_id_int_tensor(['a1b2c3d4e5f6']), scen['scenario_id'])
+    sr = cmx.output_to_rollouts(scen)
+    assert len(sr) == 1 and sr[0].scenario_id == str(z['scenario_str']) and len(sr[0].joint_scenes) == 1
+    sim = sr[0].joint_scenes[0]
+    N, T = sim.x.shape
+    assert (N, T) == (20, 91) and sim.length.shape == (N, T) and sim.state.shape == (N, 19) and sim.token_pos.shape == (N, 19, 2)
+    assert sim.av_id == sim.processed_av_id == 119 and torch.equal(sim.object_id, torch.arange(100, 120))
+    sub = sim.gather_objects_by_id(torch.from_numpy(z['eval_ids']))
+    assert torch.equal(sub.x, sim.x[[19, 3, 11, 4]]) and sub.state is sim.state
+    with pytest.raises(ValueError):
+        sim.gather_objects_by_id(torch.tensor([5]))
+    every = torch.ones(N, dtype=torch.bool)
+    kin = mo.kinematic_features(sim.x, sim.y, sim.z, sim.heading, 0.1)
+    for a, n in zip(kin, ('linear_speed', 'linear_acceleration', 'angular_speed', 'angular_acceleration')):
+        assert np.array_equal(a[:, 11:].numpy(), z['f_' + n], equal_nan=True), n
+    d = mo.distance_to_nearest_object(sim.x, sim.y, sim.length, sim.width, sim.heading, sim.valid, every)[:, 11:]
+    assert np.array_equal(d.numpy(), z['f_distance_to_nearest_object'])
+    assert np.array_equal((d < 0).numpy(), z['f_collision_per_step'])
+    ttc = mo.time_to_collision(sim.x, sim.y, sim.length, sim.width, sim.heading, sim.valid, every, 0.1)[:, 11:]
+    assert np.array_equal(ttc.numpy(), z['f_time_to_collision'])
+    poly, cyc = mo.tensorize_polylines(roads)
+    road = mo.distance_to_road_edge(sim.x, sim.y, sim.z, sim.length, sim.width, sim.height, sim.heading, sim.valid, every,
+                                    poly, cyc)[:, 11:]
+    assert (road - torch.from_numpy(z['f_distance_to_road_edge'])).abs().max() <= 1e-5
+    assert np.array_equal((road > 0).numpy(), z['f_offroad_per_step'])
+    pos3 = torch.cat([sim.token_pos, torch.zeros(N, 19, 1)], -1)
+    nb, ne, db, de = mo.placement_features(pos3, sim.state, 19)
+    assert np.array_equal(nb[None, 2:].numpy(), z['f_num_placement']) and np.array_equal(ne[None, 2:].numpy(), z['f_num_removement'])
+    assert np.array_equal(db[:, 2:].numpy(), z['f_distance_placement']) and np.array_equal(de[:, 2:].numpy(), z['f_distance_removement'])
