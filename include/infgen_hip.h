@@ -201,6 +201,18 @@ int infgen_match_agent_tokens(const unsigned char* valid, const float* pos, cons
                               const int* type, const float* tok, long long tok_agent_stride, int A, int T, int shift,
                               int n_token, int* token_index, float* token_contour, void* stream);
 
+/* TokenProcessor._tokenize_agent (infgen/datasets/preprocess.py:335-550) in three launches: heading cleaning (:310-317) and
+ * extrapolation to the token grid (:319-344) IN PLACE on valid [A][T], pos [A][T][2], heading [A][T], velocity [A][T][2]
+ * (the reference modifies its inputs the same way); contour matching against tok [3][n_token][4][2] by type [A]; states,
+ * token position / heading, token ids -1 (invalid) / -2 (entering), validity masks, shape reset ([A][T][3], optional).
+ * wl_work: [A][2] scratch.  Outputs per agent and token step (T / shift): token_index, state_idx (int32), token_contour
+ * [..][4][2], token_pos [..][2], token_heading, token_valid (all 1 when predict_state), raw_token_valid (bytes). */
+int infgen_tokenize_agent(unsigned char* valid, float* pos, float* heading, float* velocity, const int* type, const float* tok,
+                          const float* shape_in, float* shape_out, float* wl_work, int A, int T, int shift, int current_step,
+                          int n_token, int invalid_state, int valid_state, int enter_state, int exit_state, int predict_state,
+                          int* token_index, float* token_contour, int* state_idx, float* token_pos, float* token_heading,
+                          unsigned char* token_valid, unsigned char* raw_token_valid, void* stream);
+
 /* InfGen.match_token_map, the matching core (infgen/model/infgen.py:918-936), noise off: traj_pos [P][3][2], theta [P],
  * sample_pt [n_token][3][2] -> token_idx [P] (int32) */
 int infgen_match_map_tokens(const float* traj_pos, const float* theta, const float* sample_pt, int P, int n_token,

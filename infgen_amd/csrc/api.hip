@@ -325,6 +325,26 @@ extern "C" int infgen_match_agent_tokens(const unsigned char* valid, const float
   return check_launch("infgen_match_agent_tokens");
 }
 
+extern "C" int infgen_tokenize_agent(unsigned char* valid, float* pos, float* heading, float* velocity, const int* type,
+                                    const float* tok, const float* shape_in, float* shape_out, float* wl_work, int A, int T,
+                                    int shift, int current_step, int n_token, int invalid_state, int valid_state,
+                                    int enter_state, int exit_state, int predict_state, int* token_index,
+                                    float* token_contour, int* state_idx, float* token_pos, float* token_heading,
+                                    unsigned char* token_valid, unsigned char* raw_token_valid, void* stream) {
+  if (A <= 0) return 0;
+  if (shift <= 0 || T <= shift || current_step < shift || current_step >= T)
+    return fail("infgen_tokenize_agent", "need 0 < shift <= current_step < T");
+  if (n_token <= 0 || n_token > 2048) return fail("infgen_tokenize_agent", "n_token must be in 1..2048");
+  TokenizeArgs t{valid, pos, heading, velocity, type, wl_work, shape_in, shape_out, A, T, shift, current_step,
+                 invalid_state, valid_state, enter_state, exit_state, predict_state, token_index, token_contour,
+                 state_idx, token_pos, token_heading, token_valid, raw_token_valid};
+  hipLaunchKernelGGL(k_tokenize_prep, dim3((A + 63) / 64), dim3(64), 0, (hipStream_t)stream, t);
+  MatchTokensArgs m{valid, pos, heading, wl_work, type, tok, 0, A, T, shift, n_token, token_index, token_contour};
+  hipLaunchKernelGGL(k_match_tokens, dim3(A), dim3(256), 0, (hipStream_t)stream, m);
+  hipLaunchKernelGGL(k_tokenize_state, dim3((A + 63) / 64), dim3(64), 0, (hipStream_t)stream, t);
+  return check_launch("infgen_tokenize_agent");
+}
+
 extern "C" int infgen_distance_to_nearest_object(const float* cx, const float* cy, const float* length, const float* width,
                                                 const float* heading, const unsigned char* valid, int B, int N, int T,
                                                 int n_eval, float corner_rounding_factor, float* work, float* out,

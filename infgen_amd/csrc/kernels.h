@@ -100,6 +100,17 @@ struct TtcArgs {                     // compute_time_to_collision_with_object_in
   float* out;                        // [B][n_eval][T]
 };
 
+struct TokenizeArgs {                // _tokenize_agent bookkeeping (k_tokenize_prep / k_tokenize_state)
+  unsigned char* valid; float* pos; float* heading; float* velocity;       // [A][T], [A][T][2], [A][T], [A][T][2] in/out
+  const int* type; float* wl;                                              // [A], [A][2] out (width, length)
+  const float* shape_in; float* shape_out;                                 // [A][T][3] (may be null)
+  int A, T, shift, current_step;
+  int invalid_state, valid_state, enter_state, exit_state, predict_state;
+  int* token_index; const float* token_contour;                            // [A][T/shift] in/out, [A][T/shift][4][2]
+  int* state_idx; float* token_pos; float* token_heading;                  // [A][T/shift](,2)
+  unsigned char* token_valid; unsigned char* raw_token_valid;              // [A][T/shift]
+};
+
 struct RoadEdgeArgs {                // compute_distance_to_road_edge; boxes [B][N][T]
   const float* cx; const float* cy; const float* cz; const float* length; const float* width; const float* height;
   const float* heading; const unsigned char* valid; const int* eval_idx;     // eval_idx [B][n_eval]
@@ -299,6 +310,8 @@ __global__ void k_placement(PlacementArgs a);
 __global__ void k_road_edge(RoadEdgeArgs a);
 __global__ void k_heads_h(HeadsArgs a);
 __global__ void k_match_map_tokens(MatchMapArgs a);
+__global__ void k_tokenize_prep(TokenizeArgs a);
+__global__ void k_tokenize_state(TokenizeArgs a);
 template <int WAVES> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);

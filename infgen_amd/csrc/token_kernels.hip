@@ -168,4 +168,93 @@ __global__ __launch_bounds__(MT_THREADS) void k_match_map_tokens(MatchMapArgs a)
   if (lane == 0) a.token_idx[p] = bidx;
 }
 
+// ------------------------------------------------------------------------------------------
+// k_tokenize_prep / k_tokenize_state: the bookkeeping of TokenProcessor._tokenize_agent around the contour matching
+// (reference infgen/datasets/preprocess.py:335-550).  One thread per agent; both are sequential scans over a track.
+//   prep   clean_heading (:310-317: a heading that jumps by more than 1.5 rad between two valid steps keeps the previous
+//          value), _extrapolate_agent_to_prev_token_step (:319-344: constant-velocity steps back to the token grid), the
+//          per-type (width, length) of _get_agent_shape (:346-354)
+//   state  token validity (both ends of a 0.5 s window valid), enter / exit / invalid states (:425-434), token position
+//          and heading from the matched contour, the position of entering agents, token ids -1 / -2, the shape reset
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_tokenize_prep(TokenizeArgs a) {
+  const int ag = blockIdx.x * 64 + threadIdx.x;
+  if (ag >= a.A) return;
+  unsigned char* valid = a.valid + (size_t)ag * a.T;
+  float* head = a.heading + (size_t)ag * a.T;
+  float2* pos = reinterpret_cast<float2*>(a.pos) + (size_t)ag * a.T;
+  float2* vel = reinterpret_cast<float2*>(a.velocity) + (size_t)ag * a.T;
+  const float PI_F = 3.14159274f, TWO_PI_F = 6.28318548f;
+  float prev = head[0];
+  int first = -1;
+  for (int i = 0; i + 1 < a.T; ++i) {
+    if (first < 0 && valid[i]) first = i;
+    const float next = head[i + 1];
+    float keep = next;
+    if (valid[i] && valid[i + 1]) {
+      float r = fmodf(__fadd_rn(__fsub_rn(prev, next), PI_F), TWO_PI_F);
+      if (r < 0.f) r += TWO_PI_F;
+      if (fabsf(__fadd_rn(-PI_F, r)) > 1.5f) { keep = prev; head[i + 1] = prev; }
+    }
+    prev = keep;
+  }
+  if (first < 0 && valid[a.T - 1]) first = a.T - 1;
+  const int ty = a.type[ag];
+  a.wl[2 * ag] = ty == 0 ? 2.f : 1.f;
+  a.wl[2 * ag + 1] = ty == 0 ? 4.8f : (ty == 1 ? 2.f : 1.f);
+  if (first < 0) return;
+  int n = first % a.shift;
+  if (first == a.current_step && !valid[a.current_step - a.shift]) n = a.shift;
+  const float2 v = vel[first];
+  const float h = head[first];
+  const float sx = __fmul_rn(v.x, 0.1f), sy = __fmul_rn(v.y, 0.1f);
+  float2 p = pos[first];
+  for (int j = 1; j <= n; ++j) {
+    const int k = first - j;
+    p.x = __fsub_rn(p.x, sx); p.y = __fsub_rn(p.y, sy);
+    pos[k] = p; vel[k] = v; head[k] = h; valid[k] = 1;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_tokenize_state(TokenizeArgs a) {
+  const int ag = blockIdx.x * 64 + threadIdx.x;
+  if (ag >= a.A) return;
+  const unsigned char* valid = a.valid + (size_t)ag * a.T;
+  const float2* pos = reinterpret_cast<const float2*>(a.pos) + (size_t)ag * a.T;
+  const int n_tok = a.T / a.shift;
+  int first = -1, last = -1;
+  for (int k = 0; k < n_tok; ++k)
+    if (valid[k * a.shift] && valid[k * a.shift + a.shift]) { if (first < 0) first = k; last = k; }
+  if (first < 0) { first = 0; last = n_tok - 1; }
+  for (int k = 0; k < n_tok; ++k) {
+    const size_t o = (size_t)ag * n_tok + k;
+    int st = a.valid_state;
+    if (k == first) st = a.enter_state;
+    if (k == last) st = a.exit_state;
+    if (k < first || k > last) st = a.invalid_state;
+    if (k == n_tok - 1 && st == a.exit_state) st = a.valid_state;
+    const bool tv = valid[k * a.shift] && valid[k * a.shift + a.shift] && st != a.enter_state;
+    const float* c = a.token_contour + o * 8;
+    float px = (((c[0] + c[2]) + c[4]) + c[6]) * 0.25f, py = (((c[1] + c[3]) + c[5]) + c[7]) * 0.25f;
+    float ph = atan2f(c[1] - c[7], c[0] - c[6]);
+    if (st == a.invalid_state) { px = 0.f; py = 0.f; ph = 0.f; }
+    if (st == a.enter_state) { const float2 p = pos[(k + 1) * a.shift]; px = p.x; py = p.y; }
+    a.state_idx[o] = st;
+    a.token_pos[2 * o] = px; a.token_pos[2 * o + 1] = py;
+    a.token_heading[o] = ph;
+    if (st == a.invalid_state) a.token_index[o] = -1;
+    if (st == a.enter_state) a.token_index[o] = -2;
+    a.raw_token_valid[o] = tv;
+    a.token_valid[o] = a.predict_state ? 1 : tv;
+  }
+  if (a.shape_in) {                                          // every step takes the first fully non-zero (l, w, h) row
+    const float* s = a.shape_in + (size_t)ag * a.T * 3;
+    int k = 0;
+    while (k < a.T && !(s[3 * k] != 0.f && s[3 * k + 1] != 0.f && s[3 * k + 2] != 0.f)) ++k;
+    const float l = k < a.T ? s[3 * k] : 0.f, w = k < a.T ? s[3 * k + 1] : 0.f, h = k < a.T ? s[3 * k + 2] : 0.f;
+    float* d = a.shape_out + (size_t)ag * a.T * 3;
+    for (int t = 0; t < a.T; ++t) { d[3 * t] = l; d[3 * t + 1] = w; d[3 * t + 2] = h; }
+  }
+}
+
 }  // namespace ig

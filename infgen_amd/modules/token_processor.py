@@ -1,7 +1,11 @@
-"""Device-side agent tokenisation - mirror of the reference's ``TokenProcessor._match_agent_token``
-(infgen/datasets/preprocess.py:552-653).  Same signature and return values; the work
-runs in ``k_match_tokens`` through the C ABI (``infgen_match_agent_tokens``).  There is no CPU fallback."""
-from typing import Optional, Tuple
+"""Device-side agent tokenisation - mirror of the reference's ``TokenProcessor`` (infgen/datasets/preprocess.py:236-653;
+SURVEY section 8f rank 1): ``_tokenize_agent`` / ``forward`` (three launches through ``infgen_tokenize_agent``) and the
+contour-matching core ``_match_agent_token`` (``infgen_match_agent_tokens``).  Same signatures, dict keys and in-place
+side effects as the reference.  There is no CPU fallback."""
+import pickle
+from typing import Dict, Optional, Tuple
+
+import numpy as np
 
 import torch
 
@@ -9,11 +13,102 @@ from .. import _lib
 
 
 class TokenProcessor(torch.nn.Module):
-    """Only the contour-matching core is provided (the rest of ``_tokenize_agent`` is bookkeeping on its outputs)."""
+    """reference preprocess.py:236-287.  The token tables come from ``agent_tokens`` ({'veh' | 'ped' | 'cyc': (n_token, 6, 4,
+    2)}) or ``agent_token_path`` (a pickle with the reference's layout, ``['token_all'][type]``); the reference reads its own
+    ``tokens/agent_vocab_555_s2.pkl``, which is data of that repository and not shipped here."""
 
-    def __init__(self, token_size: int = 2048, shift: int = 5):
+    def __init__(self, token_size: int = 2048, training: bool = False, predict_motion: bool = False,
+                 predict_state: bool = False, predict_map: bool = False, state_token: Optional[Dict[str, int]] = None,
+                 agent_tokens: Optional[Dict[str, np.ndarray]] = None, agent_token_path: Optional[str] = None, **kwargs):
         super().__init__()
-        self.token_size, self.shift, self.noise = token_size, shift, False
+        self.token_size, self.shift, self.noise, self.current_step = token_size, 5, False, 10
+        self.training = False
+        self.disable_invalid = not predict_state
+        self.predict_motion, self.predict_state, self.predict_map = predict_motion, predict_state, predict_map
+        st = state_token or dict(invalid=0, valid=1, enter=2, exit=3)
+        self.invalid_state, self.valid_state = int(st['invalid']), int(st['valid'])
+        self.enter_state, self.exit_state = int(st['enter']), int(st['exit'])
+        self.pl2seed_radius = kwargs.get('pl2seed_radius', None)
+        if agent_tokens is None and agent_token_path is not None:
+            with open(agent_token_path, 'rb') as f:
+                agent_tokens = pickle.load(f)['token_all']
+        if agent_tokens is not None:
+            for name in ('veh', 'ped', 'cyc'):
+                self.register_buffer(f'agent_token_all_{name}', torch.as_tensor(np.asarray(agent_tokens[name]),
+                                                                                 dtype=torch.float32), persistent=False)
+
+    def forward(self, data):
+        """reference preprocess.py:289-306"""
+        data['agent']['av_index'] = data['agent']['av_idx']
+        data = self._tokenize_agent(data)
+        if 'city' in data:
+            del data['city']
+        for k in ('polygon_is_intersection', 'route_type'):
+            if 'map_polygon' in data and k in data['map_polygon']:
+                del data['map_polygon'][k]
+        av = int(data['agent']['av_idx'])
+        data['ego_pos'] = data['agent']['token_pos'][[av]]
+        data['ego_heading'] = data['agent']['token_heading'][[av]]
+        return data
+
+    @torch.no_grad()
+    def _tokenize_agent(self, data):
+        """reference preprocess.py:335-550.  Reads data['agent'][valid_mask (A, T) bool, heading (A, T), position (A, T, 3),
+        velocity (A, T, 2), type (A,), shape (A, T, 3)] on the GPU; like the reference it cleans / extrapolates
+        ``valid_mask``, ``heading`` and ``velocity`` in place and resets ``shape``; adds token_idx, state_idx, token_contour,
+        token_pos, token_heading, agent_valid_mask, raw_agent_valid_mask, raw_height, token_traj(_all), traj_pos /
+        traj_heading (None) and trajectory_token_{veh,ped,cyc}."""
+        if not hasattr(self, 'agent_token_all_veh'):
+            raise RuntimeError('TokenProcessor needs agent_tokens / agent_token_path')
+        ag = data['agent']
+        dev = ag['position'].device
+        if dev.type != 'cuda':
+            raise RuntimeError('TokenProcessor._tokenize_agent runs on the GPU only (no CPU fallback)')
+        A, T = ag['valid_mask'].shape
+        n_tok = T // self.shift
+        valid = ag['valid_mask'].to(torch.uint8).contiguous()
+        head = ag['heading'].to(torch.float32).contiguous()
+        vel = ag['velocity'][..., :2].to(torch.float32).contiguous()
+        pos = ag['position'][..., :2].to(torch.float32).contiguous()      # a private copy, like the reference's
+        ty = ag['type'].to(torch.int32).contiguous()
+        names = ('veh', 'ped', 'cyc')
+        tables = [getattr(self, f'agent_token_all_{n}').to(dev) for n in names]
+        tok_last = torch.stack([t[:, -1] for t in tables]).contiguous()
+        shape_in = ag['shape'].to(torch.float32).contiguous()
+        shape_out = torch.empty_like(shape_in)
+        wl = torch.empty(A, 2, dtype=torch.float32, device=dev)
+        idx = torch.empty(A, n_tok, dtype=torch.int32, device=dev)
+        state = torch.empty_like(idx)
+        contour = torch.empty(A, n_tok, 4, 2, dtype=torch.float32, device=dev)
+        tpos = torch.empty(A, n_tok, 2, dtype=torch.float32, device=dev)
+        thead = torch.empty(A, n_tok, dtype=torch.float32, device=dev)
+        tv = torch.empty(A, n_tok, dtype=torch.uint8, device=dev)
+        raw = torch.empty_like(tv)
+        p = _lib.ptr
+        _lib.check(_lib.load().infgen_tokenize_agent(
+            p(valid), p(pos), p(head), p(vel), p(ty), p(tok_last), p(shape_in), p(shape_out), p(wl), A, T, self.shift,
+            self.current_step, tok_last.shape[1], self.invalid_state, self.valid_state, self.enter_state, self.exit_state,
+            int(not self.disable_invalid), p(idx), p(contour), p(state), p(tpos), p(thead), p(tv), p(raw),
+            torch.cuda.current_stream(dev).cuda_stream), 'infgen_tokenize_agent')
+        if (shape_out[:, 0] == 0).all(-1).any():
+            raise ValueError('Found invalid shape values.')
+        ag['valid_mask'].copy_(valid.bool())
+        ag['heading'].copy_(head)
+        ag['velocity'][..., :2] = vel
+        ag['shape'].copy_(shape_out)
+        height = ag['position'][:, self.current_step, 2]
+        seen = raw[:, 1].bool()
+        mean_z = {}
+        for k, n in enumerate(names):
+            m = height[(ty == k) & seen].mean()
+            mean_z[n] = m if k == 0 else torch.where(torch.isnan(m), mean_z['veh'], m)
+        token_traj_all = torch.stack(tables)[ty.long()]                      # (A, n_token, 6, 4, 2)
+        ag.update(token_traj_all=token_traj_all, token_traj=token_traj_all[:, :, -1], token_idx=idx.long(),
+                  state_idx=state.long(), token_contour=contour, traj_pos=None, traj_heading=None, token_pos=tpos,
+                  token_heading=thead, agent_valid_mask=tv.bool(), raw_agent_valid_mask=raw.bool(), raw_height=mean_z)
+        for n, t in zip(names, tables):
+            ag[f'trajectory_token_{n}'] = t
+        return data
 
     @torch.no_grad()
     def _match_agent_token(self, valid_mask: torch.Tensor, pos: torch.Tensor, heading: torch.Tensor,

@@ -183,3 +183,25 @@ def test_rollout_sink_layout_and_oracle_features():
     nb, ne, db, de = mo.placement_features(pos3, sim.state, 19)
     assert np.array_equal(nb[None, 2:].numpy(), z['f_num_placement']) and np.array_equal(ne[None, 2:].numpy(), z['f_num_removement'])
     assert np.array_equal(db[:, 2:].numpy(), z['f_distance_placement']) and np.array_equal(de[:, 2:].numpy(), z['f_distance_removement'])
+
+
+@pytest.mark.parametrize('case', ['tokenize_a40', 'tokenize_a6'])
+def test_tokenize_agent_oracle_matches_reference(case):
+    """oracle/token_match_oracle.tokenize_agent vs the reference's TokenProcessor._tokenize_agent
+    (tests/golden/make_golden_tokenize.py): everything bit-identical except token_heading (atan2 of a strided view takes
+    torch's scalar path: 2.4e-7)"""
+    import os
+    from conftest import GOLDEN
+    from infgen_amd import synth
+    from oracle import token_match_oracle as tm
+    z = np.load(os.path.join(GOLDEN, case + '.npz'))
+    vocab = synth.make_agent_vocab(synth.standard_config().token_size)
+    last = torch.stack([torch.from_numpy(vocab[k][:, -1]) for k in ('veh', 'ped', 'cyc')])
+    i = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('in_')}
+    o = tm.tokenize_agent(i['valid_mask'], i['position'], i['heading'], i['velocity'], i['type'], i['shape'], last)
+    for k in ('token_idx', 'state_idx', 'token_contour', 'token_pos', 'agent_valid_mask', 'raw_agent_valid_mask', 'shape',
+              'valid_mask', 'heading', 'velocity'):
+        assert np.array_equal(o[k].numpy(), z['out_' + k]), k
+    assert np.abs(o['token_heading'].numpy() - z['out_token_heading']).max() <= 1e-6
+    h = np.array([float(o['raw_height'][k]) for k in ('veh', 'ped', 'cyc')], np.float32)
+    assert np.array_equal(h, z['out_raw_height'], equal_nan=True)

@@ -140,3 +140,40 @@ def test_match_token_map_large_vs_oracle():
     dev = torch.device('cuda:0')
     idx = match_token_map(torch.from_numpy(pos).to(dev), torch.from_numpy(theta).to(dev), sample_pt).cpu().numpy()
     assert (idx == ref).mean() >= 0.999, float((idx == ref).mean())
+
+
+@pytest.mark.parametrize('case', ['tokenize_a40', 'tokenize_a6'])
+def test_tokenize_agent_golden(case):
+    """TokenProcessor._tokenize_agent on the device against the REFERENCE's own output: ids, states, masks, the cleaned
+    inputs and the shape reset exact; contours / positions to 1e-3 m like the matching core (ulp drift over 18 steps);
+    headings to 1e-3 rad"""
+    import os
+    from conftest import GOLDEN
+    from infgen_amd import synth
+    from infgen_amd.modules import TokenProcessor
+    dev = torch.device('cuda:0')
+    z = np.load(os.path.join(GOLDEN, case + '.npz'))
+    vocab = synth.make_agent_vocab(synth.standard_config().token_size)
+    tp = TokenProcessor(2048, predict_state=True, state_token=dict(invalid=0, valid=1, enter=2, exit=3), agent_tokens=vocab)
+    data = {'agent': {k[3:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith('in_')}}
+    out = tp._tokenize_agent(data)['agent']
+    g = lambda k: out[k].cpu().numpy()
+    for k in ('state_idx', 'agent_valid_mask', 'raw_agent_valid_mask', 'shape', 'valid_mask', 'heading', 'velocity'):
+        assert np.array_equal(g(k), z['out_' + k]), k
+    same = g('token_idx') == z['out_token_idx']
+    assert same.mean() >= 0.995
+    special = z['out_token_idx'] < 0
+    assert np.array_equal(g('token_idx')[special], z['out_token_idx'][special])
+    assert np.abs(g('token_contour') - z['out_token_contour'])[same].max() <= 1e-3
+    assert np.abs(g('token_pos') - z['out_token_pos'])[same].max() <= 1e-3
+    dh = np.abs(g('token_heading') - z['out_token_heading'])
+    assert np.minimum(dh, 2 * np.pi - dh)[same].max() <= 1e-3
+    h = np.array([float(out['raw_height'][k]) for k in ('veh', 'ped', 'cyc')], np.float32)
+    assert np.allclose(h, z['out_raw_height'], atol=1e-6, equal_nan=True)
+    assert out['token_traj_all'].shape == (same.shape[0], 2048, 6, 4, 2) and out['traj_pos'] is None
+    assert torch.equal(out['token_traj'], out['token_traj_all'][:, :, -1])
+    # forward() adds the ego rows like the reference
+    data2 = {'agent': {k[3:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith('in_')}, 'city': 'x'}
+    data2['agent']['av_idx'] = same.shape[0] - 1
+    d2 = tp(data2)
+    assert 'city' not in d2 and d2['ego_pos'].shape == (1, 18, 2) and torch.equal(d2['ego_pos'][0], d2['agent']['token_pos'][-1])
