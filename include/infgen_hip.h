@@ -213,6 +213,19 @@ int infgen_tokenize_agent(unsigned char* valid, float* pos, float* heading, floa
                           int* token_index, float* token_contour, int* state_idx, float* token_pos, float* token_heading,
                           unsigned char* token_valid, unsigned char* raw_token_valid, void* stream);
 
+/* InfGen._fetch_enterings (infgen/model/infgen.py:1008-1128): token_pos [A][T][2], token_heading [A][T], state_idx [A][T]
+ * (int32) of B scenes whose agents are rows agent_ptr[b] .. agent_ptr[b+1] (at most max_agents <= 2048 each), av_index [B]
+ * = row of the ego inside its scene; grid_xy [grid_size][2] = Attr_Tokenizer.grid.  Per agent and step: grid_token_idx
+ * (-1 = invalid or beyond radius), grid_offset_xy, heading_token_idx, sort_indices (entering agents by bearing, then the
+ * ego's row), inrange / bos masks (bytes), pos_xy, heading_theta.  Optional: pt_pos [M][pt_stride] (x, y first) with
+ * pt_ptr [B+1] -> pt_grid_token_idx [T][M]. */
+int infgen_fetch_enterings(const float* token_pos, const float* token_heading, const int* state_idx, const int* agent_ptr,
+                           const int* av_index, int B, int max_agents, int T, const float* grid_xy, int grid_size,
+                           float radius, float angle_interval, int enter_state, int invalid_state, int* grid_token_idx,
+                           float* grid_offset_xy, int* heading_token_idx, int* sort_indices, unsigned char* inrange_mask,
+                           unsigned char* bos_mask, float* pos_xy, float* heading_theta, const float* pt_pos, int pt_stride,
+                           const int* pt_ptr, int M, int* pt_grid_token_idx, void* stream);
+
 /* InfGen.match_token_map, the matching core (infgen/model/infgen.py:918-936), noise off: traj_pos [P][3][2], theta [P],
  * sample_pt [n_token][3][2] -> token_idx [P] (int32) */
 int infgen_match_map_tokens(const float* traj_pos, const float* theta, const float* sample_pt, int P, int n_token,

@@ -345,6 +345,27 @@ extern "C" int infgen_tokenize_agent(unsigned char* valid, float* pos, float* he
   return check_launch("infgen_tokenize_agent");
 }
 
+extern "C" int infgen_fetch_enterings(const float* token_pos, const float* token_heading, const int* state_idx,
+                                     const int* agent_ptr, const int* av_index, int B, int max_agents, int T,
+                                     const float* grid_xy, int grid_size, float radius, float angle_interval,
+                                     int enter_state, int invalid_state, int* grid_token_idx, float* grid_offset_xy,
+                                     int* heading_token_idx, int* sort_indices, unsigned char* inrange_mask,
+                                     unsigned char* bos_mask, float* pos_xy, float* heading_theta, const float* pt_pos,
+                                     int pt_stride, const int* pt_ptr, int M, int* pt_grid_token_idx, void* stream) {
+  if (B <= 0 || T <= 0) return 0;
+  if (max_agents > 2048) return fail("infgen_fetch_enterings", "more than 2048 agents in a scene");
+  if (grid_size <= 0) return fail("infgen_fetch_enterings", "empty grid");
+  EnteringsArgs a{token_pos, token_heading, state_idx, agent_ptr, av_index, B, T, grid_xy, grid_size, radius, angle_interval,
+                  enter_state, invalid_state, grid_token_idx, grid_offset_xy, heading_token_idx, sort_indices, inrange_mask,
+                  bos_mask, pos_xy, heading_theta, pt_pos, pt_stride, pt_ptr, M, pt_grid_token_idx};
+  hipLaunchKernelGGL(k_fetch_enterings, dim3(B * T), dim3(256), 0, (hipStream_t)stream, a);
+  if (pt_grid_token_idx && M > 0) {
+    const long long waves = (long long)T * M;
+    hipLaunchKernelGGL(k_pt_grid_cells, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  }
+  return check_launch("infgen_fetch_enterings");
+}
+
 extern "C" int infgen_distance_to_nearest_object(const float* cx, const float* cy, const float* length, const float* width,
                                                 const float* heading, const unsigned char* valid, int B, int N, int T,
                                                 int n_eval, float corner_rounding_factor, float* work, float* out,

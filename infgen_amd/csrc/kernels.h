@@ -111,6 +111,16 @@ struct TokenizeArgs {                // _tokenize_agent bookkeeping (k_tokenize_
   unsigned char* token_valid; unsigned char* raw_token_valid;              // [A][T/shift]
 };
 
+struct EnteringsArgs {               // _fetch_enterings (k_fetch_enterings / k_pt_grid_cells)
+  const float* token_pos; const float* token_heading; const int* state_idx;    // [A][T][2], [A][T], [A][T]
+  const int* agent_ptr; const int* av_index;                                   // [B+1], [B] (row inside the scene)
+  int B, T; const float* grid_xy; int grid_size;
+  float radius, angle_interval; int enter_state, invalid_state;
+  int* grid_token_idx; float* grid_offset_xy; int* heading_token_idx; int* sort_indices;
+  unsigned char* inrange_mask; unsigned char* bos_mask; float* pos_xy; float* heading_theta;
+  const float* pt_pos; int pt_stride; const int* pt_ptr; int M; int* pt_grid_token_idx;   // [M][pt_stride], [B+1], [T][M]
+};
+
 struct RoadEdgeArgs {                // compute_distance_to_road_edge; boxes [B][N][T]
   const float* cx; const float* cy; const float* cz; const float* length; const float* width; const float* height;
   const float* heading; const unsigned char* valid; const int* eval_idx;     // eval_idx [B][n_eval]
@@ -311,6 +321,8 @@ __global__ void k_road_edge(RoadEdgeArgs a);
 __global__ void k_heads_h(HeadsArgs a);
 __global__ void k_match_map_tokens(MatchMapArgs a);
 __global__ void k_tokenize_prep(TokenizeArgs a);
+__global__ void k_fetch_enterings(EnteringsArgs a);
+__global__ void k_pt_grid_cells(EnteringsArgs a);
 __global__ void k_tokenize_state(TokenizeArgs a);
 template <int WAVES> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);

@@ -14,6 +14,7 @@
 // kernels are within 1 ulp of that and usually equal to it, so poses agree bit for bit on most steps and drift by
 // ulps otherwise; a token can differ from the reference only where two tokens tie to within rounding.
 #include "kernels.h"
+#include "tile.cuh"
 
 namespace ig {
 
@@ -255,6 +256,119 @@ __global__ __launch_bounds__(64) void k_tokenize_state(TokenizeArgs a) {
     float* d = a.shape_out + (size_t)ag * a.T * 3;
     for (int t = 0; t < a.T; ++t) { d[3 * t] = l; d[3 * t + 1] = w; d[3 * t + 2] = h; }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_fetch_enterings / k_pt_grid_cells: InfGen._fetch_enterings (reference infgen/model/infgen.py:1008-1128) - what the
+// insertion branch needs per scene and token step: agents within pl2seed_radius of the ego, their cell of the polar-
+// cropped grid in the ego frame (Attr_Tokenizer.encode_pos, attr_tokenizer.py:77-89) + offset, the relative heading and
+// its bin (encode_heading :101-104), the entering agents ordered by bearing from the ego's heading (others -> ego), and
+// the cell of every map token (predict_occ).  One workgroup per (scene, step): a wave per agent with lanes over the grid
+// cells (first minimum), then a rank sort of the bearings in LDS (ties by row, like torch's stable CPU sort).
+// ------------------------------------------------------------------------------------------
+constexpr int FE_MAX_AGENTS = 2048;
+
+struct EgoFrame { float ex, ey, cs, sn, hc, hs; };
+
+__device__ __forceinline__ EgoFrame ego_frame(const float* pos, const float* head, size_t i) {
+  EgoFrame f;
+  f.ex = pos[2 * i]; f.ey = pos[2 * i + 1];
+  const float th = head[i], phi = -(th - HALF_PI_F);
+  f.cs = cos_cr(phi); f.sn = sin_cr(phi); f.hc = cos_cr(th); f.hs = sin_cr(th);
+  return f;
+}
+
+// nearest grid cell of (rx, ry) over the lanes of a wave; returns the cell to every lane
+__device__ __forceinline__ int nearest_cell(const float* __restrict__ grid, int n, float rx, float ry, int lane) {
+  float best = INFINITY;
+  int bi = 0x7fffffff;
+  for (int g = lane; g < n; g += 64) {
+    const float2 gc = *reinterpret_cast<const float2*>(grid + 2 * g);
+    const float ux = rx - gc.x, uy = ry - gc.y;
+    const float d = sqrtf(ux * ux + uy * uy);
+    if (d < best) { best = d; bi = g; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  return bi;
+}
+
+__device__ __forceinline__ float wrap_pi(float a) {          // func.py:58-62 in fp32
+  const float PI_F = 3.14159274f, TWO_PI_F = 6.28318548f;
+  float r = fmodf(__fadd_rn(a, PI_F), TWO_PI_F);
+  if (r < 0.f) r += TWO_PI_F;
+  return __fadd_rn(-PI_F, r);
+}
+
+__global__ __launch_bounds__(256) void k_fetch_enterings(EnteringsArgs a) {
+  __shared__ float key[FE_MAX_AGENTS];
+  __shared__ int n_born;
+  const int t = blockIdx.x % a.T, b = blockIdx.x / a.T;
+  const int r0 = a.agent_ptr[b], n = a.agent_ptr[b + 1] - r0, av = a.av_index[b];
+  const EgoFrame f = ego_frame(a.token_pos, a.token_heading, (size_t)(r0 + av) * a.T + t);
+  const float ego_head = a.token_heading[(size_t)(r0 + av) * a.T + t];
+  const int lane = lane_id();
+  if (threadIdx.x == 0) n_born = 0;
+  for (int ag = wave_id(); ag < n; ag += 4) {
+    const size_t i = (size_t)(r0 + ag) * a.T + t;
+    const int st = a.state_idx[i];
+    const float dx = a.token_pos[2 * i] - f.ex, dy = a.token_pos[2 * i + 1] - f.ey;
+    const bool near = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy))) <= a.radius;
+    const bool born = st == a.enter_state, use = near && st != a.invalid_state;
+    const float rx = dx * f.cs + dy * (-f.sn), ry = dx * f.sn + dy * f.cs;
+    int cell = -1;
+    if (use) cell = nearest_cell(a.grid_xy, a.grid_size, rx, ry, lane);       // wave-uniform branch
+    if (lane == 0) {
+      a.grid_token_idx[i] = cell;
+      a.grid_offset_xy[2 * i] = use ? rx - a.grid_xy[2 * cell] : 0.f;
+      a.grid_offset_xy[2 * i + 1] = use ? ry - a.grid_xy[2 * cell + 1] : 0.f;
+      a.pos_xy[2 * i] = use ? dx : 0.f;
+      a.pos_xy[2 * i + 1] = use ? dy : 0.f;
+      a.inrange_mask[i] = near; a.bos_mask[i] = born;
+      const float w = wrap_pi(__fsub_rn(a.token_heading[i], ego_head));
+      a.heading_theta[i] = w;
+      // ((w + pi) / (2 pi) * 360) // angle_interval with torch's floor division of floats
+      const float deg = __fmul_rn(__fdiv_rn(__fadd_rn(w, 3.14159274f), 6.28318548f), 360.f);
+      const float mod = fmodf(deg, a.angle_interval);
+      float div = __fdiv_rn(__fsub_rn(deg, mod), a.angle_interval);
+      if (mod != 0.f && (a.angle_interval < 0.f) != (mod < 0.f)) div -= 1.f;
+      float fl = floorf(div);
+      if (div - fl > 0.5f) fl += 1.f;
+      a.heading_token_idx[i] = (int)fl;
+      float den = f.hc * dx + f.hs * dy;
+      if (den == 0.f) den = 0.f;                             // torch's sum starts from +0: never -0 (atan2(0, -0) = pi)
+      key[ag] = (born && near) ? (float)atan2((double)(f.hc * dy - f.hs * dx), (double)den) : INFINITY;
+    }
+  }
+  __syncthreads();
+  for (int ag = threadIdx.x; ag < n; ag += 256) {
+    const float k = key[ag];
+    if (k == INFINITY) continue;
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += (key[j] < k) || (key[j] == k && j < ag);
+    a.sort_indices[(size_t)(r0 + rank) * a.T + t] = ag;
+    atomicAdd(&n_born, 1);
+  }
+  __syncthreads();
+  for (int r = n_born + threadIdx.x; r < n; r += 256) a.sort_indices[(size_t)(r0 + r) * a.T + t] = av;
+}
+
+__global__ __launch_bounds__(256) void k_pt_grid_cells(EnteringsArgs a) {
+  const int w = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = lane_id();
+  if (w >= a.T * a.M) return;
+  const int t = w / a.M, m = w % a.M;
+  int b = 0;
+  while (m >= a.pt_ptr[b + 1]) ++b;                            // few scenes per call
+  const EgoFrame f = ego_frame(a.token_pos, a.token_heading, (size_t)(a.agent_ptr[b] + a.av_index[b]) * a.T + t);
+  const float dx = a.pt_pos[(size_t)m * a.pt_stride] - f.ex, dy = a.pt_pos[(size_t)m * a.pt_stride + 1] - f.ey;
+  int cell = -1;
+  if (sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy))) <= a.radius)
+    cell = nearest_cell(a.grid_xy, a.grid_size, dx * f.cs + dy * (-f.sn), dx * f.sn + dy * f.cs, lane);
+  if (lane == 0) a.pt_grid_token_idx[(size_t)t * a.M + m] = cell;
 }
 
 }  // namespace ig

@@ -163,3 +163,54 @@ def match_token_map(traj_pos: torch.Tensor, traj_theta: torch.Tensor, token_samp
     _lib.check(lib.infgen_match_map_tokens(_lib.ptr(tp), _lib.ptr(th), _lib.ptr(sp), P, n_token, _lib.ptr(out),
                                            torch.cuda.current_stream(dev).cuda_stream), 'infgen_match_map_tokens')
     return out.long()
+
+
+@torch.no_grad()
+def fetch_enterings(data, attr_tokenizer, pl2seed_radius: float, enter_state: int = 2, invalid_state: int = 0,
+                    predict_occ: bool = False):
+    """The reference's ``InfGen._fetch_enterings(self, data)`` (infgen/model/infgen.py:1008-1128) with the attributes it
+    reads from ``self`` as arguments.  ``data`` is the (batched) scene dict on the GPU: data['agent'][state_idx, token_pos,
+    token_heading, batch, av_index], data['pt_token'][token_idx, position, batch], ``data.num_graphs`` (or the length of
+    av_index).  Adds the same keys as the reference to data['agent'] and returns data.  Two launches for all scenes."""
+    ag = data['agent']
+    dev = ag['token_pos'].device
+    if dev.type != 'cuda':
+        raise RuntimeError('fetch_enterings runs on the GPU only (no CPU fallback)')
+    A, T = ag['state_idx'].shape
+    av = torch.as_tensor(ag['av_index'], device=dev).reshape(-1).to(torch.int32).contiguous()
+    B = int(getattr(data, 'num_graphs', av.numel()))
+    batch = ag['batch'] if 'batch' in ag else torch.zeros(A, dtype=torch.long, device=dev)
+    counts = torch.bincount(batch, minlength=B)
+    ptr = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    ptr[1:] = torch.cumsum(counts, 0)
+    pos = ag['token_pos'].to(torch.float32).contiguous()
+    head = ag['token_heading'].to(torch.float32).contiguous()
+    st = ag['state_idx'].to(torch.int32).contiguous()
+    grid = attr_tokenizer.grid.to(dev, torch.float32).contiguous()
+    i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=dev)
+    f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    u8 = lambda *s: torch.empty(*s, dtype=torch.uint8, device=dev)
+    cell, hbin, order = i32(A, T), i32(A, T), i32(A, T)
+    off, rel, theta = f32(A, T, 2), f32(A, T, 2), f32(A, T)
+    near, born = u8(A, T), u8(A, T)
+    pt_pos = pt_ptr = pt_cell = None
+    M = 0
+    if predict_occ:
+        pt = data['pt_token']
+        pt_pos = pt['position'].to(torch.float32).contiguous()
+        M = pt_pos.shape[0]
+        pb = pt['batch'] if 'batch' in pt else torch.zeros(M, dtype=torch.long, device=dev)
+        pt_ptr = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+        pt_ptr[1:] = torch.cumsum(torch.bincount(pb, minlength=B), 0)
+        pt_cell = i32(T, M)
+    p = _lib.ptr
+    _lib.check(_lib.load().infgen_fetch_enterings(
+        p(pos), p(head), p(st), p(ptr), p(av), B, int(counts.max()), T, p(grid), grid.shape[0], float(pl2seed_radius),
+        float(attr_tokenizer.angle_interval), enter_state, invalid_state, p(cell), p(off), p(hbin), p(order), p(near), p(born),
+        p(rel), p(theta), p(pt_pos), pt_pos.shape[1] if pt_pos is not None else 0, p(pt_ptr), M, p(pt_cell),
+        torch.cuda.current_stream(dev).cuda_stream), 'infgen_fetch_enterings')
+    ag.update(grid_token_idx=cell.long(), grid_offset_xy=off, heading_token_idx=hbin.long(), sort_indices=order.long(),
+              inrange_mask=near.bool(), bos_mask=born.bool(), pos_xy=rel, heading_theta=theta)
+    if predict_occ:
+        ag['pt_grid_token_idx'] = pt_cell.long()
+    return data

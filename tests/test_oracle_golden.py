@@ -205,3 +205,18 @@ def test_tokenize_agent_oracle_matches_reference(case):
     assert np.abs(o['token_heading'].numpy() - z['out_token_heading']).max() <= 1e-6
     h = np.array([float(o['raw_height'][k]) for k in ('veh', 'ped', 'cyc')], np.float32)
     assert np.array_equal(h, z['out_raw_height'], equal_nan=True)
+
+
+def test_fetch_enterings_oracle_matches_reference():
+    """oracle/enterings_oracle.fetch_enterings vs the reference's InfGen._fetch_enterings with its own Attr_Tokenizer
+    (tests/golden/make_golden_enterings.py): all nine outputs bit-identical (two scenes, 40 agents, 300 map tokens)"""
+    import os
+    from conftest import GOLDEN
+    from oracle import enterings_oracle as eo
+    z = np.load(os.path.join(GOLDEN, 'enterings_a40.npz'))
+    t = lambda k: torch.from_numpy(z[k])
+    o = eo.fetch_enterings(t('token_pos'), t('token_heading'), t('state_idx'), t('batch'), t('av_index'), t('grid'), 75.0,
+                           3.0, pt_pos=t('pt_pos'), pt_batch=t('pt_batch'))
+    assert len(o) == 9
+    for k, v in o.items():
+        assert np.array_equal(v.numpy(), z['out_' + k]), k

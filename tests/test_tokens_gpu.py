@@ -177,3 +177,36 @@ def test_tokenize_agent_golden(case):
     data2['agent']['av_idx'] = same.shape[0] - 1
     d2 = tp(data2)
     assert 'city' not in d2 and d2['ego_pos'].shape == (1, 18, 2) and torch.equal(d2['ego_pos'][0], d2['agent']['token_pos'][-1])
+
+
+def test_fetch_enterings_golden():
+    """fetch_enterings on the device against the REFERENCE's InfGen._fetch_enterings: masks and heading bins exact, grid
+    cells equal except where a position sits on a cell border to rounding (<= 0.5 %, then a neighbouring cell), offsets /
+    relative positions / angles to 1e-4, the order of the entering agents exact"""
+    import os
+    from conftest import GOLDEN
+    from infgen_amd.modules import Attr_Tokenizer, fetch_enterings
+    dev = torch.device('cuda:0')
+    z = np.load(os.path.join(GOLDEN, 'enterings_a40.npz'))
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+
+    class _Data(dict):
+        num_graphs = 2
+
+    tok = Attr_Tokenizer(grid_range=150., grid_interval=3., radius=75., angle_interval=3.)
+    assert np.array_equal(tok.grid.numpy(), z['grid'])
+    data = _Data(agent=dict(state_idx=t('state_idx'), token_pos=t('token_pos'), token_heading=t('token_heading'),
+                            batch=t('batch'), av_index=t('av_index')),
+                 pt_token=dict(token_idx=torch.zeros(300, dtype=torch.long, device=dev), position=t('pt_pos'),
+                               batch=t('pt_batch')))
+    out = fetch_enterings(data, tok, 75.0, enter_state=2, invalid_state=0, predict_occ=True)['agent']
+    g = lambda k: out[k].cpu().numpy()
+    for k in ('inrange_mask', 'bos_mask', 'heading_token_idx', 'sort_indices'):
+        assert np.array_equal(g(k), z['out_' + k]), k
+    same = g('grid_token_idx') == z['out_grid_token_idx']
+    assert same.mean() >= 0.995 and np.array_equal(g('grid_token_idx') < 0, z['out_grid_token_idx'] < 0)
+    assert np.abs(g('grid_offset_xy') - z['out_grid_offset_xy'])[same].max() <= 1e-4
+    assert np.abs(g('pos_xy') - z['out_pos_xy']).max() <= 1e-6
+    assert np.abs(g('heading_theta') - z['out_heading_theta']).max() <= 1e-6
+    psame = g('pt_grid_token_idx') == z['out_pt_grid_token_idx']
+    assert psame.mean() >= 0.995 and np.array_equal(g('pt_grid_token_idx') < 0, z['out_pt_grid_token_idx'] < 0)
