@@ -265,6 +265,14 @@ int infgen_placement_features(const float* x, const float* y, const float* z, co
                               int B, int N, int T, int enter_state, int exit_state, int* num_bos, int* num_eos,
                               float* bos_distance, float* eos_distance, void* stream);
 
+/* Padded row layouts (insertion on: A_cap = agents + head-room rows per scene).  infgen_active_row_groups lists, in
+ * ascending order, the 16-row groups of the [S][A_cap] layout with a row below n_agents[s] + margin (groups: capacity
+ * ceil(S * A_cap / 16), n_groups: 1 int, both on the device); infgen_set_row_groups makes every split-kernel launch of the
+ * attention node kernels over exactly `rows` rows visit only those groups (NULL switches it off).  Rows outside the list
+ * keep their previous contents. */
+int infgen_active_row_groups(const int* n_agents, int S, int A_cap, int margin, int* groups, int* n_groups, void* stream);
+int infgen_set_row_groups(const int* groups, const int* n_groups, int rows);
+
 /* ---- optional profiling (bench.py roofline leg; process-global, off by default) ----
  * HIP events are recorded on the launch stream around every launch of the kernels selected by
  * `mask` (bit = INFGEN_KID_*).  infgen_prof_collect synchronises the device, returns the summed

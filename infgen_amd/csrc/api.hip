@@ -210,7 +210,28 @@ extern "C" int infgen_set_attn_mode(int mode) {
 static inline bool attn_split(int rows) { return g_attn_mode == 1 || (g_attn_mode == 2 && rows > 10240); }
 
 // 64-row tiles, 4 waves, two workgroups per CU (attn_h.hip); INFGEN_ATTN_WAVES=8 selects the 128-row variant
-static void launch_attn_h(const AttnHArgs& a, void* stream) {
+// optional list of the 16-row groups that hold agents (infgen_set_row_groups): applied to every split-kernel launch over
+// exactly `g_group_rows` rows, i.e. the [S][A_cap] row arrays of the rollout the caller is running
+static const int* g_groups = nullptr;
+static const int* g_n_groups = nullptr;
+static int g_group_rows = 0;
+
+extern "C" int infgen_set_row_groups(const int* groups, const int* n_groups, int rows) {
+  g_groups = groups; g_n_groups = n_groups; g_group_rows = groups ? rows : 0;
+  return 0;
+}
+
+extern "C" int infgen_active_row_groups(const int* n_agents, int S, int A_cap, int margin, int* groups, int* n_groups,
+                                        void* stream) {
+  if (S <= 0 || A_cap <= 0) return fail("infgen_active_row_groups", "empty layout");
+  ActiveGroupsArgs a{n_agents, S, A_cap, margin, groups, n_groups};
+  hipLaunchKernelGGL(k_active_groups, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_active_row_groups");
+}
+
+static void launch_attn_h(const AttnHArgs& a_in, void* stream) {
+  AttnHArgs a = a_in;
+  if (g_groups && a.rows == g_group_rows) { a.groups = g_groups; a.n_groups = g_n_groups; }
   static const int waves = getenv("INFGEN_ATTN_WAVES") ? atoi(getenv("INFGEN_ATTN_WAVES")) : 4;
   if (waves != 8) {
     int grid = ceil_div(a.rows, 64);

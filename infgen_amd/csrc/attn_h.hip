@@ -65,7 +65,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnH
   __shared__ __attribute__((aligned(16))) float Vt[VT_SIZE];
   __shared__ const unsigned short* seg_ptr[5];
   __shared__ int seg_n[5];
-  const int ntiles = (a.rows + TILE - 1) / TILE;
+  // with a group list (rows padded to A_cap per scene, insertion on) only the 16-row groups that hold agents are visited
+  const int ngroups = a.groups ? *a.n_groups : (a.rows + 15) / 16;
+  const int ntiles = (ngroups + WAVES - 1) / WAVES;
   if ((int)blockIdx.x >= ntiles) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
@@ -114,8 +116,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnH
   };
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int row = tile * TILE + w * 16 + j;
-    const bool valid = row < a.rows;
+    const int gi = tile * WAVES + w;
+    const int grp = gi < ngroups ? (a.groups ? a.groups[gi] : gi) : -1;
+    const int row = grp * 16 + j;
+    const bool valid = grp >= 0 && row < a.rows;
     float* xrow = valid ? a.X + (size_t)row * D : nullptr;
     f32x4 x[8];
     load_row(x, xrow, rg);
@@ -299,5 +303,36 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnH
 
 template __global__ void k_attn_h<4>(AttnHArgs);
 template __global__ void k_attn_h<8>(AttnHArgs);
+
+// k_active_groups: the 16-row groups of the [S][A_cap] row layout that hold at least one row below n_agents[s] + margin
+// (margin = rows a decode step may append), in ascending order.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void k_active_groups(ActiveGroupsArgs a) {
+  __shared__ int wave_cnt[16];
+  __shared__ int base;
+  const int total = (a.S * a.A_cap + 15) / 16;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int g0 = 0; g0 < total; g0 += 1024) {
+    const int g = g0 + threadIdx.x;
+    bool on = false;
+    if (g < total) {
+      const int r0 = 16 * g, r1 = min(16 * g + 15, a.S * a.A_cap - 1);
+      const int s0 = r0 / a.A_cap, s1 = r1 / a.A_cap;
+      on = (r0 - s0 * a.A_cap) < a.n_agents[s0] + a.margin;            // first row of the group in its scene
+      if (s1 != s0) on = on || a.n_agents[s1] + a.margin > 0;            // the group runs into the next scene
+    }
+    const unsigned long long m = __ballot(on);
+    if (lane == 0) wave_cnt[w] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int k = 0; k < w; ++k) off += wave_cnt[k];
+    if (on) a.groups[off + __popcll(m & ((1ull << lane) - 1))] = g;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wave_cnt[k]; base += t; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *a.n_groups = base;
+}
 
 }  // namespace ig

@@ -75,7 +75,10 @@ struct AttnHArgs {
   const float* next_pack;            // layer whose pre part runs (null: none)
   int next_src_ln;                   // 1: LayerNorm with the *_src parameters (K/V of a bipartite source)
   float* nQ; float* nU; float* nK; float* nV;
+  const int* groups; const int* n_groups;   // optional: the 16-row groups to process (device list + count), see k_active_groups
 };
+
+struct ActiveGroupsArgs { const int* n_agents; int S, A_cap, margin; int* groups; int* n_groups; };
 
 // metric_kernels.hip: compute_distance_to_nearest_object; all arrays [B][N][T], evaluated objects first
 struct NearestArgs {
@@ -324,6 +327,7 @@ __global__ void k_tokenize_prep(TokenizeArgs a);
 __global__ void k_fetch_enterings(EnteringsArgs a);
 __global__ void k_pt_grid_cells(EnteringsArgs a);
 __global__ void k_tokenize_state(TokenizeArgs a);
+__global__ void k_active_groups(ActiveGroupsArgs a);
 template <int WAVES> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);

@@ -13,6 +13,7 @@ map_decoder.py:70-130, agent_decoder.py:1605-2389), greedy decoding, insertion d
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Mapping, Optional, Sequence
 
 import numpy as np
@@ -534,7 +535,8 @@ class RolloutEngine:
             occ_off=ar.clone(), occ_cnt=torch.ones(S, device=dev, dtype=torch.int32), occ_src=ar.clone(),
             active=i32(S), n_new=i32(S), inserted=i32(S), new_row=i32(S), new_cell=i32(S), new_shape=f(S, 3),
             first_new=torch.full((S,), A_cap, device=dev, dtype=torch.int32), hv_ovr=f(S, 2), shape_all=torch.full((rows, 3), INVALID_SHAPE, device=dev),
-            scene_base=(ar * A_cap).contiguous(), inserted_rows=[[] for _ in range(S)])
+            scene_base=(ar * A_cap).contiguous(), inserted_rows=[[] for _ in range(S)],
+            groups=i32((rows + 15) // 16), n_groups=i32(1))
 
     def _ebuf_struct(self, e):
         b = _lib.EdgeBuf()
@@ -720,10 +722,23 @@ class RolloutEngine:
         if not self.insertion:
             _lib.check(self.lib.infgen_rollout_run(C.byref(self._ctx), t0, t1, self.ops.stream), 'infgen_rollout_run')
             return
-        for t in range(t0, t1):
-            if t > 0:
-                self._insert_step(t)
-            self.step(t)
+        # rows are padded to A_cap per scene: the split node kernels visit only the 16-row groups that hold agents (or may
+        # receive one of the <= 10 rows a step appends); INFGEN_ROW_GROUPS=0 switches the compaction off
+        lib, I, st = self.lib, self.ins, self.ops.stream
+        use_groups = os.environ.get('INFGEN_ROW_GROUPS', '1') != '0'
+        try:
+            if use_groups:
+                _lib.check(lib.infgen_set_row_groups(_lib.ptr(I['groups']), _lib.ptr(I['n_groups']), self.rows))
+            for t in range(t0, t1):
+                if use_groups:
+                    _lib.check(lib.infgen_active_row_groups(_lib.ptr(self.n_agents), self.S, self.A_cap, 10,
+                                                            _lib.ptr(I['groups']), _lib.ptr(I['n_groups']), st),
+                               'infgen_active_row_groups')
+                if t > 0:
+                    self._insert_step(t)
+                self.step(t)
+        finally:
+            _lib.check(lib.infgen_set_row_groups(None, None, 0))
 
     def step(self, t: int):
         _lib.check(self.lib.infgen_decode_step(C.byref(self._ctx), t, self.ops.stream), 'infgen_decode_step')

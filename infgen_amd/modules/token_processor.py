@@ -23,6 +23,8 @@ class TokenProcessor(torch.nn.Module):
         super().__init__()
         self.token_size, self.shift, self.noise, self.current_step = token_size, 5, False, 10
         self.training = False
+        # False: skip the reference's per-agent copy of the tables (token_traj_all, 393 KB per agent; token_traj)
+        self.materialize_token_traj_all = True
         self.disable_invalid = not predict_state
         self.predict_motion, self.predict_state, self.predict_map = predict_motion, predict_state, predict_map
         st = state_token or dict(invalid=0, valid=1, enter=2, exit=3)
@@ -102,8 +104,9 @@ class TokenProcessor(torch.nn.Module):
         for k, n in enumerate(names):
             m = height[(ty == k) & seen].mean()
             mean_z[n] = m if k == 0 else torch.where(torch.isnan(m), mean_z['veh'], m)
-        token_traj_all = torch.stack(tables)[ty.long()]                      # (A, n_token, 6, 4, 2)
-        ag.update(token_traj_all=token_traj_all, token_traj=token_traj_all[:, :, -1], token_idx=idx.long(),
+        token_traj_all = torch.stack(tables)[ty.long()] if self.materialize_token_traj_all else None   # (A, n_token, 6, 4, 2)
+        ag.update(token_traj_all=token_traj_all, token_traj=token_traj_all[:, :, -1] if token_traj_all is not None else None,
+                  token_idx=idx.long(),
                   state_idx=state.long(), token_contour=contour, traj_pos=None, traj_heading=None, token_pos=tpos,
                   token_heading=thead, agent_valid_mask=tv.bool(), raw_agent_valid_mask=raw.bool(), raw_height=mean_z)
         for n, t in zip(names, tables):
