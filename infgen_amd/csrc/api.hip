@@ -161,7 +161,9 @@ extern "C" int infgen_linear(const float* X, int ldx, const int* gather, int row
     return fail("infgen_linear", "LayerNorm prologue/epilogue needs K == 128 / N == 128");
   LinearArgs a{X, ldx, gather, rows, K, ((K + 7) / 8) * 8, Wp, Np, bias, N, pre_g, pre_b, post_g, post_b, relu, Y, ldy};
   { ProfScope _ps(INFGEN_KID_LINEAR, stream, (double)rows * K * N);
-    hipLaunchKernelGGL(k_linear, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a); }
+    const int tiles = ceil_div(rows, TR), passes = ceil_div(Np, 128);
+    const int gy = (K <= 128 && !post_g && passes > 1 && tiles < 512) ? min(passes, ceil_div(512, tiles)) : 1;
+    hipLaunchKernelGGL(k_linear, dim3(tiles, gy), dim3(NT), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_linear");
 }
 

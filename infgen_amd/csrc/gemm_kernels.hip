@@ -38,7 +38,8 @@ __global__ __launch_bounds__(NT) void k_linear(LinearArgs a) {
       ln_tile(As, LDT, As, LDT, a.pre_g, a.pre_b, false);
       __syncthreads();
     }
-    for (int p = 0; p < passes; ++p) {
+    // a wide output (token / grid heads) over few rows: the column passes are spread over gridDim.y
+    for (int p = blockIdx.y; p < passes; p += gridDim.y) {
       const int n0 = p * 128 + 32 * w;
       f32x16 acc = zero16();
       if (n0 < a.Np) mfma_32x32_rt(acc, As, LDT, a.Kp, a.Wp, a.Np, n0);
