@@ -136,3 +136,41 @@ def test_synth_is_deterministic():
     w1 = synth.fill_state_dict({'x.weight': (4, 4)}, seed=3)
     w2 = synth.fill_state_dict({'x.weight': (4, 4)}, seed=3)
     assert np.array_equal(w1['x.weight'], w2['x.weight'])
+
+
+def test_infgen_caller_mirror_host_side(tmp_path):
+    """infgen_amd.model.InfGen (mirror of infgen/model/infgen.py): constructor from a model_config with the reference's
+    attribute names, checkpoint layout `encoder.*`, map-token sample points (:201-211), mode switches; the data path
+    itself refuses to run without a GPU"""
+    from types import SimpleNamespace
+    from infgen_amd import synth
+    from infgen_amd.model import InfGen
+    cfg = synth.standard_config()
+    dec = SimpleNamespace(num_future_steps=80, pl2seed_radius=cfg.pl2seed_radius, token_size=cfg.token_size, seed_size=1,
+                          num_map_layers=3, num_agent_layers=6, pl2pl_radius=cfg.pl2pl_radius, pl2a_radius=cfg.pl2a_radius,
+                          a2a_radius=cfg.a2a_radius, a2sa_radius=cfg.a2sa_radius, pl2sa_radius=cfg.pl2sa_radius,
+                          time_span=cfg.time_span, buffer_size=128)
+    mc = SimpleNamespace(dataset='waymo', input_dim=2, hidden_dim=128, num_historical_steps=11, num_freq_bands=64, num_heads=8,
+                         head_dim=16, dropout=0.1, decoder_type='agent_decoder', predict_motion=True, predict_state=True,
+                         predict_map=False, predict_occ=True, state_token=cfg.state_token, grid_range=cfg.grid_range,
+                         grid_interval=cfg.grid_interval, angle_interval=cfg.angle_interval,
+                         num_recurrent_steps_val=80, decoder=dec)
+    with pytest.raises(ValueError):
+        InfGen(mc)                                        # no map token table given
+    mv = synth.make_map_vocab()
+    m = InfGen(mc, save_path=str(tmp_path), map_token_traj=mv, agent_tokens=synth.make_agent_vocab(2048))
+    assert {k[len('encoder.'):] for k in m.state_dict() if k.startswith('encoder.')} == set(load_shapes())
+    # besides the encoder only the tokenizer's buffers, like the reference's checkpoints (SURVEY 8b)
+    assert {k for k in m.state_dict() if not k.startswith('encoder.')} == {'attr_tokenizer.grid', 'attr_tokenizer.dist', 'attr_tokenizer.dir'}
+    assert m.map_token['sample_pt'].shape == (mv.shape[0], 3, 2)
+    assert np.array_equal(m.map_token['sample_pt'].numpy(), mv[:, [0, 5, 10]])
+    assert m.noise and not m._online_metric
+    m.set('validation')
+    assert m._online_metric and m._save_validate_reuslts
+    with pytest.raises(NotImplementedError):
+        m(None)
+    data = {'agent': {'av_idx': 0, 'valid_mask': torch.ones(2, 91, dtype=torch.bool), 'heading': torch.zeros(2, 91),
+                      'position': torch.zeros(2, 91, 3), 'velocity': torch.zeros(2, 91, 2), 'type': torch.zeros(2),
+                      'shape': torch.ones(2, 91, 3)}}
+    with pytest.raises(RuntimeError, match='GPU only'):
+        m.validation_step(data, 0)
