@@ -259,6 +259,14 @@ int infgen_distance_to_road_edge(const float* cx, const float* cy, const float* 
                                  int B, int N, int T, int n_eval, const float* polylines, const unsigned char* cyclic,
                                  const int* poly_off, int L, float z_stretch, float* out, void* stream);
 
+/* Scoring of a feature under its logged distribution (infgen/metrics/compute_metrics.py:845-878 and :744-762), fused over
+ * the windows the reference unfolds: values / valid [n][T] (valid NULL = all), windows of `size` steps every `step`;
+ * edges [num_bins + 1] (float32 linspace of the histogram), logp [num_bins] log-probabilities of the logged distribution.
+ * -> out_sum / out_cnt [n][(T - size) / step + 1]: sum of log-probabilities over the valid steps of a window, their number */
+int infgen_window_log_likelihood(const float* values, const unsigned char* valid, int n, int T, int size, int step,
+                                 const float* edges, const float* logp, int num_bins, float* out_sum, int* out_cnt,
+                                 void* stream);
+
 /* compute_num_placement + compute_distance_placement (infgen/metrics/placement_features.py:6-48): x, y, z (NULL = 0) and
  * state [B][N][T], av_index [B] (row of the ego, excluded) -> num_bos / num_eos [B][T], bos / eos distance [B][N][T] */
 int infgen_placement_features(const float* x, const float* y, const float* z, const int* state, const int* av_index,

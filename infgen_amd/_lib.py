@@ -71,6 +71,7 @@ SYMBOLS = {
     'infgen_fetch_enterings': (_i, [_p] * 5 + [_i] * 3 + [_p, _i, _f, _f, _i, _i] + [_p] * 9 + [_i, _p, _i, _p, _p]),
     'infgen_tokenize_agent': (_i, [_p] * 9 + [_i] * 10 + [_p] * 8),
     'infgen_distance_to_road_edge': (_i, [_p] * 9 + [_i] * 4 + [_p, _p, _p, _i, _f, _p, _p]),
+    'infgen_window_log_likelihood': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
     'infgen_placement_features': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     'infgen_match_map_tokens': (_i, [_p, _p, _p, _i, _i, _p, _p]),
     'infgen_match_agent_tokens': (_i, [_p, _p, _p, _p, _p, _p, C.c_longlong, _i, _i, _i, _i, _p, _p, _p]),

@@ -437,6 +437,18 @@ extern "C" int infgen_distance_to_road_edge(const float* cx, const float* cy, co
   return check_launch("infgen_distance_to_road_edge");
 }
 
+extern "C" int infgen_window_log_likelihood(const float* values, const unsigned char* valid, int n, int T, int size, int step,
+                                           const float* edges, const float* logp, int num_bins, float* out_sum,
+                                           int* out_cnt, void* stream) {
+  if (n <= 0) return 0;
+  if (size <= 0 || step <= 0 || size > T) return fail("infgen_window_log_likelihood", "need 0 < size <= T and step > 0");
+  if (num_bins <= 0 || num_bins > 64) return fail("infgen_window_log_likelihood", "num_bins must be in 1..64");
+  WindowLoglikArgs a{values, valid, n, T, size, step, edges, logp, num_bins, out_sum, out_cnt};
+  const long long tot = (long long)n * ((T - size) / step + 1);
+  hipLaunchKernelGGL(k_window_loglik, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_window_log_likelihood");
+}
+
 extern "C" int infgen_placement_features(const float* x, const float* y, const float* z, const int* state, const int* av_index,
                                         int B, int N, int T, int enter_state, int exit_state, int* num_bos, int* num_eos,
                                         float* bos_distance, float* eos_distance, void* stream) {

@@ -132,6 +132,13 @@ struct RoadEdgeArgs {                // compute_distance_to_road_edge; boxes [B]
   float* out;                                                                // [B][n_eval][T]
 };
 
+struct WindowLoglikArgs {            // k_window_loglik
+  const float* values; const unsigned char* valid;      // [n][T]; valid may be null (all)
+  int n, T, size, step;
+  const float* edges; const float* logp; int nb;        // [nb + 1], [nb], nb <= 64
+  float* out_sum; int* out_cnt;                         // [n][(T - size) / step + 1]
+};
+
 struct PlacementArgs {               // placement_features; arrays [B][N][T]
   const float* x; const float* y; const float* z;      // z may be null
   const int* state; const int* av_index;               // [B][N][T], [B]
@@ -320,6 +327,7 @@ __global__ void k_nearest_distance(NearestArgs a);
 __global__ void k_kinematic(KinematicArgs a);
 __global__ void k_ttc(TtcArgs a);
 __global__ void k_placement(PlacementArgs a);
+__global__ void k_window_loglik(WindowLoglikArgs a);
 __global__ void k_road_edge(RoadEdgeArgs a);
 __global__ void k_heads_h(HeadsArgs a);
 __global__ void k_match_map_tokens(MatchMapArgs a);

@@ -299,4 +299,40 @@ __global__ __launch_bounds__(256) void k_road_edge(RoadEdgeArgs a) {
   if (lane == 0) a.out[box] = res;
 }
 
+// ------------------------------------------------------------------------------------------
+// k_window_loglik: the scoring step of LongMetric (reference infgen/metrics/compute_metrics.py:845-878 with :744-762) fused
+// over the unfolded windows: a value is scored by the log-probability (under the logged distribution) of the histogram
+// bin it falls into - edges[i] <= v < edges[i + 1], the last bin closed on the right, anything else (or NaN) bin 0, like
+// torch.histogram followed by argmax -; per (row, window of `size` steps every `step`) the sum over the valid steps and
+// their number.  One thread per (row, window); the <= 64 edges and log-probabilities sit in LDS.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_window_loglik(WindowLoglikArgs a) {
+  __shared__ float edges[65], logp[64];
+  for (int i = threadIdx.x; i <= a.nb; i += 256) edges[i] = a.edges[i];
+  for (int i = threadIdx.x; i < a.nb; i += 256) logp[i] = a.logp[i];
+  __syncthreads();
+  const int W = (a.T - a.size) / a.step + 1;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.n * W) return;
+  const int w = idx % W, r = idx / W;
+  const float* v = a.values + (size_t)r * a.T + (size_t)w * a.step;
+  const unsigned char* ok = a.valid ? a.valid + (size_t)r * a.T + (size_t)w * a.step : nullptr;
+  float sum = 0.f;
+  int cnt = 0;
+  for (int k = 0; k < a.size; ++k) {
+    if (ok && !ok[k]) continue;
+    const float x = v[k];
+    int b = 0;
+    if (x >= edges[0] && x <= edges[a.nb]) {
+      int lo = 0, hi = a.nb;                     // invariant: edges[lo] <= x < edges[hi] (or x == edges[nb])
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (x >= edges[mid]) lo = mid; else hi = mid; }
+      b = lo;
+    }
+    sum += logp[b];
+    ++cnt;
+  }
+  a.out_sum[idx] = sum;
+  a.out_cnt[idx] = cnt;
+}
+
 }  // namespace ig

@@ -5,8 +5,9 @@ from .map_features import compute_distance_to_road_edge, tensorize_polylines
 from .placement_features import compute_num_placement, compute_distance_placement
 from .compute_metrics import (MetricFeatures, ObjectTrajectories, ScenarioRollouts, compute_metric_features,
                               format_rollouts, get_scenario_id_int_tensor, output_to_rollouts)
+from .scores import compute_scenario_metrics, window_log_likelihood
 
-__all__ = ['MetricFeatures', 'ObjectTrajectories', 'ScenarioRollouts', 'compute_metric_features', 'format_rollouts',
+__all__ = ['compute_scenario_metrics', 'window_log_likelihood', 'MetricFeatures', 'ObjectTrajectories', 'ScenarioRollouts', 'compute_metric_features', 'format_rollouts',
            'get_scenario_id_int_tensor', 'output_to_rollouts', 'compute_distance_to_nearest_object', 'compute_time_to_collision_with_object_in_front',
            'compute_kinematic_features', 'compute_num_placement', 'compute_distance_placement',
            'compute_distance_to_road_edge', 'tensorize_polylines']

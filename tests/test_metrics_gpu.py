@@ -215,3 +215,50 @@ def test_rollout_to_features_end_to_end():
     assert torch.equal(cpu(f.num_placement)[0], nb[2:]) and torch.equal(cpu(f.num_removement)[0], ne[2:])
     pickled = format_rollouts(data, [out], to_cpu=True)
     assert not pickled['pred_traj'].is_cuda
+
+
+def test_window_log_likelihood_vs_oracle():
+    """the fused scoring kernel against the oracle's bin lookup and windows: values on the bin edges, outside the range and
+    NaN included; sums to 2e-6 relative (fp32 summation order), counts exact"""
+    from oracle import scores_oracle as so
+    from infgen_amd.metrics import window_log_likelihood
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    n, T, nb, lo, hi = 37, 203, 11, -12.0, 12.0
+    v = (torch.rand(n, T, generator=g) * 30 - 15)
+    edges = torch.linspace(lo, hi, nb + 1).float()
+    v[0, :12] = edges
+    v[1, :5] = torch.tensor([float('nan'), float('inf'), -float('inf'), hi, lo])
+    ok = torch.rand(n, T, generator=g) > 0.2
+    ok[2] = False
+    logp = torch.log_softmax(torch.randn(nb, generator=g), 0)
+    ll = so.windows(logp[so.bin_index(v, lo, hi, nb)], 80, 5)
+    w = so.windows(ok, 80, 5)
+    s, c = window_log_likelihood(v.to(dev), ok.to(dev), lo, hi, nb, logp.to(dev), 80, 5)
+    assert torch.equal(c.cpu().long(), w.sum(-1))
+    want = torch.where(w, ll, torch.zeros_like(ll)).sum(-1)
+    assert float((s.cpu() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    s2, c2 = window_log_likelihood(v.to(dev), None, lo, hi, nb, logp.to(dev), 16, 1)
+    assert int(c2.min()) == 16 and float((s2.cpu() - so.windows(logp[so.bin_index(v, lo, hi, nb)], 16, 1).sum(-1)).abs().max()) <= 1e-4
+
+
+def test_scenario_scores_golden():
+    """rollouts dict -> features -> likelihoods and meta-metric, all on the GPU, against the REFERENCE's
+    compute_scenario_metrics_for_bundle (tests/golden/make_golden_scores.py).  2e-3: a feature value that differs in its
+    last bits from the reference's can fall into the neighbouring histogram bin"""
+    from infgen_amd.metrics import compute_metric_features, compute_scenario_metrics, output_to_rollouts
+    from test_oracle_golden import _scores_fixture
+    dev = torch.device('cuda:0')
+    z, scen, fields, cfg, logp = _scores_fixture()
+    scen = {k: v.to(dev) if torch.is_tensor(v) else v for k, v in scen.items()}
+    feats = compute_metric_features(output_to_rollouts(scen)[0].joint_scenes[0])
+    config = {f: dict(histogram=dict(min_val=c[0], max_val=c[1], num_bins=int(c[2])), metametric_weight=c[4]) for f, c in cfg.items()}
+    out, long = compute_scenario_metrics(config, logp, feats)
+    for f in fields:
+        assert abs(out[f + '_likelihood'] - float(z['m_' + f + '_likelihood'])) <= 2e-3, f
+        want = z['l_' + f + '_likelihood']
+        assert long[f + '_likelihood'].shape == want.shape, f
+        assert np.abs(long[f + '_likelihood'].cpu().numpy() - want).max() <= 5e-3, f
+    assert abs(out['metametric'] - float(z['metametric'])) <= 1e-3
+    assert np.abs(long['metametric'].cpu().numpy() - z['l_metametric']).max() <= 2e-3
+    assert abs(out['simulated_collision_rate'] - float(z['simulated_collision_rate'])) <= 1e-6

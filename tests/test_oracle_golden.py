@@ -220,3 +220,46 @@ def test_fetch_enterings_oracle_matches_reference():
     assert len(o) == 9
     for k, v in o.items():
         assert np.array_equal(v.numpy(), z['out_' + k]), k
+
+
+def _scores_fixture():
+    """inputs of tests/golden/make_golden_scores.py -> (rollouts dict, feature dict by the oracle functions, logp, cfg, z)"""
+    import os
+    from conftest import GOLDEN
+    from oracle import metrics_oracle as mo, scores_oracle as so
+    z = np.load(os.path.join(GOLDEN, 'scores_platoon_n20_r200.npz'))
+    scen = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('in_')}
+    scen['av_id'] = int(z['av_id'])
+    fields = [str(f) for f in z['fields']]
+    cfg = {f: z['config'][i].tolist() for i, f in enumerate(fields)}
+    logp = {f: torch.from_numpy(z['logp_' + f]) for f in fields}
+    return z, scen, fields, cfg, logp
+
+
+def test_scoring_oracle_matches_reference():
+    """oracle/scores_oracle.scenario_scores on features from the oracle functions vs the reference's
+    compute_scenario_metrics_for_bundle with its own metric_config.textproto (25 windows of a 200-step rollout): the eleven
+    likelihoods, their per-window values, the meta-metric and the collision rate"""
+    from oracle import metrics_oracle as mo, scores_oracle as so
+    z, scen, fields, cfg, logp = _scores_fixture()
+    x, y = scen['pred_traj'][:, 0, :, 0], scen['pred_traj'][:, 0, :, 1]
+    N, T = x.shape
+    hd, valid = scen['pred_head'][:, 0], scen['pred_valid'][:, 0]
+    ln, wd = scen['pred_shape'][:, 0, 0:1].expand(N, T), scen['pred_shape'][:, 0, 1:2].expand(N, T)
+    every = torch.ones(N, dtype=torch.bool)
+    feat = dict(valid=valid[:, 11:])
+    for k, a in zip(so.KINEMATIC, mo.kinematic_features(x, y, torch.zeros_like(x), hd, 0.1)):
+        feat[k] = a[:, 11:]
+    d = mo.distance_to_nearest_object(x, y, ln, wd, hd, valid, every)[:, 11:]
+    feat.update(distance_to_nearest_object=d, collision_per_step=d < 0,
+                time_to_collision=mo.time_to_collision(x, y, ln, wd, hd, valid, every, 0.1)[:, 11:])
+    pos3 = torch.cat([scen['token_pos'][:, 0], torch.zeros(N, scen['token_pos'].shape[2], 1)], -1)
+    nb, ne, db, de = mo.placement_features(pos3, scen['pred_state'][:, 0], N - 1)
+    feat.update(num_placement=nb[None, 2:], num_removement=ne[None, 2:], distance_placement=db[:, 2:], distance_removement=de[:, 2:])
+    scal, long = so.scenario_scores(feat, logp, cfg)
+    for f in fields:
+        assert abs(scal[f] - float(z['m_' + f + '_likelihood'])) <= 1e-7, f
+        assert torch.equal(long[f], torch.from_numpy(z['l_' + f + '_likelihood'])), f
+    assert abs(scal['metametric'] - float(z['metametric'])) <= 1e-6
+    assert torch.equal(long['metametric'], torch.from_numpy(z['l_metametric']))
+    assert abs(scal['simulated_collision_rate'] - float(z['simulated_collision_rate'])) <= 1e-7
