@@ -281,6 +281,10 @@ int infgen_placement_features(const float* x, const float* y, const float* z, co
 int infgen_active_row_groups(const int* n_agents, int S, int A_cap, int margin, int* groups, int* n_groups, void* stream);
 int infgen_set_row_groups(const int* groups, const int* n_groups, int rows);
 
+/* Arithmetic of the split GEMM kernels: 3 (default) = fp16 three-term split, fp32 accuracy; 1 = the hi x hi term only = plain
+ * fp16 operands with fp32 accumulation (reduced precision, for BASELINE config C5; outside the 1e-3 parity bar). */
+int infgen_set_gemm_terms(int terms);
+
 /* ---- optional profiling (bench.py roofline leg; process-global, off by default) ----
  * HIP events are recorded on the launch stream around every launch of the kernels selected by
  * `mask` (bit = INFGEN_KID_*).  infgen_prof_collect synchronises the device, returns the summed

@@ -66,6 +66,7 @@ SYMBOLS = {
     'infgen_distance_to_nearest_object': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_float, _p, _p, _p]),
     'infgen_kinematic_features': (_i, [_p, _p, _p, _p, _i, _i, C.c_float, _p, _p, _p, _p, _p]),
     'infgen_time_to_collision': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    'infgen_set_gemm_terms': (_i, [_i]),
     'infgen_active_row_groups': (_i, [_p, _i, _i, _i, _p, _p, _p]),
     'infgen_set_row_groups': (_i, [_p, _p, _i]),
     'infgen_fetch_enterings': (_i, [_p] * 5 + [_i] * 3 + [_p, _i, _f, _f, _i, _i] + [_p] * 9 + [_i, _p, _i, _p, _p]),

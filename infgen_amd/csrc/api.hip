@@ -173,6 +173,16 @@ extern "C" int infgen_layernorm(const float* X, int rows, const float* gamma, co
   return check_launch("infgen_layernorm");
 }
 
+// 3 (default): fp16 three-term split = fp32 accuracy; 1: only the hi x hi product of the same packed operands, i.e. plain fp16
+// arithmetic (11 bits per operand) in the split kernels - the reduced-precision mode for BASELINE config C5 ("bf16"), which
+// forfeits the 1e-3 logits bar.  Governs k_fourier_h, k_attn_h, k_mlpemb_h, k_heads_h.
+static int g_gemm_terms = 3;
+extern "C" int infgen_set_gemm_terms(int terms) {
+  if (terms != 1 && terms != 3) return fail("infgen_set_gemm_terms", "terms must be 3 (split, fp32 accuracy) or 1 (fp16)");
+  g_gemm_terms = terms;
+  return 0;
+}
+
 static int g_fourier_mode = 1;   // 1: fp16 three-term split (k_fourier_h), 0: fp32-input MFMA (k_fourier)
 extern "C" int infgen_set_fourier_mode(int mode) {
   if (mode != 0 && mode != 1) return fail("infgen_set_fourier_mode", "mode must be 0 (fp32 MFMA) or 1 (fp16 split)");
@@ -195,7 +205,8 @@ extern "C" int infgen_fourier_embed(const float* raw, int n, const int* count_de
     int grid = ceil_div(e_cap, 128);     // 128-row tiles (8 waves x 16 rows), persistent
     if (grid > 256) grid = 256;          // one workgroup per CU (fourier_h.hip explains why)
     ProfScope _ps(INFGEN_KID_FOURIER, stream);
-    hipLaunchKernelGGL(k_fourier_h, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    if (g_gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h<1>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_fourier_h<3>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
   }
   return check_launch("infgen_fourier_embed");
 }
@@ -238,11 +249,12 @@ static void launch_attn_h(const AttnHArgs& a_in, void* stream) {
   if (waves != 8) {
     int grid = ceil_div(a.rows, 64);
     if (grid > 512) grid = 512;          // two workgroups per CU, persistent over the 64-row tiles beyond that
-    hipLaunchKernelGGL(k_attn_h<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    if (g_gemm_terms == 1) hipLaunchKernelGGL((k_attn_h<4, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_attn_h<4, 3>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   } else {
     int grid = ceil_div(a.rows, 128);
     if (grid > 256) grid = 256;
-    hipLaunchKernelGGL(k_attn_h<8>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((k_attn_h<8, 3>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
   }
 }
 
@@ -476,7 +488,8 @@ extern "C" int infgen_heads(const float* X, int rows, const float* tok_pack, con
     if (attn_split(rows)) {
       int grid = ceil_div(rows, 64);
       if (grid > 512) grid = 512;
-      hipLaunchKernelGGL(k_heads_h, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+      if (g_gemm_terms == 1) hipLaunchKernelGGL(k_heads_h<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL(k_heads_h<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     } else {
       hipLaunchKernelGGL(k_heads, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a);
     } }
@@ -570,7 +583,8 @@ extern "C" int infgen_raw_feature(const InfgenRollout* r, int col, void* stream)
     int grid = ceil_div(rows, 64);
     if (grid > 512) grid = 512;
     { ProfScope _ps(INFGEN_KID_LINEAR, stream, (double)rows * (512 + 128 + 128) * 128.0);
-      hipLaunchKernelGGL(k_mlpemb_h, dim3(grid), dim3(256), 0, (hipStream_t)stream, m); }
+      if (g_gemm_terms == 1) hipLaunchKernelGGL(k_mlpemb_h<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m);
+      else hipLaunchKernelGGL(k_mlpemb_h<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m); }
     return check_launch("infgen_raw_feature/fusion");
   }
   const int o2 = mlpemb_off2(512), o3 = mlpemb_off3(512);

@@ -55,7 +55,7 @@ __device__ __forceinline__ void scale_bias(f32x4 (&v)[8], float s, const float* 
   for (int t = 0; t < 8; ++t) v[t] = bias ? fma4(v[t], s4, lds4(bias + 16 * t + 4 * rg)) : v[t] * s4;
 }
 
-template <int WAVES>
+template <int WAVES, int TERMS>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnHArgs a) {
   constexpr int NTH = 64 * WAVES, TILE = 16 * WAVES;
   // 4 waves: three quarter buffers (59 KB with the vectors) and <= 256 registers -> two workgroups per CU;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnH
   auto take = [&]() { return qs.take(); };
   auto gemm_unit = [&](f32x4 (&acc)[8], const u32x4 (&Bh)[4], const u32x4 (&Bl)[4]) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) gemm_quarter(acc, take(), Bh[s], Bl[s], lane);
+    for (int s = 0; s < 4; ++s) gemm_quarter<TERMS>(acc, take(), Bh[s], Bl[s], lane);
   };
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -160,8 +160,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnH
               const v8h al = *reinterpret_cast<const v8h*>(Wl + ((hh * 4 + s) * 2 + 1) * 512 + lane * 8);
               const v8h vbh = __builtin_bit_cast(v8h, bh), vbl = __builtin_bit_cast(v8h, bl);
               acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, vbh, acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, vbl, acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, vbh, acc, 0, 0, 0);
+              if constexpr (TERMS == 3) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, vbl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, vbh, acc, 0, 0, 0);
+              }
             }
             const float sg = valid ? a.SIG[(size_t)row * H + h] : 0.f;
             const float4 bvr = *reinterpret_cast<const float4*>(Vt + VT_BVR + 16 * h + 4 * rg);
@@ -276,8 +278,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnH
                 const v4h al = *reinterpret_cast<const v4h*>(Wl + ((hh * 8 + ct) * 2 + 1) * 256 + lane * 4);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, vqh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, vql, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(al, vqh, acc, 0, 0, 0);
+                if constexpr (TERMS == 3) {
+                  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, vql, acc, 0, 0, 0);
+                  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(al, vqh, acc, 0, 0, 0);
+                }
                 if (urow)
                   *reinterpret_cast<float4*>(urow + (2 * hp + hh) * D + 16 * ct + 4 * rg) =
                       make_float4(acc[0] * cq, acc[1] * cq, acc[2] * cq, acc[3] * cq);
@@ -301,8 +305,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnH
   }
 }
 
-template __global__ void k_attn_h<4>(AttnHArgs);
-template __global__ void k_attn_h<8>(AttnHArgs);
+template __global__ void k_attn_h<4, 3>(AttnHArgs);
+template __global__ void k_attn_h<8, 3>(AttnHArgs);
+template __global__ void k_attn_h<4, 1>(AttnHArgs);
 
 // k_active_groups: the 16-row groups of the [S][A_cap] row layout that hold at least one row below n_agents[s] + margin
 // (margin = rows a decode step may append), in ascending order.  One workgroup of 1024 threads.

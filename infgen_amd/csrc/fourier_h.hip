@@ -74,6 +74,7 @@ __device__ __forceinline__ void sincos_fast(float z, float& s, float& c) {
   c = __uint_as_float(cv ^ ((((unsigned)qi + 1u) & 2u) << 30));
 }
 
+template <int TERMS>
 __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned short Wb[RING][QUARTER];    // 80 KB: also keeps the CU to ONE workgroup
   __shared__ __attribute__((aligned(16))) float Vt[FH_VEC_SIZE];
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < 4; ++s) gemm_quarter(acc1, take(), Bh[s], Bl[s], lane);
+      for (int s = 0; s < 4; ++s) gemm_quarter<TERMS>(acc1, take(), Bh[s], Bl[s], lane);
       {
         const float inv1 = Vt[FH_HDR + i];
 #pragma unroll
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
       ln_regs<true, true>(acc1, dv + FHD_G1, dv + FHD_BE1, rg);     // gamma/beta carry the activation prescale
       regs_to_frags(acc1, Bh, Bl);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) gemm_quarter(acc2, take(), Bh[s], Bl[s], lane);
+      for (int s = 0; s < 4; ++s) gemm_quarter<TERMS>(acc2, take(), Bh[s], Bl[s], lane);
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc3[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 4; ++s) gemm_quarter(acc3, take(), Bh[s], Bl[s], lane);
+    for (int s = 0; s < 4; ++s) gemm_quarter<TERMS>(acc3, take(), Bh[s], Bl[s], lane);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       acc3[t] = fma4(acc3[t], splat4(inv3), lds4(tail + FHT_B3 + 16 * t + 4 * rg));
@@ -178,5 +179,8 @@ __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
     }
   }
 }
+
+template __global__ void k_fourier_h<3>(FourierArgs);
+template __global__ void k_fourier_h<1>(FourierArgs);
 
 }  // namespace ig

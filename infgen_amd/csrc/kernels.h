@@ -319,9 +319,9 @@ struct MapGraphArgs {
 
 __global__ void k_linear(LinearArgs a);
 __global__ void k_fourier(FourierArgs a);
-__global__ void k_fourier_h(FourierArgs a);
+template <int TERMS> __global__ void k_fourier_h(FourierArgs a);
 __global__ void k_match_tokens(MatchTokensArgs a);   // token_kernels.hip
-__global__ void k_mlpemb_h(MlpEmbHArgs a);           // mlp_h.hip
+template <int TERMS> __global__ void k_mlpemb_h(MlpEmbHArgs a);           // mlp_h.hip
 __global__ void k_box_corners(NearestArgs a);        // metric_kernels.hip
 __global__ void k_nearest_distance(NearestArgs a);
 __global__ void k_kinematic(KinematicArgs a);
@@ -329,14 +329,14 @@ __global__ void k_ttc(TtcArgs a);
 __global__ void k_placement(PlacementArgs a);
 __global__ void k_window_loglik(WindowLoglikArgs a);
 __global__ void k_road_edge(RoadEdgeArgs a);
-__global__ void k_heads_h(HeadsArgs a);
+template <int TERMS> __global__ void k_heads_h(HeadsArgs a);
 __global__ void k_match_map_tokens(MatchMapArgs a);
 __global__ void k_tokenize_prep(TokenizeArgs a);
 __global__ void k_fetch_enterings(EnteringsArgs a);
 __global__ void k_pt_grid_cells(EnteringsArgs a);
 __global__ void k_tokenize_state(TokenizeArgs a);
 __global__ void k_active_groups(ActiveGroupsArgs a);
-template <int WAVES> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
+template <int WAVES, int TERMS> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);
 __global__ void k_edge_attn_fu(EdgeAttnArgs a);

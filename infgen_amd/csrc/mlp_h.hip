@@ -31,6 +31,7 @@ __device__ __forceinline__ void mh_scale_bias(f32x4 (&v)[8], float s, const floa
 
 constexpr int MH_NT = 256, MH_TILE = 64, MH_RING = 3;
 
+template <int TERMS>
 __global__ __launch_bounds__(MH_NT, 2) void k_mlpemb_h(MlpEmbHArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned short Wb[MH_RING][QUARTER];
   __shared__ __attribute__((aligned(16))) float Vt[16 + 7 * 128];      // hdr | b0 g0 be0 | b1 g1 be1 | b2
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(MH_NT, 2) void k_mlpemb_h(MlpEmbHArgs a) {
       f32x4 part[8];
       mh_zero(part);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) gemm_quarter(part, qs.take(), Bh[s], Bl[s], lane);
+      for (int s = 0; s < 4; ++s) gemm_quarter<TERMS>(part, qs.take(), Bh[s], Bl[s], lane);
 #pragma unroll
       for (int t = 0; t < 8; ++t) h[t] = fma4(part[t], splat4(inv), h[t]);
     }
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(MH_NT, 2) void k_mlpemb_h(MlpEmbHArgs a) {
       const float inv = frags_scaled(h, Bh, Bl) * Vt[1];
       mh_zero(h);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) gemm_quarter(h, qs.take(), Bh[s], Bl[s], lane);
+      for (int s = 0; s < 4; ++s) gemm_quarter<TERMS>(h, qs.take(), Bh[s], Bl[s], lane);
       mh_scale_bias(h, inv, Vt + 16 + 384, rg);
       ln_regs<true, true>(h, Vt + 16 + 512, Vt + 16 + 640, rg);
     }
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(MH_NT, 2) void k_mlpemb_h(MlpEmbHArgs a) {
       const float inv = frags_scaled(h, Bh, Bl) * Vt[2];
       mh_zero(h);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) gemm_quarter(h, qs.take(), Bh[s], Bl[s], lane);
+      for (int s = 0; s < 4; ++s) gemm_quarter<TERMS>(h, qs.take(), Bh[s], Bl[s], lane);
       mh_scale_bias(h, inv, Vt + 16 + 768, rg);
     }
     if (valid) {
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(MH_NT, 2) void k_mlpemb_h(MlpEmbHArgs a) {
   }
 }
 
+template <int TERMS>
 __global__ __launch_bounds__(MH_NT, 2) void k_heads_h(HeadsArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned short Wb[MH_RING][QUARTER];
   // token head: hdr | b0 g0 be0 ; state head: hdr | b0 g0 be0 | W3 [3][128] | b3 [3]
@@ -138,9 +140,9 @@ __global__ __launch_bounds__(MH_NT, 2) void k_heads_h(HeadsArgs a) {
     const float inv_x = frags_scaled(x, Bh, Bl);
     mh_zero(ht); mh_zero(hs);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) gemm_quarter(ht, qs.take(), Bh[s], Bl[s], lane);
+    for (int s = 0; s < 4; ++s) gemm_quarter<TERMS>(ht, qs.take(), Bh[s], Bl[s], lane);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) gemm_quarter(hs, qs.take(), Bh[s], Bl[s], lane);
+    for (int s = 0; s < 4; ++s) gemm_quarter<TERMS>(hs, qs.take(), Bh[s], Bl[s], lane);
     mh_scale_bias(ht, inv_x * Vt[0], Vt + 16, rg);
     ln_regs<true, true>(ht, Vt + 16 + 128, Vt + 16 + 256, rg);
     mh_scale_bias(hs, inv_x * VS[0], VS + 16, rg);
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(MH_NT, 2) void k_heads_h(HeadsArgs a) {
       f32x4 lg[8];
       mh_zero(lg);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) gemm_quarter(lg, qs.take(), Bh[s], Bl[s], lane);
+      for (int s = 0; s < 4; ++s) gemm_quarter<TERMS>(lg, qs.take(), Bh[s], Bl[s], lane);
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const int col = 128 * c + 16 * t + 4 * rg;
@@ -191,5 +193,10 @@ __global__ __launch_bounds__(MH_NT, 2) void k_heads_h(HeadsArgs a) {
     if (valid && rg == 0) a.next_token[row] = bidx;
   }
 }
+
+template __global__ void k_mlpemb_h<3>(MlpEmbHArgs);
+template __global__ void k_mlpemb_h<1>(MlpEmbHArgs);
+template __global__ void k_heads_h<3>(HeadsArgs);
+template __global__ void k_heads_h<1>(HeadsArgs);
 
 }  // namespace ig

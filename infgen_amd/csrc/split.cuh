@@ -49,23 +49,29 @@ __device__ __forceinline__ void stage_quarter(const unsigned short* __restrict__
 }
 
 // acc[t] += W[16 t .., this k-step] * B   (three MFMAs per feature tile; the two A fragments of tile t + 1 are
-// read from LDS while the MFMAs of tile t run)
+// read from LDS while the MFMAs of tile t run).  TERMS = 1 keeps only the hi x hi product: plain fp16 arithmetic
+// (11 significant bits per operand, truncated) at a third of the matrix work and half of the LDS reads - the reduced-
+// precision mode behind infgen_set_gemm_terms(1), never the default.
+template <int TERMS = 3>
 __device__ __forceinline__ void gemm_quarter(f32x4 (&acc)[8], const unsigned short* Wl, u32x4 Bh, u32x4 Bl, int lane) {
   const v8h bh = __builtin_bit_cast(v8h, Bh);
   const v8h bl = __builtin_bit_cast(v8h, Bl);
   const unsigned short* p = Wl + lane * 8;
   v8h ah = *reinterpret_cast<const v8h*>(p);
-  v8h al = *reinterpret_cast<const v8h*>(p + 512);
+  v8h al = ah;
+  if constexpr (TERMS == 3) al = *reinterpret_cast<const v8h*>(p + 512);
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     v8h nh = ah, nl = al;
     if (t + 1 < 8) {
       nh = *reinterpret_cast<const v8h*>(p + (t + 1) * 1024);
-      nl = *reinterpret_cast<const v8h*>(p + (t + 1) * 1024 + 512);
+      if constexpr (TERMS == 3) nl = *reinterpret_cast<const v8h*>(p + (t + 1) * 1024 + 512);
     }
     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[t], 0, 0, 0);
-    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[t], 0, 0, 0);
-    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[t], 0, 0, 0);
+    if constexpr (TERMS == 3) {
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[t], 0, 0, 0);
+    }
     ah = nh; al = nl;
   }
 }
