@@ -262,3 +262,43 @@ def test_scenario_scores_golden():
     assert abs(out['metametric'] - float(z['metametric'])) <= 1e-3
     assert np.abs(long['metametric'].cpu().numpy() - z['l_metametric']).max() <= 2e-3
     assert abs(out['simulated_collision_rate'] - float(z['simulated_collision_rate'])) <= 1e-6
+
+
+def test_widening_entries_edge_cases():
+    """empty and degenerate inputs of the widening entry points: no evaluated object, a single object (no partner: the
+    reference's 1e10 sentinel), one polyline of two points, all-invalid boxes, windows as long as the series, and the
+    C ABI's error returns for impossible sizes"""
+    from infgen_amd import _lib
+    from infgen_amd.metrics import (compute_distance_to_nearest_object, compute_distance_to_road_edge,
+                                    compute_kinematic_features, window_log_likelihood)
+    from oracle import metrics_oracle as mo
+    dev = torch.device('cuda:0')
+    lib = _lib.load()
+    T = 7
+    one = lambda v: torch.full((1, T), float(v), device=dev)
+    x = torch.arange(T, device=dev, dtype=torch.float32)[None] * 0.5
+    valid = torch.ones(1, T, dtype=torch.bool, device=dev)
+    none = torch.zeros(1, dtype=torch.bool, device=dev)
+    every = torch.ones(1, dtype=torch.bool, device=dev)
+    assert compute_distance_to_nearest_object(x, one(0), one(0), one(4), one(2), one(1.5), one(0), valid, none).shape == (0, T)
+    alone = compute_distance_to_nearest_object(x, one(0), one(0), one(4), one(2), one(1.5), one(0), valid, every)
+    want = mo.distance_to_nearest_object(x.cpu(), one(0).cpu(), one(4).cpu(), one(2).cpu(), one(0).cpu(), valid.cpu(), every.cpu())
+    assert torch.equal(alone.cpu(), want)
+    kin = compute_kinematic_features(x, one(0), one(0), one(0), 0.1)
+    assert torch.isnan(kin[0][:, 0]).all() and abs(float(kin[0][0, 3]) - 5.0) < 1e-4
+    road = [np.array([[0.0, -3.0, 0.0], [10.0, -3.0, 0.0]], np.float32)]
+    kw = dict(center_x=x, center_y=one(0), center_z=one(0), length=one(4), width=one(2), height=one(1.5), heading=one(0))
+    d = compute_distance_to_road_edge(valid=valid, evaluated_object_mask=every, road_edge_polylines=road, **kw)
+    assert abs(float(d[0, 2]) + 2.0) < 1e-5                       # left of a +x edge at y = -3: on the road, 2 m from it
+    d0 = compute_distance_to_road_edge(valid=~valid, evaluated_object_mask=every, road_edge_polylines=road, **kw)
+    assert (d0 == -1e10).all()
+    assert compute_distance_to_road_edge(valid=valid, evaluated_object_mask=none, road_edge_polylines=road, **kw).shape == (0, T)
+    logp = torch.log(torch.tensor([0.25, 0.75], device=dev))
+    s, c = window_log_likelihood(x, valid, 0.0, 4.0, 2, logp, T, 5)            # one window covering the whole series
+    assert s.shape == (1, 1) and int(c) == T
+    assert abs(float(s) - float(4 * logp[0] + 3 * logp[1])) < 1e-5             # 0, .5, 1, 1.5 | 2, 2.5, 3
+    p = _lib.ptr
+    assert lib.infgen_window_log_likelihood(p(x), None, 1, T, T + 1, 1, p(logp), p(logp), 2, p(s), p(c), None) != 0
+    assert lib.infgen_window_log_likelihood(p(x), None, 1, T, 2, 1, p(logp), p(logp), 65, p(s), p(c), None) != 0
+    assert lib.infgen_window_log_likelihood(p(x), None, 0, T, 2, 1, p(logp), p(logp), 2, p(s), p(c), None) == 0
+    assert b'num_bins' in lib.infgen_last_error()
