@@ -57,22 +57,28 @@ __device__ __forceinline__ void gemm_quarter(f32x4 (&acc)[8], const unsigned sho
   const v8h bh = __builtin_bit_cast(v8h, Bh);
   const v8h bl = __builtin_bit_cast(v8h, Bl);
   const unsigned short* p = Wl + lane * 8;
-  v8h ah = *reinterpret_cast<const v8h*>(p);
-  v8h al = ah;
-  if constexpr (TERMS == 3) al = *reinterpret_cast<const v8h*>(p + 512);
+  // Four feature tiles at a time: all their A fragments are requested from LDS first, then the products are issued term
+  // by term ACROSS the tiles, so that consecutive MFMAs never share an accumulator (a dependent MFMA waits ~40 cycles, and
+  // any instruction between two MFMAs on one accumulator costs another ~43).  The scheduling barriers keep hipcc from
+  // sinking each tile's ds_reads back in front of its own MFMAs, which serialises LDS latency and MFMA latency per tile.
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    v8h nh = ah, nl = al;
-    if (t + 1 < 8) {
-      nh = *reinterpret_cast<const v8h*>(p + (t + 1) * 1024);
-      if constexpr (TERMS == 3) nl = *reinterpret_cast<const v8h*>(p + (t + 1) * 1024 + 512);
+  for (int g = 0; g < 8; g += 4) {
+    v8h ah[4], al[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      ah[t] = *reinterpret_cast<const v8h*>(p + (g + t) * 1024);
+      if constexpr (TERMS == 3) al[t] = *reinterpret_cast<const v8h*>(p + (g + t) * 1024 + 512);
     }
-    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[g + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc[g + t], 0, 0, 0);
     if constexpr (TERMS == 3) {
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[g + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acc[g + t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[g + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc[g + t], 0, 0, 0);
     }
-    ah = nh; al = nl;
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
