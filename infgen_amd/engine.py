@@ -189,6 +189,12 @@ class Ops:
         _lib.check(self.lib.infgen_attn_post(_lib.ptr(x), rows, _lib.ptr(pack), _lib.ptr(agg), _lib.ptr(z),
                                              _lib.ptr(sig), int(has_pos), self.stream), 'infgen_attn_post')
 
+    def attn_post_pre(self, x, pack, agg, z, sig, next_pack, has_pos=True, q=None, u=None, k=None, v=None):
+        """the post part of one layer and the pre part (q / absorbed query / K / V) of the next in one launch"""
+        _lib.check(self.lib.infgen_attn_post_pre(_lib.ptr(x), x.shape[0], _lib.ptr(pack), _lib.ptr(agg), _lib.ptr(z),
+                                                 _lib.ptr(sig), int(has_pos), _lib.ptr(next_pack), _lib.ptr(q), _lib.ptr(u),
+                                                 _lib.ptr(k), _lib.ptr(v), self.stream), 'infgen_attn_post_pre')
+
     def attention_layer(self, x, pack, off, cnt, src, rhat, x_src=None, scratch=None, wide=None):
         """AttentionLayer.forward (layers.py:61-76) on CSR edges; in place on ``x``."""
         rows = x.shape[0]
@@ -611,19 +617,22 @@ class RolloutEngine:
             # the seed node
             XS = I['XS']
             XS.copy_(f_seed.expand(S, D))
+            # every post part also computes the query (and absorbed query) of the next sublayer
+            ops.attn_pre(XS, w.attn_occ2sa[0], q=I['QS'])
             for i in range(3):
-                ops.attn_pre(XS, w.attn_occ2sa[i], q=I['QS'])
                 ops.edge_attn(S, I['QS'], None, I['Kocc'][i], I['Vocc'][i], I['occ_off'], I['occ_cnt'], I['occ_src'], None,
                               I['AGGS'], None, I['SIGS'])
-                ops.attn_post(XS, w.attn_occ2sa[i], I['AGGS'], I['ZS'], I['SIGS'], has_pos=False)
-                ops.attn_pre(XS, w.attn_pt2sa[i], q=I['QS'], u=I['US'])
+                ops.attn_post_pre(XS, w.attn_occ2sa[i], I['AGGS'], I['ZS'], I['SIGS'], w.attn_pt2sa[i], has_pos=False,
+                                  q=I['QS'], u=I['US'])
                 ops.edge_attn(S, I['QS'], I['US'], I['mapK'][i], I['mapV'][i], I['em_s']['off'], I['em_s']['cnt'],
                               I['em_s']['src'], I['em_s']['rhat'], I['AGGS'], I['ZS'], I['SIGS'], wide=True)
-                ops.attn_post(XS, w.attn_pt2sa[i], I['AGGS'], I['ZS'], I['SIGS'])
-                ops.attn_pre(XS, w.attn_a2sa[i], q=I['QS'], u=I['US'])
+                ops.attn_post_pre(XS, w.attn_pt2sa[i], I['AGGS'], I['ZS'], I['SIGS'], w.attn_a2sa[i], q=I['QS'], u=I['US'])
                 ops.edge_attn(S, I['QS'], I['US'], I['Ksa'][i], I['Vsa'][i], I['ea_s']['off'], I['ea_s']['cnt'],
                               I['ea_s']['src'], I['ea_s']['rhat'], I['AGGS'], I['ZS'], I['SIGS'], wide=True)
-                ops.attn_post(XS, w.attn_a2sa[i], I['AGGS'], I['ZS'], I['SIGS'])
+                if i < 2:
+                    ops.attn_post_pre(XS, w.attn_a2sa[i], I['AGGS'], I['ZS'], I['SIGS'], w.attn_occ2sa[i + 1], q=I['QS'])
+                else:
+                    ops.attn_post(XS, w.attn_a2sa[i], I['AGGS'], I['ZS'], I['SIGS'])
             lg_state = ops.mlp_layer(XS, H['seed_state_predict_head'], 128, 2)
             lg_type = ops.mlp_layer(XS, H['seed_type_predict_head'], 128, 3)
             shape = ops.mlp_layer(XS, H['seed_shape_predict_head'], 128, 3)
@@ -662,15 +671,17 @@ class RolloutEngine:
                     self._edgeless(Xc, w.attn_a[i])
                 h_ready = True
             XN = self.X[I['new_row'].long().clamp(0, rows - 1)].contiguous()
+            ops.attn_pre(XN, w.attn_m[0], q=I['QS'], u=I['US'])
             for i in range(3):
-                ops.attn_pre(XN, w.attn_m[i], q=I['QS'], u=I['US'])
                 ops.edge_attn(S, I['QS'], I['US'], self.mapK[i], self.mapV[i], I['em_h']['off'], I['em_h']['cnt'],
                               I['em_h']['src'], I['em_h']['rhat'], I['AGGS'], I['ZS'], I['SIGS'])
-                ops.attn_post(XN, w.attn_m[i], I['AGGS'], I['ZS'], I['SIGS'])
-                ops.attn_pre(XN, w.attn_a[i], q=I['QS'], u=I['US'])
+                ops.attn_post_pre(XN, w.attn_m[i], I['AGGS'], I['ZS'], I['SIGS'], w.attn_a[i], q=I['QS'], u=I['US'])
                 ops.edge_attn(S, I['QS'], I['US'], I['Kh'][i], I['Vh'][i], I['ea_h']['off'], I['ea_h']['cnt'],
                               I['ea_h']['src'], I['ea_h']['rhat'], I['AGGS'], I['ZS'], I['SIGS'])
-                ops.attn_post(XN, w.attn_a[i], I['AGGS'], I['ZS'], I['SIGS'])
+                if i < 2:
+                    ops.attn_post_pre(XN, w.attn_a[i], I['AGGS'], I['ZS'], I['SIGS'], w.attn_m[i + 1], q=I['QS'], u=I['US'])
+                else:
+                    ops.attn_post(XN, w.attn_a[i], I['AGGS'], I['ZS'], I['SIGS'])
             n_head = int(360.0 / cfg.angle_interval)
             lg_heading = ops.mlp_layer(XN, H['seed_heading_rel_token_predict_head'], 128, n_head)
             offset = ops.mlp_layer(XN, H['seed_offset_xy_predict_head'], 128, 2)
