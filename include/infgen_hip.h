@@ -165,6 +165,8 @@ int infgen_map_graph(int S, int M_cap, const int* n_map, const float* pos, const
 int infgen_build_edges(const InfgenRollout* r, int c, int edgeless, void* stream);
 int infgen_integrate(const InfgenRollout* r, int t, void* stream);
 int infgen_raw_feature(const InfgenRollout* r, int col, void* stream);
+/* the same for the rows row_list[k] with row_mask[k] != 0 only (k < n; the rows a sub-loop iteration of the insertion appended) */
+int infgen_raw_feature_rows(const InfgenRollout* r, int col, const int* row_list, const int* row_mask, int n, void* stream);
 int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless, void* stream);
 int infgen_decode_step(const InfgenRollout* r, int t, void* stream);
 /* steps t0 .. t1-1 back to back (one host call per rollout) */

@@ -86,6 +86,7 @@ SYMBOLS = {
     'infgen_build_edges': (_i, [C.POINTER(Rollout), _i, _i, _p]),
     'infgen_integrate': (_i, [C.POINTER(Rollout), _i, _p]),
     'infgen_raw_feature': (_i, [C.POINTER(Rollout), _i, _p]),
+    'infgen_raw_feature_rows': (_i, [_p, _i, _p, _p, _i, _p]),
     'infgen_decode_layers': (_i, [C.POINTER(Rollout), _i, _i, _p]),
     'infgen_decode_step': (_i, [C.POINTER(Rollout), _i, _p]),
     'infgen_rollout_run': (_i, [C.POINTER(Rollout), _i, _i, _p]),

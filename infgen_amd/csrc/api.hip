@@ -573,6 +573,7 @@ extern "C" int infgen_raw_feature(const InfgenRollout* r, int col, void* stream)
   a.st = scene_of(r); a.col = col; a.tok_tab = r->tok_tab; a.token_size = r->token_size;
   a.grid_tab = r->grid_tab; a.grid_size = r->grid_size; a.state_emb = r->state_emb;
   a.cat_agent = r->cat_agent; a.cat_seed = r->cat_seed; a.raw2 = r->raw2; a.cat = r->cat; a.fus_in = r->fus_in;
+  a.row_list = nullptr; a.row_mask = nullptr; a.n_list = 0;
   { ProfScope _ps(INFGEN_KID_RAWFEAT, stream);
     hipLaunchKernelGGL(k_rawfeat_prep, dim3(ceil_div(rows * 32, NT)), dim3(NT), 0, (hipStream_t)stream, a); }
   RET_IF(check_launch("infgen_raw_feature/prep"));
@@ -595,6 +596,35 @@ extern "C" int infgen_raw_feature(const InfgenRollout* r, int col, void* stream)
   RET_IF(infgen_linear(r->tmp2, 128, nullptr, rows, 128, P + o3, 128, P + o3 + 16384, 128, nullptr, nullptr,
                        nullptr, nullptr, 0, r->X, 128, stream));
   return 0;
+}
+
+// the same for a few rows only (insertion: the rows appended in this sub-loop iteration): row_list[k] = row, used where
+// row_mask[k] != 0.  The first n rows of the scratch arrays raw2 / cat / fus_in / tmp1 / tmp2 hold the compact intermediate
+// results (every all-rows call rewrites them); X is updated at the listed rows only.
+extern "C" int infgen_raw_feature_rows(const InfgenRollout* r, int col, const int* row_list, const int* row_mask, int n,
+                                       void* stream) {
+  RET_IF(validate(r, "infgen_raw_feature_rows"));
+  if (n <= 0) return 0;
+  if (n > r->S * r->A_cap) return fail("infgen_raw_feature_rows", "more rows than the layout holds");
+  RawFeatArgs a;
+  a.st = scene_of(r); a.col = col; a.tok_tab = r->tok_tab; a.token_size = r->token_size;
+  a.grid_tab = r->grid_tab; a.grid_size = r->grid_size; a.state_emb = r->state_emb;
+  a.cat_agent = r->cat_agent; a.cat_seed = r->cat_seed; a.raw2 = r->raw2; a.cat = r->cat; a.fus_in = r->fus_in;
+  a.row_list = row_list; a.row_mask = row_mask; a.n_list = n;
+  { ProfScope _ps(INFGEN_KID_RAWFEAT, stream);
+    hipLaunchKernelGGL(k_rawfeat_prep, dim3(ceil_div(n * 32, NT)), dim3(NT), 0, (hipStream_t)stream, a); }
+  RET_IF(check_launch("infgen_raw_feature_rows/prep"));
+  RET_IF(infgen_fourier_embed(r->raw2, 2, nullptr, n, r->four_xa, r->cat, 128, r->fus_in + 128, 512, 0, stream));
+  const float* P = r->fusion_pack;
+  const int o2 = mlpemb_off2(512), o3 = mlpemb_off3(512);
+  RET_IF(infgen_linear(r->fus_in, 512, nullptr, n, 512, P, 128, P + 512 * 128, 128, nullptr, nullptr,
+                       P + 512 * 128 + 128, P + 512 * 128 + 256, 1, r->tmp1, 128, stream));
+  RET_IF(infgen_linear(r->tmp1, 128, nullptr, n, 128, P + o2, 128, P + o2 + 16384, 128, nullptr, nullptr,
+                       P + o2 + 16384 + 128, P + o2 + 16384 + 256, 1, r->tmp2, 128, stream));
+  RET_IF(infgen_linear(r->tmp2, 128, nullptr, n, 128, P + o3, 128, P + o3 + 16384, 128, nullptr, nullptr,
+                       nullptr, nullptr, 0, r->tmp1, 128, stream));
+  hipLaunchKernelGGL(k_scatter_rows, dim3(ceil_div(n * 32, NT)), dim3(NT), 0, (hipStream_t)stream, r->tmp1, row_list, row_mask, n, r->X);
+  return check_launch("infgen_raw_feature_rows/scatter");
 }
 
 extern "C" int infgen_sample_topk(const float* logits, int rows, int n, int k, const float* uniform, int* token,

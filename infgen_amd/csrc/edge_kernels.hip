@@ -659,9 +659,11 @@ __global__ __launch_bounds__(NT) void k_integrate(IntegrateArgs a) {
 __global__ __launch_bounds__(NT) void k_rawfeat_prep(RawFeatArgs a) {
   const SceneState& st = a.st;
   const int gid = blockIdx.x * NT + threadIdx.x;
-  const int row = gid >> 5, c4 = gid & 31;
+  const int slot = gid >> 5, c4 = gid & 31;
   const int rows = st.S * st.A_cap;
-  if (row >= rows) return;
+  if (slot >= (a.row_list ? a.n_list : rows)) return;
+  // row subset (insertion: the rows appended in this iteration): read row_list[slot], write the compact slot
+  const int row = a.row_list ? (a.row_mask[slot] ? a.row_list[slot] : 0) : slot;
   const int s = row / st.A_cap, ag = row % st.A_cap;
   const int j = a.col;
   const size_t i = sidx(st, s, j, ag);
@@ -682,11 +684,11 @@ __global__ __launch_bounds__(NT) void k_rawfeat_prep(RawFeatArgs a) {
       if (stj == ENTER) { mx = MOTION_GAP; my = MOTION_GAP; }
     }
     const float h = st.head[i];
-    *reinterpret_cast<float4*>(a.raw2 + 4 * (size_t)row) =
+    *reinterpret_cast<float4*>(a.raw2 + 4 * (size_t)slot) =
         make_float4(norm2(mx, my), angle_between(cosf(h), sinf(h), mx, my), 0.f, 0.f);
   }
   const float* catsrc = st.catflag[i] ? a.cat_agent + (size_t)row * D : a.cat_seed;
-  *reinterpret_cast<float4*>(a.cat + (size_t)row * D + 4 * c4) = *reinterpret_cast<const float4*>(catsrc + 4 * c4);
+  *reinterpret_cast<float4*>(a.cat + (size_t)slot * D + 4 * c4) = *reinterpret_cast<const float4*>(catsrc + 4 * c4);
   int tok = st.token[i];
   if (tok < 0) tok += a.token_size + 2;             // python negative indexing: -1 no_token, -2 bos
   const int ty = st.type[row];
@@ -695,10 +697,18 @@ __global__ __launch_bounds__(NT) void k_rawfeat_prep(RawFeatArgs a) {
   if (g < 0) g += a.grid_size + 1;                  // -1 -> invalid row
   const float* gsrc = a.grid_tab + (size_t)g * D;
   const float* ssrc = a.state_emb + (size_t)stj * D;
-  float* f = a.fus_in + (size_t)row * 512;
+  float* f = a.fus_in + (size_t)slot * 512;
   *reinterpret_cast<float4*>(f + 4 * c4) = *reinterpret_cast<const float4*>(tsrc + 4 * c4);
   *reinterpret_cast<float4*>(f + 256 + 4 * c4) = *reinterpret_cast<const float4*>(ssrc + 4 * c4);
   *reinterpret_cast<float4*>(f + 384 + 4 * c4) = *reinterpret_cast<const float4*>(gsrc + 4 * c4);
+}
+
+// dst[row_list[k]][:] = src[k][:] for the rows with row_mask[k] != 0 (128 floats per row, 32 threads per row)
+__global__ __launch_bounds__(NT) void k_scatter_rows(const float* src, const int* row_list, const int* row_mask, int n, float* dst) {
+  const int gid = blockIdx.x * NT + threadIdx.x;
+  const int k = gid >> 5, c4 = gid & 31;
+  if (k >= n || !row_mask[k]) return;
+  *reinterpret_cast<float4*>(dst + (size_t)row_list[k] * D + 4 * c4) = *reinterpret_cast<const float4*>(src + (size_t)k * D + 4 * c4);
 }
 
 

@@ -255,6 +255,7 @@ struct RawFeatArgs {
   float* raw2;                      // [rows][4]  (|mv|, angle, -, -)
   float* cat;                       // [rows][128]
   float* fus_in;                    // [rows][512]
+  const int* row_list; const int* row_mask; int n_list;   // optional: only these rows (row_mask[k] != 0), outputs compact at k
 };
 
 // edges into ONE query point per scene (insertion: the seed node at the ego pose, or a freshly
@@ -346,6 +347,7 @@ __global__ void k_heads(HeadsArgs a);
 __global__ void k_build_edges(BuildEdgesArgs a);
 __global__ void k_integrate(IntegrateArgs a);
 __global__ void k_rawfeat_prep(RawFeatArgs a);
+__global__ void k_scatter_rows(const float* src, const int* row_list, const int* row_mask, int n, float* dst);
 __global__ void k_map_graph(MapGraphArgs a);
 __global__ void k_point_edges(PointEdgesArgs a);
 __global__ void k_occupancy(OccupancyArgs a);

@@ -653,7 +653,7 @@ class RolloutEngine:
             shp = ops.mlp_embedding(I['new_shape'], w.shape_emb, 3)
             self.cat_agent[nr] = w.type_a_emb[self.atype.reshape(-1)[nr].long()] + shp[ins]
             I['shape_all'][nr] = I['new_shape'][ins]
-            _lib.check(lib.infgen_raw_feature(ctx, c, st), 'raw_feature')
+            _lib.check(lib.infgen_raw_feature_rows(ctx, c, _lib.ptr(I['new_row']), _lib.ptr(I['inserted']), S, st), 'raw_feature_rows')
             # heading stage: the new row attends agents / map tokens within 10 m through the motion layers 0..2
             new_local = (I['new_row'] - I['scene_base']).clamp_(0, self.A_cap - 1).contiguous()
             _lib.check(lib.infgen_point_edges(ctx, c, _lib.ptr(new_local), _lib.ptr(I['inserted']), 1, 3,
@@ -688,7 +688,7 @@ class RolloutEngine:
             _lib.check(lib.infgen_insert_finalize(ctx, c, float(cfg.angle_interval), _lib.ptr(I['inserted']),
                                                   _lib.ptr(I['new_row']), _lib.ptr(lg_heading), n_head, _lib.ptr(offset),
                                                   _lib.ptr(I['hv_ovr']), st), 'infgen_insert_finalize')
-            _lib.check(lib.infgen_raw_feature(ctx, c, st), 'raw_feature')
+            _lib.check(lib.infgen_raw_feature_rows(ctx, c, _lib.ptr(I['new_row']), _lib.ptr(I['inserted']), S, st), 'raw_feature_rows')
             prev_new = nr
 
     def _build_ctx(self):
