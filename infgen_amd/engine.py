@@ -536,7 +536,8 @@ class RolloutEngine:
             Ksa=[f(rows, D) for _ in range(3)], Vsa=[f(rows, D) for _ in range(3)],
             Kh=[f(rows, D) for _ in range(3)], Vh=[f(rows, D) for _ in range(3)],
             Xc=f(rows, D), AGG0=f(rows, D), Z0=f(rows, 8 * D), SIG0=f(rows, 8),
-            XS=f(S, D), QS=f(S, D), US=f(S, 8 * D), AGGS=f(S, D), ZS=f(S, 8 * D), SIGS=f(S, 8),
+            XS=f(2 * S, D), QS=f(2 * S, D), US=f(2 * S, 8 * D), AGGS=f(2 * S, D), ZS=f(2 * S, 8 * D), SIGS=f(2 * S, 8),
+            KN=f(2 * S, D), VN=f(2 * S, D),
             ea_s=ebuf(S * A_cap), em_s=ebuf(S * min(M_cap, 2048)), ea_h=ebuf(S * 24), em_h=ebuf(S * 128),
             occ_off=ar.clone(), occ_cnt=torch.ones(S, device=dev, dtype=torch.int32), occ_src=ar.clone(),
             active=i32(S), n_new=i32(S), inserted=i32(S), new_row=i32(S), new_cell=i32(S), new_shape=f(S, 3),
@@ -551,8 +552,9 @@ class RolloutEngine:
         return b
 
     def _edgeless(self, x, pack, has_pos=True):
+        # a row without edges has agg = z = sigma = 0: the positional part adds exactly nothing, so it is skipped
         I = self.ins
-        self.ops.attn_post(x, pack, I['AGG0'], I['Z0'], I['SIG0'], has_pos=has_pos)
+        self.ops.attn_post(x, pack, I['AGG0'], I['Z0'], I['SIG0'], has_pos=False)
 
     def _insert_step(self, t: int):
         """the insertion sub-loop of decode step t (reference agent_decoder.py:1773-2105).
@@ -596,43 +598,37 @@ class RolloutEngine:
                     self._edgeless(Xc, w.attn_pt2sa[i])
                     ops.attn_pre(Xc, w.attn_a2sa[i], k=I['Ksa'][i], v=I['Vsa'][i])
                     self._edgeless(Xc, w.attn_a2sa[i])
-            else:
-                xn = self.X[prev_new].contiguous()
-                kn, vn = torch.empty_like(xn), torch.empty_like(xn)
-                for i in range(3):
-                    self._edgeless(xn, w.attn_occ2sa[i], has_pos=False)
-                    self._edgeless(xn, w.attn_pt2sa[i])
-                    ops.attn_pre(xn, w.attn_a2sa[i], k=kn, v=vn)
-                    I['Ksa'][i][prev_new] = kn
-                    I['Vsa'][i][prev_new] = vn
-                    self._edgeless(xn, w.attn_a2sa[i])
-                if h_ready:
-                    xn = self.X[prev_new].contiguous()
-                    for i in range(3):
-                        self._edgeless(xn, w.attn_m[i])
-                        ops.attn_pre(xn, w.attn_a[i], k=kn, v=vn)
-                        I['Kh'][i][prev_new] = kn
-                        I['Vh'][i][prev_new] = vn
-                        self._edgeless(xn, w.attn_a[i])
-            # the seed node
-            XS = I['XS']
-            XS.copy_(f_seed.expand(S, D))
-            # every post part also computes the query (and absorbed query) of the next sublayer
-            ops.attn_pre(XS, w.attn_occ2sa[0], q=I['QS'])
+            # the seed node.  The rows appended by the previous iteration ("riders") pass the same sublayers edgelessly - their
+            # K/V feed the a2sa layers (A.6(a)) -, so they ride along in the same launches: rows [S, S + n) of the seed arrays,
+            # whose agg / z / sigma stay zero
+            n_r = 0 if prev_new is None else int(prev_new.numel())
+            R = S + n_r
+            XS, QS, US = I['XS'][:R], I['QS'][:R], I['US'][:R]
+            AGGS, ZS, SIGS, KN, VN = I['AGGS'][:R], I['ZS'][:R], I['SIGS'][:R], I['KN'][:R], I['VN'][:R]
+            XS[:S] = f_seed.expand(S, D)
+            if n_r:
+                XS[S:] = self.X[prev_new]
+                AGGS[S:].zero_(); ZS[S:].zero_(); SIGS[S:].zero_()
+            ops.attn_pre(XS, w.attn_occ2sa[0], q=QS)
             for i in range(3):
-                ops.edge_attn(S, I['QS'], None, I['Kocc'][i], I['Vocc'][i], I['occ_off'], I['occ_cnt'], I['occ_src'], None,
-                              I['AGGS'], None, I['SIGS'])
-                ops.attn_post_pre(XS, w.attn_occ2sa[i], I['AGGS'], I['ZS'], I['SIGS'], w.attn_pt2sa[i], has_pos=False,
-                                  q=I['QS'], u=I['US'])
-                ops.edge_attn(S, I['QS'], I['US'], I['mapK'][i], I['mapV'][i], I['em_s']['off'], I['em_s']['cnt'],
-                              I['em_s']['src'], I['em_s']['rhat'], I['AGGS'], I['ZS'], I['SIGS'], wide=True)
-                ops.attn_post_pre(XS, w.attn_pt2sa[i], I['AGGS'], I['ZS'], I['SIGS'], w.attn_a2sa[i], q=I['QS'], u=I['US'])
-                ops.edge_attn(S, I['QS'], I['US'], I['Ksa'][i], I['Vsa'][i], I['ea_s']['off'], I['ea_s']['cnt'],
-                              I['ea_s']['src'], I['ea_s']['rhat'], I['AGGS'], I['ZS'], I['SIGS'], wide=True)
+                ops.edge_attn(S, QS, None, I['Kocc'][i], I['Vocc'][i], I['occ_off'], I['occ_cnt'], I['occ_src'], None,
+                              AGGS, None, SIGS)
+                ops.attn_post_pre(XS, w.attn_occ2sa[i], AGGS, ZS, SIGS, w.attn_pt2sa[i], has_pos=False, q=QS, u=US)
+                ops.edge_attn(S, QS, US, I['mapK'][i], I['mapV'][i], I['em_s']['off'], I['em_s']['cnt'],
+                              I['em_s']['src'], I['em_s']['rhat'], AGGS, ZS, SIGS, wide=True)
+                ops.attn_post_pre(XS, w.attn_pt2sa[i], AGGS, ZS, SIGS, w.attn_a2sa[i], q=QS, u=US,
+                                  k=KN if n_r else None, v=VN if n_r else None)
+                if n_r:
+                    I['Ksa'][i][prev_new] = KN[S:]
+                    I['Vsa'][i][prev_new] = VN[S:]
+                ops.edge_attn(S, QS, US, I['Ksa'][i], I['Vsa'][i], I['ea_s']['off'], I['ea_s']['cnt'],
+                              I['ea_s']['src'], I['ea_s']['rhat'], AGGS, ZS, SIGS, wide=True)
                 if i < 2:
-                    ops.attn_post_pre(XS, w.attn_a2sa[i], I['AGGS'], I['ZS'], I['SIGS'], w.attn_occ2sa[i + 1], q=I['QS'])
+                    ops.attn_post_pre(XS, w.attn_a2sa[i], AGGS, ZS, SIGS, w.attn_occ2sa[i + 1], q=QS)
                 else:
-                    ops.attn_post(XS, w.attn_a2sa[i], I['AGGS'], I['ZS'], I['SIGS'])
+                    ops.attn_post(XS, w.attn_a2sa[i], AGGS, ZS, SIGS)
+            riders_h = prev_new if (n_r and h_ready) else None     # riders of the heading chain below (h_ready as of now)
+            XS = XS[:S]
             lg_state = ops.mlp_layer(XS, H['seed_state_predict_head'], 128, 2)
             lg_type = ops.mlp_layer(XS, H['seed_type_predict_head'], 128, 3)
             shape = ops.mlp_layer(XS, H['seed_shape_predict_head'], 128, 3)
@@ -670,18 +666,31 @@ class RolloutEngine:
                     ops.attn_pre(Xc, w.attn_a[i], k=I['Kh'][i], v=I['Vh'][i])
                     self._edgeless(Xc, w.attn_a[i])
                 h_ready = True
-            XN = self.X[I['new_row'].long().clamp(0, rows - 1)].contiguous()
-            ops.attn_pre(XN, w.attn_m[0], q=I['QS'], u=I['US'])
+            # the new rows (with edges) and, edgelessly, the riders whose K/V the agent sublayers below read
+            n_h = 0 if riders_h is None else int(riders_h.numel())
+            R = S + n_h
+            XN, QS, US = I['XS'][:R], I['QS'][:R], I['US'][:R]
+            AGGS, ZS, SIGS, KN, VN = I['AGGS'][:R], I['ZS'][:R], I['SIGS'][:R], I['KN'][:R], I['VN'][:R]
+            XN[:S] = self.X[I['new_row'].long().clamp(0, rows - 1)]
+            if n_h:
+                XN[S:] = self.X[riders_h]
+                AGGS[S:].zero_(); ZS[S:].zero_(); SIGS[S:].zero_()
+            ops.attn_pre(XN, w.attn_m[0], q=QS, u=US)
             for i in range(3):
-                ops.edge_attn(S, I['QS'], I['US'], self.mapK[i], self.mapV[i], I['em_h']['off'], I['em_h']['cnt'],
-                              I['em_h']['src'], I['em_h']['rhat'], I['AGGS'], I['ZS'], I['SIGS'])
-                ops.attn_post_pre(XN, w.attn_m[i], I['AGGS'], I['ZS'], I['SIGS'], w.attn_a[i], q=I['QS'], u=I['US'])
-                ops.edge_attn(S, I['QS'], I['US'], I['Kh'][i], I['Vh'][i], I['ea_h']['off'], I['ea_h']['cnt'],
-                              I['ea_h']['src'], I['ea_h']['rhat'], I['AGGS'], I['ZS'], I['SIGS'])
+                ops.edge_attn(S, QS, US, self.mapK[i], self.mapV[i], I['em_h']['off'], I['em_h']['cnt'],
+                              I['em_h']['src'], I['em_h']['rhat'], AGGS, ZS, SIGS)
+                ops.attn_post_pre(XN, w.attn_m[i], AGGS, ZS, SIGS, w.attn_a[i], q=QS, u=US,
+                                  k=KN if n_h else None, v=VN if n_h else None)
+                if n_h:
+                    I['Kh'][i][riders_h] = KN[S:]
+                    I['Vh'][i][riders_h] = VN[S:]
+                ops.edge_attn(S, QS, US, I['Kh'][i], I['Vh'][i], I['ea_h']['off'], I['ea_h']['cnt'],
+                              I['ea_h']['src'], I['ea_h']['rhat'], AGGS, ZS, SIGS)
                 if i < 2:
-                    ops.attn_post_pre(XN, w.attn_a[i], I['AGGS'], I['ZS'], I['SIGS'], w.attn_m[i + 1], q=I['QS'], u=I['US'])
+                    ops.attn_post_pre(XN, w.attn_a[i], AGGS, ZS, SIGS, w.attn_m[i + 1], q=QS, u=US)
                 else:
-                    ops.attn_post(XN, w.attn_a[i], I['AGGS'], I['ZS'], I['SIGS'])
+                    ops.attn_post(XN, w.attn_a[i], AGGS, ZS, SIGS)
+            XN = XN[:S]
             n_head = int(360.0 / cfg.angle_interval)
             lg_heading = ops.mlp_layer(XN, H['seed_heading_rel_token_predict_head'], 128, n_head)
             offset = ops.mlp_layer(XN, H['seed_offset_xy_predict_head'], 128, 2)
