@@ -282,6 +282,8 @@ int infgen_placement_features(const float* x, const float* y, const float* z, co
  * keep their previous contents. */
 int infgen_active_row_groups(const int* n_agents, int S, int A_cap, int margin, int* groups, int* n_groups, void* stream);
 int infgen_set_row_groups(const int* groups, const int* n_groups, int rows);
+/* the same bound for the edge kernel of those launches: n_agents [S], A_cap and the margin given to infgen_active_row_groups */
+int infgen_set_row_limits(const int* n_agents, int A_cap, int margin);
 
 /* Arithmetic of the split GEMM kernels: 3 (default) = fp16 three-term split, fp32 accuracy; 1 = the hi x hi term only = plain
  * fp16 operands with fp32 accumulation (reduced precision, for BASELINE config C5; outside the 1e-3 parity bar). */

@@ -69,6 +69,7 @@ SYMBOLS = {
     'infgen_set_gemm_terms': (_i, [_i]),
     'infgen_active_row_groups': (_i, [_p, _i, _i, _i, _p, _p, _p]),
     'infgen_set_row_groups': (_i, [_p, _p, _i]),
+    'infgen_set_row_limits': (_i, [_p, _i, _i]),
     'infgen_fetch_enterings': (_i, [_p] * 5 + [_i] * 3 + [_p, _i, _f, _f, _i, _i] + [_p] * 9 + [_i, _p, _i, _p, _p]),
     'infgen_tokenize_agent': (_i, [_p] * 9 + [_i] * 10 + [_p] * 8),
     'infgen_distance_to_road_edge': (_i, [_p] * 9 + [_i] * 4 + [_p, _p, _p, _i, _f, _p, _p]),

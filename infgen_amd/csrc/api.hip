@@ -229,8 +229,19 @@ static const int* g_groups = nullptr;
 static const int* g_n_groups = nullptr;
 static int g_group_rows = 0;
 
+static const int* g_limit_n_agents = nullptr;
+static int g_limit_A_cap = 0, g_limit_margin = 0;
+
 extern "C" int infgen_set_row_groups(const int* groups, const int* n_groups, int rows) {
   g_groups = groups; g_n_groups = n_groups; g_group_rows = groups ? rows : 0;
+  if (!groups) g_limit_n_agents = nullptr;
+  return 0;
+}
+
+// the same information for the edge kernel (one wave per row): n_agents [S] of the [S][A_cap] layout and the margin the group
+// list was built with; applies to launches over exactly the rows given to infgen_set_row_groups
+extern "C" int infgen_set_row_limits(const int* n_agents, int A_cap, int margin) {
+  g_limit_n_agents = n_agents; g_limit_A_cap = A_cap; g_limit_margin = margin;
   return 0;
 }
 
@@ -277,7 +288,10 @@ static int edge_attn_impl(int rows, const float* Q, const float* U, const float*
                           const int* off, const int* cnt, const int* src, const float* rhat,
                           float* AGG, float* Z, float* SIG, int wide, void* stream) {
   if (rows <= 0) return 0;
-  EdgeAttnArgs a{rows, Q, U, Ksrc, Vsrc, EdgeSet{off, cnt, src, rhat}, AGG, Z, SIG, nullptr};
+  EdgeAttnArgs a{rows, Q, U, Ksrc, Vsrc, EdgeSet{off, cnt, src, rhat}, AGG, Z, SIG, nullptr, nullptr, 0, 0};
+  if (g_limit_n_agents && g_groups && rows == g_group_rows && !wide) {
+    a.n_agents = g_limit_n_agents; a.A_cap = g_limit_A_cap; a.margin = g_limit_margin;
+  }
   { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
     if (wide) hipLaunchKernelGGL(k_edge_attn_wide, dim3(rows), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_edge_attn, dim3(ceil_div(rows, 4)), dim3(NT), 0, (hipStream_t)stream, a); }

@@ -162,6 +162,9 @@ __device__ __forceinline__ void edge_attn_write(const EdgeAttnArgs& a, int row, 
 __global__ __launch_bounds__(NT) void k_edge_attn(EdgeAttnArgs a) {
   const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave_id());
   if (row >= a.rows) return;
+  // padded layout (insertion): a row that holds no agent and cannot receive one in this step is left untouched, like in
+  // the node kernels that consume agg / z / sigma (k_active_groups)
+  if (a.n_agents && (row % a.A_cap) >= a.n_agents[row / a.A_cap] + a.margin + 15) return;
   const int E = __builtin_amdgcn_readfirstlane(a.es.cnt[row]);
   const int e_base = __builtin_amdgcn_readfirstlane(a.es.off[row]);
   const bool has_r = a.es.rhat != nullptr && a.U != nullptr;

@@ -52,6 +52,7 @@ struct EdgeAttnArgs {
   float* Z;                          // [rows][8][128] sum_e attn * rhat   (pos-emb layers only)
   float* SIG;                        // [rows][8]    sum_e attn
   const float* wkr;                  // k_edge_attn_fu: W'_kr [128][128] fp32 (row 16 h + d', column = rhat dim); U unused
+  const int* n_agents; int A_cap, margin;   // optional (k_edge_attn): rows at or beyond n_agents[s] + margin of their scene are skipped
 };
 
 struct AttnPostArgs {

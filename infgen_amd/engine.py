@@ -749,6 +749,7 @@ class RolloutEngine:
         try:
             if use_groups:
                 _lib.check(lib.infgen_set_row_groups(_lib.ptr(I['groups']), _lib.ptr(I['n_groups']), self.rows))
+                _lib.check(lib.infgen_set_row_limits(_lib.ptr(self.n_agents), self.A_cap, 10))
             for t in range(t0, t1):
                 if use_groups:
                     _lib.check(lib.infgen_active_row_groups(_lib.ptr(self.n_agents), self.S, self.A_cap, 10,
