@@ -117,6 +117,8 @@ def main():
     ap.add_argument('--agents', type=int, default=64)
     ap.add_argument('--map-tokens', type=int, default=1024)
     ap.add_argument('--insertion', action='store_true', help='scenario insertion on (configs/ours_long_term.yaml style)')
+    ap.add_argument('--insert-headroom', type=int, default=None,
+                    help='rows per scene reserved for inserted agents (default: min(10 per decode step, 96); A_cap <= 1024)')
     ap.add_argument('--rollout-steps', type=int, default=80, help='R = num_recurrent_steps_val (multiple of 5)')
     ap.add_argument('--streams', type=int, default=1, help='split the per-GPU batch over this many HIP streams')
     ap.add_argument('--gemm-terms', type=int, default=3, choices=(1, 3),
@@ -148,7 +150,8 @@ def main():
     w = engine.PackedWeights(sd, cfg, dev)
     ns = max(1, args.streams)
     per = (len(scenes) + ns - 1) // ns
-    engines = [engine.RolloutEngine(w, scenes[i * per:(i + 1) * per], vocab, map_vocab, grid, store_logits=False)
+    engines = [engine.RolloutEngine(w, scenes[i * per:(i + 1) * per], vocab, map_vocab, grid, store_logits=False,
+                                    insert_headroom=args.insert_headroom)
                for i in range(ns) if scenes[i * per:(i + 1) * per]]
     streams = [torch.cuda.Stream(device=dev) for _ in engines] if ns > 1 else [None]
 
@@ -273,7 +276,7 @@ def main():
                             f'insertion {"on" if args.insertion else "disabled"}, '
                             f'{args.scenes} scenes per GPU, one step = reset + map encoder + full rollout',
                 'scenes_per_gpu': args.scenes, 'streams': ns, 'gemm_terms': args.gemm_terms, 'agents': args.agents, 'map_tokens': args.map_tokens,
-                'decode_steps': cfg.num_decode_steps, 'insertion': bool(args.insertion), 'agents_inserted_last_rollout': inserted, 'agent_token_steps_per_s': agent_steps / dt / cfg.shift,
+                'decode_steps': cfg.num_decode_steps, 'insertion': bool(args.insertion), 'rows_per_scene': engines[0].A_cap, 'agents_inserted_last_rollout': inserted, 'agent_token_steps_per_s': agent_steps / dt / cfg.shift,
                 'parallelism': f'scenes sharded over {world} rank(s), no data-path collective',
             },
             'roofline': roof,

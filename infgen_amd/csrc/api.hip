@@ -105,7 +105,7 @@ extern "C" int infgen_layout_query(int what) {
     case INFGEN_Q_FOURIER_PACK_SIZE_N4: return fourier_pack_size(4);
     case INFGEN_Q_TILE_ROWS: return TR;
     case INFGEN_Q_EDGE_ATTN_CAP: return 1 << 30;   /* single-pass kernel: no per-row edge cap */
-    case INFGEN_Q_MAX_AGENTS: return 256;
+    case INFGEN_Q_MAX_AGENTS: return 1024;
     case INFGEN_Q_ABI_VERSION: return 1;
     case INFGEN_Q_SIZEOF_ROLLOUT: return (int)sizeof(InfgenRollout);
     default: return -1;
@@ -537,7 +537,7 @@ static EdgeBuf ebuf(const InfgenEdgeBuf& e) { return EdgeBuf{e.off, e.cnt, e.src
 
 static int validate(const InfgenRollout* r, const char* where) {
   if (!r) return fail(where, "null context");
-  if (r->A_cap > 256 || r->A_cap <= 0) return fail(where, "A_cap must be in 1..256");
+  if (r->A_cap > 1024 || r->A_cap <= 0) return fail(where, "A_cap must be in 1..1024");
   if (r->A_cap % 32) return fail(where, "A_cap must be a multiple of 32");
   if (r->num_layers <= 0 || r->num_layers > INFGEN_MAX_LAYERS) return fail(where, "bad num_layers");
   if (r->ring <= r->W) return fail(where, "ring must exceed the temporal window");
@@ -559,7 +559,8 @@ extern "C" int infgen_build_edges(const InfgenRollout* r, int c, int edgeless, v
   a.rows = r->S * r->A_cap; a.t = ebuf(r->et); a.m = ebuf(r->em); a.a = ebuf(r->ea);
   a.prof = (g_prof.mask & ((1u << INFGEN_KID_EDGE_ATTN) | (1u << INFGEN_KID_BUILD_EDGES))) ? g_prof.rows_dev : nullptr;
   { ProfScope _ps(INFGEN_KID_BUILD_EDGES, stream);
-    hipLaunchKernelGGL(k_build_edges, dim3(r->S), dim3(NT), 0, s, a); }
+    if (r->A_cap <= 256) hipLaunchKernelGGL(k_build_edges<256>, dim3(r->S), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_build_edges<1024>, dim3(r->S), dim3(1024), 0, s, a); }
   return check_launch("infgen_build_edges");
 }
 
@@ -572,7 +573,8 @@ extern "C" int infgen_integrate(const InfgenRollout* r, int t, void* stream) {
   a.vocab = r->vocab; a.token_size = r->token_size; a.grid_xy = r->grid_xy; a.grid_size = r->grid_size;
   a.pred_traj = r->pred_traj; a.pred_head = r->pred_head; a.pred_state = r->pred_state;
   { ProfScope _ps(INFGEN_KID_INTEGRATE, stream);
-    hipLaunchKernelGGL(k_integrate, dim3(r->S), dim3(NT), 0, (hipStream_t)stream, a); }
+    if (r->A_cap <= 256) hipLaunchKernelGGL(k_integrate<256>, dim3(r->S), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_integrate<1024>, dim3(r->S), dim3(1024), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_integrate");
 }
 

@@ -254,19 +254,20 @@ __device__ __forceinline__ size_t sidx(const SceneState& st, int s, int col, int
   return ((size_t)s * st.T + col) * st.A_cap + a;
 }
 
-// block-wide exclusive scan of one int per thread (256 threads); returns exclusive prefix, total in *tot
-__device__ __forceinline__ int block_excl_scan(int v, int* sh /*[NT+1]*/, int* tot) {
+// block-wide exclusive scan of one int per thread (BT threads); returns exclusive prefix, total in *tot
+template <int BT>
+__device__ __forceinline__ int block_excl_scan(int v, int* sh /*[BT+1]*/, int* tot) {
   const int t = threadIdx.x;
   sh[t] = v;
   __syncthreads();
-  for (int o = 1; o < NT; o <<= 1) {
+  for (int o = 1; o < BT; o <<= 1) {
     int x = (t >= o) ? sh[t - o] : 0;
     __syncthreads();
     sh[t] += x;
     __syncthreads();
   }
   const int incl = sh[t];
-  *tot = sh[NT - 1];
+  *tot = sh[BT - 1];
   __syncthreads();
   return incl - v;
 }
@@ -280,16 +281,17 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh /*[NT+1]*/, int* t
 // src holds the row index into the K/V source array of that edge type:
 //   temporal: (j % ring) * rows + row ; map: s * M_cap + m ; agent: s * A_cap + j
 // ------------------------------------------------------------------------------------------
-constexpr int MAXA = 256;     // max agents per scene handled by one workgroup pass
+// one thread per agent row of the scene: BT = 256 threads for A_cap <= 256, 1024 beyond (long rollouts with insertion)
 constexpr int MAP_LDS = 4096; // map-token positions staged in LDS by k_build_edges
 
-__global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
-  __shared__ float px[MAXA], py[MAXA], hd[MAXA], hc[MAXA], hs[MAXA];
-  __shared__ int stt[MAXA];
-  __shared__ unsigned char im[MAXA];
-  __shared__ int scan[NT + 1];
-  __shared__ int mapidx[MAXA * 5];
-  __shared__ int mapcnt[MAXA];
+template <int BT>
+__global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
+  __shared__ float px[BT], py[BT], hd[BT], hc[BT], hs[BT];
+  __shared__ int stt[BT];
+  __shared__ unsigned char im[BT];
+  __shared__ int scan[BT + 1];
+  __shared__ int mapidx[BT * 5];
+  __shared__ int mapcnt[BT];
   __shared__ int base_t, base_m, base_a;
   __shared__ __attribute__((aligned(8))) float2 mxy[MAP_LDS];
   const SceneState& st = a.st;
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
       cnt = __popc(ok_mask);
     }
     int tot;
-    const int excl = block_excl_scan(cnt, scan, &tot);
+    const int excl = block_excl_scan<BT>(cnt, scan, &tot);
     if (t == 0) { base_t = atomicAdd(a.t.total, tot); if (a.prof) atomicAdd(a.prof + 8, (unsigned long long)tot); }
     __syncthreads();
     if (t < st.A_cap) {
@@ -383,10 +385,10 @@ __global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
     const int lane = lane_id();
     const bool map_in_lds = M <= MAP_LDS;
     if (map_in_lds) {
-      for (int m = t; m < M; m += NT) mxy[m] = *reinterpret_cast<const float2*>(mp + 2 * m);
+      for (int m = t; m < M; m += BT) mxy[m] = *reinterpret_cast<const float2*>(mp + 2 * m);
       __syncthreads();
     }
-    for (int ag = wave_id(); ag < st.A_cap; ag += 4) {
+    for (int ag = wave_id(); ag < st.A_cap; ag += BT / 64) {
       int found = 0;
       if (ag < A && im[ag]) {
         const float ax = px[ag], ay = py[ag];
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
     __syncthreads();
     const int cnt = (t < st.A_cap) ? mapcnt[t] : 0;
     int tot;
-    const int excl = block_excl_scan(cnt, scan, &tot);
+    const int excl = block_excl_scan<BT>(cnt, scan, &tot);
     if (t == 0) { base_m = atomicAdd(a.m.total, tot); if (a.prof) atomicAdd(a.prof + 9, (unsigned long long)tot); }
     __syncthreads();
     if (t < st.A_cap) {
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
       }
     }
     int tot;
-    const int excl = block_excl_scan(cnt, scan, &tot);
+    const int excl = block_excl_scan<BT>(cnt, scan, &tot);
     if (t == 0) { base_a = atomicAdd(a.a.total, tot); if (a.prof) atomicAdd(a.prof + 10, (unsigned long long)tot); }
     __syncthreads();
     if (t < st.A_cap) {
@@ -476,6 +478,8 @@ __global__ __launch_bounds__(NT) void k_build_edges(BuildEdgesArgs a) {
     }
   }
 }
+template __global__ void k_build_edges<256>(BuildEdgesArgs);
+template __global__ void k_build_edges<1024>(BuildEdgesArgs);
 
 // ------------------------------------------------------------------------------------------
 // k_map_graph: radius_graph(pos, r, loop=False, max_num_neighbors=K) of the map tokens of each
@@ -561,13 +565,14 @@ __global__ __launch_bounds__(NT) void k_map_graph(MapGraphArgs a) {
 // One workgroup per scene.
 // ------------------------------------------------------------------------------------------
 constexpr int GRID_LDS = 2048;   // grid cells staged in LDS (1961 for the 150 m / 3 m / 75 m grid)
-__global__ __launch_bounds__(NT) void k_integrate(IntegrateArgs a) {
-  __shared__ float npx[MAXA], npy[MAXA], nth[MAXA];
-  __shared__ int nst[MAXA];
+template <int BT>
+__global__ __launch_bounds__(BT) void k_integrate(IntegrateArgs a) {
+  __shared__ float npx[BT], npy[BT], nth[BT];
+  __shared__ int nst[BT];
   __shared__ __attribute__((aligned(8))) float2 gxy[GRID_LDS];
   const bool grid_in_lds = a.grid_size <= GRID_LDS;
   if (grid_in_lds)
-    for (int g = threadIdx.x; g < a.grid_size; g += NT) gxy[g] = *reinterpret_cast<const float2*>(a.grid_xy + 2 * g);
+    for (int g = threadIdx.x; g < a.grid_size; g += BT) gxy[g] = *reinterpret_cast<const float2*>(a.grid_xy + 2 * g);
   const SceneState& st = a.st;
   const int s = blockIdx.x, t = threadIdx.x;
   const int A = st.n_agents[s];
@@ -616,7 +621,7 @@ __global__ __launch_bounds__(NT) void k_integrate(IntegrateArgs a) {
     const float phi = -(nth[av] - HALF_PI_F);
     const float cs = cosf(phi), sn = sinf(phi);
     const int lane = lane_id();
-    for (int ag = wave_id(); ag < A; ag += 4) {
+    for (int ag = wave_id(); ag < A; ag += BT / 64) {
       const float dx = npx[ag] - ex, dy = npy[ag] - ey;
       const float rx = dx * cs + dy * (-sn);
       const float ry = dx * sn + dy * cs;
@@ -652,6 +657,8 @@ __global__ __launch_bounds__(NT) void k_integrate(IntegrateArgs a) {
     }
   }
 }
+template __global__ void k_integrate<256>(IntegrateArgs);
+template __global__ void k_integrate<1024>(IntegrateArgs);
 
 // ------------------------------------------------------------------------------------------
 // k_rawfeat_prep: inputs of the raw per-column agent feature (reference agent_decoder.py:426-509,
@@ -789,8 +796,8 @@ __global__ __launch_bounds__(NT) void k_occupancy(OccupancyArgs a) {
   for (int g = threadIdx.x; g < a.grid_size; g += NT) o[g] = 0.f;
   __syncthreads();
   const int A = st.n_agents[s];
-  if (threadIdx.x < A) {
-    const int g = st.grid[sidx(st, s, a.c, threadIdx.x)];
+  for (int ag = threadIdx.x; ag < A; ag += NT) {
+    const int g = st.grid[sidx(st, s, a.c, ag)];
     if (g >= 0) o[g] = 1.f;
   }
 }

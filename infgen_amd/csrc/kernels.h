@@ -345,8 +345,8 @@ __global__ void k_edge_attn_fu(EdgeAttnArgs a);
 __global__ void k_edge_attn_wide(EdgeAttnArgs a);
 __global__ void k_attn_post(AttnPostArgs a);
 __global__ void k_heads(HeadsArgs a);
-__global__ void k_build_edges(BuildEdgesArgs a);
-__global__ void k_integrate(IntegrateArgs a);
+template <int BT> __global__ void k_build_edges(BuildEdgesArgs a);
+template <int BT> __global__ void k_integrate(IntegrateArgs a);
 __global__ void k_rawfeat_prep(RawFeatArgs a);
 __global__ void k_scatter_rows(const float* src, const int* row_list, const int* row_mask, int n, float* dst);
 __global__ void k_map_graph(MapGraphArgs a);

@@ -257,7 +257,7 @@ class RolloutEngine:
         head = 0
         if self.insertion:
             head = insert_headroom if insert_headroom is not None else min(10 * cfg.num_decode_steps, 96)
-        self.A_cap = A_cap = a_cap or min(_round_up(max(amax + head, 1), 32), 256)
+        self.A_cap = A_cap = a_cap or min(_round_up(max(amax + head, 1), 32), self.lib.infgen_layout_query(_lib.Q_MAX_AGENTS))
         self.M_cap = M_cap = m_cap or _round_up(max(mmax, 1), 32)
         assert amax <= A_cap <= self.lib.infgen_layout_query(_lib.Q_MAX_AGENTS) and A_cap % 32 == 0
         assert mmax <= M_cap

@@ -417,3 +417,30 @@ def test_reduced_precision_mode_stays_close():
     assert 1e-6 < err.max() <= 5e-3
     assert (half.argmax(-1) == full.argmax(-1)).mean() >= 0.99
     assert lib.infgen_set_gemm_terms(2) != 0
+
+
+def test_more_than_256_rows_per_scene():
+    """A_cap > 256 (long rollouts with insertion need the head-room): the per-scene kernels switch to 1024-thread workgroups.
+    (a) 320 agents against the CPU oracle; (b) the natural-insertion fixture with a 288-row layout reproduces the reference
+    fixture exactly like the 128-row layout does (same kernels, other workgroup size)"""
+    from infgen_amd import engine, synth
+    c = load_case('c1_a8_m128')
+    cfg = synth.standard_config(num_recurrent_steps_val=10)
+    sd = make_weights(seed=8, head_gain=64.0)
+    scene = synth.make_scene(43, 320, 512, cfg, half_extent=90.0, vocab=c['vocab'], grid=c['grid'], slip=0.2)
+    o, ref = _oracle_vs_engine(cfg, scene, sd, c)
+    assert o['pos_a'].shape[0] == 320
+    ci = load_case('ins_natural_a20_m256')
+    cfg_i = ci['cfg']
+    cfg_i.disable_insertion = False
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(ci['sd'], cfg_i, dev)
+    eng = engine.RolloutEngine(w, [ci['scene']], ci['vocab'], ci['map_vocab'], ci['grid'], store_logits=False, a_cap=288)
+    assert eng.A_cap == 288
+    eng.rollout()
+    out = eng.outputs()[0]
+    z = ci['z']
+    assert np.array_equal(out['next_token_idx'], z['next_token_idx'])
+    assert np.array_equal(out['next_state_idx'], z['next_state_idx'])
+    assert np.array_equal(out['agent_id'], z['agent_id'])
+    assert np.abs(out['pos_a'] - z['pos_a']).max() <= 1e-3
