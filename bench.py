@@ -276,7 +276,7 @@ def main():
                             f'insertion {"on" if args.insertion else "disabled"}, '
                             f'{args.scenes} scenes per GPU, one step = reset + map encoder + full rollout',
                 'scenes_per_gpu': args.scenes, 'streams': ns, 'gemm_terms': args.gemm_terms, 'agents': args.agents, 'map_tokens': args.map_tokens,
-                'decode_steps': cfg.num_decode_steps, 'insertion': bool(args.insertion), 'rows_per_scene': engines[0].A_cap, 'agents_inserted_last_rollout': inserted, 'agent_token_steps_per_s': agent_steps / dt / cfg.shift,
+                'decode_steps': cfg.num_decode_steps, 'insertion': bool(args.insertion), 'rows_per_scene': engines[0].A_cap, 'agents_inserted_last_rollout': inserted, 'scenes_at_row_cap': sum(e.scenes_at_row_cap() for e in engines), 'agent_token_steps_per_s': agent_steps / dt / cfg.shift,
                 'parallelism': f'scenes sharded over {world} rank(s), no data-path collective',
             },
             'roofline': roof,

@@ -761,6 +761,11 @@ class RolloutEngine:
         finally:
             _lib.check(lib.infgen_set_row_groups(None, None, 0))
 
+    def scenes_at_row_cap(self) -> int:
+        """scenes whose insertion head-room ran out (n_agents == A_cap): their later insertions were dropped - give the engine a
+        larger ``insert_headroom`` (A_cap <= 1024) to avoid that"""
+        return int((self.n_agents >= self.A_cap).sum().item()) if self.insertion else 0
+
     def step(self, t: int):
         _lib.check(self.lib.infgen_decode_step(C.byref(self._ctx), t, self.ops.stream), 'infgen_decode_step')
 

@@ -438,6 +438,7 @@ def test_more_than_256_rows_per_scene():
     eng = engine.RolloutEngine(w, [ci['scene']], ci['vocab'], ci['map_vocab'], ci['grid'], store_logits=False, a_cap=288)
     assert eng.A_cap == 288
     eng.rollout()
+    assert eng.scenes_at_row_cap() == 0
     out = eng.outputs()[0]
     z = ci['z']
     assert np.array_equal(out['next_token_idx'], z['next_token_idx'])
