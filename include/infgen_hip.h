@@ -30,11 +30,23 @@
  *                            (infgen/modules/agent_decoder.py:2123-2158)
  *   infgen_decode_step       one iteration of the rollout loop (infgen/modules/agent_decoder.py:1740-2301,
  *                            insertion disabled)
+ *   infgen_point_edges, infgen_occupancy, infgen_insert_decide, infgen_insert_finalize, infgen_raw_feature_rows
+ *                            the insertion sub-loop (infgen/modules/agent_decoder.py:1773-2105)
+ *
+ * and, around the path:
+ *
+ *   infgen_tokenize_agent, infgen_match_agent_tokens   TokenProcessor (infgen/datasets/preprocess.py:335-653)
+ *   infgen_match_map_tokens, infgen_fetch_enterings    InfGen.match_token_map / _fetch_enterings
+ *                                                      (infgen/model/infgen.py:918-984, 1008-1128)
+ *   infgen_distance_to_nearest_object, infgen_time_to_collision, infgen_kinematic_features,
+ *   infgen_distance_to_road_edge, infgen_placement_features   infgen/metrics/{interact,trajectory,map,placement}_features.py
+ *   infgen_window_log_likelihood                       the scoring of LongMetric (infgen/metrics/compute_metrics.py:845-878)
  *
  * Conventions: every pointer is a DEVICE pointer (fp32 / int32 / uint8) borrowed for the duration
  * of the call; outputs are pre-allocated by the caller; `stream` is a hipStream_t; nothing
- * synchronises with the host; no global state; functions return 0 on success or a negative code
- * and leave a message retrievable with infgen_last_error() (thread-local).
+ * synchronises with the host; functions return 0 on success or a negative code and leave a message
+ * retrievable with infgen_last_error() (thread-local).  The only process-wide state are the switches
+ * infgen_set_* (kernel choice, arithmetic, overlap, padded-row lists): they are read at launch time.
  */
 #ifndef INFGEN_HIP_H_
 #define INFGEN_HIP_H_
