@@ -445,3 +445,34 @@ def test_more_than_256_rows_per_scene():
     assert np.array_equal(out['next_state_idx'], z['next_state_idx'])
     assert np.array_equal(out['agent_id'], z['agent_id'])
     assert np.abs(out['pos_a'] - z['pos_a']).max() <= 1e-3
+
+
+def test_reference_internal_invariants_hold():
+    """the reference's own runtime asserts as properties of the device state after a batch rollout with insertion
+    (agent_decoder.py:1785-1789: the interact mask is exactly "state != invalid" on every processed column; :2351: an
+    invalid step has an all-zero position; :2033-2034: one row per initial or inserted agent)"""
+    from infgen_amd import engine, synth
+    from infgen_amd.synth import INVALID
+    c = load_case('ins_natural_a20_m256')
+    cfg = c['cfg']
+    cfg.disable_insertion = False
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], cfg, dev)
+    scenes = [synth.make_scene(8300 + i, a, m, cfg, ego_last=(i % 2 == 0), edge_cases=(i % 3 == 0 and a >= 8),
+                               vocab=c['vocab'], grid=c['grid'], slip=0.2)
+              for i, (a, m) in enumerate([(20, 256), (9, 100), (33, 300), (16, 128), (40, 256), (12, 64)])]
+    eng = engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=False)
+    eng.rollout()
+    outs = eng.outputs()
+    assert sum(o['num_inserted'] for o in outs) > 0
+    state = eng.state.cpu().numpy()          # [S][T][A_cap]
+    imask = eng.imask.cpu().numpy().astype(bool)
+    n = eng.n_agents.cpu().numpy()
+    for s, o in enumerate(outs):
+        A = int(n[s])
+        assert o['pos_a'].shape[0] == o['agent_id'].shape[0] == o['next_state_idx'].shape[0]
+        # decoded columns (the history columns carry the masks of the input scene, which synthetic edge cases decouple)
+        assert np.array_equal(imask[s, 2:, :A], state[s, 2:, :A] != INVALID)
+        assert not imask[s, :, A:].any()
+        inv = o['next_state_idx'] == INVALID
+        assert (o['pos_a'][inv] == 0).all() and (o['head_a'][inv] == 0).all()
