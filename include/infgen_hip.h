@@ -132,6 +132,16 @@ int infgen_linear(const float* X, int ldx, const int* gather, int rows, int K,
                   const float* Wp, int Np, const float* bias, int N,
                   const float* pre_g, const float* pre_b, const float* post_g, const float* post_b, int relu,
                   float* Y, int ldy, void* stream);
+
+/* n (<= 6) independent infgen_linear calls in one launch (the heads of the insertion sub-loop); fields as infgen_linear's
+ * arguments */
+typedef struct InfgenLinearDesc {
+  const float* X; int ldx; const int* gather; int rows; int K;
+  const float* Wp; int Np; const float* bias; int N;
+  const float* pre_g; const float* pre_b; const float* post_g; const float* post_b; int relu;
+  float* Y; int ldy;
+} InfgenLinearDesc;
+int infgen_linear_multi(const InfgenLinearDesc* desc, int n, void* stream);
 /* row-wise LayerNorm over 128 columns (torch.nn.LayerNorm, eps 1e-5); gamma == NULL: affine-free */
 int infgen_layernorm(const float* X, int rows, const float* gamma, const float* beta, float* Y, void* stream);
 int infgen_fourier_embed(const float* raw, int n_dims, const int* count_dev, int e_cap, const float* pack,

@@ -18,6 +18,14 @@ _i = C.c_int
 _f = C.c_float
 
 
+class LinearDesc(C.Structure):
+    """InfgenLinearDesc of include/infgen_hip.h"""
+    _fields_ = [('X', C.c_void_p), ('ldx', C.c_int), ('gather', C.c_void_p), ('rows', C.c_int), ('K', C.c_int),
+                ('Wp', C.c_void_p), ('Np', C.c_int), ('bias', C.c_void_p), ('N', C.c_int),
+                ('pre_g', C.c_void_p), ('pre_b', C.c_void_p), ('post_g', C.c_void_p), ('post_b', C.c_void_p), ('relu', C.c_int),
+                ('Y', C.c_void_p), ('ldy', C.c_int)]
+
+
 class EdgeBuf(C.Structure):
     _fields_ = [('off', _p), ('cnt', _p), ('src', _p), ('raw', _p), ('rhat', _p), ('total', _p),
                 ('cap', _i), ('_pad', _i)]
@@ -56,6 +64,7 @@ SYMBOLS = {
     'infgen_fourier_pack_offset': (_i, [C.c_char_p, _i, _i]),
     'infgen_last_error': (C.c_char_p, []),
     'infgen_linear': (_i, [_p, _i, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p]),
+    'infgen_linear_multi': (_i, [_p, _i, _p]),
     'infgen_layernorm': (_i, [_p, _i, _p, _p, _p, _p]),
     'infgen_fourier_embed': (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _p]),
     'infgen_set_fourier_mode': (_i, [_i]),

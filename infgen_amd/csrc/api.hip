@@ -167,6 +167,33 @@ extern "C" int infgen_linear(const float* X, int ldx, const int* gather, int row
   return check_launch("infgen_linear");
 }
 
+// n (<= 6) independent infgen_linear calls in one launch; desc[i] mirrors infgen_linear's arguments
+extern "C" int infgen_linear_multi(const InfgenLinearDesc* desc, int n, void* stream) {
+  if (n <= 0) return 0;
+  if (n > LINEAR_MULTI_MAX) return fail("infgen_linear_multi", "at most 6 descriptors");
+  LinearMultiArgs m;
+  int tiles = 0, gy = 1;
+  double flops = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const InfgenLinearDesc& d = desc[i];
+    if (d.rows <= 0) return fail("infgen_linear_multi", "empty descriptor");
+    if (d.Np % 32) return fail("infgen_linear_multi", "Np must be a multiple of 32");
+    if (d.K > 128 && d.Np > 128) return fail("infgen_linear_multi", "K > 128 requires N <= 128");
+    if ((d.pre_g && d.K != 128) || (d.post_g && (d.N != 128 || d.Np != 128)))
+      return fail("infgen_linear_multi", "LayerNorm prologue/epilogue needs K == 128 / N == 128");
+    m.d[i] = LinearArgs{d.X, d.ldx, d.gather, d.rows, d.K, ((d.K + 7) / 8) * 8, d.Wp, d.Np, d.bias, d.N, d.pre_g, d.pre_b,
+                        d.post_g, d.post_b, d.relu, d.Y, d.ldy};
+    tiles = tiles > ceil_div(d.rows, TR) ? tiles : ceil_div(d.rows, TR);
+    const int passes = ceil_div(d.Np, 128);
+    if (d.K <= 128 && !d.post_g && passes > gy) gy = passes;
+    flops += (double)d.rows * d.K * d.N;
+  }
+  if (tiles * gy > 2048) gy = 2048 / tiles > 0 ? 2048 / tiles : 1;
+  { ProfScope _ps(INFGEN_KID_LINEAR, stream, flops);
+    hipLaunchKernelGGL(k_linear_multi, dim3(tiles, gy, n), dim3(NT), 0, (hipStream_t)stream, m); }
+  return check_launch("infgen_linear_multi");
+}
+
 extern "C" int infgen_layernorm(const float* X, int rows, const float* gamma, const float* beta, float* Y, void* stream) {
   if (rows <= 0) return 0;
   hipLaunchKernelGGL(k_layernorm, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, X, rows, gamma, beta, Y);

@@ -9,7 +9,19 @@ namespace ig {
 // Used for everything off the per-step hot path (embedding tables, heads' first layers,
 // map K/V, fusion MLP) and as the reference implementation of the tile helpers in tests.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_linear(LinearArgs a) {
+__device__ __forceinline__ void linear_body(const LinearArgs& a);
+
+__global__ __launch_bounds__(NT) void k_linear(LinearArgs a) { linear_body(a); }
+
+// several independent Linear launches in one (the heads of the insertion sub-loop all read the same few rows):
+// blockIdx.z picks the descriptor
+__global__ __launch_bounds__(NT) void k_linear_multi(LinearMultiArgs m) {
+  const LinearArgs& a = m.d[blockIdx.z];
+  if ((int)blockIdx.x * TR >= a.rows) return;
+  linear_body(a);
+}
+
+__device__ __forceinline__ void linear_body(const LinearArgs& a) {
   __shared__ __attribute__((aligned(16))) float As[TR * LDT];
   __shared__ __attribute__((aligned(16))) float Os[TR * LDT];
   const int row0 = blockIdx.x * TR;
@@ -68,6 +80,7 @@ __global__ __launch_bounds__(NT) void k_linear(LinearArgs a) {
     return;
   }
   // K > 128: single pass of <= 128 output columns, accumulate over K chunks
+  if (blockIdx.y) return;
   const int n0 = 32 * w;
   f32x16 acc = zero16();
   for (int kc = 0; kc < a.K; kc += 128) {

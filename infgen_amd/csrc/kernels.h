@@ -14,6 +14,9 @@ struct LinearArgs {
   float* Y; int ldy;
 };
 
+constexpr int LINEAR_MULTI_MAX = 6;
+struct LinearMultiArgs { LinearArgs d[LINEAR_MULTI_MAX]; };
+
 struct FourierArgs {
   const float* raw;        // [E][4]
   int n;                   // continuous dims (2..4)
@@ -320,6 +323,7 @@ struct MapGraphArgs {
 };
 
 __global__ void k_linear(LinearArgs a);
+__global__ void k_linear_multi(LinearMultiArgs m);
 __global__ void k_fourier(FourierArgs a);
 template <int TERMS> __global__ void k_fourier_h(FourierArgs a);
 __global__ void k_match_tokens(MatchTokensArgs a);   // token_kernels.hip

@@ -159,6 +159,33 @@ class Ops:
         o_w3 = o_b0 + 3 * 128
         return self.linear(h, pack, o_w3, n_out, 128, bias_off=o_w3 + 128 * _round_up(n_out, 32), out=out)
 
+    def mlp_layers(self, x, packs_nout):
+        """several MLPLayers (``mlp_layer``) on the same input in two launches: all first Linears (+ LayerNorm, ReLU), then
+        all output Linears.  packs_nout: [(pack, n_out), ...] -> list of outputs"""
+        rows, n = x.shape[0], len(packs_nout)
+        hid = torch.empty(n, rows, 128, device=self.device, dtype=torch.float32)
+        outs = [torch.empty(rows, no, device=self.device, dtype=torch.float32) for _, no in packs_nout]
+        d1, d2 = (_lib.LinearDesc * n)(), (_lib.LinearDesc * n)()
+        o_b0, o_w3 = 128 * 128, 128 * 128 + 3 * 128
+        for i, (pack, no) in enumerate(packs_nout):
+            base = pack.data_ptr()
+            a = d1[i]
+            a.X, a.ldx, a.gather, a.rows, a.K = x.data_ptr(), x.stride(0), None, rows, 128
+            a.Wp, a.Np, a.bias, a.N = base, 128, base + 4 * o_b0, 128
+            a.pre_g = a.pre_b = None
+            a.post_g, a.post_b, a.relu = base + 4 * (o_b0 + 128), base + 4 * (o_b0 + 256), 1
+            a.Y, a.ldy = hid[i].data_ptr(), 128
+            b = d2[i]
+            npad = _round_up(no, 32)
+            b.X, b.ldx, b.gather, b.rows, b.K = hid[i].data_ptr(), 128, None, rows, 128
+            b.Wp, b.Np, b.bias, b.N = base + 4 * o_w3, npad, base + 4 * (o_w3 + 128 * npad), no
+            b.pre_g = b.pre_b = b.post_g = b.post_b = None
+            b.relu = 0
+            b.Y, b.ldy = outs[i].data_ptr(), outs[i].stride(0)
+        _lib.check(self.lib.infgen_linear_multi(d1, n, self.stream), 'infgen_linear_multi')
+        _lib.check(self.lib.infgen_linear_multi(d2, n, self.stream), 'infgen_linear_multi')
+        return outs
+
     def fourier(self, raw, n, pack, out, count_dev=None, rows=None, cat=None, normalize=False):
         rows = raw.shape[0] if rows is None else rows
         _lib.check(self.lib.infgen_fourier_embed(_lib.ptr(raw), n, _lib.ptr(count_dev), rows, _lib.ptr(pack),
@@ -629,10 +656,9 @@ class RolloutEngine:
                     ops.attn_post(XS, w.attn_a2sa[i], AGGS, ZS, SIGS)
             riders_h = prev_new if (n_r and h_ready) else None     # riders of the heading chain below (h_ready as of now)
             XS = XS[:S]
-            lg_state = ops.mlp_layer(XS, H['seed_state_predict_head'], 128, 2)
-            lg_type = ops.mlp_layer(XS, H['seed_type_predict_head'], 128, 3)
-            shape = ops.mlp_layer(XS, H['seed_shape_predict_head'], 128, 3)
-            lg_pos = ops.mlp_layer(XS, H['seed_pos_rel_token_predict_head'], 128, G)
+            lg_state, lg_type, shape, lg_pos = ops.mlp_layers(XS, [
+                (H['seed_state_predict_head'], 2), (H['seed_type_predict_head'], 3), (H['seed_shape_predict_head'], 3),
+                (H['seed_pos_rel_token_predict_head'], G)])
             _lib.check(lib.infgen_insert_decide(ctx, t, int(self.force_enter), 10, _lib.ptr(lg_state), _lib.ptr(lg_type),
                                                 _lib.ptr(shape), _lib.ptr(lg_pos), _lib.ptr(I['occ']), _lib.ptr(I['active']),
                                                 _lib.ptr(I['n_new']), _lib.ptr(I['inserted']), _lib.ptr(I['new_row']),
@@ -692,8 +718,8 @@ class RolloutEngine:
                     ops.attn_post(XN, w.attn_a[i], AGGS, ZS, SIGS)
             XN = XN[:S]
             n_head = int(360.0 / cfg.angle_interval)
-            lg_heading = ops.mlp_layer(XN, H['seed_heading_rel_token_predict_head'], 128, n_head)
-            offset = ops.mlp_layer(XN, H['seed_offset_xy_predict_head'], 128, 2)
+            lg_heading, offset = ops.mlp_layers(XN, [(H['seed_heading_rel_token_predict_head'], n_head),
+                                                     (H['seed_offset_xy_predict_head'], 2)])
             _lib.check(lib.infgen_insert_finalize(ctx, c, float(cfg.angle_interval), _lib.ptr(I['inserted']),
                                                   _lib.ptr(I['new_row']), _lib.ptr(lg_heading), n_head, _lib.ptr(offset),
                                                   _lib.ptr(I['hv_ovr']), st), 'infgen_insert_finalize')
