@@ -16,6 +16,7 @@ FIELDS = KINEMATIC + ('distance_to_nearest_object', 'collision_indication', 'tim
 
 def bin_index(v, lo, hi, nb):
     edges = torch.linspace(lo, hi, nb + 1).float()
+    v = v.contiguous()
     idx = torch.bucketize(v, edges, right=True) - 1            # edges[i] <= v < edges[i + 1]
     idx = torch.where(v == edges[-1], torch.full_like(idx, nb - 1), idx)      # the last bin is closed on the right
     return torch.where((idx < 0) | (idx >= nb) | torch.isnan(v), torch.zeros_like(idx), idx)
