@@ -80,6 +80,7 @@ class InfGen(nn.Module):
         self.val_close_loop = bool(_get(mc, 'val_close_loop', True))
         self.n_rollout_close_val = int(_get(mc, 'n_rollout_close_val', 1))
         self._mode = 'training'
+        self._long_metrics = None
         self._online_metric = self._save_validate_reuslts = self._plot_rollouts = False
         self.scenario_rollouts, self.scenario_features = [], []
 
@@ -222,7 +223,11 @@ class InfGen(nn.Module):
         if self._online_metric:
             sims = compute_metrics.output_to_rollouts(formatted)
             self.scenario_rollouts.extend(sims)
-            self.scenario_features.extend(compute_metrics.compute_metric_features(s.joint_scenes[0]) for s in sims)
+            feats = [compute_metrics.compute_metric_features(s.joint_scenes[0]) for s in sims]
+            self.scenario_features.extend(feats)
+            if self._long_metrics is not None:          # an infgen_amd.metrics.LongMetric the caller assigned (the reference
+                for f in feats:                         # builds its own from data/waymo_processed/log_features, :193-196)
+                    self._long_metrics.update(features=f)
         return rollout
 
     def on_validation_start(self):

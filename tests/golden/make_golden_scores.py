@@ -69,6 +69,15 @@ def main():
         sr = cm.output_to_rollouts(scen)[0]
         metrics, long = cm.compute_scenario_metrics_for_bundle(config, log_d, None, sr)
     out = {'in_' + k: v.numpy() for k, v in scen.items() if torch.is_tensor(v)}
+    out.update({'logv_' + k: torch.nan_to_num(v, nan=0.0).numpy() for k, v in vals.items()})     # what the distributions were built from
+    # LongMetric.compute (:1401-1447) for this one scenario: means = the scenario's values, then the bucket aggregation
+    with torch.no_grad():
+        buck = cm.LongMetric.aggregate_metrics_to_buckets(config, metrics)
+        long_mean = {k: cm._reduce_mean(v, dim=0) for k, v in long.items() if torch.is_tensor(v)}
+        buck_long = cm.LongMetric.aggregate_metrics_long_to_buckets(config, long_mean)
+    for k in ('realism_meta_metric', 'kinematic_metrics', 'interactive_metrics', 'map_based_metrics', 'placement_based_metrics'):
+        out['b_' + k] = np.float32(getattr(buck, k))
+        out['bl_' + k] = buck_long[k].numpy()
     out.update({'logp_' + k: d.logits.numpy()[0] for k, d in dists.items()})
     out.update({'m_' + k + '_likelihood': np.float32(getattr(metrics, k + '_likelihood')) for k in FIELDS})
     out.update({'l_' + k: v.numpy() for k, v in long.items() if torch.is_tensor(v)})

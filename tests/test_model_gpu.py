@@ -103,6 +103,19 @@ def test_infgen_validation_step_end_to_end(tmp_path):
     assert model.validation_step(data, 0) is None            # an existing rollouts file is skipped, like the reference
     feats = model.scenario_features[0]
     assert feats.linear_speed.shape == (A, 80) and feats.distance_to_nearest_object.is_cuda
+    # scoring: a LongMetric whose logged distributions come from this scenario's own features (stand-in for the WOMD logs)
+    from infgen_amd.metrics import LongMetric
+    hist = lambda lo, hi, nb: dict(histogram=dict(min_val=lo, max_val=hi, num_bins=nb, additive_smoothing_pseudocount=0.1),
+                                   bernoulli=dict(additive_smoothing_pseudocount=0.001), metametric_weight=0.1)
+    mcfg = dict(linear_speed=hist(0., 25., 10), linear_acceleration=hist(-12., 12., 11), angular_speed=hist(-0.628, 0.628, 11),
+                angular_acceleration=hist(-3.14, 3.14, 11), distance_to_nearest_object=hist(-5., 40., 10),
+                collision_indication=hist(-0.5, 0.5, 2), time_to_collision=hist(0., 5., 10), num_placement=hist(0., 10., 10),
+                num_removement=hist(0., 10., 10), distance_placement=hist(0., 100., 10), distance_removement=hist(0., 100., 10))
+    model._long_metrics = LongMetric('val_close_long', mcfg, log_features=feats)
+    model._long_metrics.update(features=feats)
+    res = model._long_metrics.compute()
+    assert res['val_close_long/wosac/scenario_counter'] == 1
+    assert 0.0 < res['val_close_long/wosac/kinematic_metrics'] <= 1.0 and 0.0 < res['val_close_long/wosac/realism_meta_metric'] <= 1.1
     # the rollout equals the CPU oracle's on the scene the device pre-processing produced
     scene = scene_from_data(data)
     tsd = {k: torch.from_numpy(v) for k, v in sd.items()}

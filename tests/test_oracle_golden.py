@@ -263,3 +263,34 @@ def test_scoring_oracle_matches_reference():
     assert abs(scal['metametric'] - float(z['metametric'])) <= 1e-6
     assert torch.equal(long['metametric'], torch.from_numpy(z['l_metametric']))
     assert abs(scal['simulated_collision_rate'] - float(z['simulated_collision_rate'])) <= 1e-7
+
+
+def test_long_metric_host_side_matches_reference():
+    """infgen_amd.metrics.long_metric (host side of LongMetric): the logged distributions equal the reference's
+    _get_log_distributions on the same logged values; update + compute of one scenario reproduce the reference's bucket
+    aggregation (tests/golden/make_golden_scores.py)"""
+    from infgen_amd.metrics.long_metric import LongMetric, get_log_distributions
+    z, scen, fields, cfg, logp = _scores_fixture()
+    config = {f: dict(histogram=dict(min_val=c[0], max_val=c[1], num_bins=int(c[2]), additive_smoothing_pseudocount=c[3]),
+                      bernoulli=dict(additive_smoothing_pseudocount=c[3]), metametric_weight=c[4]) for f, c in cfg.items()}
+    for f in fields:
+        d = get_log_distributions(f, config, torch.from_numpy(z['logv_' + f]))
+        assert torch.equal(d.logits[0], logp[f]), f
+    scal = {f + '_likelihood': float(z['m_' + f + '_likelihood']) for f in fields}
+    scal.update(metametric=float(z['metametric']), simulated_collision_rate=float(z['simulated_collision_rate']))
+    long = {f + '_likelihood': torch.from_numpy(z['l_' + f + '_likelihood']) for f in fields}
+    long['metametric'] = torch.from_numpy(z['l_metametric'])
+    lm = LongMetric('val', config, log_distributions=logp)
+    lm.update(metrics=(scal, long))
+    out = lm.compute()
+    assert out['val/wosac/scenario_counter'] == 1
+    for b in ('kinematic', 'interactive', 'map_based', 'placement_based'):
+        assert abs(out[f'val/wosac/{b}_metrics'] - float(z[f'b_{b}_metrics'])) <= 1e-6, b
+        assert np.abs(lm._last_long[f'{b}_metrics'].numpy() - z[f'bl_{b}_metrics']).max() <= 1e-6, b
+    assert abs(out['val/wosac/realism_meta_metric'] - float(z['b_realism_meta_metric'])) <= 1e-6
+    assert np.abs(lm._last_long['realism_meta_metric'].numpy() - z['bl_realism_meta_metric']).max() <= 1e-6
+    other = LongMetric('val', config, log_distributions=logp)
+    other.update(metrics=(scal, long))
+    lm.merge(other.state())
+    assert lm.compute()['val/wosac/scenario_counter'] == 2
+    assert abs(lm.compute()['val/wosac/kinematic_metrics'] - float(z['b_kinematic_metrics'])) <= 1e-6
