@@ -157,12 +157,15 @@ int infgen_attn_pre(const float* X, int rows, const float* pack, int use_src_ln,
 int infgen_edge_attn(int rows, const float* Q, const float* U, const float* Ksrc, const float* Vsrc,
                      const int* off, const int* cnt, const int* src, const float* rhat,
                      float* AGG, float* Z, float* SIG, void* stream);
-/* the same with the absorbed query u_h = q_h W'_kr,h computed inside the kernel (wkr = W'_kr [128][128] fp32, the
- * "h_wkr_plain" field of the layer pack): no U array.  infgen_decode_layers uses it after infgen_set_edge_fuse(1) (default 0: it trades 4 KB per row of
- * HBM traffic for a 64 KB per row LDS mat-vec and measured neutral). */
-int infgen_edge_attn_fused(int rows, const float* Q, const float* wkr, const float* Ksrc, const float* Vsrc,
+/* The edge side of one sublayer for 16-row tiles with the absorbed query U and the positional aggregate Z kept on chip
+ * (k_edge_fused): u = q W'_kr on the matrix pipe -> LDS, the edge loop of infgen_edge_attn, then
+ * AGG = sum_e a_e v_src + W'_vr z + b' sigma on the matrix pipe.  `pack` is the layer's attention pack; the node-side
+ * entries that follow take this AGG with has_pos = 0 and no Z / SIG / U.  Replaces, like infgen_edge_attn, the reference's
+ * MessagePassing.propagate + softmax (infgen/modules/layers.py:78-92,109).  infgen_set_edge_fuse(0) makes
+ * infgen_decode_layers fall back to the unfused sequence (default 1). */
+int infgen_edge_attn_fused(int rows, const float* Q, const float* pack, const float* Ksrc, const float* Vsrc,
                            const int* off, const int* cnt, const int* src, const float* rhat,
-                           float* AGG, float* Z, float* SIG, void* stream);
+                           float* AGG, void* stream);
 int infgen_set_edge_fuse(int mode);
 /* 1: infgen_decode_layers runs the Fourier embeddings of the map and agent edge sets on an internal side stream, overlapped
  * with the first temporal / map sublayers on the caller's stream (joined with events before their first use) */

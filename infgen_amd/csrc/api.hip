@@ -122,7 +122,7 @@ extern "C" int infgen_attn_pack_offset(const char* f) {
   F("ln_ffpre_g", AL_LN_FFPRE_G) F("ln_ffpre_b", AL_LN_FFPRE_B)
   F("w1", AL_W1) F("b1", AL_B1) F("w2", AL_W2) F("b2", AL_B2)
   F("ln_ffpost_g", AL_LN_FFPOST_G) F("ln_ffpost_b", AL_LN_FFPOST_B)
-  F("h_hdr", AH_HDR) F("h_pre", AH_PRE) F("h_post", AH_POST) F("h_wkr_plain", AH_WKR_PLAIN)
+  F("h_hdr", AH_HDR) F("h_pre", AH_PRE) F("h_post", AH_POST)
 #undef F
   return -1;
 }
@@ -325,24 +325,26 @@ static int edge_attn_impl(int rows, const float* Q, const float* U, const float*
   return check_launch("infgen_edge_attn");
 }
 
-static int g_edge_fuse = 0;      // 1: infgen_decode_layers computes the absorbed query inside the edge kernel (no U round trip);
-                                 // measured neutral (edge kernel +7 ms, node kernel -7 ms per 512-scene rollout), so off by default
+// 1 (default): infgen_decode_layers runs the edge side of every sublayer with k_edge_fused - the absorbed query U and the
+// positional aggregate Z of a 16-row tile stay on chip (LDS) and the node kernels run with has_pos = 0; 0: the unfused
+// sequence with U / Z / SIG in HBM (kept for comparison and used below 257 rows, where k_edge_attn_wide splits long edge lists)
+static int g_edge_fuse = 1;
 extern "C" int infgen_set_edge_fuse(int mode) {
-  if (mode != 0 && mode != 1) return fail("infgen_set_edge_fuse", "mode must be 0 or 1");
+  if (mode < 0 || mode > 2) return fail("infgen_set_edge_fuse", "mode must be 0 (off), 1 (from 257 rows) or 2 (always)");
   g_edge_fuse = mode;
   return 0;
 }
 
-extern "C" int infgen_edge_attn_fused(int rows, const float* Q, const float* wkr, const float* Ksrc, const float* Vsrc,
+extern "C" int infgen_edge_attn_fused(int rows, const float* Q, const float* pack, const float* Ksrc, const float* Vsrc,
                                       const int* off, const int* cnt, const int* src, const float* rhat,
-                                      float* AGG, float* Z, float* SIG, void* stream) {
+                                      float* AGG, void* stream) {
   if (rows <= 0) return 0;
-  if (!wkr || !rhat) return fail("infgen_edge_attn_fused", "needs W'_kr and rhat");
-  EdgeAttnArgs a{rows, Q, nullptr, Ksrc, Vsrc, EdgeSet{off, cnt, src, rhat}, AGG, Z, SIG, wkr};
-  int grid = ceil_div(rows, 12);
-  if (grid > 512) grid = 512;          // two 12-wave workgroups per CU, persistent over the rows
+  if (!pack || !rhat) return fail("infgen_edge_attn_fused", "needs the layer pack and rhat");
+  EdgeFusedArgs a{rows, Q, pack, Ksrc, Vsrc, EdgeSet{off, cnt, src, rhat}, AGG, nullptr, nullptr};
+  int grid = ceil_div(rows, 16);
+  if (g_groups && rows == g_group_rows) { a.groups = g_groups; a.n_groups = g_n_groups; }
   { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
-    hipLaunchKernelGGL(k_edge_attn_fu, dim3(grid), dim3(768), 0, (hipStream_t)stream, a); }
+    hipLaunchKernelGGL(k_edge_fused, dim3(grid), dim3(512), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_edge_attn_fused");
 }
 
@@ -720,33 +722,36 @@ extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless,
   const int L = r->num_layers;
   // prologue of the first (temporal) layer; every later layer's prologue is fused into the previous
   // layer's k_attn_post
-  const bool fuse = g_edge_fuse && rows > 256;      // the absorbed query is computed inside the edge kernel: no U round trip
+  const bool fuse = g_edge_fuse == 2 || (g_edge_fuse == 1 && rows > 256);      // U / Z / SIG stay on chip inside k_edge_fused
   float* U = fuse ? nullptr : r->U;
+  const float* Z = fuse ? nullptr : r->Z;
+  const float* SIG = fuse ? nullptr : r->SIG;
+  const int has_pos = fuse ? 0 : 1;                 // the fused edge kernel already added W'vr z + b' sigma to AGG
   auto edge = [&](const float* pack, const float* Ks, const float* Vs, const InfgenEdgeBuf& e) {
-    return fuse ? infgen_edge_attn_fused(rows, r->Q, pack + AH_WKR_PLAIN, Ks, Vs, e.off, e.cnt, e.src, e.rhat, r->AGG, r->Z, r->SIG, stream)
+    return fuse ? infgen_edge_attn_fused(rows, r->Q, pack, Ks, Vs, e.off, e.cnt, e.src, e.rhat, r->AGG, stream)
                 : infgen_edge_attn(rows, r->Q, r->U, Ks, Vs, e.off, e.cnt, e.src, e.rhat, r->AGG, r->Z, r->SIG, stream);
   };
   RET_IF(infgen_attn_pre(r->X, rows, r->attn_t[0], 0, r->Q, U, r->ringK[0] + slot, r->ringV[0] + slot, stream));
   for (int i = 0; i < L; ++i) {
     // temporal: K/V of this column sit in the ring (they are the cached layer inputs' projections)
     RET_IF(edge(r->attn_t[i], r->ringK[i], r->ringV[i], r->et));
-    RET_IF(infgen_attn_post_pre(r->X, rows, r->attn_t[i], r->AGG, r->Z, r->SIG, 1, r->attn_m[i], r->Q, U,
+    RET_IF(infgen_attn_post_pre(r->X, rows, r->attn_t[i], r->AGG, Z, SIG, has_pos, r->attn_m[i], r->Q, U,
                                 nullptr, nullptr, stream));
     // map -> agent (bipartite: K/V of the map tokens are per-scene constants)
     if (overlap && i == 0 && hipStreamWaitEvent((hipStream_t)stream, g_ev_m, 0) != hipSuccess)
       return fail("infgen_decode_layers", "join failed");
     RET_IF(edge(r->attn_m[i], r->mapK[i], r->mapV[i], r->em));
-    RET_IF(infgen_attn_post_pre(r->X, rows, r->attn_m[i], r->AGG, r->Z, r->SIG, 1, r->attn_a[i], r->Q, U,
+    RET_IF(infgen_attn_post_pre(r->X, rows, r->attn_m[i], r->AGG, Z, SIG, has_pos, r->attn_a[i], r->Q, U,
                                 r->Ka, r->Va, stream));
     // agent <-> agent
     if (overlap && i == 0 && hipStreamWaitEvent((hipStream_t)stream, g_ev_a, 0) != hipSuccess)
       return fail("infgen_decode_layers", "join failed");
     RET_IF(edge(r->attn_a[i], r->Ka, r->Va, r->ea));
     if (i + 1 < L) {
-      RET_IF(infgen_attn_post_pre(r->X, rows, r->attn_a[i], r->AGG, r->Z, r->SIG, 1, r->attn_t[i + 1], r->Q, U,
+      RET_IF(infgen_attn_post_pre(r->X, rows, r->attn_a[i], r->AGG, Z, SIG, has_pos, r->attn_t[i + 1], r->Q, U,
                                   r->ringK[i + 1] + slot, r->ringV[i + 1] + slot, stream));
     } else {
-      RET_IF(infgen_attn_post(r->X, rows, r->attn_a[i], r->AGG, r->Z, r->SIG, 1, stream));
+      RET_IF(infgen_attn_post(r->X, rows, r->attn_a[i], r->AGG, Z, SIG, has_pos, stream));
     }
   }
   return 0;

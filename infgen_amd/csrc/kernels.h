@@ -54,8 +54,20 @@ struct EdgeAttnArgs {
   float* AGG;                        // [rows][128]  sum_e attn * v_src
   float* Z;                          // [rows][8][128] sum_e attn * rhat   (pos-emb layers only)
   float* SIG;                        // [rows][8]    sum_e attn
-  const float* wkr;                  // k_edge_attn_fu: W'_kr [128][128] fp32 (row 16 h + d', column = rhat dim); U unused
+  const float* wkr;                  // unused (kept for layout stability)
   const int* n_agents; int A_cap, margin;   // optional (k_edge_attn): rows at or beyond n_agents[s] + margin of their scene are skipped
+};
+
+// k_edge_fused (edge_fused.hip): edge attention of a 16-row tile with the absorbed query and the positional aggregate kept on
+// chip: q in, agg' = sum_e a_e v_src + W'_vr z + b' sigma out (what k_attn_h / k_attn_post then take with has_pos = 0)
+struct EdgeFusedArgs {
+  int rows;
+  const float* Q;                    // [rows][128] scaled query
+  const float* pack;                 // AttnLayout of the layer (AH_HDR scales, W'_kr / W'_vr quarter-matrices, AL_BVR)
+  const float* Ksrc; const float* Vsrc;
+  EdgeSet es;                        // rhat must be present
+  float* AGG;                        // [rows][128] out
+  const int* groups; const int* n_groups;   // optional: the 16-row groups to process (k_active_groups)
 };
 
 struct AttnPostArgs {
@@ -345,7 +357,7 @@ __global__ void k_active_groups(ActiveGroupsArgs a);
 template <int WAVES, int TERMS> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);
-__global__ void k_edge_attn_fu(EdgeAttnArgs a);
+__global__ void k_edge_fused(EdgeFusedArgs a);        // edge_fused.hip
 __global__ void k_edge_attn_wide(EdgeAttnArgs a);
 __global__ void k_attn_post(AttnPostArgs a);
 __global__ void k_heads(HeadsArgs a);

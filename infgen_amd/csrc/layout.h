@@ -41,8 +41,7 @@ enum AttnLayout : int {
   AH_PRE = AH_HDR + 16,                  // 16 quarters: Wq (4)  W'kr (4: two heads each)  Wk (4)  Wv (4)
   AH_POST = AH_PRE + 16 * 4096,          // 52 quarters: W'vr (4: two heads each)  Wg[:, :128] (4)  Wg[:, 128:] (4)  Ws (4)
                                          //   Wo (4)  then per 128-wide FFN chunk c: W1[128c:128c+128, :] (4)  W2[:, 128c:128c+128] (4)
-  AH_WKR_PLAIN = AH_POST + 52 * 4096,   // [128][128] fp32: W'_kr row 16 h + d', column = rhat dim (k_edge_attn_fu keeps it in LDS)
-  AL_SIZE = AH_WKR_PLAIN + 16384,
+  AL_SIZE = AH_POST + 52 * 4096,
 };
 
 // ---- FourierEmbedding (layers.py:116-160), n input dims (n <= 4) -------------------------------

@@ -202,9 +202,8 @@ class Ops:
     def edge_attn(self, rows, q, u, ksrc, vsrc, off, cnt, src, rhat, agg, z, sig, wide=None):
         args = (rows, _lib.ptr(q), _lib.ptr(u), _lib.ptr(ksrc), _lib.ptr(vsrc), _lib.ptr(off), _lib.ptr(cnt),
                 _lib.ptr(src), _lib.ptr(rhat), _lib.ptr(agg), _lib.ptr(z), _lib.ptr(sig))
-        if wide == 'fused':         # u is the layer pack: the absorbed query is computed inside the kernel
-            wkr = u[self.lib.infgen_attn_pack_offset(b'h_wkr_plain'):]
-            _lib.check(self.lib.infgen_edge_attn_fused(rows, _lib.ptr(q), _lib.ptr(wkr), *args[3:], self.stream),
+        if wide == 'fused':         # u is the layer pack: U / Z / SIG stay on chip, agg already holds the positional part
+            _lib.check(self.lib.infgen_edge_attn_fused(rows, _lib.ptr(q), _lib.ptr(u), *args[3:10], self.stream),
                        'infgen_edge_attn_fused')
         elif wide is None:
             _lib.check(self.lib.infgen_edge_attn(*args, self.stream), 'infgen_edge_attn')
@@ -232,17 +231,18 @@ class Ops:
         agg = sc.get('AGG', torch.empty(rows, D, device=dev))
         z = sc.get('Z', torch.empty(rows, 8 * D, device=dev))
         sig = sc.get('SIG', torch.empty(rows, 8, device=dev))
+        fused = wide == 'fused'
         if x_src is None:
             k = torch.empty(rows, D, device=dev)
             v = torch.empty(rows, D, device=dev)
-            self.attn_pre(x, pack, q=q, u=u, k=k, v=v)
+            self.attn_pre(x, pack, q=q, u=None if fused else u, k=k, v=v)
         else:
             k = torch.empty(x_src.shape[0], D, device=dev)
             v = torch.empty(x_src.shape[0], D, device=dev)
             self.attn_pre(x_src, pack, use_src_ln=True, k=k, v=v)
-            self.attn_pre(x, pack, q=q, u=u)
-        self.edge_attn(rows, q, pack if wide == 'fused' else u, k, v, off, cnt, src, rhat, agg, z, sig, wide=wide)
-        self.attn_post(x, pack, agg, z, sig, has_pos=rhat is not None)
+            self.attn_pre(x, pack, q=q, u=None if fused else u)
+        self.edge_attn(rows, q, pack if fused else u, k, v, off, cnt, src, rhat, agg, z, sig, wide=wide)
+        self.attn_post(x, pack, agg, z, sig, has_pos=rhat is not None and not fused)
         return x
 
 
@@ -786,6 +786,10 @@ class RolloutEngine:
                 self.step(t)
         finally:
             _lib.check(lib.infgen_set_row_groups(None, None, 0))
+
+    def edge_totals(self):
+        """(temporal, map, agent) edge counts of the last decode step's edge sets (one host sync)"""
+        return tuple(int(self.edges[k]['total'].item()) for k in ('t', 'm', 'a'))
 
     def scenes_at_row_cap(self) -> int:
         """scenes whose insertion head-room ran out (n_agents == A_cap): their later insertions were dropped - give the engine a

@@ -100,8 +100,6 @@ def pack_attention_layer(sd, prefix: str, has_pos_emb: bool = True) -> np.ndarra
     assert halfs.size == 68 * 8192
     o = lib.infgen_attn_pack_offset(b'h_pre')
     out[o:o + halfs.size // 2] = halfs.view(np.float32)
-    o = lib.infgen_attn_pack_offset(b'h_wkr_plain')
-    out[o:o + 16384] = np.asarray(wkr_, np.float32).reshape(-1)      # row 16 h + d', column = rhat dim
     return out
 
 
