@@ -126,6 +126,7 @@ def main():
                          'for BASELINE config C5 (outside the 1e-3 parity bar)')
     ap.add_argument('--edge-fuse', type=int, default=-1, choices=(-1, 0, 1, 2),
                     help='infgen_set_edge_fuse: 1 (library default) k_edge_fused from 257 rows, 0 the unfused sequence with U / Z in HBM')
+    ap.add_argument('--edge-loop', type=int, default=-1, choices=(-1, 1, 2))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
@@ -194,6 +195,8 @@ def main():
     if args.overlap >= 0:
         _lib.check(lib.infgen_set_overlap(args.overlap))
     _lib.check(lib.infgen_set_gemm_terms(args.gemm_terms))
+    if args.edge_loop >= 0:
+        _lib.check(lib.infgen_set_edge_loop(args.edge_loop))
     if args.edge_fuse >= 0:
         _lib.check(lib.infgen_set_edge_fuse(args.edge_fuse))
     for _ in range(args.warmup):

@@ -70,6 +70,7 @@ SYMBOLS = {
     'infgen_set_fourier_mode': (_i, [_i]),
     'infgen_set_attn_mode': (_i, [_i]),
     'infgen_set_edge_fuse': (_i, [_i]),
+    'infgen_set_edge_loop': (_i, [_i]),
     'infgen_set_overlap': (_i, [_i]),
     'infgen_edge_attn_fused': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'infgen_distance_to_nearest_object': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_float, _p, _p, _p]),

@@ -335,6 +335,14 @@ extern "C" int infgen_set_edge_fuse(int mode) {
   return 0;
 }
 
+// 2 (default): the lazy-reference / log2-domain edge loop (edge_attn.cuh: edge_attn_wave2), 1: the first form
+static int g_edge_loop = 2;
+extern "C" int infgen_set_edge_loop(int v) {
+  if (v != 1 && v != 2) return fail("infgen_set_edge_loop", "variant must be 1 or 2");
+  g_edge_loop = v;
+  return 0;
+}
+
 extern "C" int infgen_edge_attn_fused(int rows, const float* Q, const float* pack, const float* Ksrc, const float* Vsrc,
                                       const int* off, const int* cnt, const int* src, const float* rhat,
                                       float* AGG, void* stream) {
@@ -344,7 +352,8 @@ extern "C" int infgen_edge_attn_fused(int rows, const float* Q, const float* pac
   int grid = ceil_div(rows, 16);
   if (g_groups && rows == g_group_rows) { a.groups = g_groups; a.n_groups = g_n_groups; }
   { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
-    hipLaunchKernelGGL(k_edge_fused, dim3(grid), dim3(512), 0, (hipStream_t)stream, a); }
+    if (g_edge_loop == 2) hipLaunchKernelGGL(k_edge_fused<2>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_edge_fused<1>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_edge_attn_fused");
 }
 

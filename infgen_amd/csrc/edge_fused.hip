@@ -26,6 +26,7 @@ constexpr int EF_NT = 64 * EF_WAVES;
 constexpr int EF_LDU = H * D + 4;           // row stride of the U / Z tile in floats (+4: conflict-free b128 column writes)
 constexpr int EF_LDA = D + 4;
 
+template <int LOOP>
 __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
   __shared__ __attribute__((aligned(16))) float UZ[EF_ROWS * EF_LDU];
   __shared__ __attribute__((aligned(16))) float AG[EF_ROWS * EF_LDA];
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
       const int E = live ? __builtin_amdgcn_readfirstlane(a.es.cnt[drow]) : 0;
       const int e_base = live ? __builtin_amdgcn_readfirstlane(a.es.off[drow]) : 0;
       AttnState st;
-      edge_attn_wave(ea, live ? drow : 0, E, e_base, 0, 1, has_r, st, uz);
+      if constexpr (LOOP == 2) edge_attn_wave2<3, true, true>(ea, live ? drow : 0, E, e_base, 0, 1, st, uz);
+      else edge_attn_wave(ea, live ? drow : 0, E, e_base, 0, 1, has_r, st, uz);
       const float inv = 1.0f / (st.lsum + 1e-16f);
       *reinterpret_cast<float2*>(AG + rl * EF_LDA + 2 * lane) = make_float2(st.ag.x * inv, st.ag.y * inv);
 #pragma unroll
@@ -157,5 +159,8 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
     }
   }
 }
+
+template __global__ void k_edge_fused<1>(EdgeFusedArgs);
+template __global__ void k_edge_fused<2>(EdgeFusedArgs);
 
 }  // namespace ig

@@ -357,7 +357,7 @@ __global__ void k_active_groups(ActiveGroupsArgs a);
 template <int WAVES, int TERMS> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);
-__global__ void k_edge_fused(EdgeFusedArgs a);        // edge_fused.hip
+template <int LOOP> __global__ void k_edge_fused(EdgeFusedArgs a);        // edge_fused.hip
 __global__ void k_edge_attn_wide(EdgeAttnArgs a);
 __global__ void k_attn_post(AttnPostArgs a);
 __global__ void k_heads(HeadsArgs a);
