@@ -126,7 +126,7 @@ def main():
                          'for BASELINE config C5 (outside the 1e-3 parity bar)')
     ap.add_argument('--edge-fuse', type=int, default=-1, choices=(-1, 0, 1, 2),
                     help='infgen_set_edge_fuse: 1 (library default) k_edge_fused from 257 rows, 0 the unfused sequence with U / Z in HBM')
-    ap.add_argument('--edge-loop', type=int, default=-1, choices=(-1, 1, 2))
+    ap.add_argument('--edge-loop', type=int, default=-1, choices=(-1, 4, 6, 8))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()

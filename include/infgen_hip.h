@@ -167,7 +167,7 @@ int infgen_edge_attn_fused(int rows, const float* Q, const float* pack, const fl
                            const int* off, const int* cnt, const int* src, const float* rhat,
                            float* AGG, void* stream);
 int infgen_set_edge_fuse(int mode);
-/* edge loop of k_edge_fused: 2 (default) lazy softmax reference + log2-domain scores, 1 the first form (comparison) */
+/* edges per trip of k_edge_fused's edge loop (their K / V / rhat rows are requested together): 4, 6 (default) or 8 */
 int infgen_set_edge_loop(int variant);
 /* 1: infgen_decode_layers runs the Fourier embeddings of the map and agent edge sets on an internal side stream, overlapped
  * with the first temporal / map sublayers on the caller's stream (joined with events before their first use) */

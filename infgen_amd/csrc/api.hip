@@ -335,26 +335,49 @@ extern "C" int infgen_set_edge_fuse(int mode) {
   return 0;
 }
 
-// 2 (default): the lazy-reference / log2-domain edge loop (edge_attn.cuh: edge_attn_wave2), 1: the first form
-static int g_edge_loop = 2;
+// edges per trip of k_edge_fused's edge loop (their K / V / rhat rows are requested together): 4, 6 (default) or 8
+static int g_edge_loop = 6;
 extern "C" int infgen_set_edge_loop(int v) {
-  if (v != 1 && v != 2) return fail("infgen_set_edge_loop", "variant must be 1 or 2");
+  if (v != 4 && v != 6 && v != 8) return fail("infgen_set_edge_loop", "edges per trip must be 4, 6 or 8");
   g_edge_loop = v;
   return 0;
+}
+
+// resident workgroups per CU the runtime reports for k_edge_fused<6> (diagnostics; tools/edge_probe.sh)
+extern "C" int infgen_edge_fused_occupancy(void) {
+  int n = -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_edge_fused<6>, 1024, 0) != hipSuccess) return -1;
+  return n;
+}
+
+static int edge_fused_launch(int rows, const float* Q, const float* pack, const float* Ksrc, const float* Vsrc,
+                             const int* off, const int* cnt, const int* src, const float* rhat, float* AGG,
+                             int rows_per_scene, int kv_once, void* stream) {
+  if (rows <= 0) return 0;
+  if (!pack || !rhat) return fail("infgen_edge_attn_fused", "needs the layer pack and rhat");
+  static const int dbg = getenv("INFGEN_EDGE_DBG") ? atoi(getenv("INFGEN_EDGE_DBG")) : 0;
+  static const int no_xcd = getenv("INFGEN_EDGE_NOXCD") ? atoi(getenv("INFGEN_EDGE_NOXCD")) : 0;
+  EdgeFusedArgs a{rows, Q, pack, Ksrc, Vsrc, EdgeSet{off, cnt, src, rhat}, AGG, nullptr, nullptr, dbg, 0, kv_once};
+  int grid = ceil_div(rows, 32);           // 32-row tiles (two 16-row groups); with a group list at most that many
+  if (g_groups && rows == g_group_rows) { a.groups = g_groups; a.n_groups = g_n_groups; }
+  else if (rows_per_scene > 32 && rows_per_scene % 32 == 0 && !(no_xcd & 1)) {
+    a.tiles_per_scene = rows_per_scene / 32;
+    const int grp = 8 * a.tiles_per_scene;
+    grid = ceil_div(grid, grp) * grp;
+  }
+  if (no_xcd & 2) a.kv_once = 0;
+  a.n_virtual = grid;
+  { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
+    if (g_edge_loop == 4) hipLaunchKernelGGL(k_edge_fused<4>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, a);
+    else if (g_edge_loop == 8) hipLaunchKernelGGL(k_edge_fused<8>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_edge_fused<6>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, a); }
+  return check_launch("infgen_edge_attn_fused");
 }
 
 extern "C" int infgen_edge_attn_fused(int rows, const float* Q, const float* pack, const float* Ksrc, const float* Vsrc,
                                       const int* off, const int* cnt, const int* src, const float* rhat,
                                       float* AGG, void* stream) {
-  if (rows <= 0) return 0;
-  if (!pack || !rhat) return fail("infgen_edge_attn_fused", "needs the layer pack and rhat");
-  EdgeFusedArgs a{rows, Q, pack, Ksrc, Vsrc, EdgeSet{off, cnt, src, rhat}, AGG, nullptr, nullptr};
-  int grid = ceil_div(rows, 16);
-  if (g_groups && rows == g_group_rows) { a.groups = g_groups; a.n_groups = g_n_groups; }
-  { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
-    if (g_edge_loop == 2) hipLaunchKernelGGL(k_edge_fused<2>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_edge_fused<1>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a); }
-  return check_launch("infgen_edge_attn_fused");
+  return edge_fused_launch(rows, Q, pack, Ksrc, Vsrc, off, cnt, src, rhat, AGG, 0, 0, stream);
 }
 
 // one wave per destination; few destinations (<= 256 rows) get the 8-wave split so that the chip is not idle
@@ -736,14 +759,14 @@ extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless,
   const float* Z = fuse ? nullptr : r->Z;
   const float* SIG = fuse ? nullptr : r->SIG;
   const int has_pos = fuse ? 0 : 1;                 // the fused edge kernel already added W'vr z + b' sigma to AGG
-  auto edge = [&](const float* pack, const float* Ks, const float* Vs, const InfgenEdgeBuf& e) {
-    return fuse ? infgen_edge_attn_fused(rows, r->Q, pack, Ks, Vs, e.off, e.cnt, e.src, e.rhat, r->AGG, stream)
+  auto edge = [&](const float* pack, const float* Ks, const float* Vs, const InfgenEdgeBuf& e, int kv_once = 0) {
+    return fuse ? edge_fused_launch(rows, r->Q, pack, Ks, Vs, e.off, e.cnt, e.src, e.rhat, r->AGG, r->A_cap, kv_once, stream)
                 : infgen_edge_attn(rows, r->Q, r->U, Ks, Vs, e.off, e.cnt, e.src, e.rhat, r->AGG, r->Z, r->SIG, stream);
   };
   RET_IF(infgen_attn_pre(r->X, rows, r->attn_t[0], 0, r->Q, U, r->ringK[0] + slot, r->ringV[0] + slot, stream));
   for (int i = 0; i < L; ++i) {
     // temporal: K/V of this column sit in the ring (they are the cached layer inputs' projections)
-    RET_IF(edge(r->attn_t[i], r->ringK[i], r->ringV[i], r->et));
+    RET_IF(edge(r->attn_t[i], r->ringK[i], r->ringV[i], r->et, 1));
     RET_IF(infgen_attn_post_pre(r->X, rows, r->attn_t[i], r->AGG, Z, SIG, has_pos, r->attn_m[i], r->Q, U,
                                 nullptr, nullptr, stream));
     // map -> agent (bipartite: K/V of the map tokens are per-scene constants)

@@ -2,16 +2,20 @@
 // destination rows with the absorbed relative-position query U and the aggregate Z kept on chip:
 //
 //   phase 1 (matrix pipe)  u_h = q_h W'_kr,h for the 16 rows, wave w = head w; three-term fp16 split like k_attn_h
-//                          (split.cuh), weights straight from L2 as MFMA A fragments; result -> LDS tile [16][8][128]
-//   phase 2 (vector pipe)  the per-destination edge loop of edge_attn.cuh (online softmax with PyG's + 1e-16, one wave
-//                          per row, rows dealt to the 8 waves through an LDS counter), u read from LDS, the normalised
+//                          (split.cuh), weights straight from L2 as MFMA A fragments; result -> LDS tile [16][8][128];
+//                          the q tile is parked in LDS as well (in the buffer that later takes agg)
+//   phase 2 (vector pipe)  the edge loop (edge_attn.cuh: EdgeAcc - online softmax with PyG's + 1e-16, one wave per row,
+//                          rows dealt to the 8 waves through an LDS counter), u and q read from LDS, the normalised
 //                          z_h = sum_e a_e,h rhat_e written back over the row's own u
 //   phase 3 (matrix pipe)  agg' = agg + W'_vr,h z_h + b'_h sigma_h, wave w = head w, -> global AGG
 //
 // so that the node kernel (k_attn_h / k_attn_post with has_pos = 0) never sees U, Z or SIG: per row and sublayer 512 B of
 // q in and 512 B of agg' out instead of 9.2 KB (4 KB of U in, 4 KB of Z out, q, agg, sigma) here and 8 KB in the node
 // kernel.  The GEMM arithmetic (operand scaling, split, order of the products) is that of k_attn_h's z-GEMM and u-GEMM.
-// 512 threads, 75 KB of LDS: two workgroups per CU.
+// 1024 threads = 16 waves = two 16-row halves (wave w: head w & 7 of half w >> 3 in the matrix phases), 150 KB of LDS: ONE
+// workgroup per CU.  Two co-resident 8-wave workgroups (75 KB each) were ~5 % faster and WRONG: the workgroup that is not the
+// first on its CU got single rows off by ~1e-2, different rows every run (tools/determinism_probe2.py; never with one
+// workgroup per CU - the "bring-up scare" of fourier_h.hip again, now reproducible: DESIGN.md section 5.1).
 #include "kernels.h"
 #include "layout.h"
 #include "tile.cuh"
@@ -20,29 +24,49 @@
 
 namespace ig {
 
-constexpr int EF_ROWS = 16;                 // destination rows per workgroup (the N dimension of the 16x16 MFMAs)
-constexpr int EF_WAVES = 8;                 // one per head in the matrix phases
+constexpr int EF_HALVES = 2;                // 16-row halves per workgroup (the N dimension of the 16x16 MFMAs is 16 rows)
+constexpr int EF_WAVES = 8 * EF_HALVES;     // one per (head, half) in the matrix phases
 constexpr int EF_NT = 64 * EF_WAVES;
+constexpr int EF_ROWS = 16 * EF_HALVES;
 constexpr int EF_LDU = H * D + 4;           // row stride of the U / Z tile in floats (+4: conflict-free b128 column writes)
 constexpr int EF_LDA = D + 4;
 
-template <int LOOP>
+// G = edges per trip of the edge loop (their K / V / rhat rows are requested together)
+template <int G>
 __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
   __shared__ __attribute__((aligned(16))) float UZ[EF_ROWS * EF_LDU];
-  __shared__ __attribute__((aligned(16))) float AG[EF_ROWS * EF_LDA];
+  __shared__ __attribute__((aligned(16))) float AG[EF_ROWS * EF_LDA];     // q tile (phase 1 -> 2), then agg (phase 2 -> 3)
   __shared__ float SG[EF_ROWS * H];
   __shared__ int next_row;
-  const int ngroups = a.groups ? *a.n_groups : (a.rows + EF_ROWS - 1) / EF_ROWS;
-  if ((int)blockIdx.x >= ngroups) return;
-  const int r0 = (a.groups ? a.groups[blockIdx.x] : (int)blockIdx.x) * EF_ROWS;
+  const int ngroups = a.groups ? *a.n_groups : (a.rows + 15) / 16;        // 16-row groups; a tile takes two of them
+  const int ntiles = (ngroups + EF_HALVES - 1) / EF_HALVES;
+  // XCD-aware tile order: consecutive workgroups go to consecutive XCDs (b % 8), each with its own L2.  With tps tiles per
+  // scene, workgroups b, b + 8, ..., b + 8 (tps - 1) - one XCD - take the tiles of ONE scene, so that the scene's K / V rows
+  // (agent set: read by every row of the scene) are fetched into one L2 instead of tps of them.
+  int tile = blockIdx.x;
+  if (a.tiles_per_scene > 1) {
+    const int tps = a.tiles_per_scene, grp = 8 * tps;
+    const int bq = tile / grp, br = tile % grp;
+    tile = bq * grp + (br % 8) * tps + br / 8;
+  }
+  if (tile >= ntiles) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int h = w, hp = h >> 1, hh = h & 1;
+  const int h = w & 7, half = w >> 3, hp = h >> 1, hh = h & 1;
+  // first row of each half (-1: no such group)
+  int r0h[EF_HALVES];
+#pragma unroll
+  for (int b = 0; b < EF_HALVES; ++b) {
+    const int gi = EF_HALVES * tile + b;
+    r0h[b] = gi < ngroups ? 16 * (a.groups ? a.groups[gi] : gi) : -1;
+  }
+  const int r0 = half ? r0h[1] : r0h[0];
+  const int jl = 16 * half + j;                    // this lane's row of the LDS tiles in the matrix phases
   const int row = r0 + j;
-  const bool valid = row < a.rows;
+  const bool valid = r0 >= 0 && row < a.rows;
   const float* hdr = a.pack + AH_HDR;
-  if (tid == 0) next_row = 0;
+  if (threadIdx.x == 0) next_row = 0;
 
   // ---- phase 1: u_h = q_h W'_kr,h (K = 16: v_mfma_f32_16x16x16_f16; B fragment = the head's 16 query values of row j)
   {
@@ -56,13 +80,14 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
       ah[ct] = *reinterpret_cast<const v4h*>(Wk + (ct * 2) * 256);
       al[ct] = *reinterpret_cast<const v4h*>(Wk + (ct * 2 + 1) * 256);
     }
+    *reinterpret_cast<float4*>(AG + jl * EF_LDA + DH * h + 4 * g) = qv;
     // per (row, head) power-of-two scale into the fp16 range, as frags_scaled does per row
     float m = fmaxf(fmaxf(fabsf(qv.x), fabsf(qv.y)), fmaxf(fabsf(qv.z), fabsf(qv.w)));
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    unsigned eb = __float_as_uint(m) >> 23;
-    eb = min(max(eb, 15u), 253u);
-    const float sc = __uint_as_float((268u - eb) << 23), inv = __uint_as_float((eb - 14u) << 23);
+    unsigned ebits = __float_as_uint(m) >> 23;
+    ebits = min(max(ebits, 15u), 253u);
+    const float sc = __uint_as_float((268u - ebits) << 23), inv = __uint_as_float((ebits - 14u) << 23);
     u32x2 qh, ql;
     {
       unsigned hi, lo;
@@ -78,7 +103,7 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
     for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[ct], vql, acc[ct], 0, 0, 0);
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(al[ct], vqh, acc[ct], 0, 0, 0);
-    float* urow = UZ + j * EF_LDU + h * D + 4 * g;
+    float* urow = UZ + jl * EF_LDU + h * D + 4 * g;
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct)
       *reinterpret_cast<float4*>(urow + 16 * ct) = make_float4(acc[ct][0] * cq, acc[ct][1] * cq, acc[ct][2] * cq, acc[ct][3] * cq);
@@ -87,40 +112,61 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
 
   // ---- phase 2: edge loop, one wave per destination row
   {
-    EdgeAttnArgs ea;
-    ea.rows = a.rows; ea.Q = a.Q; ea.U = nullptr; ea.Ksrc = a.Ksrc; ea.Vsrc = a.Vsrc; ea.es = a.es;
-    ea.AGG = nullptr; ea.Z = nullptr; ea.SIG = nullptr; ea.wkr = nullptr; ea.n_agents = nullptr; ea.A_cap = 0; ea.margin = 0;
-    // (a compile-time `true` here sends this hipcc build's simplifycfg pass into a crash; rhat is always present)
-    const bool has_r = a.es.rhat != nullptr;
+    const bool b3 = lane & 8;
+    const bool kv_once = a.kv_once != 0;
+    // rows are dealt to the waves through an LDS counter (the agent set's lists vary in length)
     auto take_row = [&]() {
       int r = 0;
       if (lane == 0) r = atomicAdd(&next_row, 1);
       return __builtin_amdgcn_readfirstlane(r);
     };
     for (int rl = take_row(); rl < EF_ROWS; rl = take_row()) {
-      const int drow = r0 + rl;
-      float* uz = UZ + rl * EF_LDU;
-      const bool live = drow < a.rows;
+      const int rbase = (rl >> 4) ? r0h[1] : r0h[0];
+      const int drow = rbase + (rl & 15);
+      const bool live = rbase >= 0 && drow < a.rows && !(a.dbg & 1);
       const int E = live ? __builtin_amdgcn_readfirstlane(a.es.cnt[drow]) : 0;
       const int e_base = live ? __builtin_amdgcn_readfirstlane(a.es.off[drow]) : 0;
-      AttnState st;
-      if constexpr (LOOP == 2) edge_attn_wave2<3, true, true>(ea, live ? drow : 0, E, e_base, 0, 1, st, uz);
-      else edge_attn_wave(ea, live ? drow : 0, E, e_base, 0, 1, has_r, st, uz);
-      const float inv = 1.0f / (st.lsum + 1e-16f);
-      *reinterpret_cast<float2*>(AG + rl * EF_LDA + 2 * lane) = make_float2(st.ag.x * inv, st.ag.y * inv);
+      int sv = E > 0 ? a.es.src[e_base + min(lane, E - 1)] : 0;            // source indices of up to 64 edges in one register
+      float* uz = UZ + rl * EF_LDU;
+      EdgeAcc<true> acc;
+      acc.q = *reinterpret_cast<const float2*>(AG + rl * EF_LDA + 2 * lane);
+      acc.load_u(uz, lane);
+      acc.reset();
+      for (int c0 = 0; c0 < E; c0 += 64) {
+        const int mc = min(64, E - c0);
+        if (c0 > 0) sv = a.es.src[e_base + c0 + min(lane, mc - 1)];        // lists beyond 64 edges: next chunk of indices
+        // G edges per trip: all their K / V / rhat rows are requested at the top of the trip (index clamped at the end of the
+        // list: no branch around the loads, the waits are counted ones) and consumed in turn; nothing is carried in registers
+        // from trip to trip (edge_attn.cuh explains why), the trip's fill latency is hidden by the SIMD's other waves
+        for (int i0 = 0; i0 < mc; i0 += G) {
+          pk2 kb[G], vb[G], rb[G];
+#pragma unroll
+          for (int s = 0; s < G; ++s) {
+            const int ic = min(i0 + s, mc - 1);
+            const int sj = __builtin_amdgcn_readlane(sv, ic);
+            kb[s] = ea_ld(a.Ksrc + (size_t)sj * D + 2 * lane, kv_once);
+            vb[s] = ea_ld(a.Vsrc + (size_t)sj * D + 2 * lane, kv_once);
+            rb[s] = ea_ld(a.es.rhat + (size_t)(e_base + c0 + ic) * D + 2 * lane, true);
+          }
+#pragma unroll
+          for (int s = 0; s < G; ++s) acc.step(kb[s], vb[s], rb[s], i0 + s < mc, b3);
+        }
+      }
+      const float inv = 1.0f / (acc.lsum + 1e-16f);
+      *reinterpret_cast<float2*>(AG + rl * EF_LDA + 2 * lane) = make_float2(acc.ag[0] * inv, acc.ag[1] * inv);
 #pragma unroll
       for (int hd = 0; hd < H; ++hd) {
         const float ih = readlane_f(inv, 8 * hd);
-        *reinterpret_cast<float2*>(uz + hd * D + 2 * lane) = make_float2(st.z[hd].x * ih, st.z[hd].y * ih);
+        *reinterpret_cast<float2*>(uz + hd * D + 2 * lane) = make_float2(acc.zz[hd][0] * ih, acc.zz[hd][1] * ih);
       }
-      if ((lane & 7) == 0) SG[rl * H + (lane >> 3)] = st.lsum * inv;
+      if ((lane & 7) == 0) SG[rl * H + (lane >> 3)] = acc.lsum * inv;
     }
   }
   __syncthreads();
 
   // ---- phase 3: agg' = agg + W'_vr,h z_h + b'_h sigma_h  (k_attn_h's z-GEMM: |z| <= sqrt(127), static prescale 1024)
   {
-    const float* zrow = UZ + j * EF_LDU + h * D + 8 * g;
+    const float* zrow = UZ + jl * EF_LDU + h * D + 8 * g;
     const unsigned short* Wv = reinterpret_cast<const unsigned short*>(a.pack + AH_POST) + (size_t)hp * QUARTER +
                                (size_t)(hh * 4) * 2 * 512 + lane * 8;
     v8h ah[4], al[4];
@@ -147,9 +193,9 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s], vbh, acc, 0, 0, 0);
     }
     if (valid) {
-      const float sg = SG[j * H + h];
+      const float sg = SG[jl * H + h];
       const float4 bvr = *reinterpret_cast<const float4*>(a.pack + AL_BVR + DH * h + 4 * g);
-      const float4 ag = *reinterpret_cast<const float4*>(AG + j * EF_LDA + DH * h + 4 * g);
+      const float4 ag = *reinterpret_cast<const float4*>(AG + jl * EF_LDA + DH * h + 4 * g);
       float4 o;
       o.x = ag.x + (acc[0] * zinv + bvr.x * sg);
       o.y = ag.y + (acc[1] * zinv + bvr.y * sg);
@@ -160,7 +206,8 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
   }
 }
 
-template __global__ void k_edge_fused<1>(EdgeFusedArgs);
-template __global__ void k_edge_fused<2>(EdgeFusedArgs);
+template __global__ void k_edge_fused<4>(EdgeFusedArgs);
+template __global__ void k_edge_fused<6>(EdgeFusedArgs);
+template __global__ void k_edge_fused<8>(EdgeFusedArgs);
 
 }  // namespace ig

@@ -17,8 +17,8 @@ constexpr float MOTION_GAP = 1.0f, HEADING_GAP = 1.0f, INVALID_MOTION = -2.0f, I
 //   score_h = q_h . k_src,h + u_h . rhat_e      reduced with wave shuffles; the 8 per-head partial
 //             sums are folded with a halving exchange (4 + 2 + 1 shuffles over lane bits 5,4,3) so
 //             that lane l ends with the score of ITS head, then 3 more over bits 0..2
-//   softmax   PyG semantics (layers.py:89): exp(s - max) / (sum + 1e-16), max/sum kept per head and
-//             rescaled when the running max grows
+//   softmax   PyG semantics (layers.py:89): exp(s - max) / (sum + 1e-16); reference / sum kept per head, rescaled when a
+//             score exceeds the reference by more than a factor 256 (edge_attn.cuh)
 //   outputs   AGG = sum_e a_e v_src (own columns), Z_h = sum_e a_e,h rhat_e (all heads), SIG_h = sum_e a_e,h
 // Rows without incoming edges produce exact zeros (0 / (0 + 1e-16)).
 // ------------------------------------------------------------------------------------------
@@ -32,7 +32,8 @@ __global__ __launch_bounds__(NT) void k_edge_attn(EdgeAttnArgs a) {
   const int e_base = __builtin_amdgcn_readfirstlane(a.es.off[row]);
   const bool has_r = a.es.rhat != nullptr && a.U != nullptr;
   AttnState st;
-  edge_attn_wave(a, row, E, e_base, 0, 1, has_r, st);
+  if (has_r) edge_attn_wave2<4, false, true>(a, row, E, e_base, 0, 1, st);
+  else edge_attn_wave2<4, false, false>(a, row, E, e_base, 0, 1, st);
   edge_attn_write(a, row, st);
 }
 
@@ -51,7 +52,8 @@ __global__ __launch_bounds__(64 * WIDE_WAVES) void k_edge_attn_wide(EdgeAttnArgs
   const int e_base = a.es.off[row];
   const bool has_r = a.es.rhat != nullptr && a.U != nullptr;
   AttnState st;
-  edge_attn_wave(a, row, E, e_base, w, WIDE_WAVES, has_r, st);
+  if (has_r) edge_attn_wave2<4, false, true>(a, row, E, e_base, w, WIDE_WAVES, st);
+  else edge_attn_wave2<4, false, false>(a, row, E, e_base, w, WIDE_WAVES, st);
   if ((lane & 7) == 0) { sm[w][lane >> 3] = st.m; sl[w][lane >> 3] = st.lsum; }
   __syncthreads();
   // rescale this wave's partial state to the global max of every head, publish, then wave 0 sums
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(64 * WIDE_WAVES) void k_edge_attn_wide(EdgeAttnArgs
   float mt = -INFINITY;
 #pragma unroll
   for (int ww = 0; ww < WIDE_WAVES; ++ww) mt = fmaxf(mt, sm[ww][myh]);
-  const float sc = (st.m == -INFINITY) ? 0.f : expf(st.m - mt);   // waves that saw no edge contribute nothing
+  const float sc = (st.m == -INFINITY) ? 0.f : exp2f(st.m - mt);  // (references live in the log2 domain) waves that saw no edge contribute nothing
   *reinterpret_cast<float2*>(&sag[w][2 * lane]) = make_float2(st.ag.x * sc, st.ag.y * sc);
 #pragma unroll
   for (int h = 0; h < H; ++h) {

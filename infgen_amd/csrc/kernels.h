@@ -68,6 +68,10 @@ struct EdgeFusedArgs {
   EdgeSet es;                        // rhat must be present
   float* AGG;                        // [rows][128] out
   const int* groups; const int* n_groups;   // optional: the 16-row groups to process (k_active_groups)
+  int dbg;                           // timing experiments only (INFGEN_EDGE_DBG): bit 0 no edges
+  int tiles_per_scene;               // > 1: XCD-aware tile order (rows of a scene are A_cap = 32 * tiles_per_scene consecutive rows)
+  int kv_once;                       // 1: every K / V source row is read once (temporal ring): non-temporal loads
+  int n_virtual;                     // tile slots to visit (tiles rounded up to whole XCD groups)
 };
 
 struct AttnPostArgs {
@@ -357,7 +361,7 @@ __global__ void k_active_groups(ActiveGroupsArgs a);
 template <int WAVES, int TERMS> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);
-template <int LOOP> __global__ void k_edge_fused(EdgeFusedArgs a);        // edge_fused.hip
+template <int G> __global__ void k_edge_fused(EdgeFusedArgs a);        // edge_fused.hip
 __global__ void k_edge_attn_wide(EdgeAttnArgs a);
 __global__ void k_attn_post(AttnPostArgs a);
 __global__ void k_heads(HeadsArgs a);

@@ -480,9 +480,7 @@ class RolloutEngine:
                             src=torch.zeros(cap, device=dev, dtype=torch.int32), raw=torch.zeros(cap, 4, device=dev),
                             rhat=torch.empty(cap, D, device=dev), total=torch.zeros(1, device=dev, dtype=torch.int32),
                             cap=cap, K=torch.empty(mrows, D, device=dev), V=torch.empty(mrows, D, device=dev),
-                            Q=torch.empty(mrows, D, device=dev), U=torch.empty(mrows, 8 * D, device=dev),
-                            AGG=torch.empty(mrows, D, device=dev), Z=torch.empty(mrows, 8 * D, device=dev),
-                            SIG=torch.empty(mrows, 8, device=dev))
+                            Q=torch.empty(mrows, D, device=dev), AGG=torch.empty(mrows, D, device=dev))
         g = self._mg
         _lib.check(self.lib.infgen_map_graph(S, M_cap, _lib.ptr(self.n_map), _lib.ptr(self.map_pos),
                                              _lib.ptr(self.map_orient), float(cfg.pl2pl_radius), K, _lib.ptr(g['off']),
@@ -493,14 +491,24 @@ class RolloutEngine:
             if tot > g['cap']:
                 self._map_nbr_cap = (tot + mrows - 1) // mrows + 4
                 self._mg = None
-                return self.prologue()
+                return self.prologue(map_only=map_only)
             self._mg_checked = True
         ops.fourier(g['raw'], 3, w.four_pt, g['rhat'], count_dev=g['total'], rows=g['cap'], normalize=True)
         for i in range(cfg.num_map_layers):
-            ops.attn_pre(x_pt, w.attn_pt[i], q=g['Q'], u=g['U'], k=g['K'], v=g['V'])
-            ops.edge_attn(mrows, g['Q'], g['U'], g['K'], g['V'], g['off'], g['cnt'], g['src'], g['rhat'],
-                          g['AGG'], g['Z'], g['SIG'])
-            ops.attn_post(x_pt, w.attn_pt[i], g['AGG'], g['Z'], g['SIG'])
+            if os.environ.get('INFGEN_MAP_FUSE', '1') == '0':       # the unfused sequence (comparison)
+                if 'U' not in g:
+                    g.update(U=torch.empty(mrows, 8 * D, device=dev), Z=torch.empty(mrows, 8 * D, device=dev),
+                             SIG=torch.empty(mrows, 8, device=dev))
+                ops.attn_pre(x_pt, w.attn_pt[i], q=g['Q'], u=g['U'], k=g['K'], v=g['V'])
+                ops.edge_attn(mrows, g['Q'], g['U'], g['K'], g['V'], g['off'], g['cnt'], g['src'], g['rhat'],
+                              g['AGG'], g['Z'], g['SIG'])
+                ops.attn_post(x_pt, w.attn_pt[i], g['AGG'], g['Z'], g['SIG'])
+                continue
+            # edge side with k_edge_fused: the absorbed query and the positional aggregate stay on chip (no U / Z arrays)
+            ops.attn_pre(x_pt, w.attn_pt[i], q=g['Q'], k=g['K'], v=g['V'])
+            ops.edge_attn(mrows, g['Q'], w.attn_pt[i], g['K'], g['V'], g['off'], g['cnt'], g['src'], g['rhat'],
+                          g['AGG'], None, None, wide='fused')
+            ops.attn_post(x_pt, w.attn_pt[i], g['AGG'], None, None, has_pos=False)
         if map_only:
             return
         self._finish_prologue()
