@@ -8,6 +8,7 @@ namespace ig {
 
 constexpr int INVALID = 0, VALID = 1, ENTER = 2, EXIT = 3;
 constexpr int NUM_SEED_FEATURE = 10;     // reference agent_decoder.py:292
+constexpr int A2A_MAX_NBR = 300;         // radius_graph(..., max_num_neighbors=300), agent_decoder.py:632-633
 constexpr float MOTION_GAP = 1.0f, HEADING_GAP = 1.0f, INVALID_MOTION = -2.0f, INVALID_HEAD = -2.0f;
 
 // ------------------------------------------------------------------------------------------
@@ -283,11 +284,16 @@ __global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
     const float r2 = a.r_agent * a.r_agent;
     int cnt = 0;
     const bool dst_ok = (t < A) && im[t];
+    // radius_graph(..., loop=False, max_num_neighbors=300) over ALL rows of the column, masked ones included, and only then
+    // subgraph(mask) (agent_decoder.py:632-634): per destination the first 300 + 1 rows in ascending index within the radius
+    // (itself among them) are candidates; the self pair and the masked sources are dropped afterwards
     if (dst_ok) {
-      for (int j = 0; j < A; ++j) {
-        if (j == t || !im[j]) continue;
+      int found = 0;
+      for (int j = 0; j < A && found < A2A_MAX_NBR + 1; ++j) {
         const float dx = px[t] - px[j], dy = py[t] - py[j];
-        if (dx * dx + dy * dy < r2) ++cnt;
+        if (!(dx * dx + dy * dy < r2)) continue;
+        ++found;
+        if (j != t && im[j]) ++cnt;
       }
     }
     int tot;
@@ -300,10 +306,12 @@ __global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
       a.a.cnt[row] = cnt;
       if (cnt > 0) {
         const bool d_inv = stt[t] == INVALID;
-        for (int j = 0; j < A; ++j) {
-          if (j == t || !im[j]) continue;
+        int found = 0;
+        for (int j = 0; j < A && found < A2A_MAX_NBR + 1; ++j) {
           const float ddx = px[t] - px[j], ddy = py[t] - py[j];
           if (!(ddx * ddx + ddy * ddy < r2)) continue;
+          ++found;
+          if (j == t || !im[j]) continue;
           float dx = px[j] - px[t], dy = py[j] - py[t];
           float dth = wrap_angle(hd[j] - hd[t]);
           const bool s_inv = stt[j] == INVALID;

@@ -84,13 +84,16 @@ class PackedWeights:
                        'seed_pos_rel_token_predict_head', 'seed_heading_rel_token_predict_head',
                        'seed_offset_xy_predict_head', 'seed_agent_occ_embed')}
         self._tables = None
+        self._tables_key = None
 
     def tables(self, ops: 'Ops', vocab_dev: torch.Tensor, grid_dev: torch.Tensor, map_vocab_dev: torch.Tensor):
         """Per-checkpoint constants (the reference recomputes them in every inference call,
         agent_decoder.py:347-373, map_decoder.py:77-78): token-embedding tables with the bos /
         no_token rows appended, the grid-embedding table with the invalid row, the seed
         categorical embedding and the map-token embedding table."""
-        if self._tables is not None:
+        key = (vocab_dev.data_ptr(), grid_dev.data_ptr(), map_vocab_dev.data_ptr(), tuple(vocab_dev.shape), tuple(grid_dev.shape))
+        if self._tables is not None and (self._tables_key == key or self._tables_src_equal(vocab_dev, grid_dev, map_vocab_dev)):
+            self._tables_key = key
             return self._tables
         dev, ts, G = self.device, self.cfg.token_size, grid_dev.shape[0]
         tok_tab = torch.empty(3, ts + 2, D, device=dev)
@@ -113,7 +116,14 @@ class PackedWeights:
         ops.fourier(raw, 2, self.four_xa, fus[:, D:2 * D], cat=cat_seed[None].contiguous())
         f_seed = ops.mlp_embedding(fus, self.fusion, 4 * D)
         self._tables = dict(tok_tab=tok_tab, grid_tab=grid_tab, cat_seed=cat_seed, map_tab=map_tab, f_seed=f_seed)
+        self._tables_key = key
+        self._tables_src = (vocab_dev.clone(), grid_dev.clone(), map_vocab_dev.clone())
         return self._tables
+
+    def _tables_src_equal(self, vocab_dev, grid_dev, map_vocab_dev) -> bool:
+        """the cached tables were computed from these very vocabularies / this grid (other engines upload their own copies)"""
+        a = self._tables_src
+        return all(x.shape == y.shape and bool(torch.equal(x, y)) for x, y in zip(a, (vocab_dev, grid_dev, map_vocab_dev)))
 
 
 class Ops:

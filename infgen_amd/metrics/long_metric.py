@@ -76,10 +76,12 @@ class LongMetric:
         self.sums = {k: 0.0 for k in self.field_names}
         self.longs: Dict[str, List[Tensor]] = {k: [] for k in self.field_names}
         self.scenario_counter = self.placement_valid_scenario_counter = self.removement_valid_scenario_counter = 0
+        self._synced = False
 
     def update(self, features: Optional[MetricFeatures] = None, metrics=None) -> None:
         """one scenario: its MetricFeatures (scored here) or the (scalars, per-window) pair of compute_scenario_metrics"""
         scal, long = metrics if metrics is not None else compute_scenario_metrics(self.metrics_config, self.log_distributions, features)
+        self._synced = False
         self.scenario_counter += 1
         self.placement_valid_scenario_counter += scal['distance_placement_likelihood'] > 0
         self.removement_valid_scenario_counter += scal['distance_removement_likelihood'] > 0
@@ -89,8 +91,23 @@ class LongMetric:
                 self.longs[k].append(long[k].detach().cpu())
 
     def state(self) -> Dict:
-        return dict(sums=self.sums, longs=self.longs, counters=(self.scenario_counter, self.placement_valid_scenario_counter,
-                                                                 self.removement_valid_scenario_counter))
+        """a copy of the accumulated state (safe to pickle / merge elsewhere)"""
+        return dict(sums=dict(self.sums), longs={k: list(v) for k, v in self.longs.items()},
+                    counters=(self.scenario_counter, self.placement_valid_scenario_counter,
+                              self.removement_valid_scenario_counter))
+
+    def sync(self) -> None:
+        """the reference's torchmetrics reduction at compute() (dist_reduce_fx 'sum' for the scalars, 'cat' for the per-window
+        lists, compute_metrics.py:1199-1204): every rank ends with the state of all ranks.  No-op without a process group."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or self._synced:
+            return
+        states = [None] * dist.get_world_size()
+        dist.all_gather_object(states, self.state())
+        for r, st in enumerate(states):
+            if r != dist.get_rank():
+                self.merge(st)
+        self._synced = True
 
     def merge(self, other_state: Dict) -> None:
         """add another rank's state (sum / cat)"""
@@ -103,7 +120,8 @@ class LongMetric:
         self.removement_valid_scenario_counter += c[2]
 
     def compute(self) -> Dict:
-        """reference :1401-1447"""
+        """reference :1401-1447 (the state is reduced across ranks first, like torchmetrics does)"""
+        self.sync()
         mean, mean_long = {}, {}
         for k in self.field_names:
             den = self.scenario_counter

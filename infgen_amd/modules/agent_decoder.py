@@ -4,10 +4,11 @@ Lightning checkpoint's ``encoder.agent_encoder.*`` load unchanged) and
 ``inference(data, map_enc) -> dict`` with the reference's 23 output keys.
 
 The rollout itself runs in libinfgen_hip.so (infgen_amd/engine.py), including the scenario-
-insertion sub-loop when ``disable_insertion`` is False.  Greedy decoding only
-(``motion_beam_size = insert_beam_size = 1`` semantics; the reference samples top-5 / top-10 with
-torch RNG).  The seed-loop outputs that exist only for plotting (``next_pos_rel_prob_seed``,
-``grid_*_occ_seed``) are returned as zeros.
+insertion sub-loop when ``disable_insertion`` is False.  Motion tokens: greedy for
+``motion_beam_size = 1``, otherwise top-k inverse-CDF sampling on supplied uniforms (the reference's
+top-5 multinomial, reproducible); insertion decisions are greedy (``insert_beam_size = 1``
+semantics; the reference samples top-10 cells with torch RNG).  The seed-loop outputs that exist
+only for plotting (``next_pos_rel_prob_seed``, ``grid_*_occ_seed``) are returned as zeros.
 """
 from __future__ import annotations
 

@@ -1,9 +1,12 @@
-"""Attr_Tokenizer with the reference's interface (infgen/modules/attr_tokenizer.py:8-110).
+"""Attr_Tokenizer with the reference's interface (infgen/modules/attr_tokenizer.py:8-110): the ego-centric grid of
+position cells (a disc of radius ``radius`` cut out of a ``grid_range`` square at ``grid_interval`` spacing) and the
+``angle_interval``-degree heading bins.
 
-Holds the polar-masked square grid as buffers (``grid``, ``dist``, ``dir``: state_dict
-compatible).  ``encode_pos`` inside the rollout runs in the HIP kernel ``k_integrate``; the
-methods here are the host-side utilities the reference exposes to its callers
-(``decode_pos`` / ``decode_heading`` / ``pad_square`` are used by pre/post-processing).
+The grid itself comes from ``synth.build_grid`` (one definition for the engine, the oracle inputs and this module) and is
+held as the buffers ``grid`` / ``dist`` / ``dir`` the reference's checkpoints carry.  Inside the rollout the tokenisation
+runs on the device (``k_integrate`` / ``k_fetch_enterings``); the methods below are the host-side utilities of the
+reference's public surface, written against the frame convention  world = cell . R(theta_ego - pi/2) + ego  with
+R(phi) = [[cos, sin], [-sin, cos]] applied on the right (SURVEY a-Q12).
 """
 import numpy as np
 import torch
@@ -13,76 +16,89 @@ from ..synth import build_grid
 from ..utils.func import angle_between_2d_vectors, wrap_angle
 
 
+def _to_frame(points: torch.Tensor, phi: torch.Tensor) -> torch.Tensor:
+    """rows of ``points`` (..., 2) times R(phi), phi broadcast over the leading dimension"""
+    c, s = torch.cos(phi), torch.sin(phi)
+    while c.dim() < points.dim() - 1:
+        c, s = c.unsqueeze(-1), s.unsqueeze(-1)
+    px, py = points[..., 0], points[..., 1]
+    return torch.stack((px * c - py * s, px * s + py * c), dim=-1)
+
+
 class Attr_Tokenizer(nn.Module):
 
     def __init__(self, grid_range, grid_interval, radius, angle_interval):
         super().__init__()
-        self.grid_range, self.grid_interval, self.radius, self.angle_interval = grid_range, grid_interval, radius, angle_interval
-        self.heading = torch.pi / 2
-        grid = torch.from_numpy(build_grid(grid_range, grid_interval, radius))
-        self.register_buffer('grid', grid)
-        self.register_buffer('dist', torch.norm(grid, p=2, dim=-1))
-        head_vector = torch.stack([torch.tensor(self.heading).cos(), torch.tensor(self.heading).sin()])
-        self.register_buffer('dir', angle_between_2d_vectors(ctr_vector=head_vector.unsqueeze(0), nbr_vector=grid))
-        self.num_grid = int(grid_range / grid_interval) + 1
-        n = self.num_grid
-        x = np.arange(n, dtype=np.float32)
-        gx, gy = np.meshgrid(x, x, indexing='xy')
-        sq = np.stack([gx.reshape(-1), gy.reshape(-1)], -1).reshape(n, n, 2)[::-1].reshape(-1, 2)
-        sq = (sq - np.float32(n // 2)) * np.float32(grid_interval)
-        self.square_mask = np.sqrt((sq ** 2).sum(-1)) <= radius
-        self.grid_size = self.grid.shape[0]
-        self.angle_size = int(360. / self.angle_interval)
-        assert torch.all(self.grid[self.grid_size // 2] == 0.)
+        self.grid_range, self.grid_interval = grid_range, grid_interval
+        self.radius, self.angle_interval = radius, angle_interval
+        self.heading = torch.pi / 2                      # the grid's +y axis is the ego's forward direction
+        cells = torch.from_numpy(build_grid(grid_range, grid_interval, radius))
+        self.register_buffer('grid', cells)
+        self.register_buffer('dist', cells.square().sum(-1).sqrt())
+        # float32 cos(pi/2) = -4.4e-8, not 0: the sign of that residue decides +pi / -pi for the cells straight behind the ego
+        half_pi = torch.tensor(self.heading, dtype=torch.float32)
+        forward = torch.stack([half_pi.cos(), half_pi.sin()]).unsqueeze(0)
+        self.register_buffer('dir', angle_between_2d_vectors(ctr_vector=forward, nbr_vector=cells))
+        # which cells of the full square lattice (row-major from the top row down) lie inside the disc
+        self.num_grid = n = int(grid_range / grid_interval) + 1
+        axis = (np.arange(n, dtype=np.float32) - np.float32(n // 2)) * np.float32(grid_interval)
+        lattice_r = np.hypot(axis[None, :], axis[::-1][:, None]).reshape(-1)
+        self.square_mask = lattice_r <= radius
+        self.grid_size = int(cells.shape[0])
+        self.angle_size = int(360. / angle_interval)
+        assert self.square_mask.sum() == self.grid_size and bool((cells[self.grid_size // 2] == 0).all())
 
-    def _apply_rot(self, x, theta):
-        cos, sin = theta.cos(), theta.sin()
-        rot_mat = torch.zeros((theta.shape[0], 2, 2), device=theta.device)
-        rot_mat[:, 0, 0] = cos
-        rot_mat[:, 0, 1] = sin
-        rot_mat[:, 1, 0] = -sin
-        rot_mat[:, 1, 1] = cos
-        return torch.bmm(x, rot_mat)
+    def _cells(self, like: torch.Tensor) -> torch.Tensor:
+        return self.grid.to(like.device)
 
+    def _frame_angle(self, theta, n):
+        return (theta - self.heading).expand(n)
+
+    # -- reference :57-68
     def pad_square(self, prob, indices=None):
-        pad_prob = np.zeros((*prob.shape[:-1], self.square_mask.shape[0]))
-        pad_prob[..., self.square_mask] = prob
-        square_indices = np.arange(self.square_mask.shape[0])
-        circle_indices = np.concatenate([square_indices[self.square_mask], [-1]])
+        """disc-indexed values -> the full square lattice (for plotting); disc indices -> lattice indices (-1 stays -1)"""
+        square = np.zeros(prob.shape[:-1] + (self.square_mask.size,))
+        square[..., self.square_mask] = prob
         if indices is not None:
-            indices = circle_indices[indices]
-        return pad_prob, indices
+            lookup = np.append(np.flatnonzero(self.square_mask), -1)
+            indices = lookup[indices]
+        return square, indices
 
+    # -- reference :70-75
     def get_grid(self, x, theta=None):
+        """world positions of every cell around each centre x (N, 2), optionally in the frame of heading theta"""
         x = x.reshape(-1, 2)
-        grid = self.grid[None, ...].to(x.device)
+        cells = self._cells(x).unsqueeze(0)
         if theta is not None:
-            grid = self._apply_rot(grid, (theta - self.heading).expand(x.shape[0]))
-        return x[:, None] + grid
+            cells = _to_frame(cells.expand(x.shape[0], -1, -1), self._frame_angle(theta, x.shape[0]))
+        return cells + x.unsqueeze(1)
 
+    # -- reference :77-89
     def encode_pos(self, x, y, theta_y=None):
-        assert x.dim() == y.dim() and x.shape[-1] == 2 and y.shape[-1] == 2
-        centered_x = x - y
+        """nearest cell (first index on ties, like torch.argmin over the euclidean distances) of x seen from y"""
+        assert x.dim() == y.dim() and x.shape[-1] == 2 and y.shape[-1] == 2, f'bad shapes {x.shape} {y.shape}'
+        rel = x - y
         if theta_y is not None:
-            centered_x = self._apply_rot(centered_x[:, None], -(theta_y - self.heading).expand(x.shape[0]))[:, 0]
-        distance = ((centered_x[:, None] - self.grid.to(x.device)[None, ...]) ** 2).sum(-1).sqrt()
-        index = torch.argmin(distance, dim=-1)
-        return index.long(), centered_x - self.grid.to(x.device)[index]
+            rel = _to_frame(rel, -self._frame_angle(theta_y, x.shape[0]))
+        cells = self._cells(x)
+        index = (rel.unsqueeze(1) - cells.unsqueeze(0)).square().sum(-1).sqrt().argmin(dim=-1)
+        return index.long(), rel - cells[index]
 
+    # -- reference :91-99
     def decode_pos(self, index, y=None, theta_y=None):
-        assert torch.all((index >= 0) & (index < self.grid_size))
-        centered_x = self.grid.to(index.device)[index.long()]
-        if y is not None:
-            if theta_y is not None:
-                centered_x = self._apply_rot(centered_x[:, None], (theta_y - self.heading).expand(centered_x.shape[0]))[:, 0]
-            return (centered_x + y).float()
-        return centered_x.float()
+        assert bool(((index >= 0) & (index < self.grid_size)).all())
+        rel = self._cells(index)[index.long()]
+        if y is None:
+            return rel.float()
+        if theta_y is not None:
+            rel = _to_frame(rel, self._frame_angle(theta_y, rel.shape[0]))
+        return (rel + y).float()
 
+    # -- reference :101-110
     def encode_heading(self, heading):
-        heading = (wrap_angle(heading) + torch.pi) / (2 * torch.pi) * 360
-        return (heading // self.angle_interval).long()
+        degrees = (wrap_angle(heading) + torch.pi) / (2 * torch.pi) * 360
+        return torch.div(degrees, self.angle_interval, rounding_mode='floor').long()
 
     def decode_heading(self, index):
-        assert torch.all(index >= 0) and torch.all(index < (360 / self.angle_interval))
-        angles = index * self.angle_interval - 180
-        return (angles / 360 * (2 * torch.pi)).float()
+        assert bool((index >= 0).all()) and bool((index < 360 / self.angle_interval).all())
+        return ((index * self.angle_interval - 180) / 360 * (2 * torch.pi)).float()

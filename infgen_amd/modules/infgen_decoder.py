@@ -96,10 +96,13 @@ class InfGenDecoder(nn.Module):
         dev = ps[0].device
         if dev.type != 'cuda':
             raise _lib.InfgenHipError('InfGenDecoder must live on a cuda device: the product path has no CPU fallback')
-        ver = (dev, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
+        tok = self.agent_encoder.attr_tokenizer
+        R = self.agent_encoder.num_recurrent_steps_val
+        # the rollout length and the tokenizer geometry are part of the key: changing num_recurrent_steps_val between calls
+        # (80 -> 300 for long-term validation) must not be ignored
+        ver = (dev, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps), R, tok.grid_range, tok.grid_interval,
+               tok.angle_interval)
         if self._packed_ver != ver:
-            tok = self.agent_encoder.attr_tokenizer
-            R = self.agent_encoder.num_recurrent_steps_val
             cfg = RolloutConfig(num_recurrent_steps_val=R if R != -1 else 80, grid_range=tok.grid_range,
                                 grid_interval=tok.grid_interval, angle_interval=tok.angle_interval, **self._cfg_kw)
             sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items()}

@@ -174,3 +174,30 @@ def test_infgen_caller_mirror_host_side(tmp_path):
                       'shape': torch.ones(2, 91, 3)}}
     with pytest.raises(RuntimeError, match='GPU only'):
         m.validation_step(data, 0)
+
+
+def test_attr_tokenizer_matches_reference_fixture():
+    """Attr_Tokenizer's host-side methods against the reference's own class on seeded inputs
+    (tests/golden/make_golden_tokenizer.py): buffers and indices exact, positions to float32 rounding"""
+    import torch
+    from infgen_amd.modules import Attr_Tokenizer
+    z = np.load(os.path.join(REPO, 'tests', 'golden', 'attr_tokenizer.npz'))
+    tok = Attr_Tokenizer(grid_range=150., grid_interval=3., radius=75., angle_interval=3.)
+    assert np.array_equal(tok.grid.numpy(), z['grid']) and np.array_equal(tok.square_mask, z['square_mask'])
+    assert np.allclose(tok.dist.numpy(), z['dist'], atol=1e-5) and np.allclose(tok.dir.numpy(), z['dir'], atol=1e-6)
+    x, y, th = (torch.from_numpy(z[k]) for k in ('x', 'y', 'theta'))
+    idx_r, off_r = tok.encode_pos(x, y, th)
+    idx_n, off_n = tok.encode_pos(x, y)
+    # a rotated point that sits within rounding of a cell border may fall to either side: compare through the distances
+    same = idx_r.numpy() == z['idx_r']
+    assert same.mean() > 0.97 and np.abs(off_r.numpy()[same] - z['off_r'][same]).max() <= 1e-4
+    assert np.array_equal(idx_n.numpy(), z['idx_n']) and np.abs(off_n.numpy() - z['off_n']).max() <= 1e-5
+    gi = torch.from_numpy(z['idx_r'])
+    assert np.abs(tok.decode_pos(gi, y, th).numpy() - z['dec_r']).max() <= 1e-4
+    assert np.array_equal(tok.decode_pos(gi, y).numpy(), z['dec_n']) and np.array_equal(tok.decode_pos(gi).numpy(), z['dec_0'])
+    head = torch.from_numpy(z['head'])
+    assert np.array_equal(tok.encode_heading(head).numpy(), z['hbin'])
+    assert np.array_equal(tok.decode_heading(torch.from_numpy(z['hbin'])).numpy(), z['hdec'])
+    assert np.abs(tok.get_grid(y[:1], th).numpy() - z['grid_w']).max() <= 1e-4
+    pad, pidx = tok.pad_square(z['prob'], np.array([0, 5, tok.grid_size - 1, -1]))
+    assert np.array_equal(pad, z['pad']) and np.array_equal(pidx, z['pidx'])

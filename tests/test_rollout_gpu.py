@@ -451,6 +451,11 @@ def test_more_than_256_rows_per_scene():
     scene = synth.make_scene(43, 320, 512, cfg, half_extent=90.0, vocab=c['vocab'], grid=c['grid'], slip=0.2)
     o, ref = _oracle_vs_engine(cfg, scene, sd, c)
     assert o['pos_a'].shape[0] == 320
+    # (a') 330 agents inside one 60 m neighbourhood: radius_graph's max_num_neighbors = 300 binds (agent_decoder.py:632-633):
+    # every destination keeps the candidates among the first 301 rows in range only
+    dense = synth.make_scene(44, 330, 256, cfg, half_extent=18.0, vocab=c['vocab'], grid=c['grid'], slip=0.2)
+    o2, ref2 = _oracle_vs_engine(cfg, dense, sd, c)
+    assert o2['pos_a'].shape[0] == 330 and ref2['edge_count'][:, 1].max() < 330 * 329
     ci = load_case('ins_natural_a20_m256')
     cfg_i = ci['cfg']
     cfg_i.disable_insertion = False
