@@ -8,12 +8,16 @@ reset, map-encoder prologue, the edgeless column-0 chain and all R/5 decode step
 (reference InfGenDecoder.inference, infgen/modules/infgen_decoder.py:123-130).  Inputs
 (scene arrays, packed weights) are resident in HBM before the timed region.
 
-Workload (config.workload): BASELINE config C3 shapes — configs/ours_standard.yaml
+Workload (config.workload): BASELINE config C3 shapes by default — configs/ours_standard.yaml
 hyper-parameters, 64 agents / 1024 map tokens per scene, R = 80 (16 decode steps), greedy
 decoding, insertion disabled — with `--scenes` scenes per GPU (weak scaling: every rank owns
-its own scenes, no data-path collective; one all-reduce of the timing/counters at the end).
+its own scenes) or, with `--scaling strong`, the literal BASELINE batch of `--total-scenes` (64)
+scenes dealt to the ranks like the reference's DistributedSampler.  No data-path collective; one
+all-reduce of the timing / counters at the end.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the roofline arithmetic).
+Prints ONE JSON line on rank 0.  `roofline` follows SURVEY section 8d: algorithmic bytes and FLOPs
+(the figures of 8d, evaluated on the edge counts the device reports) over measured time, for the
+dominant kernel and for the whole step; DESIGN.md "Measurement" has the arithmetic.
 """
 from __future__ import annotations
 
@@ -33,12 +37,116 @@ if REPO not in sys.path:
 from infgen_amd import engine, synth, _lib  # noqa: E402
 from infgen_amd import dist as igdist  # noqa: E402
 
-FP32_MATRIX_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
-# kernels that run on the fp16 matrix pipe with the three-term split: one algorithmic multiply-add costs three
-# f16 MFMA multiply-adds, so the ceiling for ALGORITHMIC flops is the dense f16 peak (2.5 PFLOP/s) / 3
-F16_SPLIT_PEAK_TFLOPS = 2500.0 / 3.0
-SPLIT_KERNELS = ('k_fourier', 'k_attn_pre', 'k_attn_post')
-HBM_PEAK_GBS = 8000.0                # HBM3E peak of the same guide
+# peaks: /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+FP32_MATRIX_PEAK_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32
+F16_DENSE_PEAK_TFLOPS = 2500.0
+# kernels on the fp16 matrix pipe with the three-term split: one algorithmic multiply-add costs three f16 MFMA
+# multiply-adds, so the ceiling for ALGORITHMIC flops at fp32 accuracy is the dense f16 peak / 3
+F16_SPLIT_PEAK_TFLOPS = F16_DENSE_PEAK_TFLOPS / 3.0
+
+# ---- SURVEY section 8d, per decode step of one scene (1 MAC = 2 FLOP, D = 128) ----------------------------------
+NODE_MAC_PER_ROW = 4_702_848        # 18 x 212,992 + 12 x 32,768 + 82,176 + 98,304 + 278,528 + 16,768
+EDGE_MAC_TEMPORAL = 346_112         # 147,968 (Fourier, 4 dims) + 6 x 33,024
+EDGE_MAC_OTHER = 313_216            # 115,072 (Fourier, 3 dims) + 6 x 33,024
+EDGE_MAC_PER_LAYER = 33_024         # the reference's per-edge W_kr / W_vr projections + the two dot products of one layer
+GRID_FLOP_PER_ROW = 1961 * 4
+KV_ROW_BYTES = 1024                 # one source row's K and V (fp32)
+ROW_FIXED_BYTES = 6144 + 12288 + 512 + 2048 + 192 + 80     # K/V written (temporal), K/V written + read (agent set), state, embedding rows, template, outputs
+WEIGHT_BYTES_PER_STEP = 23.7e6      # motion-path weights, read once per decode step per GPU
+
+
+def load_shapes():
+    with open(os.path.join(REPO, 'tests', 'golden', 'state_dict_shapes.json')) as f:
+        return {k: tuple(v) for k, v in json.load(f).items()}
+
+
+def build_scenes(cfg, indices, agents, map_tokens):
+    vocab = synth.make_agent_vocab(cfg.token_size)
+    map_vocab = synth.make_map_vocab()
+    grid = synth.build_grid(cfg.grid_range, cfg.grid_interval, cfg.pl2seed_radius)
+    scenes = [synth.make_scene(synth.scene_seed(3, i), agents, map_tokens, cfg, half_extent=60.0,
+                               ego_last=True, vocab=vocab, grid=grid) for i in indices]
+    return scenes, vocab, map_vocab, grid
+
+
+# ---------------------------------------------------------------------------------------- CPU baseline
+def _cpu_worker(job):
+    """one process of the CPU baseline: whole rollouts of ONE scene with the oracle until the budget is used"""
+    idx, agents, map_tokens, R, insertion, budget_s, threads = job
+    import torch as th
+    th.set_num_threads(threads)
+    from oracle import rollout_oracle as ro
+    cfg = synth.standard_config(disable_insertion=not insertion, num_recurrent_steps_val=R)
+    sd = synth.fill_state_dict(load_shapes(), seed=1, rich=True)
+    scenes, vocab, map_vocab, grid = build_scenes(cfg, [idx], agents, map_tokens)
+    tsd = {k: th.from_numpy(v) for k, v in sd.items()}
+    if insertion:
+        from oracle import insertion_oracle as io
+        run = lambda: io.run_scene_with_insertion(tsd, scenes[0], cfg, vocab, map_vocab, grid)
+    else:
+        run = lambda: ro.run_scene(tsd, scenes[0], cfg, vocab, map_vocab, grid)
+    run()                                   # warm-up (thread pools, allocator)
+    t0 = time.perf_counter()
+    n, steps = 0, 0
+    while True:
+        out = run()
+        n += 1
+        steps += out['pos_a'].shape[0] * R
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            break
+    return steps, dt, n
+
+
+def cpu_baseline(args, budget_s):
+    """The CPU oracle (a column-wise port of the reference algorithm) on the host's cores.  Scenes are independent, so - like
+    the reference under DDP - several processes run whole rollouts of their own scene of the same workload.  Two layouts are
+    timed (half of the budget each) and the faster one is reported with the threads it used: one process with 16 torch threads,
+    and one process per 16 hardware threads with 8 torch threads each (torch's intra-op pool does not scale on these small
+    operators, and 256 busy threads on the box's 256 hardware threads ran 2x slower than 16)."""
+    import multiprocessing as mp
+    ncpu = os.cpu_count() or 1
+    ctx = mp.get_context('spawn')
+    layouts = [(1, min(16, ncpu))]
+    if ncpu >= 32:
+        layouts.append((ncpu // 16, 8))
+    best, notes = None, []
+    for procs, threads in layouts:
+        jobs = [(i, args.agents, args.map_tokens, args.rollout_steps, bool(args.insertion), budget_s / len(layouts), threads)
+                for i in range(procs)]
+        with ctx.Pool(procs) as pool:
+            res = pool.map(_cpu_worker, jobs)
+        steps, busy, n = sum(r[0] for r in res), max(r[1] for r in res), sum(r[2] for r in res)
+        notes.append(f'{procs} process(es) x {threads} threads: {steps / busy:.0f} agent-steps/s ({n} rollouts, {busy:.1f} s)')
+        if best is None or steps / busy > best[0]:
+            best = (steps / busy, procs * threads)
+    return dict(value=best[0], unit='agent-steps/s', cores=best[1], kind='port',
+                sample=f'full rollouts incl. map encoder of one scene per process (A={args.agents}, M={args.map_tokens}, '
+                       f'R={args.rollout_steps}), windowed port of the reference algorithm (oracle/); host has {ncpu} hardware '
+                       f'threads; ' + '; '.join(notes))
+
+
+# ---------------------------------------------------------------------------------------- parity gate
+def parity_gate(dev):
+    """parity reported with every perf number - the C1 fixture and the A = 24 edge-case fixture (outputs of the
+    reference's own InfGenDecoder.inference) free-running through the library that is about to be timed"""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from conftest import load_case
+    res = {}
+    for name in ('c1_a8_m128', 'a24_m256_edge'):
+        c = load_case(name)
+        w = engine.PackedWeights(c['sd'], c['cfg'], dev)
+        eng = engine.RolloutEngine(w, [c['scene']], c['vocab'], c['map_vocab'], c['grid'], store_logits=True)
+        eng.rollout()
+        o = eng.outputs()[0]
+        z = c['z']
+        res[name] = dict(tokens_exact=bool(np.array_equal(o['next_token_idx'], z['next_token_idx'])),
+                         states_exact=bool(np.array_equal(o['next_state_idx'], z['next_state_idx'])),
+                         logits_max_abs_err=float(np.abs(o['logits'] - z['logits']).max()),
+                         logits_tol=1e-3 * max(1.0, c['meta']['head_gain'] / 16))
+    res['ok'] = all(v['tokens_exact'] and v['states_exact'] and v['logits_max_abs_err'] <= v['logits_tol'] for v in res.values())
+    return res
 
 
 def pmc_traffic(kernel, args):
@@ -50,55 +158,10 @@ def pmc_traffic(kernel, args):
     except OSError:
         return None
     same = (t.get('scenes_per_gpu') == args.scenes and t.get('agents') == args.agents and
-            t.get('map_tokens') == args.map_tokens and t.get('insertion') == bool(args.insertion))
+            t.get('map_tokens') == args.map_tokens and t.get('insertion') == bool(args.insertion) and
+            t.get('rollout_steps', 80) == args.rollout_steps and args.scaling == 'weak')
     k = t.get('kernels', {}).get(kernel)
     return float(k['fetch_bytes_per_launch'] + k['write_bytes_per_launch']) if same and k else None
-
-
-def load_shapes():
-    with open(os.path.join(REPO, 'tests', 'golden', 'state_dict_shapes.json')) as f:
-        return {k: tuple(v) for k, v in json.load(f).items()}
-
-
-def build_scenes(cfg, n, agents, map_tokens, first_idx):
-    vocab = synth.make_agent_vocab(cfg.token_size)
-    map_vocab = synth.make_map_vocab()
-    grid = synth.build_grid(cfg.grid_range, cfg.grid_interval, cfg.pl2seed_radius)
-    scenes = [synth.make_scene(synth.scene_seed(3, first_idx + i), agents, map_tokens, cfg, half_extent=60.0,
-                               ego_last=True, vocab=vocab, grid=grid) for i in range(n)]
-    return scenes, vocab, map_vocab, grid
-
-
-def cpu_baseline(cfg, sd, scene, vocab, map_vocab, grid, budget_s=20.0):
-    """The CPU oracle (a port of the reference algorithm, column-wise) timed on this host's cores
-    on a bounded sample: whole rollouts of ONE scene of the same workload until ~budget_s."""
-    from oracle import rollout_oracle as ro
-    if not cfg.disable_insertion:
-        from oracle import insertion_oracle as io
-
-        class _Shim:      # same call shape as rollout_oracle.run_scene
-            @staticmethod
-            def run_scene(tsd, scene, cfg_, vocab_, map_vocab_, grid_):
-                return io.run_scene_with_insertion(tsd, scene, cfg_, vocab_, map_vocab_, grid_)
-        ro = _Shim
-    # torch's intra-op pool degrades badly beyond a few dozen threads on these small operators
-    # (256 hardware threads on the GPU box): use 16 and say so in `cores`.
-    ncores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(ncores)
-    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
-    ro.run_scene(tsd, scene, cfg, vocab, map_vocab, grid)       # warm-up (thread pools, allocator)
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        out = ro.run_scene(tsd, scene, cfg, vocab, map_vocab, grid)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s:
-            break
-    agent_steps = out['pos_a'].shape[0] * cfg.num_recurrent_steps_val * n
-    return dict(value=agent_steps / dt, unit='agent-steps/s', cores=ncores, kind='port',
-                sample=f'{n} full rollout(s) of 1 scene (A={out["pos_a"].shape[0]}, M={len(scene["pt_token"]["orientation"])}, '
-                       f'R={cfg.num_recurrent_steps_val}) incl. map encoder, {dt:.1f} s, torch {torch.get_num_threads()} threads')
 
 
 def log(msg):
@@ -111,14 +174,18 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--scenes', type=int, default=512, help='scenes per GPU')
+    ap.add_argument('--scenes', type=int, default=512, help='scenes per GPU (weak scaling)')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='strong: a fixed batch of --total-scenes scenes dealt to the ranks (scene i -> rank i mod N)')
+    ap.add_argument('--total-scenes', type=int, default=64, help='batch size of --scaling strong (BASELINE C3: 64)')
     ap.add_argument('--overlap', type=int, default=-1, help='infgen_set_overlap (default: library default)')
     ap.add_argument('--roofline-kernel', default='', help='report the roofline of this kernel instead of the dominant one')
     ap.add_argument('--agents', type=int, default=64)
     ap.add_argument('--map-tokens', type=int, default=1024)
     ap.add_argument('--insertion', action='store_true', help='scenario insertion on (configs/ours_long_term.yaml style)')
     ap.add_argument('--insert-headroom', type=int, default=None,
-                    help='rows per scene reserved for inserted agents (default: min(10 per decode step, 96); A_cap <= 1024)')
+                    help='rows per scene reserved for inserted agents (default: min(10 per decode step, 96), doubled until the '
+                         'rollout fits; A_cap <= 1024)')
     ap.add_argument('--rollout-steps', type=int, default=80, help='R = num_recurrent_steps_val (multiple of 5)')
     ap.add_argument('--streams', type=int, default=1, help='split the per-GPU batch over this many HIP streams')
     ap.add_argument('--gemm-terms', type=int, default=3, choices=(1, 3),
@@ -128,6 +195,7 @@ def main():
                     help='infgen_set_edge_fuse: 1 (library default) k_edge_fused from 257 rows, 0 the unfused sequence with U / Z in HBM')
     ap.add_argument('--edge-loop', type=int, default=-1, choices=(-1, 4, 6, 8))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
 
@@ -145,17 +213,43 @@ def main():
     dev = torch.device('cuda', local_rank)
 
     log(f'cpu_count={os.cpu_count()} device={torch.cuda.get_device_name(dev)}')
+    # the CPU baseline runs first (rank 0, N = 1 only), before this process holds GPU work
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, args.cpu_budget)
+        log(f'cpu baseline done: {cpu}')
+
     cfg = synth.standard_config(disable_insertion=not args.insertion, num_recurrent_steps_val=args.rollout_steps)
     sd = synth.fill_state_dict(load_shapes(), seed=1, rich=True)
-    first = igdist.scenes_for_rank_weak(rank, args.scenes)[0]
-    scenes, vocab, map_vocab, grid = build_scenes(cfg, args.scenes, args.agents, args.map_tokens, first)
-    log('scenes built')
+    if args.scaling == 'strong':
+        mine = igdist.scenes_for_rank_strided(rank, world, args.total_scenes)
+    else:
+        mine = igdist.scenes_for_rank_weak(rank, args.scenes)
+    scenes, vocab, map_vocab, grid = build_scenes(cfg, mine, args.agents, args.map_tokens)
+    log(f'{len(scenes)} scenes built')
+    lib = _lib.load()
+    if args.overlap >= 0:
+        _lib.check(lib.infgen_set_overlap(args.overlap))
+    _lib.check(lib.infgen_set_gemm_terms(args.gemm_terms))
+    if args.edge_loop >= 0:
+        _lib.check(lib.infgen_set_edge_loop(args.edge_loop))
+    if args.edge_fuse >= 0:
+        _lib.check(lib.infgen_set_edge_fuse(args.edge_fuse))
+
+    parity = None
+    if rank == 0 and not args.no_parity and args.gemm_terms == 3:
+        parity = parity_gate(dev)
+        log(f'parity: {parity}')
+
     w = engine.PackedWeights(sd, cfg, dev)
     ns = max(1, args.streams)
     per = (len(scenes) + ns - 1) // ns
-    engines = [engine.RolloutEngine(w, scenes[i * per:(i + 1) * per], vocab, map_vocab, grid, store_logits=False,
-                                    insert_headroom=args.insert_headroom)
-               for i in range(ns) if scenes[i * per:(i + 1) * per]]
+
+    def make_engines(headroom):
+        return [engine.RolloutEngine(w, scenes[i * per:(i + 1) * per], vocab, map_vocab, grid, store_logits=False,
+                                     insert_headroom=headroom)
+                for i in range(ns) if scenes[i * per:(i + 1) * per]]
+    engines = make_engines(args.insert_headroom)
     streams = [torch.cuda.Stream(device=dev) for _ in engines] if ns > 1 else [None]
 
     class _Multi:
@@ -184,24 +278,23 @@ def main():
         def hosts(self):
             return [h for e in engines for h in e.hosts]
     eng = _Multi()
-
     log('engine built')
-    cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(cfg, sd, scenes[0], vocab, map_vocab, grid, args.cpu_budget)
 
-    log(f'cpu baseline done: {cpu}')
-    lib = _lib.load()
-    if args.overlap >= 0:
-        _lib.check(lib.infgen_set_overlap(args.overlap))
-    _lib.check(lib.infgen_set_gemm_terms(args.gemm_terms))
-    if args.edge_loop >= 0:
-        _lib.check(lib.infgen_set_edge_loop(args.edge_loop))
-    if args.edge_fuse >= 0:
-        _lib.check(lib.infgen_set_edge_fuse(args.edge_fuse))
-    for _ in range(args.warmup):
-        eng.rollout()
-        torch.cuda.synchronize(dev)
+    # warm-up; with insertion the row head-room is doubled until the (deterministic) rollout fits - an engine never drops
+    # an insertion silently
+    done = 0
+    while done < max(args.warmup, 1 if args.insertion else 0):
+        try:
+            eng.rollout()
+            torch.cuda.synchronize(dev)
+            done += 1
+        except engine.InsertionHeadroomError:
+            limit = lib.infgen_layout_query(_lib.Q_MAX_AGENTS)
+            if engines[0].A_cap >= limit:
+                raise
+            engines[:] = make_engines(min(2 * engines[0].A_cap, limit) - args.agents)
+            log(f'insertion head-room exhausted: rows per scene -> {engines[0].A_cap}')
+            done = 0
         log('warmup rollout done')
     # roofline leg 1 (untimed): one rollout with HIP events around EVERY kernel -> which kernel dominates
     _lib.prof_enable((1 << len(_lib.KERNEL_IDS)) - 1)
@@ -221,49 +314,76 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
-    dom = _lib.prof_collect()[dominant]
+    timed = _lib.prof_collect()
+    dom = timed[dominant]
     _lib.prof_enable(0)
-    roof = None
-    common = {'launches': dom['calls'],
-              'share_of_gpu_time': per_kernel[dominant]['ms'] / max(1e-9, sum(v['ms'] for v in per_kernel.values())),
-              'per_kernel_ms_one_rollout': {k: round(v['ms'], 3) for k, v in per_kernel.items()}}
-    if dom['calls'] > 0 and dominant == 'k_edge_attn':
-        # HBM-bound gather kernel: compulsory bytes (DESIGN.md "Measurement"): 512 B of rhat per edge; per destination
-        # row q 512 + u 4096 in, agg 512 + z 4096 + sigma 32 out; K and V (1 KB) once per DISTINCT source row of a
-        # launch: every temporal edge has its own source, the agent set re-reads the rows of its own launch, the map
-        # set at most the map tokens of the batch.
-        L = cfg.num_agent_layers
-        ed = {k: v * L for k, v in dom['edges_built'].items()}      # each set feeds one launch per layer
-        rows = args.scenes * engines[0].A_cap
-        rows_total = float(dom['calls']) * rows
-        launches_per_kind = dom['calls'] / 3.0
-        e_all = sum(ed.values())
-        kv = 1024.0 * (ed['temporal'] + launches_per_kind * rows
-                       + min(ed['map'], launches_per_kind * args.scenes * args.map_tokens))
-        nbytes = 512.0 * e_all + 9248.0 * rows_total + kv
-        avg_s = dom['ms'] * 1e-3 / dom['calls']
-        ach = nbytes / (dom['ms'] * 1e-3) / 1e9
-        roof = {'bound': 'hbm', 'kernel': dominant, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': ach / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_us': avg_s * 1e6,
-                'bytes_per_launch': nbytes / dom['calls'], 'edges_per_launch': e_all / dom['calls'], **common}
-    elif dom['calls'] > 0 and dom['macs'] > 0:
-        avg_s = dom['ms'] * 1e-3 / dom['calls']
-        flops_per_launch = 2.0 * dom['macs'] / dom['calls']
-        ach = flops_per_launch / avg_s / 1e12
-        split = dominant in SPLIT_KERNELS
-        peak = (F16_SPLIT_PEAK_TFLOPS if args.gemm_terms == 3 else 2500.0) if split else FP32_MATRIX_PEAK_TFLOPS
-        roof = {'bound': 'mfma', 'kernel': dominant, 'achieved': ach, 'peak': peak,
-                'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
-                'arithmetic': 'fp16 MFMA, three-term hi/lo split (peak = 2500 / 3)' if split else 'fp32-input MFMA',
-                'avg_launch_us': avg_s * 1e6, 'flops_per_launch': flops_per_launch, **common}
 
+    # ---- algorithmic work of the timed rollouts (this rank), from the edge totals the device counted
+    L = cfg.num_agent_layers
+    steps_dec = cfg.num_decode_steps
+    ed1 = per_kernel['k_edge_attn']['edges_built']                       # one rollout (leg 1)
+    rows_dec = float(sum(h['A'] for h in eng.hosts)) * steps_dec          # decoded rows (agent-token-steps) of one rollout
+    if args.insertion:
+        rows_dec = float(eng.n_agents.sum().item()) * steps_dec           # upper bound: the final agent count on every step
+    f_alg = 2.0 * (rows_dec * NODE_MAC_PER_ROW + ed1['temporal'] * EDGE_MAC_TEMPORAL +
+                   (ed1['map'] + ed1['agent']) * EDGE_MAC_OTHER) + rows_dec * GRID_FLOP_PER_ROW
+    b_alg = (L * KV_ROW_BYTES * (ed1['temporal'] + ed1['map']) + rows_dec * ROW_FIXED_BYTES +
+             steps_dec * (WEIGHT_BYTES_PER_STEP + 8.0 * args.map_tokens * len(scenes)))
+    t_roll = dt / args.steps
+    step_roof = {'hbm_fraction': b_alg / t_roll / (HBM_PEAK_GBS * 1e9),
+                 'mfma_fraction': f_alg / t_roll / (F16_SPLIT_PEAK_TFLOPS * 1e12),
+                 'mfma_fraction_vs_fp32_matrix_peak': f_alg / t_roll / (FP32_MATRIX_PEAK_TFLOPS * 1e12),
+                 'algorithmic_gbytes_per_rollout': b_alg / 1e9, 'algorithmic_gflop_per_rollout': f_alg / 1e9,
+                 'note': 'SURVEY 8d figures (windowed K/V, every datum moved once; reference per-edge FLOPs) over the measured '
+                         'rollout time incl. the map-encoder prologue'}
+
+    roof = None
+    common = {'launches': dom['calls'], 'avg_launch_us': 1e3 * dom['ms'] / max(1, dom['calls']),
+              'share_of_gpu_time': per_kernel[dominant]['ms'] / max(1e-9, sum(v['ms'] for v in per_kernel.values())),
+              'per_kernel_ms_one_rollout': {k: round(v['ms'], 3) for k, v in per_kernel.items()}, 'step': step_roof}
+    if dom['calls'] > 0 and dominant == 'k_edge_attn':
+        # the edge kernel (k_edge_fused): one launch per sublayer.  8d's bytes of a launch: 1 KB of K / V per temporal or map
+        # edge (every edge has its own source row), 1 KB per decoded row for the agent set (a scene's K / V rows are shared by
+        # its rows).  FLOPs: the reference's per-edge projections, 33,024 MAC per edge and layer.
+        ed = timed['k_edge_attn']['edges_built']                          # all timed rollouts
+        rows_t = rows_dec * args.steps
+        nbytes = L * KV_ROW_BYTES * (ed['temporal'] + ed['map'] + rows_t)
+        nflop = 2.0 * L * EDGE_MAC_PER_LAYER * (ed['temporal'] + ed['map'] + ed['agent'])
+        # what this design has to move for the same launches: + 512 B of rhat per edge, + q in / agg out per row
+        model = nbytes + L * 512.0 * (ed['temporal'] + ed['map'] + ed['agent']) + 3 * L * 1024.0 * rows_t
+        secs = dom['ms'] * 1e-3
+        hbm_frac = nbytes / secs / (HBM_PEAK_GBS * 1e9)
+        mfma_frac = nflop / secs / (F16_SPLIT_PEAK_TFLOPS * 1e12)
+        roof = {'bound': 'hbm', 'kernel': 'k_edge_fused', 'achieved': nbytes / secs / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': hbm_frac, 'traffic': None, 'hbm_fraction': hbm_frac, 'mfma_fraction': mfma_frac,
+                'algorithmic_bytes_per_launch': nbytes / dom['calls'], 'algorithmic_flop_per_launch': nflop / dom['calls'],
+                'traffic_model_bytes_per_launch': model / dom['calls'],
+                'traffic_model_frac': model / secs / (HBM_PEAK_GBS * 1e9),
+                'edges_per_launch': (ed['temporal'] + ed['map'] + ed['agent']) * L / dom['calls'], **common}
+    elif dom['calls'] > 0 and dom['macs'] > 0:
+        secs = dom['ms'] * 1e-3
+        flops = 2.0 * dom['macs']
+        split = dominant in ('k_fourier', 'k_attn_pre', 'k_attn_post', 'k_heads')
+        peak = (F16_SPLIT_PEAK_TFLOPS if args.gemm_terms == 3 else F16_DENSE_PEAK_TFLOPS) if split else FP32_MATRIX_PEAK_TFLOPS
+        frac = flops / secs / (peak * 1e12)
+        roof = {'bound': 'mfma', 'kernel': dominant, 'achieved': flops / secs / 1e12, 'peak': peak,
+                'unit': 'TFLOP/s', 'frac': frac, 'traffic': None, 'mfma_fraction': frac, 'hbm_fraction': None,
+                'arithmetic': 'fp16 MFMA, three-term hi/lo split (peak = 2500 / 3)' if split else 'fp32-input MFMA',
+                'algorithmic_flop_per_launch': flops / dom['calls'], **common}
     if roof is not None:
         roof['traffic'] = pmc_traffic(dominant, args)
 
     agent_steps = float(eng.agent_steps() * args.steps)
     inserted = int((eng.n_agents.sum().item() - sum(h['A'] for h in eng.hosts))) if args.insertion else 0
+    n_scenes_local = len(scenes)
     dt, agent_steps = igdist.reduce_run(dt, agent_steps, dev)
     if rank == 0:
+        c3 = args.agents == 64 and args.map_tokens == 1024 and args.rollout_steps == 80 and not args.insertion
+        c4 = args.agents == 64 and args.map_tokens == 1024 and args.rollout_steps == 800 and args.insertion
+        c5 = args.agents == 256 and args.map_tokens == 4096 and args.rollout_steps == 800
+        shape = 'C3 shapes' if c3 else 'C4 shapes' if c4 else 'C5 shapes' if c5 else 'custom shapes'
+        batch = (f'{args.total_scenes} scenes dealt to {world} rank(s) (strong scaling)' if args.scaling == 'strong'
+                 else f'{args.scenes} scenes per GPU (weak scaling)')
         line = {
             'metric': 'agent-steps/sec (closed-loop rollout)',
             'value': agent_steps / dt,
@@ -273,21 +393,24 @@ def main():
             'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': args.scaling,
             'vs_baseline': None,
             'dtype': 'f32' if args.gemm_terms == 3 else 'f16',
             'data': 'synthetic',
             'config': {
-                'workload': f'C3 shapes: configs/ours_standard.yaml, {args.agents} agents / {args.map_tokens} map tokens '
-                            f'per scene, R={args.rollout_steps} ({cfg.num_decode_steps} decode steps), greedy, '
-                            f'insertion {"on" if args.insertion else "disabled"}, '
-                            f'{args.scenes} scenes per GPU, one step = reset + map encoder + full rollout',
-                'scenes_per_gpu': args.scenes, 'streams': ns, 'gemm_terms': args.gemm_terms, 'agents': args.agents, 'map_tokens': args.map_tokens,
-                'decode_steps': cfg.num_decode_steps, 'insertion': bool(args.insertion), 'rows_per_scene': engines[0].A_cap, 'agents_inserted_last_rollout': inserted, 'scenes_at_row_cap': sum(e.scenes_at_row_cap() for e in engines), 'agent_token_steps_per_s': agent_steps / dt / cfg.shift,
+                'workload': f'{shape}: configs/ours_{"long_term" if args.insertion else "standard"}.yaml hyper-parameters, '
+                            f'{args.agents} agents / {args.map_tokens} map tokens per scene, R={args.rollout_steps} '
+                            f'({cfg.num_decode_steps} decode steps), greedy, insertion {"on" if args.insertion else "disabled"}, '
+                            f'{batch}, one step = reset + map encoder + full rollout',
+                'scenes_per_gpu': n_scenes_local, 'streams': ns, 'gemm_terms': args.gemm_terms, 'agents': args.agents,
+                'map_tokens': args.map_tokens, 'decode_steps': cfg.num_decode_steps, 'insertion': bool(args.insertion),
+                'rows_per_scene': engines[0].A_cap, 'agents_inserted_last_rollout': inserted,
+                'agent_token_steps_per_s': agent_steps / dt / cfg.shift,
                 'parallelism': f'scenes sharded over {world} rank(s), no data-path collective',
             },
             'roofline': roof,
             'cpu_baseline': cpu,
+            'parity': parity,
         }
         print(json.dumps(line))
     if dist is not None:

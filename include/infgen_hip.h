@@ -88,6 +88,19 @@ typedef struct InfgenEdgeBuf {
   int _pad;
 } InfgenEdgeBuf;
 
+/* kernel-selection switches and the padded-row bookkeeping of one rollout context (see InfgenRollout.opts) */
+typedef struct InfgenOptions {
+  int use;              /* 0: the process-wide defaults of the infgen_set_* functions apply (single-context callers) */
+  int attn_mode;        /* infgen_set_attn_mode */
+  int gemm_terms;       /* infgen_set_gemm_terms */
+  int fourier_mode;     /* infgen_set_fourier_mode */
+  int edge_fuse;        /* infgen_set_edge_fuse */
+  int edge_loop;        /* infgen_set_edge_loop */
+  int overlap;          /* infgen_set_overlap (the side stream itself is shared: keep 0 when contexts run concurrently) */
+  int row_group_margin; /* rows a decode step may append (infgen_set_row_limits) */
+  const int* row_groups; const int* n_row_groups;   /* optional list of the 16-row groups that hold agents (infgen_set_row_groups) */
+} InfgenOptions;
+
 typedef struct InfgenRollout {
   /* sizes / hyper-parameters */
   int S, A_cap, T, M_cap, W, ring, R, token_size, grid_size, num_layers;
@@ -126,6 +139,10 @@ typedef struct InfgenRollout {
    * the sample_k most probable tokens with the uniforms sample_u[t][row]; needs logits_scratch [rows][token_size] */
   int sample_k; int _pad1;
   const float* sample_u; float* logits_scratch;
+  /* per-context options (re-entrancy): with opts.use != 0 the rollout-level entries (infgen_decode_layers / _step /
+   * infgen_rollout_run, infgen_raw_feature*, infgen_build_edges) take every switch from here and never read the process-wide
+   * defaults of the infgen_set_* functions - two contexts of one process may differ and run from different host threads */
+  InfgenOptions opts;
 } InfgenRollout;
 
 int infgen_linear(const float* X, int ldx, const int* gather, int rows, int K,
@@ -167,6 +184,12 @@ int infgen_edge_attn_fused(int rows, const float* Q, const float* pack, const fl
                            const int* off, const int* cnt, const int* src, const float* rhat,
                            float* AGG, void* stream);
 int infgen_set_edge_fuse(int mode);
+/* the process-wide defaults (what the infgen_set_* functions edited so far), e.g. to seed a context's own InfgenOptions */
+int infgen_get_options(InfgenOptions* out);
+/* diagnostics: resident workgroups per CU the runtime reports for k_edge_fused; a plain streaming read of n_bytes with 8 or
+ * 16 bytes per lane for calibrating rocprofv3 FETCH_SIZE (tools/calibrate_fetch.sh; out: 2048 floats) */
+int infgen_edge_fused_occupancy(void);
+int infgen_debug_stream_read(const float* p, unsigned long long n_bytes, int width, float* out, void* stream);
 /* edges per trip of k_edge_fused's edge loop (their K / V / rhat rows are requested together): 4, 6 (default) or 8 */
 int infgen_set_edge_loop(int variant);
 /* 1: infgen_decode_layers runs the Fourier embeddings of the map and agent edge sets on an internal side stream, overlapped
@@ -207,7 +230,9 @@ int infgen_sample_topk(const float* logits, int rows, int n, int k, const float*
  *   infgen_occupancy        one-hot sum of the grid tokens of column c (:1852-1854)
  *   infgen_point_edges      _build_a2sa_edge / _build_map2sa_edge for one query point per scene (:760-904):
  *                           first-K agents / map tokens (ascending index) within a radius of centre_row's pose
- *   infgen_insert_decide    seed heads -> enter / type / shape / cell, occupied-cell rejection, row append (:1883-1999)
+ *   infgen_insert_decide    seed heads -> enter / type / shape / cell, occupied-cell rejection, row append (:1883-1999);
+ *                           inserted[s] = 1 row appended, 0 none, -1 the scene has no free row left (A_cap reached: the
+ *                           caller must re-run with more head-room - nothing is dropped silently)
  *   infgen_insert_finalize  heading token + xy offset of the new row (:2060-2074) */
 int infgen_occupancy(const InfgenRollout* r, int c, float* occ, void* stream);
 int infgen_point_edges(const InfgenRollout* r, int c, const int* centre_row, const int* active, int exclude_centre,

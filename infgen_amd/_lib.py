@@ -31,6 +31,11 @@ class EdgeBuf(C.Structure):
                 ('cap', _i), ('_pad', _i)]
 
 
+class Options(C.Structure):
+    _fields_ = [('use', _i), ('attn_mode', _i), ('gemm_terms', _i), ('fourier_mode', _i), ('edge_fuse', _i), ('edge_loop', _i),
+                ('overlap', _i), ('row_group_margin', _i), ('row_groups', _p), ('n_row_groups', _p)]
+
+
 class Rollout(C.Structure):
     _fields_ = [
         ('S', _i), ('A_cap', _i), ('T', _i), ('M_cap', _i), ('W', _i), ('ring', _i), ('R', _i),
@@ -54,6 +59,7 @@ class Rollout(C.Structure):
         ('pred_traj', _p), ('pred_head', _p), ('pred_state', _p),
         ('first_new', _p), ('hv_ovr', _p),
         ('sample_k', _i), ('_pad1', _i), ('sample_u', _p), ('logits_scratch', _p),
+        ('opts', Options),
     ]
 
 
@@ -71,6 +77,9 @@ SYMBOLS = {
     'infgen_set_attn_mode': (_i, [_i]),
     'infgen_set_edge_fuse': (_i, [_i]),
     'infgen_set_edge_loop': (_i, [_i]),
+    'infgen_get_options': (_i, [C.POINTER(Options)]),
+    'infgen_edge_fused_occupancy': (_i, []),
+    'infgen_debug_stream_read': (_i, [_p, C.c_ulonglong, _i, _p, _p]),
     'infgen_set_overlap': (_i, [_i]),
     'infgen_edge_attn_fused': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'infgen_distance_to_nearest_object': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_float, _p, _p, _p]),

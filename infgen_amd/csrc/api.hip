@@ -25,6 +25,38 @@ static int check_launch(const char* where) {
 
 extern "C" const char* infgen_last_error(void) { return g_err.c_str(); }
 
+// ---------------------------------------------------------------------------------- options
+// Every switch that changes what a launch does lives in an InfgenOptions.  g_def holds the process-wide defaults the
+// infgen_set_* functions edit (used by the operator-level entries and by contexts with opts.use == 0); a rollout-level entry
+// called with a context whose opts.use != 0 installs that context's block for the duration of the call (thread-local), so
+// contexts of one process do not see each other's settings.
+namespace {
+InfgenOptions g_def = {0, /*attn_mode*/ 2, /*gemm_terms*/ 3, /*fourier_mode*/ 1, /*edge_fuse*/ 1, /*edge_loop*/ 6, /*overlap*/ 0,
+                       /*row_group_margin*/ 0, nullptr, nullptr};
+int g_def_group_rows = 0;                  // rows of the layout the process-wide group list belongs to
+const int* g_def_limit_n_agents = nullptr; // process-wide row limits (infgen_set_row_limits)
+int g_def_limit_A_cap = 0;
+struct Active { const InfgenOptions* o; int group_rows; const int* n_agents; int A_cap; };
+thread_local Active tl_active = {nullptr, 0, nullptr, 0};
+inline const InfgenOptions& O() { return tl_active.o ? *tl_active.o : g_def; }
+inline int group_rows() { return tl_active.o ? tl_active.group_rows : g_def_group_rows; }
+inline const int* limit_n_agents() { return tl_active.o ? tl_active.n_agents : g_def_limit_n_agents; }
+inline int limit_A_cap() { return tl_active.o ? tl_active.A_cap : g_def_limit_A_cap; }
+struct OptScope {
+  Active prev;
+  explicit OptScope(const InfgenRollout* r) : prev(tl_active) {
+    if (r && r->opts.use) tl_active = Active{&r->opts, r->S * r->A_cap, r->opts.row_groups ? r->n_agents : nullptr, r->A_cap};
+  }
+  ~OptScope() { tl_active = prev; }
+};
+}  // namespace
+
+extern "C" int infgen_get_options(InfgenOptions* out) {
+  if (!out) return fail("infgen_get_options", "null pointer");
+  *out = g_def;
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------- profiling
 // Optional, process-global, off by default: HIP events recorded on the launch stream around the
 // launches of the selected kernels (bench.py's roofline leg).  Not used by the product path.
@@ -194,6 +226,15 @@ extern "C" int infgen_linear_multi(const InfgenLinearDesc* desc, int n, void* st
   return check_launch("infgen_linear_multi");
 }
 
+// counter calibration (tools/calibrate_fetch.sh): stream n_bytes with `width` (8 or 16) bytes per lane; out: [2048] floats
+extern "C" int infgen_debug_stream_read(const float* p, unsigned long long n_bytes, int width, float* out, void* stream) {
+  if (width != 8 && width != 16) return fail("infgen_debug_stream_read", "width must be 8 or 16");
+  if (hipMemsetAsync(out, 0, 2048 * sizeof(float), (hipStream_t)stream) != hipSuccess) return fail("infgen_debug_stream_read", "memset failed");
+  if (width == 8) hipLaunchKernelGGL(k_stream_read<8>, dim3(2048), dim3(256), 0, (hipStream_t)stream, p, (size_t)(n_bytes / 4), out);
+  else hipLaunchKernelGGL(k_stream_read<16>, dim3(2048), dim3(256), 0, (hipStream_t)stream, p, (size_t)(n_bytes / 4), out);
+  return check_launch("infgen_debug_stream_read");
+}
+
 extern "C" int infgen_layernorm(const float* X, int rows, const float* gamma, const float* beta, float* Y, void* stream) {
   if (rows <= 0) return 0;
   hipLaunchKernelGGL(k_layernorm, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, X, rows, gamma, beta, Y);
@@ -203,17 +244,16 @@ extern "C" int infgen_layernorm(const float* X, int rows, const float* gamma, co
 // 3 (default): fp16 three-term split = fp32 accuracy; 1: only the hi x hi product of the same packed operands, i.e. plain fp16
 // arithmetic (11 bits per operand) in the split kernels - the reduced-precision mode for BASELINE config C5 ("bf16"), which
 // forfeits the 1e-3 logits bar.  Governs k_fourier_h, k_attn_h, k_mlpemb_h, k_heads_h.
-static int g_gemm_terms = 3;
 extern "C" int infgen_set_gemm_terms(int terms) {
   if (terms != 1 && terms != 3) return fail("infgen_set_gemm_terms", "terms must be 3 (split, fp32 accuracy) or 1 (fp16)");
-  g_gemm_terms = terms;
+  g_def.gemm_terms = terms;
   return 0;
 }
 
-static int g_fourier_mode = 1;   // 1: fp16 three-term split (k_fourier_h), 0: fp32-input MFMA (k_fourier)
+// fourier_mode 1: fp16 three-term split (k_fourier_h), 0: fp32-input MFMA (k_fourier)
 extern "C" int infgen_set_fourier_mode(int mode) {
   if (mode != 0 && mode != 1) return fail("infgen_set_fourier_mode", "mode must be 0 (fp32 MFMA) or 1 (fp16 split)");
-  g_fourier_mode = mode;
+  g_def.fourier_mode = mode;
   return 0;
 }
 
@@ -223,7 +263,7 @@ extern "C" int infgen_fourier_embed(const float* raw, int n, const int* count_de
   if (n < 1 || n > 4) return fail("infgen_fourier_embed", "n_dims must be in 1..4");
   FourierArgs a{raw, n, count_dev, e_cap, pack, cat, ldcat, out, ldo, normalize,
                 (g_prof.mask >> INFGEN_KID_FOURIER) & 1u ? g_prof.rows_dev : nullptr};
-  if (g_fourier_mode == 0) {
+  if (O().fourier_mode == 0) {
     int grid = ceil_div(e_cap, TR);
     if (grid > 2048) grid = 2048;
     ProfScope _ps(INFGEN_KID_FOURIER, stream);
@@ -232,7 +272,7 @@ extern "C" int infgen_fourier_embed(const float* raw, int n, const int* count_de
     int grid = ceil_div(e_cap, 128);     // 128-row tiles (8 waves x 16 rows), persistent
     if (grid > 256) grid = 256;          // one workgroup per CU (fourier_h.hip explains why)
     ProfScope _ps(INFGEN_KID_FOURIER, stream);
-    if (g_gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h<1>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    if (O().gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h<1>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_fourier_h<3>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
   }
   return check_launch("infgen_fourier_embed");
@@ -241,34 +281,26 @@ extern "C" int infgen_fourier_embed(const float* raw, int n, const int* count_de
 // 0: fp32-input MFMA (k_attn_pre / k_attn_post), 1: fp16 three-term split (k_attn_h), 2 (default): by size - the split
 // kernel runs one workgroup per CU on 64/128-row tiles and wins from ~10 k rows (16 k rows: 99 vs 121 us, 64 k: 337 vs
 // 479 us); below, the 32-row tiles of the fp32 kernels fill the chip better (8 k rows: 73 vs 95 us, 64 rows: 54 vs 77 us)
-static int g_attn_mode = 2;
 extern "C" int infgen_set_attn_mode(int mode) {
   if (mode < 0 || mode > 2) return fail("infgen_set_attn_mode", "mode must be 0 (fp32 MFMA), 1 (fp16 split) or 2 (by size)");
-  g_attn_mode = mode;
+  g_def.attn_mode = mode;
   return 0;
 }
-static inline bool attn_split(int rows) { return g_attn_mode == 1 || (g_attn_mode == 2 && rows > 10240); }
+static inline bool attn_split(int rows) { return O().attn_mode == 1 || (O().attn_mode == 2 && rows > 10240); }
 
 // 64-row tiles, 4 waves, two workgroups per CU (attn_h.hip); INFGEN_ATTN_WAVES=8 selects the 128-row variant
 // optional list of the 16-row groups that hold agents (infgen_set_row_groups): applied to every split-kernel launch over
 // exactly `g_group_rows` rows, i.e. the [S][A_cap] row arrays of the rollout the caller is running
-static const int* g_groups = nullptr;
-static const int* g_n_groups = nullptr;
-static int g_group_rows = 0;
-
-static const int* g_limit_n_agents = nullptr;
-static int g_limit_A_cap = 0, g_limit_margin = 0;
-
 extern "C" int infgen_set_row_groups(const int* groups, const int* n_groups, int rows) {
-  g_groups = groups; g_n_groups = n_groups; g_group_rows = groups ? rows : 0;
-  if (!groups) g_limit_n_agents = nullptr;
+  g_def.row_groups = groups; g_def.n_row_groups = n_groups; g_def_group_rows = groups ? rows : 0;
+  if (!groups) g_def_limit_n_agents = nullptr;
   return 0;
 }
 
 // the same information for the edge kernel (one wave per row): n_agents [S] of the [S][A_cap] layout and the margin the group
 // list was built with; applies to launches over exactly the rows given to infgen_set_row_groups
 extern "C" int infgen_set_row_limits(const int* n_agents, int A_cap, int margin) {
-  g_limit_n_agents = n_agents; g_limit_A_cap = A_cap; g_limit_margin = margin;
+  g_def_limit_n_agents = n_agents; g_def_limit_A_cap = A_cap; g_def.row_group_margin = margin;
   return 0;
 }
 
@@ -282,12 +314,12 @@ extern "C" int infgen_active_row_groups(const int* n_agents, int S, int A_cap, i
 
 static void launch_attn_h(const AttnHArgs& a_in, void* stream) {
   AttnHArgs a = a_in;
-  if (g_groups && a.rows == g_group_rows) { a.groups = g_groups; a.n_groups = g_n_groups; }
+  if (O().row_groups && a.rows == group_rows()) { a.groups = O().row_groups; a.n_groups = O().n_row_groups; }
   static const int waves = getenv("INFGEN_ATTN_WAVES") ? atoi(getenv("INFGEN_ATTN_WAVES")) : 4;
   if (waves != 8) {
     int grid = ceil_div(a.rows, 64);
     if (grid > 512) grid = 512;          // two workgroups per CU, persistent over the 64-row tiles beyond that
-    if (g_gemm_terms == 1) hipLaunchKernelGGL((k_attn_h<4, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    if (O().gemm_terms == 1) hipLaunchKernelGGL((k_attn_h<4, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((k_attn_h<4, 3>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   } else {
     int grid = ceil_div(a.rows, 128);
@@ -316,8 +348,8 @@ static int edge_attn_impl(int rows, const float* Q, const float* U, const float*
                           float* AGG, float* Z, float* SIG, int wide, void* stream) {
   if (rows <= 0) return 0;
   EdgeAttnArgs a{rows, Q, U, Ksrc, Vsrc, EdgeSet{off, cnt, src, rhat}, AGG, Z, SIG, nullptr, nullptr, 0, 0};
-  if (g_limit_n_agents && g_groups && rows == g_group_rows && !wide) {
-    a.n_agents = g_limit_n_agents; a.A_cap = g_limit_A_cap; a.margin = g_limit_margin;
+  if (limit_n_agents() && O().row_groups && rows == group_rows() && !wide) {
+    a.n_agents = limit_n_agents(); a.A_cap = limit_A_cap(); a.margin = O().row_group_margin;
   }
   { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
     if (wide) hipLaunchKernelGGL(k_edge_attn_wide, dim3(rows), dim3(512), 0, (hipStream_t)stream, a);
@@ -328,18 +360,16 @@ static int edge_attn_impl(int rows, const float* Q, const float* U, const float*
 // 1 (default): infgen_decode_layers runs the edge side of every sublayer with k_edge_fused - the absorbed query U and the
 // positional aggregate Z of a 16-row tile stay on chip (LDS) and the node kernels run with has_pos = 0; 0: the unfused
 // sequence with U / Z / SIG in HBM (kept for comparison and used below 257 rows, where k_edge_attn_wide splits long edge lists)
-static int g_edge_fuse = 1;
 extern "C" int infgen_set_edge_fuse(int mode) {
   if (mode < 0 || mode > 2) return fail("infgen_set_edge_fuse", "mode must be 0 (off), 1 (from 257 rows) or 2 (always)");
-  g_edge_fuse = mode;
+  g_def.edge_fuse = mode;
   return 0;
 }
 
 // edges per trip of k_edge_fused's edge loop (their K / V / rhat rows are requested together): 4, 6 (default) or 8
-static int g_edge_loop = 6;
 extern "C" int infgen_set_edge_loop(int v) {
   if (v != 4 && v != 6 && v != 8) return fail("infgen_set_edge_loop", "edges per trip must be 4, 6 or 8");
-  g_edge_loop = v;
+  g_def.edge_loop = v;
   return 0;
 }
 
@@ -359,7 +389,7 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
   static const int no_xcd = getenv("INFGEN_EDGE_NOXCD") ? atoi(getenv("INFGEN_EDGE_NOXCD")) : 0;
   EdgeFusedArgs a{rows, Q, pack, Ksrc, Vsrc, EdgeSet{off, cnt, src, rhat}, AGG, nullptr, nullptr, dbg, 0, kv_once};
   int grid = ceil_div(rows, 32);           // 32-row tiles (two 16-row groups); with a group list at most that many
-  if (g_groups && rows == g_group_rows) { a.groups = g_groups; a.n_groups = g_n_groups; }
+  if (O().row_groups && rows == group_rows()) { a.groups = O().row_groups; a.n_groups = O().n_row_groups; }
   else if (rows_per_scene > 32 && rows_per_scene % 32 == 0 && !(no_xcd & 1)) {
     a.tiles_per_scene = rows_per_scene / 32;
     const int grp = 8 * a.tiles_per_scene;
@@ -368,8 +398,8 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
   if (no_xcd & 2) a.kv_once = 0;
   a.n_virtual = grid;
   { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
-    if (g_edge_loop == 4) hipLaunchKernelGGL(k_edge_fused<4>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, a);
-    else if (g_edge_loop == 8) hipLaunchKernelGGL(k_edge_fused<8>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, a);
+    if (O().edge_loop == 4) hipLaunchKernelGGL(k_edge_fused<4>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, a);
+    else if (O().edge_loop == 8) hipLaunchKernelGGL(k_edge_fused<8>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_edge_fused<6>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_edge_attn_fused");
 }
@@ -563,7 +593,7 @@ extern "C" int infgen_heads(const float* X, int rows, const float* tok_pack, con
     if (attn_split(rows)) {
       int grid = ceil_div(rows, 64);
       if (grid > 512) grid = 512;
-      if (g_gemm_terms == 1) hipLaunchKernelGGL(k_heads_h<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+      if (O().gemm_terms == 1) hipLaunchKernelGGL(k_heads_h<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
       else hipLaunchKernelGGL(k_heads_h<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     } else {
       hipLaunchKernelGGL(k_heads, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a);
@@ -608,6 +638,7 @@ static int validate(const InfgenRollout* r, const char* where) {
 
 extern "C" int infgen_build_edges(const InfgenRollout* r, int c, int edgeless, void* stream) {
   RET_IF(validate(r, "infgen_build_edges"));
+  OptScope _opts(r);
   hipStream_t s = (hipStream_t)stream;
   if (!edgeless) {
     if (hipMemsetAsync(r->et.total, 0, sizeof(int), s) != hipSuccess ||
@@ -627,6 +658,7 @@ extern "C" int infgen_build_edges(const InfgenRollout* r, int c, int edgeless, v
 
 extern "C" int infgen_integrate(const InfgenRollout* r, int t, void* stream) {
   RET_IF(validate(r, "infgen_integrate"));
+  OptScope _opts(r);
   IntegrateArgs a;
   a.st = scene_of(r); a.c = 1 + t; a.t = t; a.R = r->R; a.force_valid = r->force_valid;
   a.next_token = r->next_token; a.next_state = r->next_state;
@@ -645,6 +677,7 @@ static inline int mlpemb_off3(int K0p) { return mlpemb_off2(K0p) + 16384 + 3 * 1
 
 extern "C" int infgen_raw_feature(const InfgenRollout* r, int col, void* stream) {
   RET_IF(validate(r, "infgen_raw_feature"));
+  OptScope _opts(r);
   const int rows = r->S * r->A_cap;
   RawFeatArgs a;
   a.st = scene_of(r); a.col = col; a.tok_tab = r->tok_tab; a.token_size = r->token_size;
@@ -661,7 +694,7 @@ extern "C" int infgen_raw_feature(const InfgenRollout* r, int col, void* stream)
     int grid = ceil_div(rows, 64);
     if (grid > 512) grid = 512;
     { ProfScope _ps(INFGEN_KID_LINEAR, stream, (double)rows * (512 + 128 + 128) * 128.0);
-      if (g_gemm_terms == 1) hipLaunchKernelGGL(k_mlpemb_h<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m);
+      if (O().gemm_terms == 1) hipLaunchKernelGGL(k_mlpemb_h<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m);
       else hipLaunchKernelGGL(k_mlpemb_h<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m); }
     return check_launch("infgen_raw_feature/fusion");
   }
@@ -681,6 +714,7 @@ extern "C" int infgen_raw_feature(const InfgenRollout* r, int col, void* stream)
 extern "C" int infgen_raw_feature_rows(const InfgenRollout* r, int col, const int* row_list, const int* row_mask, int n,
                                        void* stream) {
   RET_IF(validate(r, "infgen_raw_feature_rows"));
+  OptScope _opts(r);
   if (n <= 0) return 0;
   if (n > r->S * r->A_cap) return fail("infgen_raw_feature_rows", "more rows than the layout holds");
   RawFeatArgs a;
@@ -715,7 +749,6 @@ extern "C" int infgen_sample_topk(const float* logits, int rows, int n, int k, c
 
 // Optional: the Fourier embeddings of the map and agent edge sets (matrix-pipe / VALU work) run on a side stream while
 // the temporal and map sublayers of the first layer (memory-bound) run on the caller's stream.
-static int g_overlap = 0;
 static hipStream_t g_side = nullptr;
 static hipEvent_t g_ev_fork = nullptr, g_ev_m = nullptr, g_ev_a = nullptr;
 extern "C" int infgen_set_overlap(int mode) {
@@ -727,15 +760,16 @@ extern "C" int infgen_set_overlap(int mode) {
         hipEventCreateWithFlags(&g_ev_a, hipEventDisableTiming) != hipSuccess)
       return fail("infgen_set_overlap", "stream / event creation failed");
   }
-  g_overlap = mode;
+  g_def.overlap = mode;
   return 0;
 }
 
 extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless, void* stream) {
   RET_IF(validate(r, "infgen_decode_layers"));
+  OptScope _opts(r);
   const int rows = r->S * r->A_cap;
   RET_IF(infgen_build_edges(r, c, edgeless, stream));
-  const bool overlap = g_overlap && !edgeless;
+  const bool overlap = O().overlap && g_side && !edgeless;
   if (overlap) {
     hipStream_t ms = (hipStream_t)stream;
     if (hipEventRecord(g_ev_fork, ms) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork, 0) != hipSuccess)
@@ -754,7 +788,7 @@ extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless,
   const int L = r->num_layers;
   // prologue of the first (temporal) layer; every later layer's prologue is fused into the previous
   // layer's k_attn_post
-  const bool fuse = g_edge_fuse == 2 || (g_edge_fuse == 1 && rows > 256);      // U / Z / SIG stay on chip inside k_edge_fused
+  const bool fuse = O().edge_fuse == 2 || (O().edge_fuse == 1 && rows > 256);      // U / Z / SIG stay on chip inside k_edge_fused
   float* U = fuse ? nullptr : r->U;
   const float* Z = fuse ? nullptr : r->Z;
   const float* SIG = fuse ? nullptr : r->SIG;
@@ -791,6 +825,7 @@ extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless,
 
 extern "C" int infgen_decode_step(const InfgenRollout* r, int t, void* stream) {
   RET_IF(validate(r, "infgen_decode_step"));
+  OptScope _opts(r);
   const int rows = r->S * r->A_cap;
   const int c = 1 + t;
   if (t < 0 || c + 1 > r->T - 1) return fail("infgen_decode_step", "step beyond the column range");
@@ -808,6 +843,7 @@ extern "C" int infgen_decode_step(const InfgenRollout* r, int t, void* stream) {
 }
 
 extern "C" int infgen_rollout_run(const InfgenRollout* r, int t0, int t1, void* stream) {
+  OptScope _opts(r);
   for (int t = t0; t < t1; ++t) RET_IF(infgen_decode_step(r, t, stream));
   return 0;
 }

@@ -685,7 +685,9 @@ __global__ __launch_bounds__(64) void k_insert_decide(InsertDecideArgs a) {
   if (lt[2] > lt[ty]) ty = 2;
   const bool occupied = a.occ[(size_t)s * a.grid_size + cell] != 0.f;
   const int A = a.n_agents[s];
-  const bool ok = enter && !occupied && a.n_new[s] + 1 <= a.max_new && A < st.A_cap;
+  const bool ok = enter && !occupied && a.n_new[s] + 1 <= a.max_new;
+  // the reference would append a row here; if the scene's row head-room is used up that is reported (-1), never dropped
+  if (ok && A >= st.A_cap) { a.inserted[s] = -1; a.active[s] = 0; return; }
   if (!ok) { a.inserted[s] = 0; a.active[s] = 0; return; }
   const int av = st.av_index[s];
   const size_t ie = sidx(st, s, c, av);

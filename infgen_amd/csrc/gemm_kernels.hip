@@ -213,4 +213,25 @@ __global__ __launch_bounds__(NT) void k_layernorm(const float* X, int rows, cons
   unstage_rows_128(Xs, [&](int r) { return Y + (size_t)(row0 + r) * D; }, nvalid);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_stream_read<W>: calibration of the rocprofv3 FETCH_SIZE counter (tools/calibrate_fetch.sh): a plain streaming read of
+// `n` bytes with W bytes per lane (8: the edge kernel's row pieces, 16: the node kernels' float4 rows), one partial sum per
+// workgroup written out so that the loads stay.  The guide documents the factor only for 16 B per lane.
+// ------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void k_stream_read(const float* __restrict__ p, size_t n_floats, float* out) {
+  constexpr int F = W / 4;
+  float acc = 0.f;
+  const size_t stride = (size_t)gridDim.x * 256 * F;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * F; i + F <= n_floats; i += stride) {
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    if constexpr (F == 2) { const v2 v = __builtin_nontemporal_load(reinterpret_cast<const v2*>(p + i)); acc += v[0] + v[1]; }
+    else { const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + i)); acc += (v[0] + v[1]) + (v[2] + v[3]); }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out + blockIdx.x, acc);
+}
+template __global__ void k_stream_read<8>(const float*, size_t, float*);
+template __global__ void k_stream_read<16>(const float*, size_t, float*);
+
 }  // namespace ig

@@ -338,6 +338,7 @@ struct MapGraphArgs {
   EdgeBuf e;
 };
 
+template <int W> __global__ void k_stream_read(const float* p, size_t n_floats, float* out);   // gemm_kernels.hip
 __global__ void k_linear(LinearArgs a);
 __global__ void k_linear_multi(LinearMultiArgs m);
 __global__ void k_fourier(FourierArgs a);

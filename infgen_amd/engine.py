@@ -31,6 +31,15 @@ def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+class InsertionHeadroomError(RuntimeError):
+    """scenario insertion ran out of agent rows in some scene: results would differ from the reference's, so the rollout
+    stops instead of dropping the insertion; the caller re-runs with more ``insert_headroom``"""
+
+    def __init__(self, msg, needed=0):
+        super().__init__(msg)
+        self.needed = needed
+
+
 class PackedWeights:
     """Device-resident packed weights of one checkpoint (shared by every engine on the GPU)."""
 
@@ -264,8 +273,9 @@ class RolloutEngine:
                  store_logits: bool = False, live_state: bool = False,
                  teacher: Optional[Sequence] = None, x_pt_override: Optional[Sequence] = None,
                  force_enter: bool = False, insert_headroom: Optional[int] = None,
-                 sample_k: int = 1, sample_uniforms: Optional[np.ndarray] = None):
+                 sample_k: int = 1, sample_uniforms: Optional[np.ndarray] = None, options: Optional[Mapping[str, int]] = None):
         self.w = weights
+        self.options = dict(options) if options else None      # per-engine kernel switches (fields of InfgenOptions)
         self.cfg = cfg = weights.cfg
         self.device = dev = weights.device
         self.ops = Ops(dev)
@@ -340,8 +350,8 @@ class RolloutEngine:
         if teacher is not None:
             tt = np.full((S, T, A_cap), -1, np.int32); ts = np.zeros((S, T, A_cap), np.int32)
             for s, (tok_s, st_s) in enumerate(teacher):
-                A = hosts[s]['A']
-                tt[s, :, :A] = np.asarray(tok_s).T; ts[s, :, :A] = np.asarray(st_s).T
+                A = min(np.asarray(tok_s).shape[0], A_cap)        # rows beyond the initial agents: inserted ones (insertion on)
+                tt[s, :, :A] = np.asarray(tok_s)[:A].T; ts[s, :, :A] = np.asarray(st_s)[:A].T
             self.teacher_token, self.teacher_state = t(tt), t(ts)
 
         # ------------------------------------------------ scratch / caches
@@ -546,6 +556,7 @@ class RolloutEngine:
                 ops.attn_pre(x_pt, w.attn_pt2sa[i], use_src_ln=True, k=self.ins['mapK'][i], v=self.ins['mapV'][i])
         if self._ctx is None:
             self._build_ctx()
+        self._refresh_opts()
         st = ops.stream
         # column 0: edgeless chain, its K/V land in ring slot 0 (SURVEY a-Q3); then column 1's raw feature
         _lib.check(self.lib.infgen_raw_feature(C.byref(self._ctx), 0, st), 'raw_feature(0)')
@@ -682,8 +693,16 @@ class RolloutEngine:
                                                 _lib.ptr(I['n_new']), _lib.ptr(I['inserted']), _lib.ptr(I['new_row']),
                                                 _lib.ptr(I['new_shape']), _lib.ptr(I['new_cell']), st),
                        'infgen_insert_decide')
-            ins = I['inserted'].bool()
-            ins_host = ins.cpu().numpy()                 # host sync: did any scene insert?
+            ins_host = I['inserted'].cpu().numpy()       # host sync: did any scene insert?
+            if (ins_host < 0).any():
+                full = np.nonzero(ins_host < 0)[0]
+                raise InsertionHeadroomError(
+                    f'decode step {t}: scene(s) {full[:8].tolist()} have used all {self.A_cap} agent rows '
+                    f'({int(self.n_agents[int(full[0])].item())} agents) and the seed head asks for another insertion; '
+                    f're-run with a larger insert_headroom (rows per scene <= {self.lib.infgen_layout_query(_lib.Q_MAX_AGENTS)})',
+                    needed=self.A_cap)
+            ins = I['inserted'] > 0
+            ins_host = ins_host > 0
             if not ins_host.any():
                 break
             nr = I['new_row'][ins].long()
@@ -777,33 +796,42 @@ class RolloutEngine:
             c.first_new, c.hv_ovr = P(self.ins['first_new']), P(self.ins['hv_ovr'])
         c.sample_k, c.sample_u, c.logits_scratch = self.sample_k, P(self.sample_u), P(self.logits_scratch)
         self._ctx = c
+        self._refresh_opts()
+
+    def _refresh_opts(self, groups: bool = False):
+        """the context carries its own kernel switches (InfgenRollout.opts, re-entrant): explicit ``options`` of this engine,
+        otherwise a snapshot of the library's process-wide defaults (infgen_set_*) taken at every prologue / run"""
+        o = self._ctx.opts
+        _lib.check(self.lib.infgen_get_options(C.byref(o)), 'infgen_get_options')
+        for k, v in (self.options or {}).items():
+            setattr(o, k, int(v))
+        o.use = 1
+        o.row_groups = o.n_row_groups = None
+        o.row_group_margin = 0
+        if groups and self.insertion and self.ins is not None and os.environ.get('INFGEN_ROW_GROUPS', '1') != '0':
+            # rows are padded to A_cap per scene: the split node kernels and the edge kernels visit only the 16-row groups
+            # that hold agents (or may receive one of the <= 10 rows a step appends)
+            o.row_groups, o.n_row_groups, o.row_group_margin = _lib.ptr(self.ins['groups']), _lib.ptr(self.ins['n_groups']), 10
 
     # ------------------------------------------------------------------ rollout
     def run(self, t0: int = 0, t1: Optional[int] = None):
         if not self._prologue_done:
             self.prologue()
         t1 = self.cfg.num_decode_steps if t1 is None else t1
+        self._refresh_opts(groups=True)        # (the group list is rebuilt on the device at every decode step below)
         if not self.insertion:
             _lib.check(self.lib.infgen_rollout_run(C.byref(self._ctx), t0, t1, self.ops.stream), 'infgen_rollout_run')
             return
-        # rows are padded to A_cap per scene: the split node kernels visit only the 16-row groups that hold agents (or may
-        # receive one of the <= 10 rows a step appends); INFGEN_ROW_GROUPS=0 switches the compaction off
         lib, I, st = self.lib, self.ins, self.ops.stream
-        use_groups = os.environ.get('INFGEN_ROW_GROUPS', '1') != '0'
-        try:
+        use_groups = bool(self._ctx.opts.row_groups)
+        for t in range(t0, t1):
             if use_groups:
-                _lib.check(lib.infgen_set_row_groups(_lib.ptr(I['groups']), _lib.ptr(I['n_groups']), self.rows))
-                _lib.check(lib.infgen_set_row_limits(_lib.ptr(self.n_agents), self.A_cap, 10))
-            for t in range(t0, t1):
-                if use_groups:
-                    _lib.check(lib.infgen_active_row_groups(_lib.ptr(self.n_agents), self.S, self.A_cap, 10,
-                                                            _lib.ptr(I['groups']), _lib.ptr(I['n_groups']), st),
-                               'infgen_active_row_groups')
-                if t > 0:
-                    self._insert_step(t)
-                self.step(t)
-        finally:
-            _lib.check(lib.infgen_set_row_groups(None, None, 0))
+                _lib.check(lib.infgen_active_row_groups(_lib.ptr(self.n_agents), self.S, self.A_cap, 10,
+                                                        _lib.ptr(I['groups']), _lib.ptr(I['n_groups']), st),
+                           'infgen_active_row_groups')
+            if t > 0:
+                self._insert_step(t)
+            self.step(t)
 
     def edge_totals(self):
         """(temporal, map, agent) edge counts of the last decode step's edge sets (one host sync)"""

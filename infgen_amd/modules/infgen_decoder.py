@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
-from ..engine import PackedWeights, RolloutEngine
+from ..engine import InsertionHeadroomError, PackedWeights, RolloutEngine
 from ..synth import RolloutConfig
 from .agent_decoder import InfGenAgentDecoder
 from .attr_tokenizer import Attr_Tokenizer
@@ -133,13 +133,26 @@ class InfGenDecoder(nn.Module):
             # stochastic decode like the reference's default (top-k multinomial), driven by torch's RNG
             amax = max(int(np.asarray(s_['agent']['state_idx']).shape[0]) for s_ in scenes)
             sample_uniforms = torch.rand(w.cfg.num_decode_steps, len(scenes), amax + 128).numpy()
-        eng = RolloutEngine(w, scenes, vocab, map_vocab, grid, x_pt_override=xo,
-                            force_enter=bool(int(os.getenv('DEBUG', 0))),    # DEBUG=1 forces 'enter' (agent_decoder.py:1888)
-                            sample_k=k if not map_only else 1, sample_uniforms=sample_uniforms)
+        def make_engine(headroom=None):
+            return RolloutEngine(w, scenes, vocab, map_vocab, grid, x_pt_override=xo, insert_headroom=headroom,
+                                 force_enter=bool(int(os.getenv('DEBUG', 0))),    # DEBUG=1 forces 'enter' (agent_decoder.py:1888)
+                                 sample_k=k if not map_only else 1, sample_uniforms=sample_uniforms)
+        eng = make_engine()
         if map_only:
             eng.prologue(map_only=True)
             return eng.x_pt[:eng.hosts[0]['M']].clone()
-        eng.rollout()
+        # the reference's agent arrays grow without bound; here rows are pre-allocated per scene.  If the inserted agents
+        # outgrow them the (deterministic) rollout is repeated with twice the rows instead of dropping insertions
+        while True:
+            try:
+                eng.rollout()
+                break
+            except InsertionHeadroomError as e:
+                amax = max(h['A'] for h in eng.hosts)
+                limit = eng.lib.infgen_layout_query(_lib.Q_MAX_AGENTS)
+                if eng.A_cap >= limit:
+                    raise
+                eng = make_engine(headroom=min(2 * eng.A_cap, limit) - amax)
         outs = eng.outputs()
         dev = w.device
         res = []

@@ -100,12 +100,16 @@ class InsertionOracle(RolloutOracle):
         enter = int(st_logit.softmax(-1).argmax(-1)) == 1
         if self.force_enter:
             enter = True
-        ty = int(mlp_layer(sd, p + '.seed_type_predict_head', xs).softmax(-1).argmax(-1))
+        ty_logit = mlp_layer(sd, p + '.seed_type_predict_head', xs)
+        ty = int(ty_logit.softmax(-1).argmax(-1))
         shape = mlp_layer(sd, p + '.seed_shape_predict_head', xs)[0]
-        pos_prob = torch.softmax(mlp_layer(sd, p + '.seed_pos_rel_token_predict_head', xs), dim=-1)
+        pos_logit = mlp_layer(sd, p + '.seed_pos_rel_token_predict_head', xs)
+        pos_prob = torch.softmax(pos_logit, dim=-1)
         cell = int(torch.topk(pos_prob, k=1, dim=-1)[1][0, 0])
+        top2 = torch.topk(pos_logit[0], k=2).values
         new_pos = rot_right(self.grid[cell][None, None], (ego_head - math.pi / 2)[None])[0, 0] + ego_pos
-        st['seed_log'].append(dict(t=t, enter=enter, cell=cell, occupied=bool(occ[cell]), type=ty))
+        st['seed_log'].append(dict(t=t, enter=enter, cell=cell, occupied=bool(occ[cell]), type=ty,
+                                   cell_margin=float(top2[0] - top2[1]), type_logits=ty_logit[0].tolist()))
         if bool(occ[cell]):
             return False, raw_c            # rejected; greedy would repeat -> no further insertion this step
         if not enter or num_new + 1 > INSERT_LIMIT:
@@ -175,6 +179,7 @@ class InsertionOracle(RolloutOracle):
         dec = ((hidx * cfg.angle_interval - 180) / 360 * (2 * math.pi)).float()
         new_head = wrap_angle(dec + ego_head)[0]
         off = torch.tanh(mlp_layer(sd, p + '.seed_offset_xy_predict_head', xn))[0] * 2
+        st['seed_log'][-1].update(offset=off.tolist(), heading_bin=int(hidx[0]), n_map_h=int(len(hm)), n_agent_h=int(len(ha)))
         st['head'][new, c] = new_head
         st['pos'][new, c] = st['pos'][new, c] + off
         # ---- (7) final raw feature of the new row; Q13 head-vector overwrite for this step's new rows
@@ -284,7 +289,8 @@ class InsertionOracle(RolloutOracle):
             pred_type=st['pred_type'], pred_shape=st['pred_shape'],
             next_token_idx=st['tok_out'], next_state_idx=st['st_out'],
             logits=logits_all, n_agents=np.asarray(n_agents), seed_log=st['seed_log'],
-            edge_count=np.asarray(st['edge_count'], dtype=np.int64))
+            edge_count=np.asarray(st['edge_count'], dtype=np.int64),
+            layer_inputs=st['X'])      # X[i][row, column]: input of layer triple i (tests compare intermediate features)
 
     # ------------------------------------------------------------------ setup shared with the base class
     def _setup(self, scene, x_pt, vocab):

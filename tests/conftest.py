@@ -32,6 +32,8 @@ def load_case(name):
     z = np.load(os.path.join(GOLDEN, name + '.npz'))
     meta = json.loads(str(z['meta']))
     cfg = synth.smart_config() if meta['cfg'] == 'smart' else synth.standard_config()
+    if meta.get('R'):
+        cfg = synth.standard_config(num_recurrent_steps_val=meta['R'])
     meta.setdefault('insertion', '')
     vocab = synth.make_agent_vocab(cfg.token_size)
     map_vocab = synth.make_map_vocab()

@@ -56,6 +56,10 @@ CASES = {
                                 edge_cases=False, head_gain=64.0, insertion='forced'),
     'ins_natural_a20_m256': dict(cfg='standard', A=20, M=256, seed=synth.scene_seed(9, 4), ego_last=False,
                                  edge_cases=False, head_gain=64.0, insertion='natural'),
+    # long horizon with forced insertion: > 100 inserted agents (the row head-room logic of the engine is exercised);
+    # logits kept for the first steps only (the rest is compared through tokens / states / poses / ids)
+    'ins_forced_long_a24_m256': dict(cfg='standard', A=24, M=256, seed=synth.scene_seed(9, 5), ego_last=True,
+                                     edge_cases=False, head_gain=64.0, insertion='forced', R=400, logit_steps=3),
     # C2-shaped, unsharpened head (teacher-forced logits comparison only)
     'c2_a32_m512': dict(cfg='standard', A=32, M=512, seed=synth.scene_seed(2, 0), ego_last=True, edge_cases=False,
                         head_gain=1.0),
@@ -130,6 +134,8 @@ def load_weights(dec, seed: int, head_gain: float):
 
 def run_case(name: str, spec: dict, out_dir: str):
     cfg = synth.smart_config() if spec['cfg'] == 'smart' else synth.standard_config()
+    if spec.get('R'):
+        cfg = synth.standard_config(num_recurrent_steps_val=spec['R'])
     ins = spec.get('insertion')
     if ins:
         cfg.disable_insertion = False
@@ -153,7 +159,15 @@ def run_case(name: str, spec: dict, out_dir: str):
         ae.__class__ = _live_state_class(type(ae))
 
     logits, edges = [], []
-    ae.token_predict_head.register_forward_hook(lambda m, i, o: logits.append(o.detach().numpy().copy()))
+    keep = spec.get('logit_steps')
+
+    def logit_hook(m, i, o):
+        full = o.detach().numpy()
+        part = np.partition(full, -2, axis=-1)
+        mg = (part[:, -1] - part[:, -2]).astype(np.float32)
+        logits.append((full.copy() if keep is None or len(logits) < keep else None, mg, full.shape[0],
+                       full.max(-1).astype(np.float32), full.argmax(-1).astype(np.int32)))
+    ae.token_predict_head.register_forward_hook(logit_hook)
 
     def edge_hook(kind):
         def fn(m, i, o):
@@ -183,18 +197,24 @@ def run_case(name: str, spec: dict, out_dir: str):
 
     meta = dict(case=name, cfg=spec['cfg'], A=spec['A'], M=spec['M'], seed=spec['seed'], ego_last=spec['ego_last'],
                 edge_cases=spec['edge_cases'], head_gain=spec['head_gain'], weight_seed=1,
-                live_state=bool(spec.get('live_state', False)), insertion=ins or '',
+                live_state=bool(spec.get('live_state', False)), insertion=ins or '', R=int(spec.get('R') or 0),
                 num_params=int(sum(int(np.prod(s)) for s in shapes.values())))
     # top-1/top-2 logit margin per (step, agent): tells the parity test where a flip is legitimate
     # with insertion the row count grows step by step: pad to the final count with NaN
-    a_fin = max(l.shape[0] for l in logits)
-    n_agents_step = np.asarray([l.shape[0] for l in logits], dtype=np.int64)
-    lg = np.full((len(logits), a_fin, logits[0].shape[1]), np.nan, dtype=np.float32)
-    for i, l in enumerate(logits):
-        lg[i, :l.shape[0]] = l
-    part = np.partition(np.nan_to_num(lg, nan=-1e30), -2, axis=-1)
-    margin = (part[..., -1] - part[..., -2]).astype(np.float32)
-    margin[np.isnan(lg[..., 0])] = np.inf          # rows that did not exist yet at that step
+    a_fin = max(e[2] for e in logits)
+    n_agents_step = np.asarray([e[2] for e in logits], dtype=np.int64)
+    n_lg = len(logits) if keep is None else min(keep, len(logits))
+    lg = np.full((n_lg, a_fin, logits[0][0].shape[1]), np.nan, dtype=np.float32)
+    margin = np.full((len(logits), a_fin), np.inf, dtype=np.float32)      # inf: rows that did not exist yet at that step
+    # per-step summaries of every row's logits (kept for all steps even when the logits themselves are not)
+    logit_max = np.full((len(logits), a_fin), np.nan, dtype=np.float32)
+    logit_argmax = np.full((len(logits), a_fin), -1, dtype=np.int32)
+    for i, (l, mg, n, lmax, lam) in enumerate(logits):
+        if i < n_lg:
+            lg[i, :n] = l
+        margin[i, :n] = mg
+        logit_max[i, :n] = lmax
+        logit_argmax[i, :n] = lam
     np.savez_compressed(
         os.path.join(out_dir, name + '.npz'),
         meta=json.dumps(meta),
@@ -207,7 +227,7 @@ def run_case(name: str, spec: dict, out_dir: str):
         pred_traj=out['pred_traj'].numpy(), pred_head=out['pred_head'].numpy(),
         pred_state=out['pred_state'].numpy(), pred_valid=out['pred_valid'].numpy(),
         agent_id=out['agent_id'].numpy(), ego_index=np.int64(out['ego_index']),
-        edge_count=ecount, n_agents_step=n_agents_step,
+        edge_count=ecount, n_agents_step=n_agents_step, logit_max=logit_max, logit_argmax=logit_argmax,
         pred_type=out['pred_type'].numpy(), pred_shape=out['pred_shape'].numpy(),
     )
     os.environ['DEBUG'] = '0'

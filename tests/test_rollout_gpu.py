@@ -174,6 +174,77 @@ def test_insertion_rollout_matches_reference_fixture(name):
     assert np.array_equal(o2['next_token_idx'], o['next_token_idx'])
 
 
+def _first_ill_conditioned_step(z, grid, ego, hist=2):
+    """first decode step whose input column is ill-conditioned in the reference itself, so that everything downstream may
+    legitimately differ between two correct implementations (the reference's CPU and GPU builds disagree there as well):
+    (a) a row moving exactly against its heading - angle_between_2d_vectors is +pi or -pi by the last ulp of cos / sin
+    (DESIGN.md "parity caveat"); (b) a row whose position sits on the border of two cells of the ego-centric grid - the
+    arg-min of encode_pos (attr_tokenizer.py:77-89) flips with the last bits of the pose, and with it the row's grid
+    embedding"""
+    pos, head, st = z['pos_a'], z['head_a'], z['next_state_idx']
+    for col in range(hist, pos.shape[1] - 1):
+        live = st[:, col] != 0
+        mv = pos[:, col] - pos[:, col - 1]
+        hv = np.stack([np.cos(head[:, col]), np.sin(head[:, col])], -1)
+        cross = hv[:, 0] * mv[:, 1] - hv[:, 1] * mv[:, 0]
+        dot = (hv * mv).sum(-1)
+        against = live & (st[:, col - 1] != 0) & (dot < 0) & (np.abs(cross) < 1e-5 * np.maximum(np.abs(dot), 1e-3))
+        phi = -(head[ego, col] - np.pi / 2)
+        rel = pos[:, col] - pos[ego, col]
+        loc = np.stack([rel[:, 0] * np.cos(phi) - rel[:, 1] * np.sin(phi), rel[:, 0] * np.sin(phi) + rel[:, 1] * np.cos(phi)], -1)
+        d = np.sqrt(((loc[:, None, :] - grid[None]) ** 2).sum(-1))
+        two = np.partition(d, 1, axis=1)[:, :2]
+        border = live & (two[:, 1] - two[:, 0] < 2e-4)
+        if against.any() or border.any():
+            return col - 1            # decode step t reads column 1 + t
+    return pos.shape[1] - 2
+
+
+def test_long_insertion_fixture_and_row_headroom():
+    """80 decode steps with forced insertion on the reference (24 -> 129 agents; tests/golden/make_golden.py
+    ins_forced_long_a24_m256), motion tokens teacher-forced (80 free-running steps are beyond what the logit margins
+    guarantee): (a) with too few rows the engine says so instead of dropping insertions; (b) with enough rows the same agents
+    are inserted at the same steps with the same cells / types / poses, and every row's top logit matches at every step, up
+    to the first step that is ill-conditioned in the reference itself (a row moving exactly against its heading)"""
+    from infgen_amd import engine
+    c = load_case('ins_forced_long_a24_m256')
+    z, m, cfg = c['z'], c['meta'], c['cfg']
+    cfg.disable_insertion = False
+    n_final = z['agent_id'].shape[0]
+    assert n_final - m['A'] >= 100 and cfg.num_decode_steps == 80
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], cfg, dev)
+    teacher = [(z['next_token_idx'], z['next_state_idx'])]
+    small = engine.RolloutEngine(w, [c['scene']], c['vocab'], c['map_vocab'], c['grid'], force_enter=True, teacher=teacher,
+                                 insert_headroom=40)
+    assert small.A_cap == 64
+    with pytest.raises(engine.InsertionHeadroomError):
+        small.rollout()
+    t_ok = _first_ill_conditioned_step(z, c['grid'], int(z['ego_index']))
+    assert 40 <= t_ok <= 80, t_ok
+    eng = engine.RolloutEngine(w, [c['scene']], c['vocab'], c['map_vocab'], c['grid'], store_logits=True, force_enter=True,
+                               teacher=teacher, insert_headroom=n_final - m['A'] + 8)
+    eng.prologue()
+    eng.run(0, t_ok)
+    o = eng.outputs()[0]
+    n = int(z['n_agents_step'][t_ok - 1])
+    assert n - m['A'] >= 60 and o['pos_a'].shape[0] == n, 'same number of agents inserted'
+    cols = slice(0, 1 + t_ok)
+    assert np.array_equal(o['agent_id'], z['agent_id'][:n]) and np.array_equal(o['pred_type'], z['pred_type'][:n])
+    assert np.array_equal(o['next_state_idx'][:, cols], z['next_state_idx'][:n, cols])
+    assert np.abs(o['pos_a'][:, cols] - z['pos_a'][:n, cols]).max() <= 2e-3
+    assert np.abs(o['head_a'][:, cols] - z['head_a'][:n, cols]).max() <= 1e-3
+    tol = 1e-3 * m['head_gain'] / 16
+    for t in range(t_ok):
+        k = int(z['n_agents_step'][t])
+        assert np.abs(o['logits'][t, :k].max(-1) - z['logit_max'][t, :k]).max() <= tol, t
+        sure = z['margin'][t, :k] > 4 * tol
+        assert np.array_equal(o['logits'][t, :k].argmax(-1)[sure], z['logit_argmax'][t, :k][sure]), t
+    for t in range(z['logits'].shape[0]):
+        k = int(z['n_agents_step'][t])
+        assert np.abs(o['logits'][t, :k] - z['logits'][t, :k]).max() <= tol
+
+
 def test_batched_insertion_equals_single_scene_runs():
     """insertion is per-scene state: a batch with ragged agent counts and different insertion histories must
     reproduce each scene decoded alone"""

@@ -1,0 +1,30 @@
+"""profiles/traffic.json from the two PMC summaries of tools/prof_round.sh (FETCH_SIZE / WRITE_SIZE per kernel, KB summed over
+the dispatches of the pass): bytes per launch, FETCH corrected by the factors tools/calibrate_fetch.sh measured.
+usage: make_traffic_json.py <pmc_FETCH_SIZE.summary.csv> <pmc_WRITE_SIZE.summary.csv> <fetch_factor_8B> <fetch_factor_16B> <tag>"""
+import csv, json, sys
+fetch, write, f8, f16, tag = sys.argv[1], sys.argv[2], float(sys.argv[3]), float(sys.argv[4]), sys.argv[5]
+names = {'k_edge_fused': ('k_edge_attn', f8), 'k_attn_h': ('k_attn_post', f16), 'k_fourier_h': ('k_fourier', f16)}
+
+
+def load(path, col):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        for k, (kid, fac) in names.items():
+            if k in r['kernel']:
+                out[kid] = (float(r[col]) * 1024.0, int(r['dispatches']), fac)
+    return out
+
+
+fe, wr = load(fetch, 'FETCH_SIZE'), load(write, 'WRITE_SIZE')
+kern = {}
+for kid in fe:
+    fb, n, fac = fe[kid]
+    wb, nw, _ = wr[kid]
+    kern[kid] = dict(fetch_bytes_per_launch=fb / n / fac, fetch_counter_bytes_per_launch=fb / n, fetch_counter_factor=fac,
+                     write_bytes_per_launch=wb / nw, dispatches=n)
+json.dump(dict(source=f'{tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of `python bench.py --no-cpu-baseline '
+                      f'--no-parity --steps 1 --warmup 1` (tools/prof_round.sh); FETCH_SIZE divided by the counted / actual factor '
+                      f'of a known-size streaming read of the same width (tools/calibrate_fetch.sh), WRITE_SIZE as counted',
+               scenes_per_gpu=512, agents=64, map_tokens=1024, insertion=False, rollout_steps=80, kernels=kern),
+          open('profiles/traffic.json', 'w'), indent=1)
+print(json.dumps(kern, indent=1))
