@@ -256,16 +256,7 @@ def main():
         """the per-GPU batch split over several HIP streams (memory-bound edge attention of one group
         overlaps the MFMA-bound kernels of another)"""
         def rollout(self):
-            if ns == 1:
-                engines[0].rollout()
-                return
-            cur = torch.cuda.current_stream(dev)
-            for e, st in zip(engines, streams):
-                st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    e.rollout()
-            for st in streams:
-                cur.wait_stream(st)
+            engine.rollout_many(engines, streams if ns > 1 else None)
 
         def agent_steps(self):
             return sum(e.agent_steps() for e in engines)

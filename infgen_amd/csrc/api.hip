@@ -278,15 +278,31 @@ extern "C" int infgen_fourier_embed(const float* raw, int n, const int* count_de
   return check_launch("infgen_fourier_embed");
 }
 
-// 0: fp32-input MFMA (k_attn_pre / k_attn_post), 1: fp16 three-term split (k_attn_h), 2 (default): by size - the split
-// kernel runs one workgroup per CU on 64/128-row tiles and wins from ~10 k rows (16 k rows: 99 vs 121 us, 64 k: 337 vs
-// 479 us); below, the 32-row tiles of the fp32 kernels fill the chip better (8 k rows: 73 vs 95 us, 64 rows: 54 vs 77 us)
+// 0: fp32-input MFMA (k_attn_pre / k_attn_post), 1: fp16 three-term split on 64-row tiles (k_attn_h), 3: the same arithmetic on
+// one 16-row group per eight-wave workgroup (k_attn_hs, low latency), 2 (default): by size - k_attn_h runs one or two workgroups
+// per CU on 64-row tiles and wins from ~10 k rows (16 k rows: 99 vs 121 us for the fp32 kernels); below, a launch is one tile's
+// dependency chain whatever the row count (k_attn_h 61-69 us, fp32 kernels 48-53 us), which k_attn_hs cuts to 27-32 us up to 4 k
+// rows (one 16-row workgroup per CU; every workgroup pulls the layer's 1.2 MB of split weights through its CU's L2 port)
 extern "C" int infgen_set_attn_mode(int mode) {
-  if (mode < 0 || mode > 2) return fail("infgen_set_attn_mode", "mode must be 0 (fp32 MFMA), 1 (fp16 split) or 2 (by size)");
+  if (mode < 0 || mode > 3) return fail("infgen_set_attn_mode", "mode must be 0 (fp32 MFMA), 1 (fp16 split), 2 (by size) or 3 (fp16 split, 16-row workgroups)");
   g_def.attn_mode = mode;
   return 0;
 }
-static inline bool attn_split(int rows) { return O().attn_mode == 1 || (O().attn_mode == 2 && rows > 10240); }
+static int hs_max_rows() {
+  static const int v = getenv("INFGEN_ATTN_HS_MAX") ? atoi(getenv("INFGEN_ATTN_HS_MAX")) : 6144;
+  return v;
+}
+// the kernels of the other split families (k_heads_h, k_mlpemb_h) keep the by-size rule of the 64-row tiles
+static inline bool attn_split(int rows) { return O().attn_mode == 1 || (O().attn_mode >= 2 && rows > 10240); }
+// 0: fp32 kernels, 1: k_attn_h, 2: k_attn_hs
+static inline int attn_kind(int rows) {
+  switch (O().attn_mode) {
+    case 0: return 0;
+    case 1: return 1;
+    case 3: return 2;
+    default: return rows > 10240 ? 1 : rows > hs_max_rows() ? 0 : 2;      // (8 k rows: 60 us for k_attn_hs and the fp32 kernels alike)
+  }
+}
 
 // 64-row tiles, 4 waves, two workgroups per CU (attn_h.hip); INFGEN_ATTN_WAVES=8 selects the 128-row variant
 // optional list of the 16-row groups that hold agents (infgen_set_row_groups): applied to every split-kernel launch over
@@ -315,6 +331,12 @@ extern "C" int infgen_active_row_groups(const int* n_agents, int S, int A_cap, i
 static void launch_attn_h(const AttnHArgs& a_in, void* stream) {
   AttnHArgs a = a_in;
   if (O().row_groups && a.rows == group_rows()) { a.groups = O().row_groups; a.n_groups = O().n_row_groups; }
+  if (attn_kind(a.rows) == 2) {            // one 16-row group per workgroup
+    const int grid = ceil_div(a.rows, 16);
+    if (O().gemm_terms == 1) hipLaunchKernelGGL(k_attn_hs<1>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_attn_hs<3>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    return;
+  }
   static const int waves = getenv("INFGEN_ATTN_WAVES") ? atoi(getenv("INFGEN_ATTN_WAVES")) : 4;
   if (waves != 8) {
     int grid = ceil_div(a.rows, 64);
@@ -331,7 +353,7 @@ static void launch_attn_h(const AttnHArgs& a_in, void* stream) {
 extern "C" int infgen_attn_pre(const float* X, int rows, const float* pack, int use_src_ln,
                                float* Q, float* U, float* K, float* V, void* stream) {
   if (rows <= 0) return 0;
-  if (attn_split(rows)) {
+  if (attn_kind(rows)) {
     AttnHArgs h{const_cast<float*>(X), rows, nullptr, nullptr, nullptr, nullptr, 0, pack, use_src_ln, Q, U, K, V};
     { ProfScope _ps(INFGEN_KID_ATTN_PRE, stream, (double)rows * 16384.0 * ((Q || U ? 1 : 0) + (K ? 1 : 0) + (V ? 1 : 0) + (U ? 1 : 0)));
       launch_attn_h(h, stream); }
@@ -440,7 +462,7 @@ extern "C" int infgen_attn_post_pre(float* X, int rows, const float* pack, const
 static int attn_post_fused(float* X, int rows, const float* pack, const float* AGG, const float* Z, const float* SIG,
                            int has_pos, const float* next_pack, float* nQ, float* nU, float* nK, float* nV, void* stream) {
   if (rows <= 0) return 0;
-  if (attn_split(rows)) {
+  if (attn_kind(rows)) {
     AttnHArgs h{X, rows, pack, AGG, Z, SIG, has_pos, next_pack, 0, nQ, nU, nK, nV};
     { ProfScope _ps(INFGEN_KID_ATTN_POST, stream, (double)rows * (196608.0 + (has_pos ? 16384.0 : 0.0) +
           (next_pack ? 16384.0 * ((nQ || nU ? 1 : 0) + (nK ? 1 : 0) + (nV ? 1 : 0) + (nU ? 1 : 0)) : 0.0)));

@@ -359,7 +359,8 @@ __global__ void k_fetch_enterings(EnteringsArgs a);
 __global__ void k_pt_grid_cells(EnteringsArgs a);
 __global__ void k_tokenize_state(TokenizeArgs a);
 __global__ void k_active_groups(ActiveGroupsArgs a);
-template <int WAVES, int TERMS> __global__ void k_attn_h(AttnHArgs a);   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
+template <int WAVES, int TERMS> __global__ void k_attn_h(AttnHArgs a);
+template <int TERMS> __global__ void k_attn_hs(AttnHArgs a);             // attn_hs.hip: the same for few rows (one 16-row group per workgroup)   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);
 template <int G> __global__ void k_edge_fused(EdgeFusedArgs a);        // edge_fused.hip

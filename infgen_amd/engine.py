@@ -599,7 +599,9 @@ class RolloutEngine:
             active=i32(S), n_new=i32(S), inserted=i32(S), new_row=i32(S), new_cell=i32(S), new_shape=f(S, 3),
             first_new=torch.full((S,), A_cap, device=dev, dtype=torch.int32), hv_ovr=f(S, 2), shape_all=torch.full((rows, 3), INVALID_SHAPE, device=dev),
             scene_base=(ar * A_cap).contiguous(), inserted_rows=[[] for _ in range(S)],
-            groups=i32((rows + 15) // 16), n_groups=i32(1))
+            groups=i32((rows + 15) // 16), n_groups=i32(1),
+            host_dec=(torch.zeros(S, dtype=torch.int32).pin_memory(), torch.zeros(S, dtype=torch.int32).pin_memory()),
+            host_ev=torch.cuda.Event())
 
     def _ebuf_struct(self, e):
         b = _lib.EdgeBuf()
@@ -614,8 +616,9 @@ class RolloutEngine:
 
     def _insert_step(self, t: int):
         """the insertion sub-loop of decode step t (reference agent_decoder.py:1773-2105).
-        Arithmetic runs in the HIP kernels; the data-dependent loop is sequenced here with one host
-        sync per iteration (did any scene insert?)."""
+        Arithmetic runs in the HIP kernels; the data-dependent loop is sequenced here.  A generator: once per iteration the
+        per-scene decisions (inserted?, which row) are copied to pinned host memory asynchronously and the event of that copy
+        is yielded - ``run`` just waits for it, ``rollout_many`` sequences other engines' streams meanwhile."""
         ops, w, cfg, lib, I = self.ops, self.w, self.cfg, self.lib, self.ins
         S, rows, G = self.S, self.rows, self.G
         c = 1 + t
@@ -693,7 +696,14 @@ class RolloutEngine:
                                                 _lib.ptr(I['n_new']), _lib.ptr(I['inserted']), _lib.ptr(I['new_row']),
                                                 _lib.ptr(I['new_shape']), _lib.ptr(I['new_cell']), st),
                        'infgen_insert_decide')
-            ins_host = I['inserted'].cpu().numpy()       # host sync: did any scene insert?
+            # hand-over to the host: did any scene insert, and into which rows?
+            I['host_dec'][0].copy_(I['inserted'], non_blocking=True)
+            I['host_dec'][1].copy_(I['new_row'], non_blocking=True)
+            ev = I['host_ev']
+            ev.record(torch.cuda.current_stream(self.device))
+            yield ev
+            ev.synchronize()
+            ins_host = I['host_dec'][0].numpy().copy()
             if (ins_host < 0).any():
                 full = np.nonzero(ins_host < 0)[0]
                 raise InsertionHeadroomError(
@@ -701,13 +711,15 @@ class RolloutEngine:
                     f'({int(self.n_agents[int(full[0])].item())} agents) and the seed head asks for another insertion; '
                     f're-run with a larger insert_headroom (rows per scene <= {self.lib.infgen_layout_query(_lib.Q_MAX_AGENTS)})',
                     needed=self.A_cap)
-            ins = I['inserted'] > 0
             ins_host = ins_host > 0
             if not ins_host.any():
                 break
-            nr = I['new_row'][ins].long()
-            for s_i, r_i in zip(np.nonzero(ins_host)[0], nr.cpu().numpy()):
+            ins_idx_host = np.nonzero(ins_host)[0]
+            nr_host = I['host_dec'][1].numpy()[ins_idx_host].astype(np.int64)
+            for s_i, r_i in zip(ins_idx_host, nr_host):
                 I['inserted_rows'][int(s_i)].append(int(r_i))
+            ins = torch.from_numpy(ins_idx_host.astype(np.int64)).to(self.device)      # scenes that inserted (index list)
+            nr = torch.from_numpy(nr_host).to(self.device)                              # the rows they appended
             # categorical embedding / shape of the new rows (agent_decoder.py:1949-1950,1993)
             shp = ops.mlp_embedding(I['new_shape'], w.shape_emb, 3)
             self.cat_agent[nr] = w.type_a_emb[self.atype.reshape(-1)[nr].long()] + shp[ins]
@@ -815,6 +827,13 @@ class RolloutEngine:
 
     # ------------------------------------------------------------------ rollout
     def run(self, t0: int = 0, t1: Optional[int] = None):
+        for _ in self.run_gen(t0, t1):      # (the generator waits for each event itself when it is resumed)
+            pass
+
+    def run_gen(self, t0: int = 0, t1: Optional[int] = None):
+        """``run`` as a generator: yields a ``torch.cuda.Event`` wherever the host needs a result of the device (the insertion
+        sub-loop's per-iteration decisions) - everything up to the event is already enqueued on the current stream.  Lets one
+        host thread keep several engines on several streams busy (``rollout_many``)."""
         if not self._prologue_done:
             self.prologue()
         t1 = self.cfg.num_decode_steps if t1 is None else t1
@@ -822,15 +841,15 @@ class RolloutEngine:
         if not self.insertion:
             _lib.check(self.lib.infgen_rollout_run(C.byref(self._ctx), t0, t1, self.ops.stream), 'infgen_rollout_run')
             return
-        lib, I, st = self.lib, self.ins, self.ops.stream
+        lib, I = self.lib, self.ins
         use_groups = bool(self._ctx.opts.row_groups)
         for t in range(t0, t1):
             if use_groups:
                 _lib.check(lib.infgen_active_row_groups(_lib.ptr(self.n_agents), self.S, self.A_cap, 10,
-                                                        _lib.ptr(I['groups']), _lib.ptr(I['n_groups']), st),
+                                                        _lib.ptr(I['groups']), _lib.ptr(I['n_groups']), self.ops.stream),
                            'infgen_active_row_groups')
             if t > 0:
-                self._insert_step(t)
+                yield from self._insert_step(t)
             self.step(t)
 
     def edge_totals(self):
@@ -918,3 +937,37 @@ class RolloutEngine:
         """agent-steps (10 Hz) decoded by a full rollout of this batch; rows inserted
         during the rollout are not counted (lower bound)."""
         return int(sum(h['A'] for h in self.hosts)) * self.R
+
+
+def rollout_many(engines: Sequence[RolloutEngine], streams: Optional[Sequence[torch.cuda.Stream]] = None):
+    """Full rollouts of several engines (disjoint scene sets of one GPU), each on its own HIP stream, sequenced by ONE host
+    thread: an engine runs until it needs a result of the device (``RolloutEngine.run_gen``), then the next engine's launches
+    are enqueued, round robin.  With scenario insertion on, the sub-loop of a decode step is a chain of small dependent launches
+    whose length is set by the slowest scene of the batch; several smaller batches in different phases fill the chip where one
+    large batch leaves it idle.  Without insertion the engines' launch sequences simply interleave."""
+    if not engines:
+        return
+    dev = engines[0].device
+    if streams is None or len(engines) == 1:
+        for e in engines:
+            e.rollout()
+        return
+    cur = torch.cuda.current_stream(dev)
+    live = []
+    for e, st in zip(engines, streams):
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            e.prologue()
+            live.append((e.run_gen(), st))
+    while live:
+        nxt = []
+        for g, st in live:
+            with torch.cuda.stream(st):
+                try:
+                    next(g)
+                    nxt.append((g, st))
+                except StopIteration:
+                    pass
+        live = nxt
+    for st in streams:
+        cur.wait_stream(st)

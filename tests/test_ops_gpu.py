@@ -159,6 +159,73 @@ def test_attn_split_is_deterministic(env):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
+@pytest.mark.parametrize('rows', [16, 50, 512, 4099])
+@pytest.mark.parametrize('has_pos', [1, 0])
+def test_attn_small_row_kernel_equals_tile_kernel(env, rows, has_pos):
+    """k_attn_hs (one 16-row group per workgroup, feature tiles dealt to the waves) issues k_attn_h's products in k_attn_h's
+    order and runs its LayerNorm / split code on the same register layout: x, q, k, v must be bit-identical; the absorbed
+    query u differs by its per-head (instead of per-row) operand scale only"""
+    from infgen_amd import _lib
+    dev, lib = env['dev'], env['lib']
+    p1 = _dev(env['packing'].pack_attention_layer(env['sd'], 'agent_encoder.a2a_attn_layers.1'), dev)
+    p2 = _dev(env['packing'].pack_attention_layer(env['sd'], 'agent_encoder.t_attn_layers.2'), dev)
+    g = torch.Generator(device='cpu').manual_seed(rows)
+    X0 = torch.randn(rows, 128, generator=g).to(dev)
+    AGG = (torch.randn(rows, 128, generator=g) * 0.5).to(dev)
+    Z = (torch.randn(rows, 8, 128, generator=g) * 0.3).to(dev)
+    SIG = torch.rand(rows, 8, generator=g).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    try:
+        for mode in (1, 3):
+            _lib.check(lib.infgen_set_attn_mode(mode))
+            X = X0.clone()
+            Q, K, V = (torch.zeros(rows, 128, device=dev) for _ in range(3))
+            U = torch.zeros(rows, 8, 128, device=dev)
+            _lib.check(lib.infgen_attn_post_pre(X.data_ptr(), rows, p1.data_ptr(), AGG.data_ptr(), Z.data_ptr(), SIG.data_ptr(),
+                                                has_pos, p2.data_ptr(), Q.data_ptr(), U.data_ptr(), K.data_ptr(), V.data_ptr(), st))
+            # the pre part alone, LayerNorm with the source parameters (K / V of a bipartite source)
+            K2, V2 = torch.zeros(rows, 128, device=dev), torch.zeros(rows, 128, device=dev)
+            _lib.check(lib.infgen_attn_pre(X0.data_ptr(), rows, p2.data_ptr(), 1, None, None, K2.data_ptr(), V2.data_ptr(), st))
+            torch.cuda.synchronize()
+            res[mode] = (X, Q, K, V, K2, V2, U)
+    finally:
+        _lib.check(lib.infgen_set_attn_mode(2))
+    for a, b in zip(res[1][:6], res[3][:6]):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert float((res[1][6] - res[3][6]).abs().max()) <= 2e-6 * max(1.0, float(res[1][6].abs().max()))
+
+
+def test_attn_small_row_kernel_is_deterministic(env):
+    from infgen_amd import _lib
+    dev, lib = env['dev'], env['lib']
+    rows = 8192
+    p1 = _dev(env['packing'].pack_attention_layer(env['sd'], 'agent_encoder.t_attn_layers.0'), dev)
+    p2 = _dev(env['packing'].pack_attention_layer(env['sd'], 'agent_encoder.pt2a_attn_layers.0'), dev)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    X0 = torch.randn(rows, 128, generator=g).to(dev)
+    AGG = (torch.randn(rows, 128, generator=g) * 0.5).to(dev)
+    Z = (torch.randn(rows, 8, 128, generator=g) * 0.3).to(dev)
+    SIG = torch.rand(rows, 8, generator=g).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.infgen_set_attn_mode(3))
+    try:
+        outs = []
+        for _ in range(8):
+            X = X0.clone()
+            Q, K, V = (torch.empty(rows, 128, device=dev) for _ in range(3))
+            U = torch.empty(rows, 8, 128, device=dev)
+            _lib.check(lib.infgen_attn_post_pre(X.data_ptr(), rows, p1.data_ptr(), AGG.data_ptr(), Z.data_ptr(), SIG.data_ptr(), 1,
+                                                p2.data_ptr(), Q.data_ptr(), U.data_ptr(), K.data_ptr(), V.data_ptr(), st))
+            outs.append((X, Q, U, K, V))
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(lib.infgen_set_attn_mode(2))
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 def _random_graph(rng, n_dst, n_src, max_deg, empty_rows=()):
     off, cnt, src, dst = [], [], [], []
     e = 0
@@ -171,9 +238,10 @@ def _random_graph(rng, n_dst, n_src, max_deg, empty_rows=()):
     return np.array(off, np.int32), np.array(cnt, np.int32), np.array(src, np.int32), np.array(dst, np.int64)
 
 
-@pytest.fixture(params=[1, 0], ids=['split16', 'fp32mfma'])
+@pytest.fixture(params=[1, 3, 0], ids=['split16', 'split16-16row', 'fp32mfma'])
 def attn_mode(request, env):
-    """1: node-side GEMMs on the fp16 matrix pipe with the three-term split (k_attn_h); 0: fp32-input MFMA kernels"""
+    """1: node-side GEMMs on the fp16 matrix pipe with the three-term split (k_attn_h); 3: the same arithmetic, one 16-row group
+    per workgroup (k_attn_hs, the kernel small launches take by default); 0: fp32-input MFMA kernels"""
     from infgen_amd import _lib
     _lib.check(env['lib'].infgen_set_attn_mode(request.param))
     yield request.param

@@ -272,6 +272,40 @@ def test_batched_insertion_equals_single_scene_runs():
     assert max(n_ins) > 0
 
 
+def test_rollout_many_streams_equals_single_engine():
+    """engine.rollout_many: engines on their own streams, sequenced cooperatively by one host thread (each yields where it
+    needs the device's insertion decisions) - the same scenes give the same rollouts as one engine after the other"""
+    from infgen_amd import engine, synth
+    c = load_case('ins_natural_a20_m256')
+    cfg = c['cfg']
+    cfg.disable_insertion = False
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], cfg, dev)
+    sets = [[c['scene'], synth.make_scene(8100, 12, 128, cfg, ego_last=True, vocab=c['vocab'], grid=c['grid'])],
+            [synth.make_scene(8101, 30, 300, cfg, ego_last=False, vocab=c['vocab'], grid=c['grid'])],
+            [synth.make_scene(8102 + i, 16 + 4 * i, 256, cfg, ego_last=True, vocab=c['vocab'], grid=c['grid']) for i in range(3)]]
+    mk = lambda: [engine.RolloutEngine(w, sc, c['vocab'], c['map_vocab'], c['grid'], store_logits=False, a_cap=128) for sc in sets]
+    ref = mk()
+    for e in ref:
+        e.rollout()
+    ref_out = [e.outputs() for e in ref]
+    many = mk()
+    streams = [torch.cuda.Stream(device=dev) for _ in many]
+    for _ in range(2):                       # twice: the second pass reuses the engines' buffers and events
+        engine.rollout_many(many, streams)
+        torch.cuda.synchronize()
+    assert np.array_equal(ref_out[0][0]['next_token_idx'], c['z']['next_token_idx'])
+    n_ins = 0
+    for e, ro_ in zip(many, ref_out):
+        for o, r in zip(e.outputs(), ro_):
+            assert o['pos_a'].shape == r['pos_a'].shape
+            assert np.array_equal(o['next_token_idx'], r['next_token_idx'])
+            assert np.array_equal(o['next_state_idx'], r['next_state_idx'])
+            assert np.array_equal(o['pos_a'], r['pos_a'])
+            n_ins += o['num_inserted']
+    assert n_ins > 0
+
+
 def test_long_horizon_rollout_vs_oracle():
     """ours_long_term-style horizon (R = 300 -> 62 columns, 60 decode steps): the temporal ring wraps several
     times; HIP vs the CPU oracle (teacher-forced after the first steps to stay on the same trajectory)"""

@@ -19,10 +19,11 @@ Q = torch.empty(rows, 128, device=dev); U = torch.empty(rows, 8, 128, device=dev
 K = torch.empty(rows, 128, device=dev); V = torch.empty(rows, 128, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 res = {}
-for mode in (0, 1):
+HAS_POS = int(os.environ.get('HAS_POS', '1'))
+for mode in (0, 1, 3):
     _lib.check(lib.infgen_set_attn_mode(mode))
     def run():
-        _lib.check(lib.infgen_attn_post_pre(X.data_ptr(), rows, p1.data_ptr(), AGG.data_ptr(), Z.data_ptr(), SIG.data_ptr(), 1,
+        _lib.check(lib.infgen_attn_post_pre(X.data_ptr(), rows, p1.data_ptr(), AGG.data_ptr(), Z.data_ptr(), SIG.data_ptr(), HAS_POS,
                                             p2.data_ptr(), Q.data_ptr(), U.data_ptr(), K.data_ptr(), V.data_ptr(), st))
     X = X0.clone(); run(); torch.cuda.synchronize()
     res[mode] = (X.clone(), Q.clone(), U.clone(), K.clone(), V.clone())
@@ -32,6 +33,6 @@ for mode in (0, 1):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
     fl = 2.0 * rows * 16384 * 17
     print(f'rows={rows} mode={mode}: {dt*1e6:.1f} us  {fl/dt/1e12:.1f} TFLOP/s (algorithmic)')
-for n, a, b in zip('XQUKV', res[0], res[1]):
-    print('  max |split - fp32mfma|', n, float((a - b).abs().max()))
+for n, a, b, c in zip('XQUKV', res[0], res[1], res[3]):
+    print('  max |split - fp32mfma|', n, float((a - b).abs().max()), ' |16-row split - split|', float((c - b).abs().max()))
 _lib.check(lib.infgen_set_attn_mode(2))
