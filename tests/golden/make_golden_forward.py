@@ -1,0 +1,151 @@
+#!/usr/bin/env python
+"""Golden vectors for the teacher-forced ``forward``: the REFERENCE's own
+``InfGenDecoder.forward`` = ``InfGenMapDecoder.forward`` + ``InfGenAgentDecoder.forward``
+(infgen/modules/infgen_decoder.py:114-121, agent_decoder.py:1104-1603) on a two-scene batch, CPU, eval mode.
+
+Inputs: the tokenised agents of tests/golden/tokenize_a40.npz (outputs of the reference's TokenProcessor) split into
+two scenes (25 + 15 agents) with the ``_fetch_enterings`` outputs of tests/golden/enterings_a40.npz (outputs of the
+reference's InfGen._fetch_enterings on the same batch), plus seeded map tokens around each ego.  Weights: the closed-form
+filler (strict load).  torch's CPU generator is seeded with ``rng_seed`` right before the call: the reference draws
+``randperm`` for the neighbour-grid evaluation masks (:1294-1295) and for the refine stage's candidate rows (:1312); the
+build's forward draws the same permutations from the same generator state, so fixtures and build agree on the selection.
+
+Build container only (needs /root/reference):  python tests/golden/make_golden_forward.py
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+from infgen_amd import synth  # noqa: E402
+import make_golden as mg  # noqa: E402
+sys.path.insert(0, os.path.dirname(HERE))
+from forward_case import build_batch  # noqa: E402
+
+RNG_SEED = 1234
+
+# tensors of the reference's return dict kept in the fixture (everything the open-loop validation reads,
+# infgen/model/infgen.py:627-686, and the seed / refine heads)
+KEEP = ('x_a', 'next_token_prob', 'next_token_idx', 'next_token_idx_gt', 'next_token_eval_mask',
+        'next_state_prob', 'next_state_idx', 'next_state_idx_gt', 'next_state_eval_mask',
+        'next_state_idx_seed', 'next_state_prob_seed', 'next_state_idx_gt_seed', 'raw_next_state_prob_seed',
+        'next_type_idx_seed', 'next_type_prob_seed', 'next_type_idx_gt_seed',
+        'next_pos_rel_prob_seed', 'next_pos_rel_index_gt_seed', 'next_pos_rel_xy_gt_seed',
+        'next_head_rel_prob_seed', 'next_head_rel_index_gt_seed', 'next_head_rel_theta_gt_seed',
+        'next_offset_xy_seed', 'next_offset_xy_gt_seed', 'next_shape_seed', 'next_shape_gt_seed',
+        'grid_agent_occ_seed', 'grid_pt_occ_seed', 'grid_agent_occ_gt_seed', 'grid_pt_occ_gt_seed',
+        'neighbor_agent_grid_idx', 'neighbor_pt_grid_idx', 'neighbor_agent_grid_index_gt', 'neighbor_pt_grid_index_gt',
+        'target_indices', 'next_state_eval_mask_seed', 'next_attr_eval_mask_seed', 'next_head_eval_mask_seed',
+        'grid_agent_occ_eval_mask_seed', 'neighbor_agent_grid_index_eval_mask', 'neighbor_pt_grid_index_eval_mask',
+        'ego_pos', 'x_pt')
+
+
+def fetch_enterings(batch, cfg):
+    """the reference's own InfGen._fetch_enterings (infgen/model/infgen.py:1008-1128) on this batch: the agent outputs equal the
+    committed enterings fixture (same agents), pt_grid_token_idx is new (these map tokens)"""
+    import types
+    from infgen.model.infgen import InfGen
+    from infgen.modules.attr_tokenizer import Attr_Tokenizer
+    tok = Attr_Tokenizer(grid_range=cfg.grid_range, grid_interval=cfg.grid_interval, radius=cfg.pl2seed_radius,
+                         angle_interval=cfg.angle_interval)
+    fake = types.SimpleNamespace(predict_occ=True, enter_state=2, invalid_state=0, pl2seed_radius=cfg.pl2seed_radius,
+                                 attr_tokenizer=tok, save_path='')
+    ag, pt = batch['agent'], batch['pt_token']
+
+    class _Data(dict):
+        num_graphs = 2
+    en = np.load(os.path.join(HERE, 'enterings_a40.npz'))
+    data = _Data(agent=dict(state_idx=torch.from_numpy(ag['state_idx']), token_pos=torch.from_numpy(ag['token_pos']),
+                            token_heading=torch.from_numpy(ag['token_heading']), batch=torch.from_numpy(ag['batch']),
+                            av_index=torch.from_numpy(en['av_index'].astype(np.int64))),
+                 pt_token=dict(token_idx=torch.from_numpy(pt['token_idx']), position=torch.from_numpy(pt['position']),
+                               batch=torch.from_numpy(pt['batch'])))
+    with torch.no_grad():
+        out = InfGen._fetch_enterings(fake, data)['agent']
+    for k in ('grid_token_idx', 'grid_offset_xy', 'heading_token_idx', 'sort_indices', 'inrange_mask', 'bos_mask', 'pos_xy',
+              'heading_theta'):
+        assert np.array_equal(out[k].numpy(), ag[k]), k
+    return out['pt_grid_token_idx'].numpy()
+
+
+def to_batch(batch):
+    from _standins import Batch
+
+    def conv(v):
+        return torch.from_numpy(v.copy()) if isinstance(v, np.ndarray) else v
+    d = Batch()
+    for k, v in batch.items():
+        d[k] = {kk: conv(vv) for kk, vv in v.items()} if isinstance(v, dict) else conv(v)
+    d[('pt_token', 'to', 'map_polygon')] = d.pop('pt_token__to__map_polygon')
+    d.num_graphs = 2
+    a = d['agent']
+    d['agent_valid_mask'], d['category'], d['valid_mask'] = a['agent_valid_mask'], a['category'], a['valid_mask']
+    d['av_index'], d['shape'] = a['av_index'], a['shape']
+    return d
+
+
+def main():
+    torch.set_num_threads(8)
+    cfg = synth.standard_config()
+    vocab, map_vocab = synth.make_agent_vocab(cfg.token_size), synth.make_map_vocab()
+    grid = synth.build_grid(cfg.grid_range, cfg.grid_interval, cfg.pl2seed_radius)
+    batch = build_batch(cfg, vocab)
+    dec, tok = mg.build_reference(cfg, map_vocab)
+    assert np.array_equal(tok.grid.numpy(), grid)
+    batch['agent']['pt_grid_token_idx'] = fetch_enterings(batch, cfg)
+    mg.load_weights(dec, seed=1, head_gain=1.0)
+    data = to_batch(batch)
+    counts = {}
+    ae = dec.agent_encoder
+    for kind, fname in (('t', '_build_temporal_edge'), ('a', '_build_interaction_edge'), ('m', '_build_map2agent_edge'),
+                        ('a2sa', '_build_a2sa_edge'), ('m2sa', '_build_map2sa_edge')):
+        orig = getattr(ae, fname)
+
+        def wrapped(*a, __orig=orig, __kind=kind, **k):
+            out = __orig(*a, **k)
+            counts.setdefault(__kind, []).append(int(out[0].shape[1]))
+            return out
+        setattr(ae, fname, wrapped)
+    torch.manual_seed(RNG_SEED)
+    with torch.no_grad():
+        out = dec(data)
+    keep = {}
+    for k in KEEP:
+        v = out[k]
+        if v is None:
+            continue
+        v = v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+        if k in ('neighbor_agent_grid_idx', 'neighbor_pt_grid_idx'):
+            # grid_index_head over every seed edge (40 k x 1961 floats): the first 128 rows in full, arg-max / max of all
+            keep['out_' + k + '_argmax'] = v.argmax(-1).astype(np.int32)
+            keep['out_' + k + '_max'] = v.max(-1).astype(np.float32)
+            v = v[:128]
+        if k in ('grid_agent_occ_seed', 'grid_pt_occ_seed'):
+            # occupancy heads: seed rows 0-1 of each scene in full, row sums of all
+            keep['out_' + k + '_rowsum'] = v.astype(np.float64).sum(-1).astype(np.float32)
+            v = v[[0, 1, 10, 11]]
+        if k in ('grid_agent_occ_gt_seed', 'grid_pt_occ_gt_seed'):
+            v = v.astype(np.int8)
+        if k == 'grid_agent_occ_eval_mask_seed':
+            v = np.packbits(v, axis=-1)
+        keep['out_' + k] = v
+    meta = dict(rng_seed=RNG_SEED, weight_seed=1, head_gain=1.0, m_per_scene=[160, 140], map_seed=7711,
+                edge_counts=counts)
+    np.savez_compressed(os.path.join(HERE, 'forward_a40.npz'), meta=json.dumps(meta),
+                        pt_grid_token_idx=batch['agent']['pt_grid_token_idx'], **keep)
+    print('edges', counts)
+    print({k: v.shape for k, v in keep.items()})
+    print('refine rows', int(keep['out_next_head_eval_mask_seed'].sum()), 'attr rows', int(keep['out_next_attr_eval_mask_seed'].sum()))
+
+
+if __name__ == '__main__':
+    main()
