@@ -246,6 +246,33 @@ int infgen_insert_finalize(const InfgenRollout* r, int c, float angle_interval, 
                            const int* new_row, const float* lg_heading, int n_heading, const float* offset,
                            float* hv_ovr, void* stream);
 
+/* ---- edge sets of the teacher-forced forward (reference agent_decoder.py:1104-1603) ----
+ * infgen_radius_edges: torch_cluster.radius / radius_graph (agent_decoder.py:632, :710, :780, :875; map_decoder.py:91) for a
+ * list of query points, with the filters the reference applies AFTER the radius call, as a compact CSR by destination:
+ *   query q: destination node q_node[q] (its off / cnt entries are written; nodes without a query keep what the caller put
+ *   there), pose p_pos / p_head / p_inv at index q_pt[q], candidates = indices [q_c0[q], q_c1[q]) of the candidate arrays in
+ *   ascending order; the first K with d^2 < radius^2 are "found", of those the ones with index != q_self[q] (optional),
+ *   c_ok[index] != 0 (optional) and pair_ok[q_pair_off[q] + index - q_c0[q]] != 0 (optional, q_pair_off < 0: no pair filter)
+ *   become edges with src = c_src[index] (optional, else the index) and
+ *   raw = (|d|, angle(heading vector of the query, d), wrap(c_head - p_head), index_diff ? index - q_pt[q] : 0),
+ *   d = candidate - query; gap_rule 1: the invalid / gap overrides of :595-601 on both components, 2: :722-723 (query
+ *   invalid), 0: none.  e->off entries get e_base added (several sets in one buffer); *e->total must be zeroed by the caller
+ *   and is the number of edges afterwards (> e->cap: overflow, rows that did not fit have cnt = 0).
+ * infgen_motion_features: (|motion vector|, angle(head vector, motion vector), 0, 0) per (row, column) of agent-major
+ *   [rows][T] arrays with the state rules of _build_vector_a (:426-447); gap_mask (optional): entries forced to the gap (:1327) */
+typedef struct InfgenRadiusEdges {
+  int n_q; int _pad0;
+  const int* q_node; const int* q_pt; const int* q_c0; const int* q_c1; const int* q_self; const int* q_pair_off;
+  const float* p_pos; const float* p_head; const unsigned char* p_inv;
+  const float* c_pos; const float* c_head; const unsigned char* c_inv; const unsigned char* c_ok; const int* c_src;
+  const unsigned char* pair_ok;
+  float radius; int K; int gap_rule; int index_diff;
+  int e_base; int _pad1;
+} InfgenRadiusEdges;
+int infgen_radius_edges(const InfgenRadiusEdges* a, const InfgenEdgeBuf* e, void* stream);
+int infgen_motion_features(const float* pos, const float* head, const int* state, const unsigned char* gap_mask, int rows, int T,
+                           float* out, void* stream);
+
 /* ---- agent tokenisation on the device ----
  * TokenProcessor._match_agent_token (infgen/datasets/preprocess.py:552-653; cal_polygon_contour :24-54), noise off:
  * valid [A][T] bytes, pos [A][T][2], heading [A][T], shape [A][2] = (width, length); tok = last contour of every token,

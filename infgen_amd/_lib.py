@@ -31,6 +31,15 @@ class EdgeBuf(C.Structure):
                 ('cap', _i), ('_pad', _i)]
 
 
+class RadiusEdges(C.Structure):
+    """InfgenRadiusEdges (include/infgen_hip.h)"""
+    _fields_ = [('n_q', _i), ('_pad0', _i),
+                ('q_node', _p), ('q_pt', _p), ('q_c0', _p), ('q_c1', _p), ('q_self', _p), ('q_pair_off', _p),
+                ('p_pos', _p), ('p_head', _p), ('p_inv', _p),
+                ('c_pos', _p), ('c_head', _p), ('c_inv', _p), ('c_ok', _p), ('c_src', _p), ('pair_ok', _p),
+                ('radius', C.c_float), ('K', _i), ('gap_rule', _i), ('index_diff', _i), ('e_base', _i), ('_pad1', _i)]
+
+
 class Options(C.Structure):
     _fields_ = [('use', _i), ('attn_mode', _i), ('gemm_terms', _i), ('fourier_mode', _i), ('edge_fuse', _i), ('edge_loop', _i),
                 ('overlap', _i), ('row_group_margin', _i), ('row_groups', _p), ('n_row_groups', _p)]
@@ -71,6 +80,8 @@ SYMBOLS = {
     'infgen_last_error': (C.c_char_p, []),
     'infgen_linear': (_i, [_p, _i, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p]),
     'infgen_linear_multi': (_i, [_p, _i, _p]),
+    'infgen_radius_edges': (_i, [_p, _p, _p]),
+    'infgen_motion_features': (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),
     'infgen_layernorm': (_i, [_p, _i, _p, _p, _p, _p]),
     'infgen_fourier_embed': (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _p]),
     'infgen_set_fourier_mode': (_i, [_i]),

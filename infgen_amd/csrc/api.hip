@@ -915,3 +915,24 @@ extern "C" int infgen_insert_finalize(const InfgenRollout* r, int c, float angle
   hipLaunchKernelGGL(k_insert_finalize, dim3(r->S), dim3(64), 0, (hipStream_t)stream, a);
   return check_launch("infgen_insert_finalize");
 }
+
+// ---------------------------------------------------------------------------------- teacher-forced forward
+extern "C" int infgen_radius_edges(const InfgenRadiusEdges* r, const InfgenEdgeBuf* e, void* stream) {
+  if (!r || !e) return fail("infgen_radius_edges", "null argument");
+  if (r->n_q <= 0) return 0;
+  if (r->K <= 0) return fail("infgen_radius_edges", "K must be positive");
+  if (r->gap_rule < 0 || r->gap_rule > 2) return fail("infgen_radius_edges", "gap_rule must be 0, 1 or 2");
+  RadiusEdgesArgs a{r->n_q, r->q_node, r->q_pt, r->q_c0, r->q_c1, r->q_self, r->q_pair_off, r->p_pos, r->p_head, r->p_inv,
+                    r->c_pos, r->c_head, r->c_inv, r->c_ok, r->c_src, r->pair_ok, r->radius, r->K, r->gap_rule, r->index_diff,
+                    EdgeBuf{e->off, e->cnt, e->src, e->raw, e->total, e->cap}, r->e_base};
+  hipLaunchKernelGGL(k_radius_edges, dim3(ceil_div(r->n_q, 4)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_radius_edges");
+}
+
+extern "C" int infgen_motion_features(const float* pos, const float* head, const int* state, const unsigned char* gap_mask,
+                                      int rows, int T, float* out, void* stream) {
+  if (rows <= 0 || T <= 0) return 0;
+  MotionFeatArgs a{pos, head, state, gap_mask, rows, T, out};
+  hipLaunchKernelGGL(k_motion_features, dim3(ceil_div(rows * T, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_motion_features");
+}

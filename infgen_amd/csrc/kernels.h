@@ -236,6 +236,24 @@ struct EdgeBuf {                    // device-side builder outputs for one edge 
   int* off; int* cnt; int* src; float* raw; int* total; int cap;
 };
 
+// forward_kernels.hip: torch_cluster.radius with an emit filter for a list of query points (the teacher-forced forward's
+// edge sets and the map-token graph); include/infgen_hip.h: InfgenRadiusEdges has the field-by-field description
+struct RadiusEdgesArgs {
+  int n_q;
+  const int* q_node; const int* q_pt; const int* q_c0; const int* q_c1; const int* q_self; const int* q_pair_off;
+  const float* p_pos; const float* p_head; const unsigned char* p_inv;
+  const float* c_pos; const float* c_head; const unsigned char* c_inv; const unsigned char* c_ok; const int* c_src;
+  const unsigned char* pair_ok;
+  float radius; int K; int gap_rule; int index_diff;
+  EdgeBuf e; int e_base;
+};
+
+struct MotionFeatArgs {
+  const float* pos; const float* head; const int* state; const unsigned char* gap_mask;
+  int rows, T;
+  float* out;                       // [rows][T][4]
+};
+
 struct BuildEdgesArgs {
   SceneState st;
   int c;                            // current column
@@ -378,5 +396,7 @@ __global__ void k_insert_decide(InsertDecideArgs a);
 __global__ void k_insert_finalize(InsertFinalizeArgs a);
 __global__ void k_sample_topk(SampleArgs a);
 __global__ void k_layernorm(const float* X, int rows, const float* g, const float* b, float* Y);
+__global__ void k_radius_edges(RadiusEdgesArgs a);            // forward_kernels.hip
+__global__ void k_motion_features(MotionFeatArgs a);
 
 }  // namespace ig
