@@ -242,6 +242,12 @@ int infgen_insert_decide(const InfgenRollout* r, int t, int force_enter, int max
                          const float* lg_state, const float* lg_type, const float* shape, const float* lg_pos,
                          const float* occ, int* active, int* n_new, int* inserted, int* new_row, float* new_shape,
                          int* new_cell, void* stream);
+/* the same with the stochastic cell choice of the reference (:1900-1904) made reproducible: inverse CDF over the sample_k (<= 16)
+ * most probable cells with uniform[s] in [0, 1); an occupied sampled cell spends the iteration, the scene stays active (:1906-1909) */
+int infgen_insert_decide_topk(const InfgenRollout* r, int t, int force_enter, int max_new,
+                              const float* lg_state, const float* lg_type, const float* shape, const float* lg_pos,
+                              const float* occ, int* active, int* n_new, int* inserted, int* new_row, float* new_shape,
+                              int* new_cell, int sample_k, const float* uniform, void* stream);
 int infgen_insert_finalize(const InfgenRollout* r, int c, float angle_interval, const int* inserted,
                            const int* new_row, const float* lg_heading, int n_heading, const float* offset,
                            float* hv_ovr, void* stream);

@@ -125,6 +125,7 @@ SYMBOLS = {
     'infgen_occupancy': (_i, [C.POINTER(Rollout), _i, _p, _p]),
     'infgen_point_edges': (_i, [C.POINTER(Rollout), _i, _p, _p, _i, _i, _f, _i, _f, _i, C.POINTER(EdgeBuf), C.POINTER(EdgeBuf), _p]),
     'infgen_insert_decide': (_i, [C.POINTER(Rollout), _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'infgen_insert_decide_topk': (_i, [C.POINTER(Rollout), _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
     'infgen_insert_finalize': (_i, [C.POINTER(Rollout), _i, _f, _p, _p, _p, _i, _p, _p, _p]),
     'infgen_prof_enable': (_i, [C.c_uint, _i]),
     'infgen_prof_collect': (_i, [C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]),

@@ -892,19 +892,41 @@ extern "C" int infgen_point_edges(const InfgenRollout* r, int c, const int* cent
   return check_launch("infgen_point_edges");
 }
 
-extern "C" int infgen_insert_decide(const InfgenRollout* r, int t, int force_enter, int max_new,
-                                    const float* lg_state, const float* lg_type, const float* shape, const float* lg_pos,
-                                    const float* occ, int* active, int* n_new, int* inserted, int* new_row,
-                                    float* new_shape, int* new_cell, void* stream) {
+static int insert_decide_impl(const InfgenRollout* r, int t, int force_enter, int max_new,
+                              const float* lg_state, const float* lg_type, const float* shape, const float* lg_pos,
+                              const float* occ, int* active, int* n_new, int* inserted, int* new_row,
+                              float* new_shape, int* new_cell, int sample_k, const float* uniform, void* stream) {
   RET_IF(validate(r, "infgen_insert_decide"));
+  if (sample_k > 16) return fail("infgen_insert_decide", "sample_k must be <= 16");
+  if (sample_k > 1 && !uniform) return fail("infgen_insert_decide", "cell sampling needs uniforms");
   InsertDecideArgs a;
   a.st = scene_of(r); a.c = 1 + t; a.t = t; a.R = r->R; a.grid_size = r->grid_size; a.force_enter = force_enter;
-  a.max_new = max_new; a.grid_xy = r->grid_xy; a.lg_state = lg_state; a.lg_type = lg_type; a.shape = shape;
+  a.max_new = max_new; a.sample_k = sample_k; a.uniform = uniform;
+  a.grid_xy = r->grid_xy; a.lg_state = lg_state; a.lg_type = lg_type; a.shape = shape;
   a.lg_pos = lg_pos; a.occ = occ; a.n_agents = const_cast<int*>(r->n_agents); a.type = const_cast<int*>(r->type);
   a.active = active; a.n_new = n_new; a.inserted = inserted; a.new_row = new_row; a.new_shape = new_shape;
   a.new_cell = new_cell; a.pred_traj = r->pred_traj; a.pred_head = r->pred_head; a.pred_state = r->pred_state;
   hipLaunchKernelGGL(k_insert_decide, dim3(r->S), dim3(64), 0, (hipStream_t)stream, a);
   return check_launch("infgen_insert_decide");
+}
+
+extern "C" int infgen_insert_decide(const InfgenRollout* r, int t, int force_enter, int max_new,
+                                    const float* lg_state, const float* lg_type, const float* shape, const float* lg_pos,
+                                    const float* occ, int* active, int* n_new, int* inserted, int* new_row,
+                                    float* new_shape, int* new_cell, void* stream) {
+  return insert_decide_impl(r, t, force_enter, max_new, lg_state, lg_type, shape, lg_pos, occ, active, n_new, inserted, new_row,
+                            new_shape, new_cell, 1, nullptr, stream);
+}
+
+// the same with the reference's stochastic cell choice (softmax -> topk(insert_beam_size) -> multinomial, agent_decoder.py:1900-1904)
+// in a reproducible form: inverse CDF over the sample_k most probable cells with uniform[s]; a sampled cell that is occupied spends
+// the iteration and leaves the scene active (:1906-1909)
+extern "C" int infgen_insert_decide_topk(const InfgenRollout* r, int t, int force_enter, int max_new,
+                                         const float* lg_state, const float* lg_type, const float* shape, const float* lg_pos,
+                                         const float* occ, int* active, int* n_new, int* inserted, int* new_row,
+                                         float* new_shape, int* new_cell, int sample_k, const float* uniform, void* stream) {
+  return insert_decide_impl(r, t, force_enter, max_new, lg_state, lg_type, shape, lg_pos, occ, active, n_new, inserted, new_row,
+                            new_shape, new_cell, sample_k, uniform, stream);
 }
 
 extern "C" int infgen_insert_finalize(const InfgenRollout* r, int c, float angle_interval, const int* inserted,

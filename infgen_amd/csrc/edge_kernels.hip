@@ -660,19 +660,45 @@ __global__ __launch_bounds__(64) void k_insert_decide(InsertDecideArgs a) {
   const int s = blockIdx.x, lane = threadIdx.x;
   const int c = a.c;
   if (!a.active[s]) { if (lane == 0) a.inserted[s] = 0; return; }
-  // arg-max of the position head (softmax is monotone; first index on ties)
+  // the position head's cell: arg-max (softmax is monotone; first index on ties) or, with sample_k > 1, the reference's
+  // softmax -> topk(insert_beam_size) -> multinomial (:1900-1904) in its reproducible form: the k largest in (value desc,
+  // index asc) order, inverse CDF over their probabilities with the caller's uniform (like k_sample_topk)
   const float* lp = a.lg_pos + (size_t)s * a.grid_size;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int g = lane; g < a.grid_size; g += 64) {
-    const float v = lp[g];
-    if (v > best) { best = v; bi = g; }
-  }
+  {
+    const int k = a.sample_k > 1 ? min(a.sample_k, 16) : 1;
+    float topv[16];
+    int topi[16];
+    float prev_v = INFINITY;
+    int prev_i = -1;
+    for (int j = 0; j < k; ++j) {
+      best = -INFINITY; bi = 0x7fffffff;
+      for (int g = lane; g < a.grid_size; g += 64) {
+        const float v = lp[g];
+        const bool after = (v < prev_v) || (v == prev_v && g > prev_i);
+        if (after && (v > best || (v == best && g < bi))) { best = v; bi = g; }
+      }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ob = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(bi, o, 64);
-    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      topv[j] = best; topi[j] = bi;
+      prev_v = best; prev_i = bi;
+    }
+    if (k > 1) {
+      float p[16], sum = 0.f;
+      for (int j = 0; j < k; ++j) { p[j] = expf(topv[j] - topv[0]); sum += p[j]; }
+      const float u = a.uniform[s] * sum;
+      float cdf = 0.f;
+      int pick = k - 1;
+      for (int j = 0; j < k; ++j) { cdf += p[j]; if (u < cdf) { pick = j; break; } }
+      bi = topi[pick];
+    } else {
+      bi = topi[0];
+    }
   }
   if (lane != 0) return;
   const int cell = bi;
@@ -685,6 +711,9 @@ __global__ __launch_bounds__(64) void k_insert_decide(InsertDecideArgs a) {
   if (lt[2] > lt[ty]) ty = 2;
   const bool occupied = a.occ[(size_t)s * a.grid_size + cell] != 0.f;
   const int A = a.n_agents[s];
+  // :1906-1909: an occupied cell `continue`s - the iteration is spent, nothing is appended and, when cells are sampled, the
+  // next iteration draws again (greedy: it would pick the same cell until the iterations run out, so the scene stops)
+  if (occupied && a.sample_k > 1) { a.inserted[s] = 0; return; }
   const bool ok = enter && !occupied && a.n_new[s] + 1 <= a.max_new;
   // the reference would append a row here; if the scene's row head-room is used up that is reported (-1), never dropped
   if (ok && A >= st.A_cap) { a.inserted[s] = -1; a.active[s] = 0; return; }

@@ -316,6 +316,7 @@ struct OccupancyArgs { SceneState st; int c; int grid_size; float* occ; /* [S][g
 struct InsertDecideArgs {
   SceneState st;
   int c, t, R, grid_size, force_enter, max_new;
+  int sample_k; const float* uniform;   // cell sampling: top-k inverse CDF with uniform[S] (sample_k <= 1: arg-max)
   const float* grid_xy;
   const float* lg_state;            // [S][2]
   const float* lg_type;             // [S][3]

@@ -273,7 +273,8 @@ class RolloutEngine:
                  store_logits: bool = False, live_state: bool = False,
                  teacher: Optional[Sequence] = None, x_pt_override: Optional[Sequence] = None,
                  force_enter: bool = False, insert_headroom: Optional[int] = None,
-                 sample_k: int = 1, sample_uniforms: Optional[np.ndarray] = None, options: Optional[Mapping[str, int]] = None):
+                 sample_k: int = 1, sample_uniforms: Optional[np.ndarray] = None, options: Optional[Mapping[str, int]] = None,
+                 insert_k: int = 1, insert_uniforms: Optional[np.ndarray] = None):
         self.w = weights
         self.options = dict(options) if options else None      # per-engine kernel switches (fields of InfgenOptions)
         self.cfg = cfg = weights.cfg
@@ -291,6 +292,13 @@ class RolloutEngine:
         self.store_logits = store_logits
         self.sample_k = int(sample_k)
         self._sample_uniforms = sample_uniforms      # [steps][S][A] float32 in [0,1) (top-k inverse-CDF sampling)
+        # scenario insertion: the cell of a new agent from the insert_k most probable ones (reference insert_beam_size = 10,
+        # agent_decoder.py:1900-1904) with insert_uniforms [steps][10][S]; 1: arg-max
+        self.insert_k = int(insert_k)
+        self._insert_u = None
+        if self.insert_k > 1:
+            assert insert_uniforms is not None, 'cell sampling needs caller-supplied uniforms [steps][10][S]'
+            self._insert_u = torch.from_numpy(np.ascontiguousarray(insert_uniforms, dtype=np.float32)).to(weights.device)
         self._x_pt_override = x_pt_override
         self.force_valid = bool(cfg.disable_insertion) and not live_state
         self.insertion = not cfg.disable_insertion
@@ -600,7 +608,7 @@ class RolloutEngine:
             first_new=torch.full((S,), A_cap, device=dev, dtype=torch.int32), hv_ovr=f(S, 2), shape_all=torch.full((rows, 3), INVALID_SHAPE, device=dev),
             scene_base=(ar * A_cap).contiguous(), inserted_rows=[[] for _ in range(S)],
             groups=i32((rows + 15) // 16), n_groups=i32(1),
-            host_dec=(torch.zeros(S, dtype=torch.int32).pin_memory(), torch.zeros(S, dtype=torch.int32).pin_memory()),
+            host_dec=tuple(torch.zeros(S, dtype=torch.int32).pin_memory() for _ in range(3)),
             host_ev=torch.cuda.Event())
 
     def _ebuf_struct(self, e):
@@ -631,6 +639,7 @@ class RolloutEngine:
         H = w.heads
         f_seed = w._tables['f_seed']
         prev_new, h_ready = None, False
+        pend_h = None       # rows appended at the last heading stage: their K / V of the motion layers 0..2 are still to be refreshed
         for it in range(10):
             # occupancy embedding and its K/V for the three occ2sa layers
             _lib.check(lib.infgen_occupancy(ctx, c, _lib.ptr(I['occ']), st), 'infgen_occupancy')
@@ -686,19 +695,23 @@ class RolloutEngine:
                     ops.attn_post_pre(XS, w.attn_a2sa[i], AGGS, ZS, SIGS, w.attn_occ2sa[i + 1], q=QS)
                 else:
                     ops.attn_post(XS, w.attn_a2sa[i], AGGS, ZS, SIGS)
-            riders_h = prev_new if (n_r and h_ready) else None     # riders of the heading chain below (h_ready as of now)
+            # riders of the heading chain below (h_ready as of now): the rows of the previous heading stage - not necessarily
+            # the previous iteration, a sampled cell that was occupied spends iterations without a heading stage
+            riders_h = pend_h if (pend_h is not None and h_ready) else None
             XS = XS[:S]
             lg_state, lg_type, shape, lg_pos = ops.mlp_layers(XS, [
                 (H['seed_state_predict_head'], 2), (H['seed_type_predict_head'], 3), (H['seed_shape_predict_head'], 3),
                 (H['seed_pos_rel_token_predict_head'], G)])
-            _lib.check(lib.infgen_insert_decide(ctx, t, int(self.force_enter), 10, _lib.ptr(lg_state), _lib.ptr(lg_type),
-                                                _lib.ptr(shape), _lib.ptr(lg_pos), _lib.ptr(I['occ']), _lib.ptr(I['active']),
-                                                _lib.ptr(I['n_new']), _lib.ptr(I['inserted']), _lib.ptr(I['new_row']),
-                                                _lib.ptr(I['new_shape']), _lib.ptr(I['new_cell']), st),
+            _lib.check(lib.infgen_insert_decide_topk(ctx, t, int(self.force_enter), 10, _lib.ptr(lg_state), _lib.ptr(lg_type),
+                                                     _lib.ptr(shape), _lib.ptr(lg_pos), _lib.ptr(I['occ']), _lib.ptr(I['active']),
+                                                     _lib.ptr(I['n_new']), _lib.ptr(I['inserted']), _lib.ptr(I['new_row']),
+                                                     _lib.ptr(I['new_shape']), _lib.ptr(I['new_cell']), self.insert_k,
+                                                     _lib.ptr(self._insert_u[t, it]) if self._insert_u is not None else None, st),
                        'infgen_insert_decide')
             # hand-over to the host: did any scene insert, and into which rows?
             I['host_dec'][0].copy_(I['inserted'], non_blocking=True)
             I['host_dec'][1].copy_(I['new_row'], non_blocking=True)
+            I['host_dec'][2].copy_(I['active'], non_blocking=True)
             ev = I['host_ev']
             ev.record(torch.cuda.current_stream(self.device))
             yield ev
@@ -713,6 +726,9 @@ class RolloutEngine:
                     needed=self.A_cap)
             ins_host = ins_host > 0
             if not ins_host.any():
+                if self.insert_k > 1 and I['host_dec'][2].numpy().any():
+                    prev_new = None         # sampled cells were occupied everywhere: the iteration is spent, active scenes draw again
+                    continue
                 break
             ins_idx_host = np.nonzero(ins_host)[0]
             nr_host = I['host_dec'][1].numpy()[ins_idx_host].astype(np.int64)
@@ -774,6 +790,7 @@ class RolloutEngine:
                                                   _lib.ptr(I['hv_ovr']), st), 'infgen_insert_finalize')
             _lib.check(lib.infgen_raw_feature_rows(ctx, c, _lib.ptr(I['new_row']), _lib.ptr(I['inserted']), S, st), 'raw_feature_rows')
             prev_new = nr
+            pend_h = nr
 
     def _build_ctx(self):
         cfg, w = self.cfg, self.w

@@ -77,6 +77,7 @@ class InfGen(nn.Module):
             disable_insertion=self.disable_insertion, seed_size=self.seed_size, buffer_size=dc.buffer_size,
             num_recurrent_steps_val=mc.num_recurrent_steps_val, loss_weight=_get(mc, 'loss_weight'), logger=logger)
         self.val_open_loop = bool(_get(mc, 'val_open_loop', False))
+        self.loss_weight = _get(mc, 'loss_weight')
         self.val_close_loop = bool(_get(mc, 'val_close_loop', True))
         self.n_rollout_close_val = int(_get(mc, 'n_rollout_close_val', 1))
         self._mode = 'training'
@@ -112,7 +113,8 @@ class InfGen(nn.Module):
         return self.encoder.get_agent_inputs(data)
 
     def forward(self, data):
-        raise NotImplementedError('the teacher-forced forward (agent_decoder.py:1104-1603) is not built: SURVEY 8f rank 3')
+        """reference infgen/model/infgen.py:217-219"""
+        return self.encoder(data)
 
     # ------------------------------------------------------------------ reference :875-916
     def load_state_from_file(self, filename, to_cpu=False):
@@ -205,8 +207,25 @@ class InfGen(nn.Module):
             pt['ptr'] = torch.tensor([0, pt['position'].shape[0]], device=dev)
         data['batch_size_a'] = ag['ptr'][1:] - ag['ptr'][:-1]
         data['batch_size_pl'] = pt['ptr'][1:] - pt['ptr'][:-1]
-        if self.val_open_loop:
-            raise NotImplementedError('open-loop validation needs the teacher-forced forward (SURVEY 8f rank 3)')
+        if self.val_open_loop or int(os.getenv('OPEN_LOOP', 0)):
+            # reference :627-686: teacher-forced forward, token + state cross-entropies as 'val_loss' (the occupancy plots of
+            # that branch are not part of the HIP path)
+            if isinstance(ag['av_index'], torch.Tensor) and ag['av_index'].numel() > 1:
+                ag['av_index'] = ag['av_index'] + ag['ptr'][:-1]                    # batched graphs (:610-611)
+            pred = self(data)
+            self.open_loop_pred = pred
+            loss = torch.zeros((), device=pred['next_token_prob'].device)
+            if self.predict_motion:
+                m_ = pred['next_token_eval_mask']
+                loss = loss + torch.nn.functional.cross_entropy(pred['next_token_prob'][m_], pred['next_token_idx_gt'][m_],
+                                                                label_smoothing=0.1)
+            if self.predict_state:
+                m_ = pred['next_state_eval_mask']
+                sw = torch.tensor(self.loss_weight['state_weight'], device=loss.device) if self.loss_weight else None
+                loss = loss + torch.nn.functional.cross_entropy(pred['next_state_prob'][m_], pred['next_state_idx_gt'][m_], weight=sw)
+            self.val_loss = loss
+            if not (self.val_close_loop and (self.predict_motion or self.predict_state)):
+                return loss
         if not (self.val_close_loop and (self.predict_motion or self.predict_state)):
             return
         rollout = None

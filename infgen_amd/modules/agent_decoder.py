@@ -6,8 +6,9 @@ Lightning checkpoint's ``encoder.agent_encoder.*`` load unchanged) and
 The rollout itself runs in libinfgen_hip.so (infgen_amd/engine.py), including the scenario-
 insertion sub-loop when ``disable_insertion`` is False.  Motion tokens: greedy for
 ``motion_beam_size = 1``, otherwise top-k inverse-CDF sampling on supplied uniforms (the reference's
-top-5 multinomial, reproducible); insertion decisions are greedy (``insert_beam_size = 1``
-semantics; the reference samples top-10 cells with torch RNG).  The seed-loop outputs that exist
+top-5 multinomial, reproducible); the cell of an inserted agent: arg-max for ``insert_beam_size = 1`` (the default here),
+otherwise drawn from the top-k cells the same way (the reference's top-10 multinomial, agent_decoder.py:1900-1909, incl. its
+retry after an occupied cell).  The seed-loop outputs that exist
 only for plotting (``next_pos_rel_prob_seed``, ``grid_*_occ_seed``) are returned as zeros.
 """
 from __future__ import annotations

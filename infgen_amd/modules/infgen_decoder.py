@@ -1,7 +1,7 @@
 """InfGenDecoder: the drop-in boundary of the hot path (reference
 infgen/modules/infgen_decoder.py:15-143).  Same constructor signature, same sub-module names
 (``map_encoder`` / ``agent_encoder``), ``forward`` / ``inference`` / ``inference_no_map`` with the
-reference's return dicts.  ``inference`` runs map encoder + closed-loop rollout on the GPU through
+reference's return dicts (``forward``: the teacher-forced open-loop pass, infgen_amd/forward_engine.py).  ``inference`` runs map encoder + closed-loop rollout on the GPU through
 libinfgen_hip.so; ``inference_batch`` is the throughput entry (many scenes in lockstep).
 """
 from __future__ import annotations
@@ -37,6 +37,29 @@ def scene_from_data(data) -> Dict[str, Dict[str, np.ndarray]]:
     agent = {k: _np(ag[k]) for k in _AGENT_KEYS}
     pt = data['pt_token']
     ptd = {k: _np(pt[k]) for k in ('position', 'orientation', 'type', 'pl_type', 'token_idx')}
+    key = ('pt_token', 'to', 'map_polygon')
+    try:
+        e = data[key]['edge_index']
+    except (KeyError, TypeError):
+        e = data['pt_token__to__map_polygon']['edge_index']
+    return {'agent': agent, 'pt_token': ptd, 'map_polygon': {'light_type': _np(data['map_polygon']['light_type'])},
+            'pt_token__to__map_polygon': {'edge_index': _np(e)}}
+
+
+_FWD_AGENT_KEYS = ('state_idx', 'raw_agent_valid_mask', 'token_pos', 'token_idx', 'token_heading', 'shape', 'type',
+                    'grid_token_idx', 'grid_offset_xy', 'heading_token_idx', 'sort_indices', 'pos_xy', 'heading_theta',
+                    'pt_grid_token_idx', 'av_index', 'trajectory_token_veh', 'trajectory_token_ped', 'trajectory_token_cyc')
+
+
+def batch_from_data(data) -> Dict[str, Dict[str, np.ndarray]]:
+    """the (batched) ``data`` the reference's forward reads (agent_decoder.py:1108-1127, map_decoder.py:71-93) -> host dict of
+    numpy arrays; ``ptr`` defaults to one scene"""
+    ag, pt = data['agent'], data['pt_token']
+    agent = {k: _np(ag[k]) for k in _FWD_AGENT_KEYS}
+    A = agent['state_idx'].shape[0]
+    agent['ptr'] = _np(ag['ptr']) if 'ptr' in ag else np.array([0, A], np.int64)
+    ptd = {k: _np(pt[k]) for k in ('position', 'orientation', 'type', 'pl_type', 'token_idx')}
+    ptd['ptr'] = _np(pt['ptr']) if 'ptr' in pt else np.array([0, ptd['position'].shape[0]], np.int64)
     key = ('pt_token', 'to', 'map_polygon')
     try:
         e = data[key]['edge_index']
@@ -133,10 +156,16 @@ class InfGenDecoder(nn.Module):
             # stochastic decode like the reference's default (top-k multinomial), driven by torch's RNG
             amax = max(int(np.asarray(s_['agent']['state_idx']).shape[0]) for s_ in scenes)
             sample_uniforms = torch.rand(w.cfg.num_decode_steps, len(scenes), amax + 128).numpy()
+        ik = int(getattr(ae, 'insert_beam_size', 1))
+        insert_uniforms = None
+        if ik > 1 and not w.cfg.disable_insertion and not map_only:
+            # the cell of an inserted agent from the insert_beam_size most probable ones (agent_decoder.py:1900-1904), torch's RNG
+            insert_uniforms = torch.rand(w.cfg.num_decode_steps, 10, len(scenes)).numpy()
         def make_engine(headroom=None):
             return RolloutEngine(w, scenes, vocab, map_vocab, grid, x_pt_override=xo, insert_headroom=headroom,
                                  force_enter=bool(int(os.getenv('DEBUG', 0))),    # DEBUG=1 forces 'enter' (agent_decoder.py:1888)
-                                 sample_k=k if not map_only else 1, sample_uniforms=sample_uniforms)
+                                 sample_k=k if not map_only else 1, sample_uniforms=sample_uniforms,
+                                 insert_k=ik if insert_uniforms is not None else 1, insert_uniforms=insert_uniforms)
         eng = make_engine()
         if map_only:
             eng.prologue(map_only=True)
@@ -183,9 +212,25 @@ class InfGenDecoder(nn.Module):
     def get_agent_inputs(self, data):
         raise NotImplementedError('training-only helper (agent_decoder.py:933) — out of the hot path')
 
-    def forward(self, data):
-        raise NotImplementedError('teacher-forced forward (agent_decoder.py:1104-1603) is out of scope of the rollout '
-                                  'hot path; use inference()')
+    @torch.no_grad()
+    def forward(self, data) -> Dict[str, torch.Tensor]:
+        """map encoder + teacher-forced forward over every token column of the batch (reference infgen_decoder.py:114-121,
+        agent_decoder.py:1104-1603) on the GPU (infgen_amd/forward_engine.py).  Evaluation only (no autograd
+        through the HIP kernels).  The candidate rows of the refine stage and the neighbour-grid evaluation masks are drawn
+        with ``torch.randperm`` from torch's CPU generator in the reference's order."""
+        from ..forward_engine import ForwardEngine
+        w = self._weights()                 # (raises on a CPU module: no CPU fallback)
+        batch = batch_from_data(data)
+        vocab = {k: batch['agent'][f'trajectory_token_{k}'] for k in ('veh', 'ped', 'cyc')}
+        map_vocab = _np(self.map_encoder.map_token['traj_src']).astype(np.float32)
+        grid = self.agent_encoder.attr_tokenizer.grid.detach().cpu().numpy()
+        out = ForwardEngine(w, batch, vocab, map_vocab, grid).run()
+        dev = w.device
+        map_enc = {'map_next_token_idx': torch.zeros(0, 10, dtype=torch.long, device=dev),
+                   'map_next_token_prob': torch.zeros(0, self.map_encoder.token_size, device=dev),
+                   'map_next_token_idx_gt': torch.zeros(0, dtype=torch.long, device=dev),
+                   'map_next_token_eval_mask': torch.zeros(0, dtype=torch.bool, device=dev)}
+        return {**map_enc, **out, **{k: data[k] for k in self.data_keys if k in data}}
 
     @torch.no_grad()
     def inference(self, data, sample_uniforms=None) -> Dict[str, torch.Tensor]:

@@ -30,9 +30,14 @@ SEED_LAYERS = 3            # agent_decoder.py:235
 
 class InsertionOracle(RolloutOracle):
 
-    def __init__(self, sd, cfg, grid, prefix='agent_encoder', force_enter: bool = False):
+    def __init__(self, sd, cfg, grid, prefix='agent_encoder', force_enter: bool = False, insert_k: int = 1,
+                 insert_uniforms=None):
         super().__init__(sd, cfg, grid, prefix=prefix, live_state=True)
         self.force_enter = force_enter
+        # cell of a new agent: arg-max, or (insert_k > 1) the reference's softmax -> topk(insert_beam_size) -> multinomial
+        # (agent_decoder.py:1900-1904) as inverse CDF over the top-k probabilities with insert_uniforms[t][iteration]
+        self.insert_k = int(insert_k)
+        self.insert_uniforms = insert_uniforms
 
     # ------------------------------------------------------------------ pieces
     def _edgeless(self, name, i, x, x_src=None):
@@ -56,8 +61,9 @@ class InsertionOracle(RolloutOracle):
         st[key] = torch.cat([st[key], row], dim=0)
 
     # ------------------------------------------------------------------ one insertion attempt
-    def try_insert(self, st, c, t, raw_c, num_new):
-        """returns (inserted: bool, new raw_c).  SURVEY A.6 steps (1)-(7)."""
+    def try_insert(self, st, c, t, raw_c, num_new, it=0):
+        """returns (inserted: True / False, or None when the chosen cell was occupied - the iteration is spent, :1906-1909 -, new
+        raw_c).  SURVEY A.6 steps (1)-(7)."""
         sd, p, cfg = self.sd, self.p, self.cfg
         A = st['pos'].shape[0]
         av = st['av']
@@ -106,12 +112,18 @@ class InsertionOracle(RolloutOracle):
         pos_logit = mlp_layer(sd, p + '.seed_pos_rel_token_predict_head', xs)
         pos_prob = torch.softmax(pos_logit, dim=-1)
         cell = int(torch.topk(pos_prob, k=1, dim=-1)[1][0, 0])
+        if self.insert_k > 1:
+            pk, ik = torch.topk(pos_prob[0], k=self.insert_k)
+            cdf = torch.cumsum(pk / pk[0], 0)                  # (ratios to the largest: the device forms exp(v - v_max) sums)
+            u = float(self.insert_uniforms[t][it]) * float(cdf[-1])
+            cell = int(ik[min(int((u >= cdf).sum()), self.insert_k - 1)])
         top2 = torch.topk(pos_logit[0], k=2).values
         new_pos = rot_right(self.grid[cell][None, None], (ego_head - math.pi / 2)[None])[0, 0] + ego_pos
         st['seed_log'].append(dict(t=t, enter=enter, cell=cell, occupied=bool(occ[cell]), type=ty,
                                    cell_margin=float(top2[0] - top2[1]), type_logits=ty_logit[0].tolist()))
         if bool(occ[cell]):
-            return False, raw_c            # rejected; greedy would repeat -> no further insertion this step
+            # rejected; greedy would pick the same cell again -> no further insertion this step; sampled: draw again next iteration
+            return (None if self.insert_k > 1 else False), raw_c
         if not enter or num_new + 1 > INSERT_LIMIT:
             return False, raw_c
         # ---- (5) append a row
@@ -213,8 +225,10 @@ class InsertionOracle(RolloutOracle):
             st['hv_override'] = None
             num_new = 0
             if t > 0:
-                while num_new < INSERT_LIMIT:
-                    ok, raw_c = self.try_insert(st, c, t, raw_c, num_new)
+                for it in range(INSERT_LIMIT):               # `while True: p += 1; if p - 1 >= insert_limit: break` (:1774-1776)
+                    ok, raw_c = self.try_insert(st, c, t, raw_c, num_new, it)
+                    if ok is None:
+                        continue
                     if not ok:
                         break
                     num_new += 1
@@ -366,11 +380,12 @@ class InsertionOracle(RolloutOracle):
         return st, dict(tabs=tabs, A0=A, ag=ag, filt=filt, state0=state0)
 
 
-def run_scene_with_insertion(sd, scene, cfg, vocab, map_vocab, grid, force_enter=False, teacher=None):
+def run_scene_with_insertion(sd, scene, cfg, vocab, map_vocab, grid, force_enter=False, teacher=None, insert_k=1,
+                             insert_uniforms=None):
     from .rollout_oracle import map_encoder
     with torch.no_grad():
         x_pt = map_encoder(sd, scene, cfg, map_vocab)
-        orc = InsertionOracle(sd, cfg, grid, force_enter=force_enter)
+        orc = InsertionOracle(sd, cfg, grid, force_enter=force_enter, insert_k=insert_k, insert_uniforms=insert_uniforms)
         tt = ts = None
         if teacher is not None:
             tt, ts = teacher

@@ -60,6 +60,11 @@ CASES = {
     # logits kept for the first steps only (the rest is compared through tokens / states / poses / ids)
     'ins_forced_long_a24_m256': dict(cfg='standard', A=24, M=256, seed=synth.scene_seed(9, 5), ego_last=True,
                                      edge_cases=False, head_gain=64.0, insertion='forced', R=400, logit_steps=3),
+    # the reference's stochastic cell choice (softmax -> top-10 -> multinomial, agent_decoder.py:1900-1904) with torch.multinomial
+    # replaced by inverse-CDF sampling on uniforms stored in the fixture: occupied cells are drawn, `continue` (:1906-1909) spends
+    # iterations, later draws succeed
+    'ins_sampled_a16_m256': dict(cfg='standard', A=16, M=256, seed=synth.scene_seed(9, 6), ego_last=True,
+                                 edge_cases=False, head_gain=64.0, insertion='forced', insert_k=10, uniform_seed=4242),
     # C2-shaped, unsharpened head (teacher-forced logits comparison only)
     'c2_a32_m512': dict(cfg='standard', A=32, M=512, seed=synth.scene_seed(2, 0), ego_last=True, edge_cases=False,
                         head_gain=1.0),
@@ -150,7 +155,26 @@ def run_case(name: str, spec: dict, out_dir: str):
     shapes = load_weights(dec, seed=1, head_gain=spec['head_gain'])
     ae = dec.agent_encoder
     ae.motion_beam_size = 1
-    ae.insert_beam_size = 1
+    ae.insert_beam_size = int(spec.get('insert_k', 1))
+    ins_u, ins_log = None, []
+    real_multinomial = torch.multinomial
+    if spec.get('insert_k', 1) > 1:
+        ins_u = np.random.default_rng(spec['uniform_seed']).random((cfg.num_decode_steps, 10)).astype(np.float32)
+        cnt = dict(step=0, it=0)
+
+        def fake_multinomial(probs, num_samples, *a, **k):
+            if probs.shape[-1] == 1:                  # the motion token draw of a greedy run (top-1): closes decode step `step`
+                cnt['step'] += 1
+                cnt['it'] = 0
+                return torch.zeros(probs.shape[:-1] + (1,), dtype=torch.long)
+            assert probs.shape == (1, spec['insert_k']) and num_samples == 1
+            cdf = torch.cumsum(probs[0] / probs[0, 0], 0)
+            u = float(ins_u[cnt['step'], cnt['it']]) * float(cdf[-1])
+            pick = min(int((u >= cdf).sum()), probs.shape[-1] - 1)
+            ins_log.append((cnt['step'], cnt['it'], pick))
+            cnt['it'] += 1
+            return torch.tensor([[pick]])
+        torch.multinomial = fake_multinomial
     if spec.get('live_state'):
         # run the state head for real but keep the insertion loop off: the loop is gated by
         # `self.disable_insertion` (agent_decoder.py:1776) and so is the state override (:2172).
@@ -186,8 +210,11 @@ def run_case(name: str, spec: dict, out_dir: str):
 
     data = to_hetero(scene)
     torch.manual_seed(0)
-    with torch.no_grad():
-        out = dec.inference(data.clone())
+    try:
+        with torch.no_grad():
+            out = dec.inference(data.clone())
+    finally:
+        torch.multinomial = real_multinomial
 
     nsteps = cfg.num_decode_steps
     assert len(logits) == nsteps, (len(logits), nsteps)
@@ -198,6 +225,7 @@ def run_case(name: str, spec: dict, out_dir: str):
     meta = dict(case=name, cfg=spec['cfg'], A=spec['A'], M=spec['M'], seed=spec['seed'], ego_last=spec['ego_last'],
                 edge_cases=spec['edge_cases'], head_gain=spec['head_gain'], weight_seed=1,
                 live_state=bool(spec.get('live_state', False)), insertion=ins or '', R=int(spec.get('R') or 0),
+                insert_k=int(spec.get('insert_k', 1)),
                 num_params=int(sum(int(np.prod(s)) for s in shapes.values())))
     # top-1/top-2 logit margin per (step, agent): tells the parity test where a flip is legitimate
     # with insertion the row count grows step by step: pad to the final count with NaN
@@ -229,6 +257,7 @@ def run_case(name: str, spec: dict, out_dir: str):
         agent_id=out['agent_id'].numpy(), ego_index=np.int64(out['ego_index']),
         edge_count=ecount, n_agents_step=n_agents_step, logit_max=logit_max, logit_argmax=logit_argmax,
         pred_type=out['pred_type'].numpy(), pred_shape=out['pred_shape'].numpy(),
+        **({'insert_uniforms': ins_u, 'insert_draws': np.asarray(ins_log, np.int64).reshape(-1, 3)} if ins_u is not None else {}),
     )
     os.environ['DEBUG'] = '0'
     print(f'{name}: A\'={out["pos_a"].shape[0]} steps={nsteps} min margin={margin.min():.3e} agents/step={n_agents_step.tolist()} '

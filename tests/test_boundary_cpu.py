@@ -167,7 +167,8 @@ def test_infgen_caller_mirror_host_side(tmp_path):
     assert m.noise and not m._online_metric
     m.set('validation')
     assert m._online_metric and m._save_validate_reuslts
-    with pytest.raises(NotImplementedError):
+    from infgen_amd import _lib as _l
+    with pytest.raises(_l.InfgenHipError):        # the teacher-forced forward exists, but only on a GPU: no CPU fallback
         m(None)
     data = {'agent': {'av_idx': 0, 'valid_mask': torch.ones(2, 91, dtype=torch.bool), 'heading': torch.zeros(2, 91),
                       'position': torch.zeros(2, 91, 3), 'velocity': torch.zeros(2, 91, 2), 'type': torch.zeros(2),

@@ -119,3 +119,41 @@ def test_forward_matches_cpu_oracle_on_a_second_batch(run):
             continue
         err = float((ref[k] - out[k].cpu()).abs().max())
         assert err <= 1e-4 * max(1.0, float(ref[k].abs().max())), (k, err)
+
+
+def test_infgen_decoder_forward_drop_in(run):
+    """the module entry: InfGenDecoder.forward(data) with the reference's dict keys (infgen_decoder.py:114-121)"""
+    from test_boundary_cpu import _decoder
+    from test_modules_gpu import _load
+    c = run
+    dev = torch.device('cuda:0')
+    dec = _decoder(c['cfg'])
+    _load(dec, c['sd'])
+    dec = dec.to(dev).eval()
+    data = {}
+    for k, v in c['batch'].items():
+        if isinstance(v, dict):
+            data[k] = {kk: (torch.from_numpy(np.ascontiguousarray(vv)).to(dev) if isinstance(vv, np.ndarray) else vv) for kk, vv in v.items()}
+        else:
+            data[k] = torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v
+    data[('pt_token', 'to', 'map_polygon')] = data.pop('pt_token__to__map_polygon')
+    for k in ('agent_valid_mask', 'category', 'valid_mask', 'av_index', 'shape'):
+        data[k] = data['agent'][k]
+    torch.manual_seed(c['meta']['rng_seed'])
+    out = dec(data)
+    z = c['z']
+    for k in ('x_a', 'next_token_prob', 'next_token_idx_gt', 'next_token_eval_mask', 'next_state_prob', 'next_state_idx_gt',
+              'next_state_eval_mask', 'next_state_idx_seed', 'next_state_idx_gt_seed', 'grid_agent_occ_seed', 'grid_pt_occ_seed',
+              'grid_agent_occ_gt_seed', 'grid_pt_occ_gt_seed', 'next_head_eval_mask_seed', 'target_indices', 'x_pt',
+              'map_next_token_prob', 'scenario_id', 'av_index'):
+        assert k in out, k
+    assert np.abs(out['next_token_prob'].cpu().numpy() - z['out_next_token_prob']).max() <= 1e-4
+    assert np.array_equal(out['next_token_eval_mask'].cpu().numpy(), z['out_next_token_eval_mask'])
+    assert np.array_equal(out['next_head_eval_mask_seed'].cpu().numpy(), z['out_next_head_eval_mask_seed'])
+    # the open-loop validation loss of the reference (infgen/model/infgen.py:627-653) from these outputs
+    m = torch.from_numpy(z['out_next_token_eval_mask'])
+    ref = torch.nn.functional.cross_entropy(torch.from_numpy(z['out_next_token_prob'])[m], torch.from_numpy(z['out_next_token_idx_gt'])[m],
+                                            label_smoothing=0.1)
+    got = torch.nn.functional.cross_entropy(out['next_token_prob'][out['next_token_eval_mask']],
+                                            out['next_token_idx_gt'][out['next_token_eval_mask']], label_smoothing=0.1)
+    assert abs(float(ref) - float(got)) <= 1e-5

@@ -36,12 +36,14 @@ def test_quirk_last_ten_rows_have_no_temporal_edges():
     assert (z['edge_count'][:, 0] > 0).all()
 
 
-INSERTION_CASES = ['ins_forced_a16_m256', 'ins_natural_a20_m256']
+INSERTION_CASES = ['ins_forced_a16_m256', 'ins_natural_a20_m256', 'ins_sampled_a16_m256']
 
 
 @pytest.mark.parametrize('case', INSERTION_CASES)
 def test_insertion_oracle_matches_reference_fixture(case):
-    """scenario insertion (agent_decoder.py:1773-2105): forced enter (DEBUG=1) and the natural seed head"""
+    """scenario insertion (agent_decoder.py:1773-2105): forced enter (DEBUG=1), the natural seed head, and the stochastic cell
+    choice (top-10 multinomial, :1900-1904) replayed from the fixture's uniforms - 119 of its 150 draws hit an occupied cell and
+    `continue` (:1906-1909)"""
     from oracle import insertion_oracle as io
     c = load_case(case)
     z, m = c['z'], c['meta']
@@ -49,7 +51,8 @@ def test_insertion_oracle_matches_reference_fixture(case):
     cfg.disable_insertion = False
     sd = {k: torch.from_numpy(v) for k, v in c['sd'].items()}
     out = io.run_scene_with_insertion(sd, c['scene'], cfg, c['vocab'], c['map_vocab'], c['grid'],
-                                      force_enter=(m['insertion'] == 'forced'))
+                                      force_enter=(m['insertion'] == 'forced'), insert_k=m.get('insert_k', 1),
+                                      insert_uniforms=z['insert_uniforms'] if 'insert_uniforms' in z.files else None)
     assert out['n_agents'].tolist() == z['n_agents_step'].tolist()          # same insertions at the same steps
     assert out['n_agents'][-1] > out['n_agents'][0]
     assert np.array_equal(out['next_token_idx'].numpy(), z['next_token_idx'])

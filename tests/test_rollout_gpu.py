@@ -139,7 +139,7 @@ def test_rollout_vs_oracle_fresh_seed():
     assert np.array_equal(o['next_token_idx'][:, :3], ref['next_token_idx'].numpy()[:, :3])
 
 
-@pytest.mark.parametrize('name', ['ins_forced_a16_m256', 'ins_natural_a20_m256'])
+@pytest.mark.parametrize('name', ['ins_forced_a16_m256', 'ins_natural_a20_m256', 'ins_sampled_a16_m256'])
 def test_insertion_rollout_matches_reference_fixture(name):
     """scenario insertion (agent_decoder.py:1773-2105): same agents inserted at the same steps with the same
     cells / types / headings as the reference, tokens bit-exact, logits within tolerance"""
@@ -150,8 +150,10 @@ def test_insertion_rollout_matches_reference_fixture(name):
     cfg.disable_insertion = False
     dev = torch.device('cuda:0')
     w = engine.PackedWeights(c['sd'], cfg, dev)
+    sampled = m.get('insert_k', 1) > 1          # the fixture's uniforms replay the reference's top-10 cell draws (:1900-1909)
     eng = engine.RolloutEngine(w, [c['scene']], c['vocab'], c['map_vocab'], c['grid'], store_logits=True,
-                               force_enter=(m['insertion'] == 'forced'))
+                               force_enter=(m['insertion'] == 'forced'), insert_k=m.get('insert_k', 1),
+                               insert_uniforms=z['insert_uniforms'][:, :, None] if sampled else None)
     eng.rollout()
     o = eng.outputs()[0]
     assert o['pos_a'].shape[0] == z['pos_a'].shape[0], (o['pos_a'].shape, z['pos_a'].shape)
