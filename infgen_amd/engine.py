@@ -274,7 +274,7 @@ class RolloutEngine:
                  teacher: Optional[Sequence] = None, x_pt_override: Optional[Sequence] = None,
                  force_enter: bool = False, insert_headroom: Optional[int] = None,
                  sample_k: int = 1, sample_uniforms: Optional[np.ndarray] = None, options: Optional[Mapping[str, int]] = None,
-                 insert_k: int = 1, insert_uniforms: Optional[np.ndarray] = None):
+                 insert_k: int = 1, insert_uniforms: Optional[np.ndarray] = None, seed_outputs: bool = False):
         self.w = weights
         self.options = dict(options) if options else None      # per-engine kernel switches (fields of InfgenOptions)
         self.cfg = cfg = weights.cfg
@@ -296,6 +296,10 @@ class RolloutEngine:
         # agent_decoder.py:1900-1904) with insert_uniforms [steps][10][S]; 1: arg-max
         self.insert_k = int(insert_k)
         self._insert_u = None
+        # record the seed node's per-insertion outputs of the reference's return dict (agent_decoder.py:2099-2113, :2364-2386:
+        # next_state_prob_seed, next_pos_rel_prob_seed, grid_*_occ_seed - plot inputs of the reference; two more heads per iteration)
+        self.seed_outputs = bool(seed_outputs)
+        self.seed_out = None
         if self.insert_k > 1:
             assert insert_uniforms is not None, 'cell sampling needs caller-supplied uniforms [steps][10][S]'
             self._insert_u = torch.from_numpy(np.ascontiguousarray(insert_uniforms, dtype=np.float32)).to(weights.device)
@@ -585,6 +589,9 @@ class RolloutEngine:
             self.ins['shape_all'].fill_(INVALID_SHAPE)
             self.ins['first_new'].fill_(self.A_cap)
             self.ins['inserted_rows'] = [[] for _ in range(self.S)]
+            if self.seed_out is not None:
+                for v in self.seed_out.values():
+                    v.zero_()
             return
         dev, S, rows, A_cap, M_cap, G = self.device, self.S, self.rows, self.A_cap, self.M_cap, self.G
         f = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.float32)
@@ -610,6 +617,14 @@ class RolloutEngine:
             groups=i32((rows + 15) // 16), n_groups=i32(1),
             host_dec=tuple(torch.zeros(S, dtype=torch.int32).pin_memory() for _ in range(3)),
             host_ev=torch.cuda.Event())
+        if self.seed_outputs:
+            steps = self.cfg.num_decode_steps
+            self.seed_out = dict(state=f(S, 11, steps), pos=f(S, 11, steps, G), occ_a=f(S, 11, steps, G), occ_p=f(S, 11, steps, G),
+                                 occ_gt=f(S, 11, steps, G))
+            sd, ap, dv = self.w.sd, self.w.ap, self.device
+            if not hasattr(self.w, 'fwd_heads'):
+                self.w.fwd_heads = {k: torch.from_numpy(np.ascontiguousarray(packing.pack_mlp_layer(sd, f'{ap}.{k}'), dtype=np.float32)).to(dv)
+                                    for k in ('grid_index_head', 'grid_agent_occ_head', 'grid_pt_occ_head')}
 
     def _ebuf_struct(self, e):
         b = _lib.EdgeBuf()
@@ -733,9 +748,18 @@ class RolloutEngine:
             ins_idx_host = np.nonzero(ins_host)[0]
             nr_host = I['host_dec'][1].numpy()[ins_idx_host].astype(np.int64)
             for s_i, r_i in zip(ins_idx_host, nr_host):
-                I['inserted_rows'][int(s_i)].append(int(r_i))
+                I['inserted_rows'][int(s_i)].append((int(r_i), t))
             ins = torch.from_numpy(ins_idx_host.astype(np.int64)).to(self.device)      # scenes that inserted (index list)
             nr = torch.from_numpy(nr_host).to(self.device)                              # the rows they appended
+            if self.seed_out is not None:
+                # slot = the scene's insertion count of this step after the append (agent_decoder.py:2099-2105)
+                so, slot = self.seed_out, I['n_new'][ins].long()
+                XS_in = I['XS'][:S][ins].contiguous()
+                so['state'][ins, slot, t] = torch.softmax(lg_state[ins], dim=-1)[:, -1]
+                so['pos'][ins, slot, t] = torch.softmax(lg_pos[ins], dim=-1)
+                so['occ_a'][ins, slot, t] = ops.mlp_layer(XS_in, w.fwd_heads['grid_agent_occ_head'], D, G)
+                so['occ_p'][ins, slot, t] = ops.mlp_layer(XS_in, w.fwd_heads['grid_pt_occ_head'], D, G)
+                so['occ_gt'][ins, slot, t] = I['occ'][ins]
             # categorical embedding / shape of the new rows (agent_decoder.py:1949-1950,1993)
             shp = ops.mlp_embedding(I['new_shape'], w.shape_emb, 3)
             self.cat_agent[nr] = w.type_a_emb[self.atype.reshape(-1)[nr].long()] + shp[ins]
@@ -943,6 +967,21 @@ class RolloutEngine:
                      pred_shape=pshape, eval_shape=eval_shape,
                      pred_z=np.zeros_like(ph), next_token_idx=ntok, next_state_idx=nstate,
                      gt_traj=np.asarray(sc['position'])[filt][:, H:, :2].copy(), num_inserted=A - A0)
+            if self.ins is not None:
+                # label 'A<k>' on the first column after the bos column of the k-th agent a step inserted (:1996-1999)
+                labels = [[None] * self.T for _ in range(A)]
+                per_step = {}
+                for row, t_ in self.ins['inserted_rows'][s]:
+                    k_ = per_step[t_] = per_step.get(t_, 0) + 1
+                    a_ = row - s * self.A_cap
+                    if a_ < A and hc + t_ < self.T:
+                        labels[a_][hc + t_] = f'A{k_}'
+                o['agent_labels'] = labels
+            if self.seed_out is not None:
+                so = self.seed_out
+                o.update(next_state_prob_seed=so['state'][s].cpu().numpy(), next_pos_rel_prob_seed=so['pos'][s].cpu().numpy(),
+                         grid_agent_occ_seed=so['occ_a'][s].cpu().numpy(), grid_pt_occ_seed=so['occ_p'][s].cpu().numpy(),
+                         grid_agent_occ_gt_seed=so['occ_gt'][s].cpu().numpy())
             if logits is not None:
                 o['logits'] = logits[:, s * self.A_cap:s * self.A_cap + A].copy()
             if x_pt is not None:

@@ -165,7 +165,9 @@ class InfGenDecoder(nn.Module):
             return RolloutEngine(w, scenes, vocab, map_vocab, grid, x_pt_override=xo, insert_headroom=headroom,
                                  force_enter=bool(int(os.getenv('DEBUG', 0))),    # DEBUG=1 forces 'enter' (agent_decoder.py:1888)
                                  sample_k=k if not map_only else 1, sample_uniforms=sample_uniforms,
-                                 insert_k=ik if insert_uniforms is not None else 1, insert_uniforms=insert_uniforms)
+                                 insert_k=ik if insert_uniforms is not None else 1, insert_uniforms=insert_uniforms,
+                                 # the seed node's per-insertion outputs (plot inputs of the reference): single-scene entry only
+                                 seed_outputs=batch is None and not w.cfg.disable_insertion and not map_only)
         eng = make_engine()
         if map_only:
             eng.prologue(map_only=True)
@@ -192,12 +194,15 @@ class InfGenDecoder(nn.Module):
             steps = w.cfg.num_decode_steps
             G = ae.grid_size
             z = lambda *s: torch.zeros(*s, device=dev)
-            r.update(next_state_prob_seed=z(11, steps), next_pos_rel_prob_seed=z(11, steps, G),
-                     grid_agent_occ_seed=z(11, steps, G), grid_pt_occ_seed=z(11, steps, G),
-                     grid_agent_occ_gt_seed=z(11, steps, G),
-                     agent_labels=[[None] * w.cfg.num_columns for _ in range(o['pos_a'].shape[0])],
-                     log_message=('No agents inserted!' if o['num_inserted'] == 0 else
-                                  f"Number of total inserted agents: {o['num_inserted']}"))
+            # without insertion (or in the batched entry) these stay what the reference initialises them to (:1746-1750, :1730)
+            for k_, shp_ in (('next_state_prob_seed', (11, steps)), ('next_pos_rel_prob_seed', (11, steps, G)),
+                             ('grid_agent_occ_seed', (11, steps, G)), ('grid_pt_occ_seed', (11, steps, G)),
+                             ('grid_agent_occ_gt_seed', (11, steps, G))):
+                if k_ not in r:
+                    r[k_] = z(*shp_)
+            r.setdefault('agent_labels', [[None] * w.cfg.num_columns for _ in range(o['pos_a'].shape[0])])
+            r['log_message'] = ('No agents inserted!' if o['num_inserted'] == 0 else
+                                f"Number of total inserted agents: {o['num_inserted']}")
             # the callee mutates data['batch_size_a'] like the reference (agent_decoder.py:1649)
             try:
                 filt = eng.hosts[len(res)]['filt']

@@ -258,6 +258,12 @@ def run_case(name: str, spec: dict, out_dir: str):
         edge_count=ecount, n_agents_step=n_agents_step, logit_max=logit_max, logit_argmax=logit_argmax,
         pred_type=out['pred_type'].numpy(), pred_shape=out['pred_shape'].numpy(),
         **({'insert_uniforms': ins_u, 'insert_draws': np.asarray(ins_log, np.int64).reshape(-1, 3)} if ins_u is not None else {}),
+        # the seed node's per-insertion outputs and the labels of the inserted agents (agent_decoder.py:2099-2113, :1996-1999)
+        **({'seed_state_prob': out['next_state_prob_seed'].numpy(), 'seed_pos_prob': out['next_pos_rel_prob_seed'].numpy(),
+            'seed_occ_a': out['grid_agent_occ_seed'].numpy(), 'seed_occ_p': out['grid_pt_occ_seed'].numpy(),
+            'seed_occ_gt': out['grid_agent_occ_gt_seed'].numpy().astype(np.int8),
+            'agent_label_k': np.asarray([[int(l[1:]) if l else 0 for l in row] for row in out['agent_labels']], np.int16)}
+           if ins and not spec.get('R') else {}),
     )
     os.environ['DEBUG'] = '0'
     print(f'{name}: A\'={out["pos_a"].shape[0]} steps={nsteps} min margin={margin.min():.3e} agents/step={n_agents_step.tolist()} '

@@ -153,7 +153,7 @@ def test_insertion_rollout_matches_reference_fixture(name):
     sampled = m.get('insert_k', 1) > 1          # the fixture's uniforms replay the reference's top-10 cell draws (:1900-1909)
     eng = engine.RolloutEngine(w, [c['scene']], c['vocab'], c['map_vocab'], c['grid'], store_logits=True,
                                force_enter=(m['insertion'] == 'forced'), insert_k=m.get('insert_k', 1),
-                               insert_uniforms=z['insert_uniforms'][:, :, None] if sampled else None)
+                               insert_uniforms=z['insert_uniforms'][:, :, None] if sampled else None, seed_outputs=True)
     eng.rollout()
     o = eng.outputs()[0]
     assert o['pos_a'].shape[0] == z['pos_a'].shape[0], (o['pos_a'].shape, z['pos_a'].shape)
@@ -170,10 +170,20 @@ def test_insertion_rollout_matches_reference_fixture(name):
     assert np.abs(o['pred_traj'] - z['pred_traj']).max() <= 1e-3
     assert np.abs(o['pred_head'] - z['pred_head']).max() <= 1e-4
     assert np.array_equal(o['pred_state'], z['pred_state'])
+    # the seed node's per-insertion outputs of the return dict (agent_decoder.py:2099-2113, :2364-2386) and the labels (:1996-1999)
+    assert np.array_equal(o['next_state_prob_seed'] > 0, z['seed_state_prob'] > 0)
+    assert np.abs(o['next_state_prob_seed'] - z['seed_state_prob']).max() <= 1e-4
+    assert np.abs(o['next_pos_rel_prob_seed'] - z['seed_pos_prob']).max() <= 1e-4
+    assert np.abs(o['grid_agent_occ_seed'] - z['seed_occ_a']).max() <= 1e-3
+    assert np.abs(o['grid_pt_occ_seed'] - z['seed_occ_p']).max() <= 1e-3
+    assert np.array_equal(o['grid_agent_occ_gt_seed'].astype(np.int8), z['seed_occ_gt'])
+    lab = np.asarray([[int(l[1:]) if l else 0 for l in row] for row in o['agent_labels']], np.int16)
+    assert np.array_equal(lab, z['agent_label_k'])
     # a second rollout of the same engine (state reset) reproduces the first
     eng.rollout()
     o2 = eng.outputs()[0]
     assert np.array_equal(o2['next_token_idx'], o['next_token_idx'])
+    assert np.array_equal(o2['next_state_prob_seed'], o['next_state_prob_seed'])
 
 
 def _first_ill_conditioned_step(z, grid, ego, hist=2):
