@@ -194,6 +194,7 @@ def main():
     ap.add_argument('--edge-fuse', type=int, default=-1, choices=(-1, 0, 1, 2),
                     help='infgen_set_edge_fuse: 1 (library default) k_edge_fused from 257 rows, 0 the unfused sequence with U / Z in HBM')
     ap.add_argument('--edge-loop', type=int, default=-1, choices=(-1, 4, 6, 8))
+    ap.add_argument('--graph', action='store_true', help='replay the decode steps of a rollout from a captured HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
@@ -247,7 +248,7 @@ def main():
 
     def make_engines(headroom):
         return [engine.RolloutEngine(w, scenes[i * per:(i + 1) * per], vocab, map_vocab, grid, store_logits=False,
-                                     insert_headroom=headroom)
+                                     insert_headroom=headroom, use_graph=args.graph)
                 for i in range(ns) if scenes[i * per:(i + 1) * per]]
     engines = make_engines(args.insert_headroom)
     streams = [torch.cuda.Stream(device=dev) for _ in engines] if ns > 1 else [None]

@@ -274,7 +274,8 @@ class RolloutEngine:
                  teacher: Optional[Sequence] = None, x_pt_override: Optional[Sequence] = None,
                  force_enter: bool = False, insert_headroom: Optional[int] = None,
                  sample_k: int = 1, sample_uniforms: Optional[np.ndarray] = None, options: Optional[Mapping[str, int]] = None,
-                 insert_k: int = 1, insert_uniforms: Optional[np.ndarray] = None, seed_outputs: bool = False):
+                 insert_k: int = 1, insert_uniforms: Optional[np.ndarray] = None, seed_outputs: bool = False,
+                 use_graph: bool = False):
         self.w = weights
         self.options = dict(options) if options else None      # per-engine kernel switches (fields of InfgenOptions)
         self.cfg = cfg = weights.cfg
@@ -300,6 +301,10 @@ class RolloutEngine:
         # next_state_prob_seed, next_pos_rel_prob_seed, grid_*_occ_seed - plot inputs of the reference; two more heads per iteration)
         self.seed_outputs = bool(seed_outputs)
         self.seed_out = None
+        # capture the decode steps of a rollout (no insertion: ~47 launches per step, all shapes static) in a HIP graph at the
+        # first run and replay it afterwards
+        self.use_graph = bool(use_graph)
+        self._graph = None
         if self.insert_k > 1:
             assert insert_uniforms is not None, 'cell sampling needs caller-supplied uniforms [steps][10][S]'
             self._insert_u = torch.from_numpy(np.ascontiguousarray(insert_uniforms, dtype=np.float32)).to(weights.device)
@@ -880,6 +885,20 @@ class RolloutEngine:
         t1 = self.cfg.num_decode_steps if t1 is None else t1
         self._refresh_opts(groups=True)        # (the group list is rebuilt on the device at every decode step below)
         if not self.insertion:
+            if self.use_graph and (t0, t1) == (0, self.cfg.num_decode_steps):
+                if self._graph is None and not getattr(self, '_graph_warm', False):
+                    # the first rollout runs eagerly: kernels are loaded lazily at their first launch, which must not happen
+                    # inside a capture
+                    self._graph_warm = True
+                    _lib.check(self.lib.infgen_rollout_run(C.byref(self._ctx), t0, t1, self.ops.stream), 'infgen_rollout_run')
+                    return
+                if self._graph is None:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        _lib.check(self.lib.infgen_rollout_run(C.byref(self._ctx), t0, t1, self.ops.stream), 'infgen_rollout_run')
+                    self._graph = g
+                self._graph.replay()
+                return
             _lib.check(self.lib.infgen_rollout_run(C.byref(self._ctx), t0, t1, self.ops.stream), 'infgen_rollout_run')
             return
         lib, I = self.lib, self.ins

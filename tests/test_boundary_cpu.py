@@ -202,3 +202,21 @@ def test_attr_tokenizer_matches_reference_fixture():
     assert np.abs(tok.get_grid(y[:1], th).numpy() - z['grid_w']).max() <= 1e-4
     pad, pidx = tok.pad_square(z['prob'], np.array([0, 5, tok.grid_size - 1, -1]))
     assert np.array_equal(pad, z['pad']) and np.array_equal(pidx, z['pidx'])
+
+
+def test_torch_library_ops_are_registered_with_shape_functions():
+    """the operators are torch.library ops (namespace infgen_hip); on meta tensors only the registered shape
+    functions run (no GPU needed)"""
+    import torch
+    from infgen_amd import torch_ops  # noqa: F401
+    for name in ('fourier_embed', 'radius_firstk', 'attn_layer', 'token_state_head', 'mlp_layer', 'mlp_embedding'):
+        assert hasattr(torch.ops.infgen_hip, name), name
+    m = lambda *s, dt=torch.float32: torch.empty(*s, device='meta', dtype=dt)
+    assert torch.ops.infgen_hip.fourier_embed(m(7, 3), m(10), True).shape == (7, 128)
+    idx, cnt = torch.ops.infgen_hip.radius_firstk(m(5, 2), m(9, 2), m(2, dt=torch.int64), m(2, dt=torch.int64), 3.0, 4)
+    assert idx.shape == (5, 4) and cnt.shape == (5,) and idx.dtype == torch.int32
+    assert torch.ops.infgen_hip.attn_layer(m(6, 128), m(10), m(6, dt=torch.int32), m(6, dt=torch.int32), m(3, dt=torch.int32),
+                                           m(3, 128), None).shape == (6, 128)
+    tok, st, lg = torch.ops.infgen_hip.token_state_head(m(6, 128), m(10), m(10), 2048, True)
+    assert tok.shape == (6,) and lg.shape == (6, 2048)
+    assert torch.ops.infgen_hip.mlp_layer(m(6, 128), m(10), 120).shape == (6, 120)

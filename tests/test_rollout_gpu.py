@@ -284,6 +284,30 @@ def test_batched_insertion_equals_single_scene_runs():
     assert max(n_ins) > 0
 
 
+def test_graph_replay_equals_eager_rollout():
+    """RolloutEngine(use_graph=True): the decode steps captured in a HIP graph (second rollout) and replayed (third) give the
+    eager rollout bit for bit"""
+    from infgen_amd import engine, synth
+    c = load_case('a24_m256_edge')
+    cfg = c['cfg']
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], cfg, dev)
+    scenes = [c['scene']] + [synth.make_scene(8200 + i, 20 + i, 200, cfg, ego_last=True, vocab=c['vocab'], grid=c['grid']) for i in range(3)]
+    ref = engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=True)
+    ref.rollout()
+    r = ref.outputs()
+    eng = engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=True, use_graph=True)
+    for i in range(3):
+        eng.rollout()
+        torch.cuda.synchronize()
+        assert (eng._graph is not None) == (i >= 1)
+        for a, b in zip(eng.outputs(), r):
+            assert np.array_equal(a['next_token_idx'], b['next_token_idx'])
+            assert np.array_equal(a['logits'], b['logits'])
+            assert np.array_equal(a['pos_a'], b['pos_a'])
+    assert np.array_equal(r[0]['next_token_idx'], c['z']['next_token_idx'])
+
+
 def test_rollout_many_streams_equals_single_engine():
     """engine.rollout_many: engines on their own streams, sequenced cooperatively by one host thread (each yields where it
     needs the device's insertion decisions) - the same scenes give the same rollouts as one engine after the other"""
