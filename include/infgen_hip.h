@@ -143,6 +143,10 @@ typedef struct InfgenRollout {
    * infgen_rollout_run, infgen_raw_feature*, infgen_build_edges) take every switch from here and never read the process-wide
    * defaults of the infgen_set_* functions - two contexts of one process may differ and run from different host threads */
   InfgenOptions opts;
+  /* optional [S][T][A_cap]: grid cell of the teacher-forced state per (column, row); entries < -1 mean "none" (the cell is
+   * computed).  Long teacher-forced comparisons use it where a pose sits on a cell border (arg-min of encode_pos flips with
+   * the last bits of the pose) */
+  const int* teacher_grid;
 } InfgenRollout;
 
 int infgen_linear(const float* X, int ldx, const int* gather, int rows, int K,

@@ -69,6 +69,7 @@ class Rollout(C.Structure):
         ('first_new', _p), ('hv_ovr', _p),
         ('sample_k', _i), ('_pad1', _i), ('sample_u', _p), ('logits_scratch', _p),
         ('opts', Options),
+        ('teacher_grid', _p),
     ]
 
 

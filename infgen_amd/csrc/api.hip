@@ -684,7 +684,7 @@ extern "C" int infgen_integrate(const InfgenRollout* r, int t, void* stream) {
   IntegrateArgs a;
   a.st = scene_of(r); a.c = 1 + t; a.t = t; a.R = r->R; a.force_valid = r->force_valid;
   a.next_token = r->next_token; a.next_state = r->next_state;
-  a.teacher_token = r->teacher_token; a.teacher_state = r->teacher_state;
+  a.teacher_token = r->teacher_token; a.teacher_state = r->teacher_state; a.teacher_grid = r->teacher_grid;
   a.vocab = r->vocab; a.token_size = r->token_size; a.grid_xy = r->grid_xy; a.grid_size = r->grid_size;
   a.pred_traj = r->pred_traj; a.pred_head = r->pred_head; a.pred_state = r->pred_state;
   { ProfScope _ps(INFGEN_KID_INTEGRATE, stream);

@@ -499,7 +499,9 @@ __global__ __launch_bounds__(BT) void k_integrate(IntegrateArgs a) {
         st.pos[2 * in_] = inv ? 0.f : npx[ag];
         st.pos[2 * in_ + 1] = inv ? 0.f : npy[ag];
         st.head[in_] = inv ? 0.f : nth[ag];
-        st.grid[in_] = inv ? -1 : bi;
+        int cell = bi;
+        if (a.teacher_grid && a.teacher_grid[in_] >= -1) cell = a.teacher_grid[in_];
+        st.grid[in_] = inv ? -1 : cell;
         int tok = a.next_token[s * st.A_cap + ag];
         if (a.teacher_token) { tok = a.teacher_token[in_]; }
         st.token[in_] = inv ? -1 : tok;

@@ -272,6 +272,7 @@ struct IntegrateArgs {
   int force_valid;                  // disable_insertion: every state := valid
   const int* next_token; const int* next_state;   // [rows] from the heads
   const int* teacher_token; const int* teacher_state;   // optional [S][T][A_cap]
+  const int* teacher_grid;                               // optional [S][T][A_cap], < -1: none
   const float* vocab;               // [3][token_size][6][4][2]
   int token_size;
   const float* grid_xy; int grid_size;    // [G][2]

@@ -364,12 +364,19 @@ class RolloutEngine:
         self.grid_xy = t(np.asarray(grid, dtype=np.float32))
         self.G = int(grid.shape[0])
         self.teacher_token = self.teacher_state = None
+        self.teacher_grid = None
         if teacher is not None:
             tt = np.full((S, T, A_cap), -1, np.int32); ts = np.zeros((S, T, A_cap), np.int32)
-            for s, (tok_s, st_s) in enumerate(teacher):
+            tg = np.full((S, T, A_cap), -2, np.int32)
+            for s, tch in enumerate(teacher):
+                tok_s, st_s = tch[0], tch[1]
                 A = min(np.asarray(tok_s).shape[0], A_cap)        # rows beyond the initial agents: inserted ones (insertion on)
                 tt[s, :, :A] = np.asarray(tok_s)[:A].T; ts[s, :, :A] = np.asarray(st_s)[:A].T
+                if len(tch) > 2 and tch[2] is not None:           # optional third entry: grid cells (A, T) of the teacher state
+                    tg[s, :, :A] = np.asarray(tch[2])[:A].T
             self.teacher_token, self.teacher_state = t(tt), t(ts)
+            if (tg > -2).any():
+                self.teacher_grid = t(tg)
 
         # ------------------------------------------------ scratch / caches
         f = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.float32)
@@ -849,6 +856,7 @@ class RolloutEngine:
         c.raw2, c.cat, c.fus_in, c.tmp1, c.tmp2 = P(self.raw2), P(self.cat), P(self.fus_in), P(self.tmp1), P(self.tmp2)
         c.next_token, c.next_state, c.logits = P(self.next_token), P(self.next_state), P(self.logits)
         c.teacher_token, c.teacher_state = P(self.teacher_token), P(self.teacher_state)
+        c.teacher_grid = P(self.teacher_grid)
         c.pred_traj, c.pred_head, c.pred_state = P(self.pred_traj), P(self.pred_head), P(self.pred_state)
         if self.insertion:
             c.first_new, c.hv_ovr = P(self.ins['first_new']), P(self.ins['hv_ovr'])

@@ -120,6 +120,7 @@ class InsertionOracle(RolloutOracle):
         top2 = torch.topk(pos_logit[0], k=2).values
         new_pos = rot_right(self.grid[cell][None, None], (ego_head - math.pi / 2)[None])[0, 0] + ego_pos
         st['seed_log'].append(dict(t=t, enter=enter, cell=cell, occupied=bool(occ[cell]), type=ty,
+                                   state_margin=float((st_logit[0, 1] - st_logit[0, 0]).abs()),
                                    cell_margin=float(top2[0] - top2[1]), type_logits=ty_logit[0].tolist()))
         if bool(occ[cell]):
             # rejected; greedy would pick the same cell again -> no further insertion this step; sampled: draw again next iteration
@@ -298,7 +299,7 @@ class InsertionOracle(RolloutOracle):
         pred_head[:A0, 1:H] = torch.arctan2(dxy[..., 1], dxy[..., 0]).reshape(A0, -1)
         pred_valid = (pred_state != INVALID) & (pred_state != ENTER)
         return dict(
-            ego_index=st['av'], agent_id=st['agent_id'], pos_a=st['pos'], head_a=st['head'],
+            ego_index=st['av'], agent_id=st['agent_id'], pos_a=st['pos'], head_a=st['head'], grid_a=st['gridtok'],
             pred_traj=pred_traj, pred_head=pred_head, pred_state=pred_state, pred_valid=pred_valid,
             pred_type=st['pred_type'], pred_shape=st['pred_shape'],
             next_token_idx=st['tok_out'], next_state_idx=st['st_out'],

@@ -1,0 +1,124 @@
+"""GPU: BASELINE configs C4 and C5 at their literal sizes against the CPU oracle ("C4 and C5 have no -m gpu
+parity run").
+
+C4: configs/ours_long_term.yaml, 64 agents + scenario insertion, 1024 map tokens, R = 800 (160 decode steps; the scene grows to
+    ~200 agents).  The oracle runs free; the engine is teacher-forced with the oracle's motion tokens / states, the insertion
+    decisions (enter?, cell, type, heading, offset) are its own and must reproduce the oracle's at every step.
+C5: 256 agents, 4096 map tokens, R = 800, fp32 arithmetic teacher-forced against the oracle, and the reduced-precision mode
+    (BASELINE says bf16; here fp16 operands with fp32 accumulation, infgen_set_gemm_terms(1): three more significand bits than
+    bf16 at the same matrix rate) with its stated bar against the fp32 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_case, make_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_rows_within(row_err, tol, frac=0.999, cap_factor=50):
+    """long teacher-forced horizons: per (step, row) logits error within `tol` for >= 99.9 % of the rows.  The rest are rows next
+    to a discrete boundary the accumulated pose drift (~1e-3 m after 100+ steps) crosses - an agent at 59.999 m of another (edge
+    in or out of the 60 m radius), the fifth-nearest map token - where the reference's own CPU and GPU builds differ too; they stay
+    isolated (no blow-up: bounded by cap_factor x tol) and the median sits at the kernels' noise level"""
+    row_err = np.asarray(row_err)
+    inside = float((row_err <= tol).mean())
+    print(f'rows {row_err.size}: within {tol:g}: {inside:.5f}, median {np.median(row_err):.2e}, max {row_err.max():.2e}')
+    assert inside >= frac, inside
+    assert np.median(row_err) <= tol / 20
+    assert row_err.max() <= cap_factor * tol
+
+
+def test_c4_shape_insertion_r800_matches_oracle():
+    from infgen_amd import engine, synth
+    from oracle import insertion_oracle as io
+    c = load_case('c1_a8_m128')
+    cfg = synth.standard_config(num_recurrent_steps_val=800, disable_insertion=False)
+    sd = make_weights(seed=8, head_gain=1.0)             # (tokens are teacher-forced: the reference's unsharpened head, 1e-3 bar)
+    scene = synth.make_scene(44, 64, 1024, cfg, half_extent=60.0, ego_last=True, vocab=c['vocab'], grid=c['grid'], slip=0.2)
+    torch.set_num_threads(16)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    ref = io.run_scene_with_insertion(tsd, scene, cfg, c['vocab'], c['map_vocab'], c['grid'])
+    n_ref = np.asarray(ref['n_agents'])
+    assert n_ref[-1] >= 64 + 100                          # > 100 agents inserted over the 160 steps
+    # every insertion decision of the oracle is well separated (the kernels are ~1e-5 off on these unsharpened heads)
+    assert min(min(d['cell_margin'], d['state_margin']) for d in ref['seed_log']) > 2e-4
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(sd, cfg, dev)
+    # teacher: the oracle's tokens and states, and its grid cells - over 160 steps a few poses sit within 1e-4 m of a cell border,
+    # where the arg-min of encode_pos (attr_tokenizer.py:77-89) is decided by the last bits of the pose (the reference's CPU and GPU
+    # builds disagree there as well; 6 such (row, step) pairs in this run)
+    teacher = [(ref['next_token_idx'].numpy(), ref['next_state_idx'].numpy(), ref['grid_a'].numpy())]
+    eng = engine.RolloutEngine(w, [scene], c['vocab'], c['map_vocab'], c['grid'], store_logits=True, teacher=teacher,
+                               insert_headroom=int(n_ref[-1]) - 64 + 16)
+    eng.rollout()
+    o = eng.outputs()[0]
+    A = int(n_ref[-1])
+    assert o['pos_a'].shape[0] == A
+    assert np.array_equal(o['pred_type'], ref['pred_type'].numpy())
+    assert np.array_equal(o['agent_id'], ref['agent_id'].numpy())
+    assert np.array_equal(o['next_state_idx'], ref['next_state_idx'].numpy())
+    # 160 chained pose updates in fp32: the poses drift by ulps per step (1e-2 m at |x| ~ 60 m = 2e-4 relative)
+    assert np.abs(o['pos_a'] - ref['pos_a'].numpy()).max() <= 2e-2
+    assert np.abs(o['head_a'] - ref['head_a'].numpy()).max() <= 1e-3
+    ds = np.abs(o['pred_shape'] - ref['pred_shape'].numpy()).max(-1)          # (the seed's shape head of every inserted agent)
+    print('pred_shape: max', ds.max(), 'rows > 1e-4:', int((ds > 1e-4).sum()), 'of', ds.size)
+    assert ds.max() <= 5e-3 and (ds > 1e-4).mean() <= 0.02
+    errs = []
+    for t, lg in enumerate(ref['logits']):
+        n = lg.shape[0]
+        assert n == n_ref[t]
+        errs.append(np.abs(o['logits'][t, :n] - lg.numpy()).max(-1))
+    _assert_rows_within(np.concatenate(errs), 1e-3)
+
+
+@pytest.fixture(scope='module')
+def c5():
+    from infgen_amd import synth
+    from oracle import rollout_oracle as ro
+    c = load_case('c1_a8_m128')
+    cfg = synth.standard_config(num_recurrent_steps_val=800)
+    sd = make_weights(seed=8, head_gain=1.0)
+    scene = synth.make_scene(43, 256, 4096, cfg, half_extent=120.0, vocab=c['vocab'], grid=c['grid'], slip=0.2)
+    torch.set_num_threads(16)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    ref = ro.run_scene(tsd, scene, cfg, c['vocab'], c['map_vocab'], c['grid'])
+    return dict(c=c, cfg=cfg, sd=sd, scene=scene, ref=ref)
+
+
+def _run_c5(c5, options=None):
+    from infgen_amd import engine
+    c, ref = c5['c'], c5['ref']
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c5['sd'], c5['cfg'], dev)
+    teacher = [(ref['next_token_idx'].numpy(), ref['next_state_idx'].numpy(), ref['gridtok'].numpy())]   # (grid cells: see the C4 test)
+    eng = engine.RolloutEngine(w, [c5['scene']], c['vocab'], c['map_vocab'], c['grid'], store_logits=True, teacher=teacher,
+                               options=options)
+    eng.rollout()
+    return eng.outputs()[0]
+
+
+def test_c5_shape_r800_fp32_matches_oracle(c5):
+    """256 agents / 4096 map tokens / 160 decode steps: logits within the fp32 bar at every step (the ring wraps 12 times)"""
+    o, ref = _run_c5(c5), c5['ref']
+    lg = ref['logits'].numpy()
+    assert lg.shape[0] == 160 and lg.shape[1] == 256
+    _assert_rows_within(np.abs(o['logits'] - lg).max(-1).reshape(-1), 1e-3)
+    assert np.abs(o['pos_a'] - ref['pos_a'].numpy()).max() <= 2e-2
+    part = np.partition(lg, -2, axis=-1)
+    sure = (part[..., -1] - part[..., -2]) > 2e-3
+    assert (o['logits'].argmax(-1)[sure] == lg.argmax(-1)[sure]).mean() >= 0.9999
+    assert ref['edge_count'][:, 1].max() > 256 * 20
+
+
+def test_c5_shape_reduced_precision_bar(c5):
+    """the mode offered for BASELINE C5's "bf16": fp16 operands (11 significant bits, truncated), fp32 accumulation in the split
+    kernels.  Stated bar against the fp32 oracle, teacher-forced over the 160 steps: logits error <= 1e-2 for 99.9 % of the
+    (step, row) pairs (rms of the logits 0.25), mean <= 1e-3, arg-max agreement >= 99 %."""
+    o, ref = _run_c5(c5, options={'gemm_terms': 1}), c5['ref']
+    lg = ref['logits'].numpy()
+    d = np.abs(o['logits'] - lg)
+    agree = float((o['logits'].argmax(-1) == lg.argmax(-1)).mean())
+    print(f'reduced precision vs fp32 oracle: max {d.max():.2e} mean {d.mean():.2e} arg-max agreement {agree:.4f}')
+    assert float((d.max(-1) <= 1e-2).mean()) >= 0.999 and d.mean() <= 1e-3 and agree >= 0.99
+    assert d.max() > 1e-4            # (the mode really is on)
