@@ -239,6 +239,8 @@ int infgen_sample_topk(const float* logits, int rows, int n, int k, const float*
  *                           caller must re-run with more head-room - nothing is dropped silently)
  *   infgen_insert_finalize  heading token + xy offset of the new row (:2060-2074) */
 int infgen_occupancy(const InfgenRollout* r, int c, float* occ, void* stream);
+/* the same plus seed_agent_occ_embed of it (MLPLayer pack of infgen_amd.packing.pack_mlp_layer) -> emb [S][128], one launch */
+int infgen_occupancy_embed(const InfgenRollout* r, int c, float* occ, const float* embed_pack, float* emb, void* stream);
 int infgen_point_edges(const InfgenRollout* r, int c, const int* centre_row, const int* active, int exclude_centre,
                        int which /* bit0 agents, bit1 map */, float r_agent, int k_agent, float r_map, int k_map,
                        const InfgenEdgeBuf* ea, const InfgenEdgeBuf* em, void* stream);

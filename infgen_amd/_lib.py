@@ -124,6 +124,7 @@ SYMBOLS = {
     'infgen_rollout_run': (_i, [C.POINTER(Rollout), _i, _i, _p]),
     'infgen_sample_topk': (_i, [_p, _i, _i, _i, _p, _p, _p]),
     'infgen_occupancy': (_i, [C.POINTER(Rollout), _i, _p, _p]),
+    'infgen_occupancy_embed': (_i, [C.POINTER(Rollout), _i, _p, _p, _p, _p]),
     'infgen_point_edges': (_i, [C.POINTER(Rollout), _i, _p, _p, _i, _i, _f, _i, _f, _i, C.POINTER(EdgeBuf), C.POINTER(EdgeBuf), _p]),
     'infgen_insert_decide': (_i, [C.POINTER(Rollout), _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'infgen_insert_decide_topk': (_i, [C.POINTER(Rollout), _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),

@@ -711,7 +711,8 @@ extern "C" int infgen_raw_feature(const InfgenRollout* r, int col, void* stream)
   RET_IF(check_launch("infgen_raw_feature/prep"));
   RET_IF(infgen_fourier_embed(r->raw2, 2, nullptr, rows, r->four_xa, r->cat, 128, r->fus_in + 128, 512, 0, stream));
   const float* P = r->fusion_pack;
-  if (attn_split(rows)) {      // the three Linear stages of fusion_emb in one launch on the fp16 split
+  if (O().attn_mode != 0) {    // the three Linear stages of fusion_emb in one launch on the fp16 split (any row count: one
+                               // 25 us chain instead of three dependent fp32 launches of 30-40 us each)
     MlpEmbHArgs m{r->fus_in, 512, rows, 512, P, r->X, 128};
     int grid = ceil_div(rows, 64);
     if (grid > 512) grid = 512;
@@ -749,13 +750,23 @@ extern "C" int infgen_raw_feature_rows(const InfgenRollout* r, int col, const in
   RET_IF(check_launch("infgen_raw_feature_rows/prep"));
   RET_IF(infgen_fourier_embed(r->raw2, 2, nullptr, n, r->four_xa, r->cat, 128, r->fus_in + 128, 512, 0, stream));
   const float* P = r->fusion_pack;
-  const int o2 = mlpemb_off2(512), o3 = mlpemb_off3(512);
-  RET_IF(infgen_linear(r->fus_in, 512, nullptr, n, 512, P, 128, P + 512 * 128, 128, nullptr, nullptr,
-                       P + 512 * 128 + 128, P + 512 * 128 + 256, 1, r->tmp1, 128, stream));
-  RET_IF(infgen_linear(r->tmp1, 128, nullptr, n, 128, P + o2, 128, P + o2 + 16384, 128, nullptr, nullptr,
-                       P + o2 + 16384 + 128, P + o2 + 16384 + 256, 1, r->tmp2, 128, stream));
-  RET_IF(infgen_linear(r->tmp2, 128, nullptr, n, 128, P + o3, 128, P + o3 + 16384, 128, nullptr, nullptr,
-                       nullptr, nullptr, 0, r->tmp1, 128, stream));
+  if (O().attn_mode != 0) {
+    MlpEmbHArgs m{r->fus_in, 512, n, 512, P, r->tmp1, 128};
+    int grid = ceil_div(n, 64);
+    if (grid > 512) grid = 512;
+    { ProfScope _ps(INFGEN_KID_LINEAR, stream, (double)n * (512 + 128 + 128) * 128.0);
+      if (O().gemm_terms == 1) hipLaunchKernelGGL(k_mlpemb_h<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m);
+      else hipLaunchKernelGGL(k_mlpemb_h<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m); }
+    RET_IF(check_launch("infgen_raw_feature_rows/fusion"));
+  } else {
+    const int o2 = mlpemb_off2(512), o3 = mlpemb_off3(512);
+    RET_IF(infgen_linear(r->fus_in, 512, nullptr, n, 512, P, 128, P + 512 * 128, 128, nullptr, nullptr,
+                         P + 512 * 128 + 128, P + 512 * 128 + 256, 1, r->tmp1, 128, stream));
+    RET_IF(infgen_linear(r->tmp1, 128, nullptr, n, 128, P + o2, 128, P + o2 + 16384, 128, nullptr, nullptr,
+                         P + o2 + 16384 + 128, P + o2 + 16384 + 256, 1, r->tmp2, 128, stream));
+    RET_IF(infgen_linear(r->tmp2, 128, nullptr, n, 128, P + o3, 128, P + o3 + 16384, 128, nullptr, nullptr,
+                         nullptr, nullptr, 0, r->tmp1, 128, stream));
+  }
   hipLaunchKernelGGL(k_scatter_rows, dim3(ceil_div(n * 32, NT)), dim3(NT), 0, (hipStream_t)stream, r->tmp1, row_list, row_mask, n, r->X);
   return check_launch("infgen_raw_feature_rows/scatter");
 }
@@ -876,6 +887,15 @@ extern "C" int infgen_occupancy(const InfgenRollout* r, int c, float* occ, void*
   OccupancyArgs a{scene_of(r), c, r->grid_size, occ};
   hipLaunchKernelGGL(k_occupancy, dim3(r->S), dim3(NT), 0, (hipStream_t)stream, a);
   return check_launch("infgen_occupancy");
+}
+
+// occupancy vector AND its embedding (seed_agent_occ_embed, an MLPLayer 1961 -> 128 -> 128) in one launch
+extern "C" int infgen_occupancy_embed(const InfgenRollout* r, int c, float* occ, const float* embed_pack, float* emb, void* stream) {
+  RET_IF(validate(r, "infgen_occupancy_embed"));
+  if (r->grid_size > 2048) return fail("infgen_occupancy_embed", "grid larger than 2048 cells");
+  OccEmbedArgs a{scene_of(r), c, r->grid_size, occ, embed_pack, emb};
+  hipLaunchKernelGGL(k_occupancy_embed, dim3(r->S), dim3(NT), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_occupancy_embed");
 }
 
 extern "C" int infgen_point_edges(const InfgenRollout* r, int c, const int* centre_row, const int* active,

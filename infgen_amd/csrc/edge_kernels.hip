@@ -655,6 +655,63 @@ __global__ __launch_bounds__(NT) void k_occupancy(OccupancyArgs a) {
   }
 }
 
+// k_occupancy_embed: k_occupancy + seed_agent_occ_embed (MLPLayer 1961 -> 128 -> 128, agent_decoder.py:1852-1856) of the 0 / 1
+// occupancy vector in one launch: the first Linear of a 0 / 1 input is the sum of the weight columns of the occupied cells
+// (ascending cell order), then LayerNorm, ReLU and the 128 x 128 Linear per scene - instead of two dependent row-tile GEMM
+// launches (K = 1961) over 16 CUs.  One workgroup (256 threads) per scene; pack = packing.pack_mlp_layer layout.
+__global__ __launch_bounds__(NT) void k_occupancy_embed(OccEmbedArgs a) {
+  __shared__ unsigned char occ_b[2048];
+  __shared__ float hv[128];
+  __shared__ float red[8];
+  const SceneState& st = a.st;
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int G = a.grid_size;
+  float* o = a.occ + (size_t)s * G;
+  for (int g = tid; g < 2048; g += NT) occ_b[g] = 0;
+  __syncthreads();
+  const int A = st.n_agents[s];
+  for (int ag = tid; ag < A; ag += NT) {
+    const int g = st.grid[sidx(st, s, a.c, ag)];
+    if (g >= 0 && g < G) occ_b[g] = 1;
+  }
+  __syncthreads();
+  for (int g = tid; g < G; g += NT) o[g] = occ_b[g] ? 1.f : 0.f;
+  const int k0p = (G + 7) / 8 * 8;
+  const float* W0 = a.pack;                         // P(k0p, 128): element (k, n) at ((k >> 3) * 128 + n) * 8 + (k & 7)
+  const float* b0 = a.pack + (size_t)k0p * 128;
+  const float* lg = b0 + 128;
+  const float* lb = b0 + 256;
+  const float* W3 = b0 + 384;                       // P(128, 128)
+  const float* b3 = W3 + 128 * 128;
+  float h = 0.f;
+  if (tid < 128) {
+    for (int g = 0; g < G; ++g)
+      if (occ_b[g]) h += W0[((size_t)(g >> 3) * 128 + tid) * 8 + (g & 7)];
+    h += b0[tid];
+  }
+  // LayerNorm over the 128 values (threads 0..127 = waves 0, 1), biased variance, eps 1e-5
+  float v = tid < 128 ? h : 0.f;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  const float mean = (red[0] + red[1]) * (1.0f / 128.0f);
+  const float d = tid < 128 ? h - mean : 0.f;
+  float q = d * d;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = q;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf((red[4] + red[5]) * (1.0f / 128.0f) + LN_EPS);
+  if (tid < 128) hv[tid] = fmaxf(d * rstd * lg[tid] + lb[tid], 0.f);
+  __syncthreads();
+  if (tid < 128) {
+    float acc = 0.f;
+    for (int k = 0; k < 128; ++k) acc += hv[k] * W3[((size_t)(k >> 3) * 128 + tid) * 8 + (k & 7)];
+    a.emb[(size_t)s * 128 + tid] = acc + b3[tid];
+  }
+}
+
 // k_insert_decide: heads of the seed node -> enter? / type / shape / grid cell; occupied-cell
 // rejection; append the new row (:1883-1999).  One wave per scene.
 __global__ __launch_bounds__(64) void k_insert_decide(InsertDecideArgs a) {

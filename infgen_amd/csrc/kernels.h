@@ -313,6 +313,7 @@ struct PointEdgesArgs {
 };
 
 struct OccupancyArgs { SceneState st; int c; int grid_size; float* occ; /* [S][grid_size] */ };
+struct OccEmbedArgs { SceneState st; int c; int grid_size; float* occ; const float* pack; float* emb; /* [S][128] */ };
 
 struct InsertDecideArgs {
   SceneState st;
@@ -394,6 +395,7 @@ __global__ void k_scatter_rows(const float* src, const int* row_list, const int*
 __global__ void k_map_graph(MapGraphArgs a);
 __global__ void k_point_edges(PointEdgesArgs a);
 __global__ void k_occupancy(OccupancyArgs a);
+__global__ void k_occupancy_embed(OccEmbedArgs a);
 __global__ void k_insert_decide(InsertDecideArgs a);
 __global__ void k_insert_finalize(InsertFinalizeArgs a);
 __global__ void k_sample_topk(SampleArgs a);

@@ -614,7 +614,7 @@ class RolloutEngine:
             return dict(off=i32(S), cnt=i32(S), src=i32(cap), raw=f(cap, 4), rhat=f(cap, D), total=i32(1), cap=cap)
         ar = torch.arange(S, device=dev, dtype=torch.int32)
         self.ins = dict(
-            occ=f(S, G), Kocc=[f(S, D) for _ in range(3)], Vocc=[f(S, D) for _ in range(3)],
+            occ=f(S, G), occ_emb=f(S, D), Kocc=[f(S, D) for _ in range(3)], Vocc=[f(S, D) for _ in range(3)],
             mapK=[f(S * M_cap, D) for _ in range(3)], mapV=[f(S * M_cap, D) for _ in range(3)],
             Ksa=[f(rows, D) for _ in range(3)], Vsa=[f(rows, D) for _ in range(3)],
             Kh=[f(rows, D) for _ in range(3)], Vh=[f(rows, D) for _ in range(3)],
@@ -669,8 +669,9 @@ class RolloutEngine:
         pend_h = None       # rows appended at the last heading stage: their K / V of the motion layers 0..2 are still to be refreshed
         for it in range(10):
             # occupancy embedding and its K/V for the three occ2sa layers
-            _lib.check(lib.infgen_occupancy(ctx, c, _lib.ptr(I['occ']), st), 'infgen_occupancy')
-            occ_emb = ops.mlp_layer(I['occ'], H['seed_agent_occ_embed'], G, 128)
+            occ_emb = I['occ_emb']
+            _lib.check(lib.infgen_occupancy_embed(ctx, c, _lib.ptr(I['occ']), _lib.ptr(H['seed_agent_occ_embed']), _lib.ptr(occ_emb), st),
+                       'infgen_occupancy_embed')
             for i in range(3):
                 ops.attn_pre(occ_emb, w.attn_occ2sa[i], use_src_ln=True, k=I['Kocc'][i], v=I['Vocc'][i])
             # edges into the seed node (ego pose): agents every iteration, map tokens once per step
