@@ -1017,6 +1017,103 @@ class RolloutEngine:
             outs.append(o)
         return outs
 
+    def outputs_device(self) -> List[Dict[str, torch.Tensor]]:
+        """``outputs`` without the host round trip: the same per-scene dicts as device tensors (views of the batch arrays where
+        the layout allows), the epilogue of agent_decoder.py:2303-2389 evaluated for all scenes at once on the device"""
+        cfg, hc, H, dev = self.cfg, self.hc, self.cfg.num_historical_steps, self.device
+        S, A_cap, T, R = self.S, self.A_cap, self.T, self.R
+        if getattr(self, '_epi', None) is None:
+            # padded copies of the inputs the epilogue reads (one upload per array)
+            z = lambda *shape, dt=np.float32: np.zeros(shape, dt)
+            Rg = max(int(np.asarray(sc['agent']['position']).shape[1]) - H for sc in self.scenes)
+            htok, hst = z(S, A_cap, hc, dt=np.int64), z(S, A_cap, hc, dt=np.int64)
+            p0, h0, ids, shp = z(S, A_cap, 2), z(S, A_cap), z(S, A_cap, dt=np.int64), z(S, A_cap, 3)
+            gt, val, n0 = z(S, A_cap, Rg, 2), z(S, A_cap, T, dt=bool), z(S, dt=np.int64)
+            for s, (h, sc_) in enumerate(zip(self.hosts, self.scenes)):
+                sc, f, A0 = sc_['agent'], h['filt'], h['A']
+                n0[s] = A0
+                htok[s, :A0] = np.asarray(sc['token_idx'])[f][:, :hc]
+                hst[s, :A0] = np.asarray(sc['state_idx'])[f][:, :hc]
+                pos = np.asarray(sc['position'])[f]
+                p0[s, :A0] = pos[:, 0, :2]
+                g = pos[:, H:, :2]
+                gt[s, :A0, :g.shape[1]] = g
+                h0[s, :A0] = np.asarray(sc['heading'])[f][:, 0]
+                i0 = np.asarray(sc['id'])[f]
+                ids[s, :A0] = i0
+                ids[s, A0:] = (i0.max() if len(i0) else -1) + 1 + np.arange(A_cap - A0)
+                shp[s, :A0] = np.asarray(sc['shape'])[f][:, hc - 1]
+                val[s, :A0] = h['valid']
+            t = lambda a: torch.from_numpy(a).to(dev)
+            self._epi = dict(htok=t(htok), hst=t(hst), p0=t(p0), h0=t(h0), ids=t(ids), shp=t(shp), gt=t(gt), val=t(val), n0=t(n0),
+                             n0_host=n0, eval_shape=t(np.asarray([[4.3, 1.8, 1.0], [0.5, 0.5, 1.0], [1.9, 0.5, 1.0]], np.float32)))
+        E = self._epi
+        n_fin = self.n_agents.long()
+        row = torch.arange(A_cap, device=dev)[None, :]
+        init = row < E['n0'][:, None]                                                 # rows of the initial agents
+        pos_a = self.pos.permute(0, 2, 1, 3)                                          # [S, A_cap, T, 2]
+        head_a = self.head.permute(0, 2, 1)
+        nstate = self.state.permute(0, 2, 1).long().clone()
+        ntok = self.token.permute(0, 2, 1).long().clone()
+        # history columns of next_token_idx / next_state_idx are the input tokens (:1733-1735); inserted rows: no token up to and
+        # including their bos column (:2303-2305)
+        ntok[:, :, :hc] = torch.where(init[..., None], E['htok'], ntok[:, :, :hc])
+        nstate[:, :, :hc] = torch.where(init[..., None], E['hst'], nstate[:, :, :hc])
+        cols = torch.arange(T, device=dev)[None, None, :]
+        ntok[(~init)[..., None] & (cols <= self.bos.long()[..., None])] = -1
+        zf = lambda *shape: torch.zeros(*shape, device=dev)
+        pt = torch.cat([zf(S, A_cap, H, 2), self.pred_traj], dim=2)
+        ph = torch.cat([zf(S, A_cap, H), self.pred_head], dim=2)
+        ps = torch.cat([zf(S, A_cap, H), self.pred_state], dim=2)
+        # history prefill of the initial agents: step 0 = the logged pose, steps 1..H-1 from the history tokens' contours
+        atype = self.atype.long()
+        hcont = self.vocab[atype[..., None].expand(S, A_cap, hc), E['htok'].clamp(min=0)]        # [S, A_cap, hc, 6, 4, 2]
+        th = head_a[:, :, 0]
+        cs, sn = torch.cos(th)[..., None, None, None], torch.sin(th)[..., None, None, None]
+        x, y = hcont[..., 0], hcont[..., 1]
+        hx = x * cs - y * sn + pos_a[:, :, 0, 0][..., None, None, None]
+        hy = x * sn + y * cs + pos_a[:, :, 0, 1][..., None, None, None]
+        i3 = init[..., None, None]
+        pt[:, :, 0] = torch.where(init[..., None], E['p0'], pt[:, :, 0])
+        ph[:, :, 0] = torch.where(init, E['h0'], ph[:, :, 0])
+        hist_xy = torch.stack([hx[:, :, :, 1:].mean(dim=4), hy[:, :, :, 1:].mean(dim=4)], dim=-1).reshape(S, A_cap, H - 1, 2)
+        pt[:, :, 1:H] = torch.where(i3, hist_xy, pt[:, :, 1:H])
+        hist_h = torch.atan2(hy[:, :, :, 1:, 0] - hy[:, :, :, 1:, 3], hx[:, :, :, 1:, 0] - hx[:, :, :, 1:, 3]).reshape(S, A_cap, H - 1)
+        ph[:, :, 1:H] = torch.where(init[..., None], hist_h, ph[:, :, 1:H])
+        ps[:, :, 1:H] = torch.where(init[..., None], E['hst'].float().repeat_interleave(cfg.shift, dim=2), ps[:, :, 1:H])
+        pvalid = (ps != INVALID) & (ps != ENTER)
+        pshape = E['shp']
+        if self.ins is not None:
+            pshape = torch.where(init[..., None], E['shp'], self.ins['shape_all'].view(S, A_cap, 3))
+        eval_shape = E['eval_shape'][atype]
+        n_host = n_fin.cpu().numpy()                                                  # the only host copy: final agent counts
+        outs = []
+        for s, h in enumerate(self.hosts):
+            A, A0, M = int(n_host[s]), h['A'], h['M']
+            o = dict(ego_index=h['av'], agent_id=E['ids'][s, :A], valid_mask=E['val'][s, :A0], pos_a=pos_a[s, :A], head_a=head_a[s, :A],
+                     pred_traj=pt[s, :A], pred_head=ph[s, :A], pred_state=ps[s, :A], pred_valid=pvalid[s, :A], pred_type=atype[s, :A],
+                     pred_shape=pshape[s, :A], eval_shape=eval_shape[s, :A], pred_z=torch.zeros_like(ph[s, :A]),
+                     next_token_idx=ntok[s, :A], next_state_idx=nstate[s, :A], gt_traj=E['gt'][s, :A0], num_inserted=A - A0)
+            if self.ins is not None:
+                labels = [[None] * T for _ in range(A)]
+                per_step = {}
+                for r_, t_ in self.ins['inserted_rows'][s]:
+                    k_ = per_step[t_] = per_step.get(t_, 0) + 1
+                    a_ = r_ - s * A_cap
+                    if a_ < A and hc + t_ < T:
+                        labels[a_][hc + t_] = f'A{k_}'
+                o['agent_labels'] = labels
+            if self.seed_out is not None:
+                so = self.seed_out
+                o.update(next_state_prob_seed=so['state'][s], next_pos_rel_prob_seed=so['pos'][s], grid_agent_occ_seed=so['occ_a'][s],
+                         grid_pt_occ_seed=so['occ_p'][s], grid_agent_occ_gt_seed=so['occ_gt'][s])
+            if self.logits is not None:
+                o['logits'] = self.logits[:, s * A_cap:s * A_cap + A]
+            if self.x_pt is not None:
+                o['x_pt'] = self.x_pt[s * self.M_cap:s * self.M_cap + M]
+            outs.append(o)
+        return outs
+
     def agent_steps(self) -> int:
         """agent-steps (10 Hz) decoded by a full rollout of this batch; rows inserted
         during the rollout are not counted (lower bound)."""

@@ -69,6 +69,52 @@ def batch_from_data(data) -> Dict[str, Dict[str, np.ndarray]]:
             'pt_token__to__map_polygon': {'edge_index': _np(e)}}
 
 
+def scenes_from_datas(datas) -> List[Dict[str, Dict[str, np.ndarray]]]:
+    """``scene_from_data`` for many scenes with ONE device -> host copy per key instead of one per key and scene (a 512-scene
+    batch is ~12,000 small synchronous copies otherwise): tensors of a key are concatenated on their device, copied once and
+    split into per-scene views on the host"""
+    if len(datas) <= 1:
+        return [scene_from_data(d) for d in datas]
+    key = ('pt_token', 'to', 'map_polygon')
+
+    def edge(d):
+        try:
+            return d[key]['edge_index']
+        except (KeyError, TypeError):
+            return d['pt_token__to__map_polygon']['edge_index']
+
+    def split(vals, axis=0):
+        """list of equal-rank arrays / tensors -> list of numpy views of one host copy"""
+        if not all(isinstance(v, torch.Tensor) for v in vals):
+            return [_np(v) for v in vals]
+        if vals[0].dim() == 0:
+            return list(torch.stack(vals).detach().cpu().numpy())
+        sizes = [int(v.shape[axis]) for v in vals]
+        host = torch.cat([v.detach() for v in vals], dim=axis).cpu().numpy()
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        return [host[offs[i]:offs[i + 1]] if axis == 0 else host[:, offs[i]:offs[i + 1]] for i in range(len(vals))]
+    shared = ('trajectory_token_veh', 'trajectory_token_ped', 'trajectory_token_cyc')
+    first = {k: _np(datas[0]['agent'][k]) for k in shared}
+    cols = {}
+    for k in _AGENT_KEYS:
+        if k in shared:
+            continue
+        vals = [d['agent'][k] for d in datas]
+        if k == 'av_index':
+            vals = [v.reshape(-1) if isinstance(v, torch.Tensor) else np.asarray(v).reshape(-1) for v in vals]
+        cols[k] = split(vals)
+    pcols = {k: split([d['pt_token'][k] for d in datas]) for k in ('position', 'orientation', 'type', 'pl_type', 'token_idx')}
+    light = split([d['map_polygon']['light_type'] for d in datas])
+    edges = split([edge(d) for d in datas], axis=1)
+    out = []
+    for i in range(len(datas)):
+        agent = {k: cols[k][i] for k in cols}
+        agent.update(first)
+        out.append({'agent': agent, 'pt_token': {k: pcols[k][i] for k in pcols}, 'map_polygon': {'light_type': light[i]},
+                    'pt_token__to__map_polygon': {'edge_index': edges[i]}})
+    return out
+
+
 class InfGenDecoder(nn.Module):
 
     def __init__(self, decoder_type: str, dataset: str, input_dim: int, hidden_dim: int, num_historical_steps: int,
@@ -137,7 +183,7 @@ class InfGenDecoder(nn.Module):
     def _run(self, data, x_pt=None, map_only=False, batch: Optional[Sequence] = None, sample_uniforms=None):
         ae = self.agent_encoder
         datas = list(batch) if batch is not None else [data]
-        scenes = [scene_from_data(d) for d in datas]
+        scenes = scenes_from_datas(datas)
         w = self._weights()
         if ae.num_recurrent_steps_val == -1:
             # sticky like the reference (agent_decoder.py:1633-1635)
@@ -184,16 +230,20 @@ class InfGenDecoder(nn.Module):
                 if eng.A_cap >= limit:
                     raise
                 eng = make_engine(headroom=min(2 * eng.A_cap, limit) - amax)
-        outs = eng.outputs()
+        outs = eng.outputs_device()            # per-scene dicts of device tensors (no host round trip of the results)
         dev = w.device
         res = []
+        steps = w.cfg.num_decode_steps
+        G = ae.grid_size
+        zero = {}                              # shared (read-only) zero tensors of the seed outputs a batch does not record
+
+        def z(*shape):
+            if shape not in zero:
+                zero[shape] = torch.zeros(*shape, device=dev)
+            return zero[shape]
         for d, o in zip(datas, outs):
             n_map = o.pop('x_pt')
-            r = {k: (torch.from_numpy(np.ascontiguousarray(v)).to(dev) if isinstance(v, np.ndarray) else v)
-                 for k, v in o.items()}
-            steps = w.cfg.num_decode_steps
-            G = ae.grid_size
-            z = lambda *s: torch.zeros(*s, device=dev)
+            r = dict(o)
             # without insertion (or in the batched entry) these stay what the reference initialises them to (:1746-1750, :1730)
             for k_, shp_ in (('next_state_prob_seed', (11, steps)), ('next_pos_rel_prob_seed', (11, steps, G)),
                              ('grid_agent_occ_seed', (11, steps, G)), ('grid_pt_occ_seed', (11, steps, G)),
@@ -206,11 +256,11 @@ class InfGenDecoder(nn.Module):
             # the callee mutates data['batch_size_a'] like the reference (agent_decoder.py:1649)
             try:
                 filt = eng.hosts[len(res)]['filt']
-                av0 = int(_np(d['agent']['av_index']).reshape(-1)[0])
+                av0 = int(np.asarray(scenes[len(res)]['agent']['av_index']).reshape(-1)[0])
                 d['batch_size_a'] -= int((~filt[:av0]).sum())
             except (KeyError, TypeError):
                 pass
-            r['_x_pt'] = torch.from_numpy(n_map).to(dev)
+            r['_x_pt'] = n_map
             res.append(r)
         return res if batch is not None else res[0]
 

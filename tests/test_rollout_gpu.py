@@ -284,6 +284,37 @@ def test_batched_insertion_equals_single_scene_runs():
     assert max(n_ins) > 0
 
 
+@pytest.mark.parametrize('insertion', [False, True])
+def test_device_epilogue_equals_host_epilogue(insertion):
+    """RolloutEngine.outputs_device (the return dict of agent_decoder.py:2303-2389 built on the device for all scenes at once)
+    against outputs() (numpy, per scene)"""
+    from infgen_amd import engine, synth
+    c = load_case('ins_natural_a20_m256' if insertion else 'a24_m256_edge')
+    cfg = c['cfg']
+    cfg.disable_insertion = not insertion
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], cfg, dev)
+    scenes = [c['scene']] + [synth.make_scene(8300 + i, 9 + 5 * i, 150 + 30 * i, cfg, ego_last=(i % 2 == 0), edge_cases=(i == 1),
+                                              vocab=c['vocab'], grid=c['grid']) for i in range(3)]
+    eng = engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=True, seed_outputs=insertion)
+    eng.rollout()
+    host, devo = eng.outputs(), eng.outputs_device()
+    assert insertion == (sum(o['num_inserted'] for o in host) > 0)
+    for h, d in zip(host, devo):
+        assert set(h) == set(d), set(h) ^ set(d)
+        for k, v in h.items():
+            g = d[k]
+            if isinstance(v, np.ndarray):
+                g = g.cpu().numpy()
+                assert g.shape == v.shape and g.dtype == v.dtype, (k, g.shape, v.shape, g.dtype, v.dtype)
+                if v.dtype.kind == 'f':
+                    assert np.abs(g - v).max() <= 1e-5 if v.size else True, k
+                else:
+                    assert np.array_equal(g, v), k
+            else:
+                assert g == v, k
+
+
 def test_graph_replay_equals_eager_rollout():
     """RolloutEngine(use_graph=True): the decode steps captured in a HIP graph (second rollout) and replayed (third) give the
     eager rollout bit for bit"""
