@@ -258,6 +258,47 @@ int infgen_insert_finalize(const InfgenRollout* r, int c, float angle_interval, 
                            const int* new_row, const float* lg_heading, int n_heading, const float* offset,
                            float* hv_ovr, void* stream);
 
+/* ---- the insertion sub-loop of one decode step, sequenced in the library (reference agent_decoder.py:1773-2105) ----
+ * One iteration = infgen_insert_seed (occupancy + its embedding, edges into the seed node, the nine seed sublayers with the
+ * previous iteration's new rows riding along edgelessly, the seed heads, the decision) -> the caller reads the per-scene
+ * decisions (host_dec, pinned memory, valid once the stream reached this point) -> if any scene inserted,
+ * infgen_insert_heading (categorical embedding and raw feature of the new rows, their 10 m neighbourhood through motion layers
+ * 0..2, heading token + offset, final raw feature).  ~60 launches per iteration behind two calls; no host synchronisation inside.
+ * All arrays are caller-allocated device memory (sizes in comments; S scenes, rows = S * A_cap, G grid cells). */
+typedef struct InfgenInsertion {
+  /* weights */
+  const float* attn_occ2sa[3]; const float* attn_pt2sa[3]; const float* attn_a2sa[3];
+  const float* four_a2sa; const float* four_pt2sa;
+  const float* head_state; const float* head_type; const float* head_shape; const float* head_pos; const float* head_heading;
+  const float* head_offset; const float* occ_embed; const float* shape_emb; const float* type_a_emb; const float* f_seed;
+  /* per-step caches */
+  float* occ; float* occ_emb;                 /* [S][G], [S][128] */
+  float* Kocc[3]; float* Vocc[3];             /* [S][128] */
+  const float* mapK[3]; const float* mapV[3]; /* [S * M_cap][128]: K / V of the map tokens for the pt2sa layers */
+  float* Ksa[3]; float* Vsa[3]; float* Kh[3]; float* Vh[3];   /* [rows][128] */
+  float* Xc;                                  /* [rows][128] */
+  float* zero_agg; float* zero_z; float* zero_sig;            /* [rows][128], [rows][8][128], [rows][8]: stay zero */
+  /* seed / new-row work arrays, 2 S rows each (rows [S, 2 S): the riders, one slot per scene) */
+  float* XS; float* QS; float* US; float* AGGS; float* ZS; float* SIGS; float* KN; float* VN;
+  InfgenEdgeBuf ea_s, em_s, ea_h, em_h;       /* off / cnt: [S] */
+  const int* occ_off; const int* occ_cnt; const int* occ_src;   /* the one occupancy edge of every seed row */
+  int* active; int* n_new; int* inserted; int* new_row; int* new_cell; int* new_local; float* new_shape;   /* [S] (new_shape [S][3]) */
+  int* prev_row; int* prev_mask;              /* [S]: rows the previous iteration appended (seed-chain riders) */
+  int* pend_row; int* pend_mask;              /* [S]: rows of the last heading stage (heading-chain riders) */
+  float* hv_ovr; float* shape_all;            /* [S][2], [rows][3] */
+  float* hid; float* lg_state; float* lg_type; float* shape; float* lg_pos; float* lg_heading; float* offset;
+                                              /* [6][S][128], [S][2], [S][3], [S][3], [S][G], [S][n_heading], [S][2] */
+  float* t1; float* t2; float* shp;           /* [S][128] each */
+  int* host_dec;                              /* PINNED HOST memory [3][S]: inserted, new_row, active */
+  float r_seed, r_a2sa, r_pl2sa, angle_interval;
+  int n_heading, force_enter, insert_k, max_new;
+} InfgenInsertion;
+/* it: iteration of the step (0: map edges of the seed are built and the agents' edgeless chains are computed); riders != 0: the
+ * previous iteration appended rows (prev_row / prev_mask); uniform: [S] for the cell draw when insert_k > 1 */
+int infgen_insert_seed(const InfgenRollout* r, const InfgenInsertion* I, int t, int it, int riders, const float* uniform, void* stream);
+/* h_ready == 0: the agents' edgeless chain through motion layers 0..2 is computed first; riders != 0: pend_row / pend_mask ride */
+int infgen_insert_heading(const InfgenRollout* r, const InfgenInsertion* I, int t, int h_ready, int riders, void* stream);
+
 /* ---- edge sets of the teacher-forced forward (reference agent_decoder.py:1104-1603) ----
  * infgen_radius_edges: torch_cluster.radius / radius_graph (agent_decoder.py:632, :710, :780, :875; map_decoder.py:91) for a
  * list of query points, with the filters the reference applies AFTER the radius call, as a compact CSR by destination:

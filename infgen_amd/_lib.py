@@ -40,6 +40,27 @@ class RadiusEdges(C.Structure):
                 ('radius', C.c_float), ('K', _i), ('gap_rule', _i), ('index_diff', _i), ('e_base', _i), ('_pad1', _i)]
 
 
+class Insertion(C.Structure):
+    """InfgenInsertion (include/infgen_hip.h)"""
+    _fields_ = [('attn_occ2sa', _p * 3), ('attn_pt2sa', _p * 3), ('attn_a2sa', _p * 3),
+                ('four_a2sa', _p), ('four_pt2sa', _p),
+                ('head_state', _p), ('head_type', _p), ('head_shape', _p), ('head_pos', _p), ('head_heading', _p),
+                ('head_offset', _p), ('occ_embed', _p), ('shape_emb', _p), ('type_a_emb', _p), ('f_seed', _p),
+                ('occ', _p), ('occ_emb', _p), ('Kocc', _p * 3), ('Vocc', _p * 3), ('mapK', _p * 3), ('mapV', _p * 3),
+                ('Ksa', _p * 3), ('Vsa', _p * 3), ('Kh', _p * 3), ('Vh', _p * 3), ('Xc', _p),
+                ('zero_agg', _p), ('zero_z', _p), ('zero_sig', _p),
+                ('XS', _p), ('QS', _p), ('US', _p), ('AGGS', _p), ('ZS', _p), ('SIGS', _p), ('KN', _p), ('VN', _p),
+                ('ea_s', EdgeBuf), ('em_s', EdgeBuf), ('ea_h', EdgeBuf), ('em_h', EdgeBuf),
+                ('occ_off', _p), ('occ_cnt', _p), ('occ_src', _p),
+                ('active', _p), ('n_new', _p), ('inserted', _p), ('new_row', _p), ('new_cell', _p), ('new_local', _p), ('new_shape', _p),
+                ('prev_row', _p), ('prev_mask', _p), ('pend_row', _p), ('pend_mask', _p),
+                ('hv_ovr', _p), ('shape_all', _p),
+                ('hid', _p), ('lg_state', _p), ('lg_type', _p), ('shape', _p), ('lg_pos', _p), ('lg_heading', _p), ('offset', _p),
+                ('t1', _p), ('t2', _p), ('shp', _p), ('host_dec', _p),
+                ('r_seed', C.c_float), ('r_a2sa', C.c_float), ('r_pl2sa', C.c_float), ('angle_interval', C.c_float),
+                ('n_heading', _i), ('force_enter', _i), ('insert_k', _i), ('max_new', _i)]
+
+
 class Options(C.Structure):
     _fields_ = [('use', _i), ('attn_mode', _i), ('gemm_terms', _i), ('fourier_mode', _i), ('edge_fuse', _i), ('edge_loop', _i),
                 ('overlap', _i), ('row_group_margin', _i), ('row_groups', _p), ('n_row_groups', _p)]
@@ -127,6 +148,8 @@ SYMBOLS = {
     'infgen_occupancy_embed': (_i, [C.POINTER(Rollout), _i, _p, _p, _p, _p]),
     'infgen_point_edges': (_i, [C.POINTER(Rollout), _i, _p, _p, _i, _i, _f, _i, _f, _i, C.POINTER(EdgeBuf), C.POINTER(EdgeBuf), _p]),
     'infgen_insert_decide': (_i, [C.POINTER(Rollout), _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'infgen_insert_seed': (_i, [C.POINTER(Rollout), C.POINTER(Insertion), _i, _i, _i, _p, _p]),
+    'infgen_insert_heading': (_i, [C.POINTER(Rollout), C.POINTER(Insertion), _i, _i, _i, _p]),
     'infgen_insert_decide_topk': (_i, [C.POINTER(Rollout), _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
     'infgen_insert_finalize': (_i, [C.POINTER(Rollout), _i, _f, _p, _p, _p, _i, _p, _p, _p]),
     'infgen_prof_enable': (_i, [C.c_uint, _i]),

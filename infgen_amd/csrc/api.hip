@@ -978,3 +978,168 @@ extern "C" int infgen_motion_features(const float* pos, const float* head, const
   hipLaunchKernelGGL(k_motion_features, dim3(ceil_div(rows * T, 256)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("infgen_motion_features");
 }
+
+// ---------------------------------------------------------------------------------- insertion sub-loop, sequenced here
+namespace {
+inline int round_up_i(int x, int m) { return (x + m - 1) / m * m; }
+// MLPLayer pack (packing.pack_mlp_layer, K0 = 128): two descriptors of infgen_linear_multi
+void mlp_layer_descs(const float* X, int rows, const float* pack, int n_out, float* hid, float* out, InfgenLinearDesc& d1,
+                     InfgenLinearDesc& d2) {
+  const int o_b0 = 128 * 128, o_w3 = o_b0 + 3 * 128, npad = round_up_i(n_out, 32);
+  d1 = InfgenLinearDesc{X, 128, nullptr, rows, 128, pack, 128, pack + o_b0, 128, nullptr, nullptr, pack + o_b0 + 128, pack + o_b0 + 256,
+                        1, hid, 128};
+  d2 = InfgenLinearDesc{hid, 128, nullptr, rows, 128, pack + o_w3, npad, pack + o_w3 + 128 * npad, n_out, nullptr, nullptr, nullptr,
+                        nullptr, 0, out, n_out};
+}
+int gather_rows(const float* src, const int* list, const int* mask, int n, int limit, float* dst, void* stream) {
+  hipLaunchKernelGGL(k_gather_rows, dim3(ceil_div(n * 32, NT)), dim3(NT), 0, (hipStream_t)stream, src, list, mask, n, limit, dst);
+  return check_launch("k_gather_rows");
+}
+int scatter_rows(const float* src, const int* list, const int* mask, int n, float* dst, void* stream) {
+  hipLaunchKernelGGL(k_scatter_rows, dim3(ceil_div(n * 32, NT)), dim3(NT), 0, (hipStream_t)stream, src, list, mask, n, dst);
+  return check_launch("k_scatter_rows");
+}
+// a row without edges has agg = z = sigma = 0: the positional part adds exactly nothing and is skipped
+int edgeless(float* X, int rows, const float* pack, const InfgenInsertion* I, void* stream) {
+  return infgen_attn_post(X, rows, pack, I->zero_agg, I->zero_z, I->zero_sig, 0, stream);
+}
+}  // namespace
+
+extern "C" int infgen_insert_seed(const InfgenRollout* r, const InfgenInsertion* I, int t, int it, int riders, const float* uniform,
+                                  void* stream) {
+  RET_IF(validate(r, "infgen_insert_seed"));
+  if (!I) return fail("infgen_insert_seed", "null insertion block");
+  OptScope _opts(r);
+  hipStream_t hs = (hipStream_t)stream;
+  const int S = r->S, rows = r->S * r->A_cap, c = 1 + t, G = r->grid_size;
+  RET_IF(infgen_occupancy_embed(r, c, I->occ, I->occ_embed, I->occ_emb, stream));
+  for (int i = 0; i < 3; ++i) RET_IF(infgen_attn_pre(I->occ_emb, S, I->attn_occ2sa[i], 1, nullptr, nullptr, I->Kocc[i], I->Vocc[i], stream));
+  // edges into the seed node (the ego's pose): agents every iteration, map tokens once per step
+  RET_IF(infgen_point_edges(r, c, r->av_index, I->active, 0, it == 0 ? 3 : 1, I->r_seed, 300, I->r_seed, 2048, &I->ea_s, &I->em_s, stream));
+  RET_IF(infgen_fourier_embed(I->ea_s.raw, 3, I->ea_s.total, I->ea_s.cap, I->four_a2sa, nullptr, 0, I->ea_s.rhat, 128, 1, stream));
+  if (it == 0) {
+    RET_IF(infgen_fourier_embed(I->em_s.raw, 3, I->em_s.total, I->em_s.cap, I->four_pt2sa, nullptr, 0, I->em_s.rhat, 128, 1, stream));
+    // every agent row passes every seed sublayer edgelessly; its K / V feed the a2sa layers: all rows once per step
+    if (hipMemcpyAsync(I->Xc, r->X, (size_t)rows * D * sizeof(float), hipMemcpyDeviceToDevice, hs) != hipSuccess)
+      return fail("infgen_insert_seed", "copy failed");
+    for (int i = 0; i < 3; ++i) {
+      RET_IF(edgeless(I->Xc, rows, I->attn_occ2sa[i], I, stream));
+      RET_IF(edgeless(I->Xc, rows, I->attn_pt2sa[i], I, stream));
+      RET_IF(infgen_attn_pre(I->Xc, rows, I->attn_a2sa[i], 0, nullptr, nullptr, I->Ksa[i], I->Vsa[i], stream));
+      RET_IF(edgeless(I->Xc, rows, I->attn_a2sa[i], I, stream));
+    }
+  }
+  // the seed rows [0, S) and, edgelessly, the rows the previous iteration appended [S, 2 S) (one slot per scene)
+  const int R = riders ? 2 * S : S;
+  RET_IF(gather_rows(I->f_seed, nullptr, nullptr, S, 1, I->XS, stream));
+  if (riders) RET_IF(gather_rows(r->X, I->prev_row, I->prev_mask, S, rows, I->XS + (size_t)S * D, stream));
+  RET_IF(infgen_attn_pre(I->XS, R, I->attn_occ2sa[0], 0, I->QS, nullptr, nullptr, nullptr, stream));
+  for (int i = 0; i < 3; ++i) {
+    RET_IF(infgen_edge_attn(S, I->QS, nullptr, I->Kocc[i], I->Vocc[i], I->occ_off, I->occ_cnt, I->occ_src, nullptr, I->AGGS, nullptr,
+                            I->SIGS, stream));
+    RET_IF(infgen_attn_post_pre(I->XS, R, I->attn_occ2sa[i], I->AGGS, I->ZS, I->SIGS, 0, I->attn_pt2sa[i], I->QS, I->US, nullptr, nullptr,
+                                stream));
+    RET_IF(infgen_edge_attn_mode(S, I->QS, I->US, I->mapK[i], I->mapV[i], I->em_s.off, I->em_s.cnt, I->em_s.src, I->em_s.rhat, I->AGGS,
+                                 I->ZS, I->SIGS, 1, stream));
+    RET_IF(infgen_attn_post_pre(I->XS, R, I->attn_pt2sa[i], I->AGGS, I->ZS, I->SIGS, 1, I->attn_a2sa[i], I->QS, I->US,
+                                riders ? I->KN : nullptr, riders ? I->VN : nullptr, stream));
+    if (riders) {
+      RET_IF(scatter_rows(I->KN + (size_t)S * D, I->prev_row, I->prev_mask, S, I->Ksa[i], stream));
+      RET_IF(scatter_rows(I->VN + (size_t)S * D, I->prev_row, I->prev_mask, S, I->Vsa[i], stream));
+    }
+    RET_IF(infgen_edge_attn_mode(S, I->QS, I->US, I->Ksa[i], I->Vsa[i], I->ea_s.off, I->ea_s.cnt, I->ea_s.src, I->ea_s.rhat, I->AGGS,
+                                 I->ZS, I->SIGS, 1, stream));
+    if (i < 2) RET_IF(infgen_attn_post_pre(I->XS, R, I->attn_a2sa[i], I->AGGS, I->ZS, I->SIGS, 1, I->attn_occ2sa[i + 1], I->QS, nullptr,
+                                           nullptr, nullptr, stream));
+    else RET_IF(infgen_attn_post(I->XS, R, I->attn_a2sa[i], I->AGGS, I->ZS, I->SIGS, 1, stream));
+  }
+  // the four seed heads in two launches
+  InfgenLinearDesc d1[4], d2[4];
+  const size_t hs_ = (size_t)S * 128;
+  mlp_layer_descs(I->XS, S, I->head_state, 2, I->hid, I->lg_state, d1[0], d2[0]);
+  mlp_layer_descs(I->XS, S, I->head_type, 3, I->hid + hs_, I->lg_type, d1[1], d2[1]);
+  mlp_layer_descs(I->XS, S, I->head_shape, 3, I->hid + 2 * hs_, I->shape, d1[2], d2[2]);
+  mlp_layer_descs(I->XS, S, I->head_pos, G, I->hid + 3 * hs_, I->lg_pos, d1[3], d2[3]);
+  RET_IF(infgen_linear_multi(d1, 4, stream));
+  RET_IF(infgen_linear_multi(d2, 4, stream));
+  RET_IF(infgen_insert_decide_topk(r, t, I->force_enter, I->max_new, I->lg_state, I->lg_type, I->shape, I->lg_pos, I->occ, I->active,
+                                   I->n_new, I->inserted, I->new_row, I->new_shape, I->new_cell, I->insert_k, uniform, stream));
+  // hand-over to the host: did any scene insert, into which rows, which scenes go on?
+  if (hipMemcpyAsync(I->host_dec, I->inserted, S * sizeof(int), hipMemcpyDeviceToHost, hs) != hipSuccess ||
+      hipMemcpyAsync(I->host_dec + S, I->new_row, S * sizeof(int), hipMemcpyDeviceToHost, hs) != hipSuccess ||
+      hipMemcpyAsync(I->host_dec + 2 * S, I->active, S * sizeof(int), hipMemcpyDeviceToHost, hs) != hipSuccess)
+    return fail("infgen_insert_seed", "hand-over copy failed");
+  return 0;
+}
+
+extern "C" int infgen_insert_heading(const InfgenRollout* r, const InfgenInsertion* I, int t, int h_ready, int riders, void* stream) {
+  RET_IF(validate(r, "infgen_insert_heading"));
+  if (!I) return fail("infgen_insert_heading", "null insertion block");
+  OptScope _opts(r);
+  hipStream_t hs = (hipStream_t)stream;
+  const int S = r->S, rows = r->S * r->A_cap, c = 1 + t;
+  // categorical embedding / shape of the new rows (agent_decoder.py:1949-1950, :1993): shape_emb is an MLPEmbedding with K0 = 3
+  {
+    const float* P = I->shape_emb;
+    const int k0p = 8, o2 = mlpemb_off2(k0p), o3 = mlpemb_off3(k0p);
+    RET_IF(infgen_linear(I->new_shape, 3, nullptr, S, 3, P, 128, P + k0p * 128, 128, nullptr, nullptr, P + k0p * 128 + 128,
+                         P + k0p * 128 + 256, 1, I->t1, 128, stream));
+    RET_IF(infgen_linear(I->t1, 128, nullptr, S, 128, P + o2, 128, P + o2 + 16384, 128, nullptr, nullptr, P + o2 + 16384 + 128,
+                         P + o2 + 16384 + 256, 1, I->t2, 128, stream));
+    RET_IF(infgen_linear(I->t2, 128, nullptr, S, 128, P + o3, 128, P + o3 + 16384, 128, nullptr, nullptr, nullptr, nullptr, 0, I->shp, 128,
+                         stream));
+  }
+  InsertCatArgs ca{S, r->A_cap, I->inserted, I->new_row, r->type, I->type_a_emb, I->shp, I->new_shape, const_cast<float*>(r->cat_agent),
+                   I->shape_all, I->new_local};
+  hipLaunchKernelGGL(k_insert_cat, dim3(ceil_div(S * 32, NT)), dim3(NT), 0, hs, ca);
+  RET_IF(check_launch("k_insert_cat"));
+  RET_IF(infgen_raw_feature_rows(r, c, I->new_row, I->inserted, S, stream));
+  // heading stage: the new row attends agents / map tokens within 10 m through the motion layers 0..2
+  RET_IF(infgen_point_edges(r, c, I->new_local, I->inserted, 1, 3, I->r_a2sa, 24, I->r_pl2sa, 128, &I->ea_h, &I->em_h, stream));
+  RET_IF(infgen_fourier_embed(I->ea_h.raw, 3, I->ea_h.total, I->ea_h.cap, r->four_a, nullptr, 0, I->ea_h.rhat, 128, 1, stream));
+  RET_IF(infgen_fourier_embed(I->em_h.raw, 3, I->em_h.total, I->em_h.cap, r->four_m, nullptr, 0, I->em_h.rhat, 128, 1, stream));
+  if (!h_ready) {
+    if (hipMemcpyAsync(I->Xc, r->X, (size_t)rows * D * sizeof(float), hipMemcpyDeviceToDevice, hs) != hipSuccess)
+      return fail("infgen_insert_heading", "copy failed");
+    for (int i = 0; i < 3; ++i) {
+      RET_IF(edgeless(I->Xc, rows, r->attn_m[i], I, stream));
+      RET_IF(infgen_attn_pre(I->Xc, rows, r->attn_a[i], 0, nullptr, nullptr, I->Kh[i], I->Vh[i], stream));
+      RET_IF(edgeless(I->Xc, rows, r->attn_a[i], I, stream));
+    }
+  }
+  const int R = riders ? 2 * S : S;
+  RET_IF(gather_rows(r->X, I->new_row, nullptr, S, rows, I->XS, stream));
+  if (riders) RET_IF(gather_rows(r->X, I->pend_row, I->pend_mask, S, rows, I->XS + (size_t)S * D, stream));
+  RET_IF(infgen_attn_pre(I->XS, R, r->attn_m[0], 0, I->QS, I->US, nullptr, nullptr, stream));
+  for (int i = 0; i < 3; ++i) {
+    RET_IF(infgen_edge_attn(S, I->QS, I->US, r->mapK[i], r->mapV[i], I->em_h.off, I->em_h.cnt, I->em_h.src, I->em_h.rhat, I->AGGS, I->ZS,
+                            I->SIGS, stream));
+    RET_IF(infgen_attn_post_pre(I->XS, R, r->attn_m[i], I->AGGS, I->ZS, I->SIGS, 1, r->attn_a[i], I->QS, I->US, riders ? I->KN : nullptr,
+                                riders ? I->VN : nullptr, stream));
+    if (riders) {
+      RET_IF(scatter_rows(I->KN + (size_t)S * D, I->pend_row, I->pend_mask, S, I->Kh[i], stream));
+      RET_IF(scatter_rows(I->VN + (size_t)S * D, I->pend_row, I->pend_mask, S, I->Vh[i], stream));
+    }
+    RET_IF(infgen_edge_attn(S, I->QS, I->US, I->Kh[i], I->Vh[i], I->ea_h.off, I->ea_h.cnt, I->ea_h.src, I->ea_h.rhat, I->AGGS, I->ZS,
+                            I->SIGS, stream));
+    if (i < 2) RET_IF(infgen_attn_post_pre(I->XS, R, r->attn_a[i], I->AGGS, I->ZS, I->SIGS, 1, r->attn_m[i + 1], I->QS, I->US, nullptr,
+                                           nullptr, stream));
+    else RET_IF(infgen_attn_post(I->XS, R, r->attn_a[i], I->AGGS, I->ZS, I->SIGS, 1, stream));
+  }
+  InfgenLinearDesc d1[2], d2[2];
+  const size_t hs_ = (size_t)S * 128;
+  mlp_layer_descs(I->XS, S, I->head_heading, I->n_heading, I->hid + 4 * hs_, I->lg_heading, d1[0], d2[0]);
+  mlp_layer_descs(I->XS, S, I->head_offset, 2, I->hid + 5 * hs_, I->offset, d1[1], d2[1]);
+  RET_IF(infgen_linear_multi(d1, 2, stream));
+  RET_IF(infgen_linear_multi(d2, 2, stream));
+  RET_IF(infgen_insert_finalize(r, c, I->angle_interval, I->inserted, I->new_row, I->lg_heading, I->n_heading, I->offset, I->hv_ovr, stream));
+  RET_IF(infgen_raw_feature_rows(r, c, I->new_row, I->inserted, S, stream));
+  // the rows of this iteration ride along in the next seed chain / heading stage
+  const size_t nb = (size_t)S * sizeof(int);
+  if (hipMemcpyAsync(I->prev_row, I->new_row, nb, hipMemcpyDeviceToDevice, hs) != hipSuccess ||
+      hipMemcpyAsync(I->prev_mask, I->inserted, nb, hipMemcpyDeviceToDevice, hs) != hipSuccess ||
+      hipMemcpyAsync(I->pend_row, I->new_row, nb, hipMemcpyDeviceToDevice, hs) != hipSuccess ||
+      hipMemcpyAsync(I->pend_mask, I->inserted, nb, hipMemcpyDeviceToDevice, hs) != hipSuccess)
+    return fail("infgen_insert_heading", "copy failed");
+  return 0;
+}

@@ -575,6 +575,41 @@ __global__ __launch_bounds__(NT) void k_scatter_rows(const float* src, const int
 }
 
 
+// k_gather_rows: dst[k] = src[row_list[k]] (128 floats) where row_mask[k] != 0 (null: everywhere), zeros elsewhere; rows clamped
+// to [0, limit).  With row_list == null: dst[k] = src[0] (a broadcast row).
+__global__ __launch_bounds__(NT) void k_gather_rows(const float* src, const int* row_list, const int* row_mask, int n, int limit,
+                                                    float* dst) {
+  const int gid = blockIdx.x * NT + threadIdx.x;
+  const int k = gid >> 5, c4 = gid & 31;
+  if (k >= n) return;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!row_list) v = *reinterpret_cast<const float4*>(src + 4 * c4);
+  else if (!row_mask || row_mask[k]) {
+    const int r = min(max(row_list[k], 0), limit - 1);
+    v = *reinterpret_cast<const float4*>(src + (size_t)r * D + 4 * c4);
+  }
+  *reinterpret_cast<float4*>(dst + (size_t)k * D + 4 * c4) = v;
+}
+
+// k_insert_cat: categorical embedding / shape of the rows a sub-loop iteration appended (agent_decoder.py:1949-1950, :1993):
+// cat_agent[new_row] = type_a_emb[type[new_row]] + shape_emb(new_shape)[s], shape_all[new_row] = new_shape[s]; and the new
+// row's index inside its scene (the centre of the heading stage's edge search).  32 threads per scene.
+__global__ __launch_bounds__(NT) void k_insert_cat(InsertCatArgs a) {
+  const int gid = blockIdx.x * NT + threadIdx.x;
+  const int s = gid >> 5, c4 = gid & 31;
+  if (s >= a.S) return;
+  const int row = a.new_row[s];
+  if (c4 == 0) a.new_local[s] = min(max(row - s * a.A_cap, 0), a.A_cap - 1);
+  if (!a.inserted[s] || a.inserted[s] < 0) return;
+  const float4 te = *reinterpret_cast<const float4*>(a.type_emb + (size_t)a.type[row] * D + 4 * c4);
+  const float4 se = *reinterpret_cast<const float4*>(a.shp + (size_t)s * D + 4 * c4);
+  *reinterpret_cast<float4*>(a.cat_agent + (size_t)row * D + 4 * c4) = make_float4(te.x + se.x, te.y + se.y, te.z + se.z, te.w + se.w);
+  if (c4 == 0) {
+    a.shape_all[3 * (size_t)row] = a.new_shape[3 * s]; a.shape_all[3 * (size_t)row + 1] = a.new_shape[3 * s + 1];
+    a.shape_all[3 * (size_t)row + 2] = a.new_shape[3 * s + 2];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Scenario insertion (reference agent_decoder.py:1773-2105)
 // ------------------------------------------------------------------------------------------

@@ -312,6 +312,11 @@ struct PointEdgesArgs {
   EdgeBuf ea, em;                   // one destination per scene: off[s], cnt[s]
 };
 
+struct InsertCatArgs {
+  int S, A_cap;
+  const int* inserted; const int* new_row; const int* type; const float* type_emb; const float* shp; const float* new_shape;
+  float* cat_agent; float* shape_all; int* new_local;
+};
 struct OccupancyArgs { SceneState st; int c; int grid_size; float* occ; /* [S][grid_size] */ };
 struct OccEmbedArgs { SceneState st; int c; int grid_size; float* occ; const float* pack; float* emb; /* [S][128] */ };
 
@@ -392,6 +397,8 @@ template <int BT> __global__ void k_build_edges(BuildEdgesArgs a);
 template <int BT> __global__ void k_integrate(IntegrateArgs a);
 __global__ void k_rawfeat_prep(RawFeatArgs a);
 __global__ void k_scatter_rows(const float* src, const int* row_list, const int* row_mask, int n, float* dst);
+__global__ void k_gather_rows(const float* src, const int* row_list, const int* row_mask, int n, int limit, float* dst);
+__global__ void k_insert_cat(InsertCatArgs a);
 __global__ void k_map_graph(MapGraphArgs a);
 __global__ void k_point_edges(PointEdgesArgs a);
 __global__ void k_occupancy(OccupancyArgs a);

@@ -627,7 +627,10 @@ class RolloutEngine:
             first_new=torch.full((S,), A_cap, device=dev, dtype=torch.int32), hv_ovr=f(S, 2), shape_all=torch.full((rows, 3), INVALID_SHAPE, device=dev),
             scene_base=(ar * A_cap).contiguous(), inserted_rows=[[] for _ in range(S)],
             groups=i32((rows + 15) // 16), n_groups=i32(1),
-            host_dec=tuple(torch.zeros(S, dtype=torch.int32).pin_memory() for _ in range(3)),
+            host_dec=torch.zeros(3, S, dtype=torch.int32).pin_memory(),
+            new_local=i32(S), prev_row=i32(S), prev_mask=i32(S), pend_row=i32(S), pend_mask=i32(S),
+            hid=f(6, S, D), lg_state=f(S, 2), lg_type=f(S, 3), shape=f(S, 3), lg_pos=f(S, G), lg_heading=f(S, int(360.0 / self.cfg.angle_interval)),
+            offset=f(S, 2), t1=f(S, D), t2=f(S, D), shp=f(S, D), struct=None,
             host_ev=torch.cuda.Event())
         if self.seed_outputs:
             steps = self.cfg.num_decode_steps
@@ -649,102 +652,59 @@ class RolloutEngine:
         I = self.ins
         self.ops.attn_post(x, pack, I['AGG0'], I['Z0'], I['SIG0'], has_pos=False)
 
+    def _insertion_struct(self):
+        """InfgenInsertion: the device arrays / weights of the sub-loop for the library's sequencing (include/infgen_hip.h)"""
+        I, w, cfg, P = self.ins, self.w, self.cfg, _lib.ptr
+        b = _lib.Insertion()
+        for i in range(3):
+            b.attn_occ2sa[i], b.attn_pt2sa[i], b.attn_a2sa[i] = P(w.attn_occ2sa[i]), P(w.attn_pt2sa[i]), P(w.attn_a2sa[i])
+            b.Kocc[i], b.Vocc[i], b.mapK[i], b.mapV[i] = P(I['Kocc'][i]), P(I['Vocc'][i]), P(I['mapK'][i]), P(I['mapV'][i])
+            b.Ksa[i], b.Vsa[i], b.Kh[i], b.Vh[i] = P(I['Ksa'][i]), P(I['Vsa'][i]), P(I['Kh'][i]), P(I['Vh'][i])
+        H = w.heads
+        b.four_a2sa, b.four_pt2sa = P(w.four_a2sa), P(w.four_pt2sa)
+        b.head_state, b.head_type, b.head_shape = P(H['seed_state_predict_head']), P(H['seed_type_predict_head']), P(H['seed_shape_predict_head'])
+        b.head_pos, b.head_heading = P(H['seed_pos_rel_token_predict_head']), P(H['seed_heading_rel_token_predict_head'])
+        b.head_offset, b.occ_embed = P(H['seed_offset_xy_predict_head']), P(H['seed_agent_occ_embed'])
+        b.shape_emb, b.type_a_emb, b.f_seed = P(w.shape_emb), P(w.type_a_emb), P(w._tables['f_seed'])
+        b.occ, b.occ_emb, b.Xc = P(I['occ']), P(I['occ_emb']), P(I['Xc'])
+        b.zero_agg, b.zero_z, b.zero_sig = P(I['AGG0']), P(I['Z0']), P(I['SIG0'])
+        for k in ('XS', 'QS', 'US', 'AGGS', 'ZS', 'SIGS', 'KN', 'VN'):
+            setattr(b, k, P(I[k]))
+        b.ea_s, b.em_s, b.ea_h, b.em_h = (self._ebuf_struct(I[k]) for k in ('ea_s', 'em_s', 'ea_h', 'em_h'))
+        b.occ_off, b.occ_cnt, b.occ_src = P(I['occ_off']), P(I['occ_cnt']), P(I['occ_src'])
+        for k in ('active', 'n_new', 'inserted', 'new_row', 'new_cell', 'new_local', 'new_shape', 'prev_row', 'prev_mask', 'pend_row',
+                  'pend_mask', 'hv_ovr', 'shape_all', 'hid', 'lg_state', 'lg_type', 'shape', 'lg_pos', 'lg_heading', 'offset', 't1', 't2', 'shp'):
+            setattr(b, k, P(I[k]))
+        b.host_dec = I['host_dec'].data_ptr()
+        b.r_seed, b.r_a2sa, b.r_pl2sa, b.angle_interval = float(cfg.pl2seed_radius), float(cfg.a2sa_radius), float(cfg.pl2sa_radius), float(cfg.angle_interval)
+        b.n_heading, b.force_enter, b.insert_k, b.max_new = int(360.0 / cfg.angle_interval), int(self.force_enter), self.insert_k, 10
+        return b
+
     def _insert_step(self, t: int):
-        """the insertion sub-loop of decode step t (reference agent_decoder.py:1773-2105).
-        Arithmetic runs in the HIP kernels; the data-dependent loop is sequenced here.  A generator: once per iteration the
-        per-scene decisions (inserted?, which row) are copied to pinned host memory asynchronously and the event of that copy
-        is yielded - ``run`` just waits for it, ``rollout_many`` sequences other engines' streams meanwhile."""
-        ops, w, cfg, lib, I = self.ops, self.w, self.cfg, self.lib, self.ins
-        S, rows, G = self.S, self.rows, self.G
-        c = 1 + t
+        """the insertion sub-loop of decode step t (reference agent_decoder.py:1773-2105).  The launches of an
+        iteration are sequenced by the library (infgen_insert_seed -> decisions -> infgen_insert_heading: two C calls instead of
+        ~60 Python-level launches); the data-dependent loop stays here.  A generator: once per iteration the per-scene decisions
+        (inserted?, which row, still active?) arrive in pinned host memory asynchronously and the event of that copy is yielded -
+        ``run`` just waits for it, ``rollout_many`` sequences other engines' streams meanwhile."""
+        lib, I, S = self.lib, self.ins, self.S
         ctx = C.byref(self._ctx)
-        st = ops.stream
+        if I.get('struct') is None:
+            I['struct'] = self._insertion_struct()
+        blk = C.byref(I['struct'])
         I['first_new'].copy_(self.n_agents)
         I['active'].fill_(1)
         I['n_new'].zero_()
-        ea_s, em_s, ea_h, em_h = (self._ebuf_struct(I[k]) for k in ('ea_s', 'em_s', 'ea_h', 'em_h'))
-        H = w.heads
-        f_seed = w._tables['f_seed']
-        prev_new, h_ready = None, False
-        pend_h = None       # rows appended at the last heading stage: their K / V of the motion layers 0..2 are still to be refreshed
+        riders = riders_h = h_ready = False
+        hd = I['host_dec'].numpy()
         for it in range(10):
-            # occupancy embedding and its K/V for the three occ2sa layers
-            occ_emb = I['occ_emb']
-            _lib.check(lib.infgen_occupancy_embed(ctx, c, _lib.ptr(I['occ']), _lib.ptr(H['seed_agent_occ_embed']), _lib.ptr(occ_emb), st),
-                       'infgen_occupancy_embed')
-            for i in range(3):
-                ops.attn_pre(occ_emb, w.attn_occ2sa[i], use_src_ln=True, k=I['Kocc'][i], v=I['Vocc'][i])
-            # edges into the seed node (ego pose): agents every iteration, map tokens once per step
-            which = 3 if it == 0 else 1
-            _lib.check(lib.infgen_point_edges(ctx, c, _lib.ptr(self.av), _lib.ptr(I['active']), 0, which,
-                                              float(cfg.pl2seed_radius), 300, float(cfg.pl2seed_radius), 2048,
-                                              C.byref(ea_s), C.byref(em_s), st), 'infgen_point_edges')
-            ops.fourier(I['ea_s']['raw'], 3, w.four_a2sa, I['ea_s']['rhat'], count_dev=I['ea_s']['total'],
-                        rows=I['ea_s']['cap'], normalize=True)
-            if it == 0:
-                ops.fourier(I['em_s']['raw'], 3, w.four_pt2sa, I['em_s']['rhat'], count_dev=I['em_s']['total'],
-                            rows=I['em_s']['cap'], normalize=True)
-            # agents pass every layer edgelessly; their K/V feed the a2sa layers (A.6(a)).  The chain is
-            # row-local: all rows once per step, afterwards only the rows inserted in the previous iteration
-            Xc = I['Xc']
-            if it == 0:
-                Xc.copy_(self.X)
-                for i in range(3):
-                    self._edgeless(Xc, w.attn_occ2sa[i], has_pos=False)
-                    self._edgeless(Xc, w.attn_pt2sa[i])
-                    ops.attn_pre(Xc, w.attn_a2sa[i], k=I['Ksa'][i], v=I['Vsa'][i])
-                    self._edgeless(Xc, w.attn_a2sa[i])
-            # the seed node.  The rows appended by the previous iteration ("riders") pass the same sublayers edgelessly - their
-            # K/V feed the a2sa layers (A.6(a)) -, so they ride along in the same launches: rows [S, S + n) of the seed arrays,
-            # whose agg / z / sigma stay zero
-            n_r = 0 if prev_new is None else int(prev_new.numel())
-            R = S + n_r
-            XS, QS, US = I['XS'][:R], I['QS'][:R], I['US'][:R]
-            AGGS, ZS, SIGS, KN, VN = I['AGGS'][:R], I['ZS'][:R], I['SIGS'][:R], I['KN'][:R], I['VN'][:R]
-            XS[:S] = f_seed.expand(S, D)
-            if n_r:
-                XS[S:] = self.X[prev_new]
-                AGGS[S:].zero_(); ZS[S:].zero_(); SIGS[S:].zero_()
-            ops.attn_pre(XS, w.attn_occ2sa[0], q=QS)
-            for i in range(3):
-                ops.edge_attn(S, QS, None, I['Kocc'][i], I['Vocc'][i], I['occ_off'], I['occ_cnt'], I['occ_src'], None,
-                              AGGS, None, SIGS)
-                ops.attn_post_pre(XS, w.attn_occ2sa[i], AGGS, ZS, SIGS, w.attn_pt2sa[i], has_pos=False, q=QS, u=US)
-                ops.edge_attn(S, QS, US, I['mapK'][i], I['mapV'][i], I['em_s']['off'], I['em_s']['cnt'],
-                              I['em_s']['src'], I['em_s']['rhat'], AGGS, ZS, SIGS, wide=True)
-                ops.attn_post_pre(XS, w.attn_pt2sa[i], AGGS, ZS, SIGS, w.attn_a2sa[i], q=QS, u=US,
-                                  k=KN if n_r else None, v=VN if n_r else None)
-                if n_r:
-                    I['Ksa'][i][prev_new] = KN[S:]
-                    I['Vsa'][i][prev_new] = VN[S:]
-                ops.edge_attn(S, QS, US, I['Ksa'][i], I['Vsa'][i], I['ea_s']['off'], I['ea_s']['cnt'],
-                              I['ea_s']['src'], I['ea_s']['rhat'], AGGS, ZS, SIGS, wide=True)
-                if i < 2:
-                    ops.attn_post_pre(XS, w.attn_a2sa[i], AGGS, ZS, SIGS, w.attn_occ2sa[i + 1], q=QS)
-                else:
-                    ops.attn_post(XS, w.attn_a2sa[i], AGGS, ZS, SIGS)
-            # riders of the heading chain below (h_ready as of now): the rows of the previous heading stage - not necessarily
-            # the previous iteration, a sampled cell that was occupied spends iterations without a heading stage
-            riders_h = pend_h if (pend_h is not None and h_ready) else None
-            XS = XS[:S]
-            lg_state, lg_type, shape, lg_pos = ops.mlp_layers(XS, [
-                (H['seed_state_predict_head'], 2), (H['seed_type_predict_head'], 3), (H['seed_shape_predict_head'], 3),
-                (H['seed_pos_rel_token_predict_head'], G)])
-            _lib.check(lib.infgen_insert_decide_topk(ctx, t, int(self.force_enter), 10, _lib.ptr(lg_state), _lib.ptr(lg_type),
-                                                     _lib.ptr(shape), _lib.ptr(lg_pos), _lib.ptr(I['occ']), _lib.ptr(I['active']),
-                                                     _lib.ptr(I['n_new']), _lib.ptr(I['inserted']), _lib.ptr(I['new_row']),
-                                                     _lib.ptr(I['new_shape']), _lib.ptr(I['new_cell']), self.insert_k,
-                                                     _lib.ptr(self._insert_u[t, it]) if self._insert_u is not None else None, st),
-                       'infgen_insert_decide')
-            # hand-over to the host: did any scene insert, and into which rows?
-            I['host_dec'][0].copy_(I['inserted'], non_blocking=True)
-            I['host_dec'][1].copy_(I['new_row'], non_blocking=True)
-            I['host_dec'][2].copy_(I['active'], non_blocking=True)
+            st = self.ops.stream
+            u = _lib.ptr(self._insert_u[t, it]) if self._insert_u is not None else None
+            _lib.check(lib.infgen_insert_seed(ctx, blk, t, it, int(riders), u, st), 'infgen_insert_seed')
             ev = I['host_ev']
             ev.record(torch.cuda.current_stream(self.device))
             yield ev
             ev.synchronize()
-            ins_host = I['host_dec'][0].numpy().copy()
+            ins_host = hd[0].copy()
             if (ins_host < 0).any():
                 full = np.nonzero(ins_host < 0)[0]
                 raise InsertionHeadroomError(
@@ -754,80 +714,30 @@ class RolloutEngine:
                     needed=self.A_cap)
             ins_host = ins_host > 0
             if not ins_host.any():
-                if self.insert_k > 1 and I['host_dec'][2].numpy().any():
-                    prev_new = None         # sampled cells were occupied everywhere: the iteration is spent, active scenes draw again
+                if self.insert_k > 1 and hd[2].any():
+                    riders = False          # sampled cells were occupied everywhere: the iteration is spent, active scenes draw again
                     continue
                 break
             ins_idx_host = np.nonzero(ins_host)[0]
-            nr_host = I['host_dec'][1].numpy()[ins_idx_host].astype(np.int64)
+            nr_host = hd[1][ins_idx_host].astype(np.int64)
             for s_i, r_i in zip(ins_idx_host, nr_host):
                 I['inserted_rows'][int(s_i)].append((int(r_i), t))
-            ins = torch.from_numpy(ins_idx_host.astype(np.int64)).to(self.device)      # scenes that inserted (index list)
-            nr = torch.from_numpy(nr_host).to(self.device)                              # the rows they appended
             if self.seed_out is not None:
                 # slot = the scene's insertion count of this step after the append (agent_decoder.py:2099-2105)
+                ops, w = self.ops, self.w
+                ins = torch.from_numpy(ins_idx_host.astype(np.int64)).to(self.device)
                 so, slot = self.seed_out, I['n_new'][ins].long()
                 XS_in = I['XS'][:S][ins].contiguous()
-                so['state'][ins, slot, t] = torch.softmax(lg_state[ins], dim=-1)[:, -1]
-                so['pos'][ins, slot, t] = torch.softmax(lg_pos[ins], dim=-1)
-                so['occ_a'][ins, slot, t] = ops.mlp_layer(XS_in, w.fwd_heads['grid_agent_occ_head'], D, G)
-                so['occ_p'][ins, slot, t] = ops.mlp_layer(XS_in, w.fwd_heads['grid_pt_occ_head'], D, G)
+                so['state'][ins, slot, t] = torch.softmax(I['lg_state'][ins], dim=-1)[:, -1]
+                so['pos'][ins, slot, t] = torch.softmax(I['lg_pos'][ins], dim=-1)
+                so['occ_a'][ins, slot, t] = ops.mlp_layer(XS_in, w.fwd_heads['grid_agent_occ_head'], D, self.G)
+                so['occ_p'][ins, slot, t] = ops.mlp_layer(XS_in, w.fwd_heads['grid_pt_occ_head'], D, self.G)
                 so['occ_gt'][ins, slot, t] = I['occ'][ins]
-            # categorical embedding / shape of the new rows (agent_decoder.py:1949-1950,1993)
-            shp = ops.mlp_embedding(I['new_shape'], w.shape_emb, 3)
-            self.cat_agent[nr] = w.type_a_emb[self.atype.reshape(-1)[nr].long()] + shp[ins]
-            I['shape_all'][nr] = I['new_shape'][ins]
-            _lib.check(lib.infgen_raw_feature_rows(ctx, c, _lib.ptr(I['new_row']), _lib.ptr(I['inserted']), S, st), 'raw_feature_rows')
-            # heading stage: the new row attends agents / map tokens within 10 m through the motion layers 0..2
-            new_local = (I['new_row'] - I['scene_base']).clamp_(0, self.A_cap - 1).contiguous()
-            _lib.check(lib.infgen_point_edges(ctx, c, _lib.ptr(new_local), _lib.ptr(I['inserted']), 1, 3,
-                                              float(cfg.a2sa_radius), 24, float(cfg.pl2sa_radius), 128,
-                                              C.byref(ea_h), C.byref(em_h), st), 'infgen_point_edges')
-            ops.fourier(I['ea_h']['raw'], 3, w.four_a, I['ea_h']['rhat'], count_dev=I['ea_h']['total'],
-                        rows=I['ea_h']['cap'], normalize=True)
-            ops.fourier(I['em_h']['raw'], 3, w.four_m, I['em_h']['rhat'], count_dev=I['em_h']['total'],
-                        rows=I['em_h']['cap'], normalize=True)
-            if not h_ready:
-                Xc.copy_(self.X)
-                for i in range(3):
-                    self._edgeless(Xc, w.attn_m[i])
-                    ops.attn_pre(Xc, w.attn_a[i], k=I['Kh'][i], v=I['Vh'][i])
-                    self._edgeless(Xc, w.attn_a[i])
-                h_ready = True
-            # the new rows (with edges) and, edgelessly, the riders whose K/V the agent sublayers below read
-            n_h = 0 if riders_h is None else int(riders_h.numel())
-            R = S + n_h
-            XN, QS, US = I['XS'][:R], I['QS'][:R], I['US'][:R]
-            AGGS, ZS, SIGS, KN, VN = I['AGGS'][:R], I['ZS'][:R], I['SIGS'][:R], I['KN'][:R], I['VN'][:R]
-            XN[:S] = self.X[I['new_row'].long().clamp(0, rows - 1)]
-            if n_h:
-                XN[S:] = self.X[riders_h]
-                AGGS[S:].zero_(); ZS[S:].zero_(); SIGS[S:].zero_()
-            ops.attn_pre(XN, w.attn_m[0], q=QS, u=US)
-            for i in range(3):
-                ops.edge_attn(S, QS, US, self.mapK[i], self.mapV[i], I['em_h']['off'], I['em_h']['cnt'],
-                              I['em_h']['src'], I['em_h']['rhat'], AGGS, ZS, SIGS)
-                ops.attn_post_pre(XN, w.attn_m[i], AGGS, ZS, SIGS, w.attn_a[i], q=QS, u=US,
-                                  k=KN if n_h else None, v=VN if n_h else None)
-                if n_h:
-                    I['Kh'][i][riders_h] = KN[S:]
-                    I['Vh'][i][riders_h] = VN[S:]
-                ops.edge_attn(S, QS, US, I['Kh'][i], I['Vh'][i], I['ea_h']['off'], I['ea_h']['cnt'],
-                              I['ea_h']['src'], I['ea_h']['rhat'], AGGS, ZS, SIGS)
-                if i < 2:
-                    ops.attn_post_pre(XN, w.attn_a[i], AGGS, ZS, SIGS, w.attn_m[i + 1], q=QS, u=US)
-                else:
-                    ops.attn_post(XN, w.attn_a[i], AGGS, ZS, SIGS)
-            XN = XN[:S]
-            n_head = int(360.0 / cfg.angle_interval)
-            lg_heading, offset = ops.mlp_layers(XN, [(H['seed_heading_rel_token_predict_head'], n_head),
-                                                     (H['seed_offset_xy_predict_head'], 2)])
-            _lib.check(lib.infgen_insert_finalize(ctx, c, float(cfg.angle_interval), _lib.ptr(I['inserted']),
-                                                  _lib.ptr(I['new_row']), _lib.ptr(lg_heading), n_head, _lib.ptr(offset),
-                                                  _lib.ptr(I['hv_ovr']), st), 'infgen_insert_finalize')
-            _lib.check(lib.infgen_raw_feature_rows(ctx, c, _lib.ptr(I['new_row']), _lib.ptr(I['inserted']), S, st), 'raw_feature_rows')
-            prev_new = nr
-            pend_h = nr
+            # heading stage of the rows just appended; the rows of the previous heading stage ride along (their K / V of the motion
+            # layers 0..2 are refreshed) - not necessarily the previous iteration's: an occupied sampled cell spends iterations
+            _lib.check(lib.infgen_insert_heading(ctx, blk, t, int(h_ready), int(riders_h and h_ready), self.ops.stream), 'infgen_insert_heading')
+            h_ready = True
+            riders = riders_h = True
 
     def _build_ctx(self):
         cfg, w = self.cfg, self.w
