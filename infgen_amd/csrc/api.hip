@@ -419,6 +419,14 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
   }
   if (no_xcd & 2) a.kv_once = 0;
   a.n_virtual = grid;
+  static const int persist = getenv("INFGEN_EDGE_P") ? atoi(getenv("INFGEN_EDGE_P")) : 0;
+  if (persist) {
+    const int pg = grid < 256 ? grid : 256;
+    ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
+    if (persist == 2) hipLaunchKernelGGL(k_edge_fused_p<4>, dim3(pg), dim3(1024), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_edge_fused_p<6>, dim3(pg), dim3(1024), 0, (hipStream_t)stream, a);
+    return check_launch("infgen_edge_attn_fused");
+  }
   { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
     if (O().edge_loop == 4) hipLaunchKernelGGL(k_edge_fused<4>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, a);
     else if (O().edge_loop == 8) hipLaunchKernelGGL(k_edge_fused<8>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, a);

@@ -390,6 +390,7 @@ template <int TERMS> __global__ void k_attn_hs(AttnHArgs a);             // attn
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);
 template <int G> __global__ void k_edge_fused(EdgeFusedArgs a);        // edge_fused.hip
+template <int G> __global__ void k_edge_fused_p(EdgeFusedArgs a);      // persistent workgroups, decoupled halves
 __global__ void k_edge_attn_wide(EdgeAttnArgs a);
 __global__ void k_attn_post(AttnPostArgs a);
 __global__ void k_heads(HeadsArgs a);
