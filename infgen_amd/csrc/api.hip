@@ -1032,8 +1032,9 @@ extern "C" int infgen_insert_seed(const InfgenRollout* r, const InfgenInsertion*
       return fail("infgen_insert_seed", "copy failed");
     for (int i = 0; i < 3; ++i) {
       RET_IF(edgeless(I->Xc, rows, I->attn_occ2sa[i], I, stream));
-      RET_IF(edgeless(I->Xc, rows, I->attn_pt2sa[i], I, stream));
-      RET_IF(infgen_attn_pre(I->Xc, rows, I->attn_a2sa[i], 0, nullptr, nullptr, I->Ksa[i], I->Vsa[i], stream));
+      // the post part of the map sublayer and the K / V projections of the agent sublayer in one launch
+      RET_IF(infgen_attn_post_pre(I->Xc, rows, I->attn_pt2sa[i], I->zero_agg, I->zero_z, I->zero_sig, 0, I->attn_a2sa[i], nullptr, nullptr,
+                                  I->Ksa[i], I->Vsa[i], stream));
       RET_IF(edgeless(I->Xc, rows, I->attn_a2sa[i], I, stream));
     }
   }
@@ -1110,8 +1111,8 @@ extern "C" int infgen_insert_heading(const InfgenRollout* r, const InfgenInserti
     if (hipMemcpyAsync(I->Xc, r->X, (size_t)rows * D * sizeof(float), hipMemcpyDeviceToDevice, hs) != hipSuccess)
       return fail("infgen_insert_heading", "copy failed");
     for (int i = 0; i < 3; ++i) {
-      RET_IF(edgeless(I->Xc, rows, r->attn_m[i], I, stream));
-      RET_IF(infgen_attn_pre(I->Xc, rows, r->attn_a[i], 0, nullptr, nullptr, I->Kh[i], I->Vh[i], stream));
+      RET_IF(infgen_attn_post_pre(I->Xc, rows, r->attn_m[i], I->zero_agg, I->zero_z, I->zero_sig, 0, r->attn_a[i], nullptr, nullptr,
+                                  I->Kh[i], I->Vh[i], stream));
       RET_IF(edgeless(I->Xc, rows, r->attn_a[i], I, stream));
     }
   }
