@@ -365,7 +365,7 @@ def main():
     if roof is not None:
         roof['traffic'] = pmc_traffic(dominant, args)
 
-    agent_steps = float(eng.agent_steps() * args.steps)
+    agent_steps = float(eng.agent_steps() * args.steps)       # (with insertion: the rows decoded at every step of the last rollout)
     inserted = int((eng.n_agents.sum().item() - sum(h['A'] for h in eng.hosts))) if args.insertion else 0
     n_scenes_local = len(scenes)
     dt, agent_steps = igdist.reduce_run(dt, agent_steps, dev)
@@ -397,6 +397,7 @@ def main():
                 'scenes_per_gpu': n_scenes_local, 'streams': ns, 'gemm_terms': args.gemm_terms, 'agents': args.agents,
                 'map_tokens': args.map_tokens, 'decode_steps': cfg.num_decode_steps, 'insertion': bool(args.insertion),
                 'rows_per_scene': engines[0].A_cap, 'agents_inserted_last_rollout': inserted,
+                'agent_steps_counted': 'rows decoded at every step incl. inserted agents x 5 (SURVEY 8d)' if args.insertion else 'agents x R',
                 'agent_token_steps_per_s': agent_steps / dt / cfg.shift,
                 'parallelism': f'scenes sharded over {world} rank(s), no data-path collective',
             },

@@ -417,6 +417,7 @@ class RolloutEngine:
         self._mg_checked = False
         self._map_nbr_cap = 40          # compacted pt<->pt edges per map token (grown on overflow)
         self._prologue_done = False
+        self._decoded_rows = torch.zeros((), device=dev, dtype=torch.int64)
 
     # ------------------------------------------------------------------ host setup of one scene
     def _setup_scene(self, scene) -> Dict[str, np.ndarray]:
@@ -581,6 +582,7 @@ class RolloutEngine:
         if self._ctx is None:
             self._build_ctx()
         self._refresh_opts()
+        self._decoded_rows.zero_()
         st = ops.stream
         # column 0: edgeless chain, its K/V land in ring slot 0 (SURVEY a-Q3); then column 1's raw feature
         _lib.check(self.lib.infgen_raw_feature(C.byref(self._ctx), 0, st), 'raw_feature(0)')
@@ -829,6 +831,7 @@ class RolloutEngine:
                            'infgen_active_row_groups')
             if t > 0:
                 yield from self._insert_step(t)
+            self._decoded_rows.add_(self.n_agents.sum())       # A_t: rows decoded at this step, incl. the inserted ones
             self.step(t)
 
     def edge_totals(self):
@@ -1025,8 +1028,10 @@ class RolloutEngine:
         return outs
 
     def agent_steps(self) -> int:
-        """agent-steps (10 Hz) decoded by a full rollout of this batch; rows inserted
-        during the rollout are not counted (lower bound)."""
+        """agent-steps (10 Hz) decoded by the last full rollout of this batch (the rows decoded at every step, incl. the
+        ones scenario insertion appended, x 5 simulated steps per decode step)"""
+        if self.insertion and self._prologue_done:
+            return int(self._decoded_rows.item()) * self.cfg.shift
         return int(sum(h['A'] for h in self.hosts)) * self.R
 
 
