@@ -649,11 +649,6 @@ class RolloutEngine:
         b.off, b.cnt, b.src, b.raw, b.rhat, b.total, b.cap = P(e['off']), P(e['cnt']), P(e['src']), P(e['raw']), P(e['rhat']), P(e['total']), e['cap']
         return b
 
-    def _edgeless(self, x, pack, has_pos=True):
-        # a row without edges has agg = z = sigma = 0: the positional part adds exactly nothing, so it is skipped
-        I = self.ins
-        self.ops.attn_post(x, pack, I['AGG0'], I['Z0'], I['SIG0'], has_pos=False)
-
     def _insertion_struct(self):
         """InfgenInsertion: the device arrays / weights of the sub-loop for the library's sequencing (include/infgen_hip.h)"""
         I, w, cfg, P = self.ins, self.w, self.cfg, _lib.ptr

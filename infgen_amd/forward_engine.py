@@ -264,8 +264,6 @@ class ForwardEngine:
                     cleared = cleared[(cleared >= 0) & (cleared < h['bsz'][b])]
                     pair[b, t_, s, cleared] = 0
             pair[b, :, :, int(h['av'][b]) - lo] = 1
-        if B > 1:                                                   # egos of other scenes never are candidates; nothing to set
-            pass
         pair_d = torch.from_numpy(pair).to(dev)
         k_seed = np.tile(np.arange(S), T)                           # seed index of qs entries
         t_seed = np.repeat(cols, S)
@@ -318,9 +316,6 @@ class ForwardEngine:
         out['next_state_idx'] = out['next_state_prob'].softmax(-1).argmax(-1, keepdim=True)
 
         # ---- occupancy ground truth (:1056-1102) from the agent -> seed edges
-        s_dst = torch.repeat_interleave(torch.arange(nn, device=dev), s_cnt.long())         # destination of every seed edge
-        s_src = e_a.src[cap_a:cap_a + totals[2]].long()
-        order = torch.argsort(s_off[s_dst.unique(sorted=True)]) if False else None          # (edges of a seed are contiguous)
         # edge list in the reference's order: seed nodes in (t, scene, s) order, sources ascending
         eo = torch.cat([torch.arange(int(o_), int(o_) + int(c_), device=dev) for o_, c_ in
                         zip((s_off[seed_nodes] - cap_a).tolist(), s_cnt[seed_nodes].tolist())]) if totals[2] else torch.zeros(0, dtype=torch.long, device=dev)
