@@ -367,9 +367,9 @@ extern "C" int infgen_attn_pre(const float* X, int rows, const float* pack, int 
 
 static int edge_attn_impl(int rows, const float* Q, const float* U, const float* Ksrc, const float* Vsrc,
                           const int* off, const int* cnt, const int* src, const float* rhat,
-                          float* AGG, float* Z, float* SIG, int wide, void* stream) {
+                          float* AGG, float* Z, float* SIG, int wide, void* stream, const int* row_mask = nullptr) {
   if (rows <= 0) return 0;
-  EdgeAttnArgs a{rows, Q, U, Ksrc, Vsrc, EdgeSet{off, cnt, src, rhat}, AGG, Z, SIG, nullptr, nullptr, 0, 0};
+  EdgeAttnArgs a{rows, Q, U, Ksrc, Vsrc, EdgeSet{off, cnt, src, rhat}, AGG, Z, SIG, nullptr, nullptr, 0, 0, wide ? row_mask : nullptr};
   if (limit_n_agents() && O().row_groups && rows == group_rows() && !wide) {
     a.n_agents = limit_n_agents(); a.A_cap = limit_A_cap(); a.margin = O().row_group_margin;
   }
@@ -898,12 +898,17 @@ extern "C" int infgen_occupancy(const InfgenRollout* r, int c, float* occ, void*
 }
 
 // occupancy vector AND its embedding (seed_agent_occ_embed, an MLPLayer 1961 -> 128 -> 128) in one launch
-extern "C" int infgen_occupancy_embed(const InfgenRollout* r, int c, float* occ, const float* embed_pack, float* emb, void* stream) {
+static int occupancy_embed_impl(const InfgenRollout* r, int c, float* occ, const float* embed_pack, float* emb, const int* active,
+                                void* stream) {
   RET_IF(validate(r, "infgen_occupancy_embed"));
   if (r->grid_size > 2048) return fail("infgen_occupancy_embed", "grid larger than 2048 cells");
-  OccEmbedArgs a{scene_of(r), c, r->grid_size, occ, embed_pack, emb};
+  OccEmbedArgs a{scene_of(r), c, r->grid_size, occ, embed_pack, emb, active};
   hipLaunchKernelGGL(k_occupancy_embed, dim3(r->S), dim3(NT), 0, (hipStream_t)stream, a);
   return check_launch("infgen_occupancy_embed");
+}
+
+extern "C" int infgen_occupancy_embed(const InfgenRollout* r, int c, float* occ, const float* embed_pack, float* emb, void* stream) {
+  return occupancy_embed_impl(r, c, occ, embed_pack, emb, nullptr, stream);
 }
 
 extern "C" int infgen_point_edges(const InfgenRollout* r, int c, const int* centre_row, const int* active,
@@ -1020,7 +1025,7 @@ extern "C" int infgen_insert_seed(const InfgenRollout* r, const InfgenInsertion*
   OptScope _opts(r);
   hipStream_t hs = (hipStream_t)stream;
   const int S = r->S, rows = r->S * r->A_cap, c = 1 + t, G = r->grid_size;
-  RET_IF(infgen_occupancy_embed(r, c, I->occ, I->occ_embed, I->occ_emb, stream));
+  RET_IF(occupancy_embed_impl(r, c, I->occ, I->occ_embed, I->occ_emb, I->active, stream));
   for (int i = 0; i < 3; ++i) RET_IF(infgen_attn_pre(I->occ_emb, S, I->attn_occ2sa[i], 1, nullptr, nullptr, I->Kocc[i], I->Vocc[i], stream));
   // edges into the seed node (the ego's pose): agents every iteration, map tokens once per step
   RET_IF(infgen_point_edges(r, c, r->av_index, I->active, 0, it == 0 ? 3 : 1, I->r_seed, 300, I->r_seed, 2048, &I->ea_s, &I->em_s, stream));
@@ -1048,8 +1053,9 @@ extern "C" int infgen_insert_seed(const InfgenRollout* r, const InfgenInsertion*
                             I->SIGS, stream));
     RET_IF(infgen_attn_post_pre(I->XS, R, I->attn_occ2sa[i], I->AGGS, I->ZS, I->SIGS, 0, I->attn_pt2sa[i], I->QS, I->US, nullptr, nullptr,
                                 stream));
-    RET_IF(infgen_edge_attn_mode(S, I->QS, I->US, I->mapK[i], I->mapV[i], I->em_s.off, I->em_s.cnt, I->em_s.src, I->em_s.rhat, I->AGGS,
-                                 I->ZS, I->SIGS, 1, stream));
+    // (the map edges of a step are built once: scenes that stopped inserting are masked out instead, their seed rows are not read)
+    RET_IF(edge_attn_impl(S, I->QS, I->US, I->mapK[i], I->mapV[i], I->em_s.off, I->em_s.cnt, I->em_s.src, I->em_s.rhat, I->AGGS,
+                          I->ZS, I->SIGS, 1, stream, I->active));
     RET_IF(infgen_attn_post_pre(I->XS, R, I->attn_pt2sa[i], I->AGGS, I->ZS, I->SIGS, 1, I->attn_a2sa[i], I->QS, I->US,
                                 riders ? I->KN : nullptr, riders ? I->VN : nullptr, stream));
     if (riders) {

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64 * WIDE_WAVES) void k_edge_attn_wide(EdgeAttnArgs
   __shared__ __attribute__((aligned(16))) float sz[WIDE_WAVES][H * D];
   const int row = blockIdx.x;
   const int w = wave_id(), lane = lane_id();
-  const int E = a.es.cnt[row];
+  const int E = (a.row_mask && !a.row_mask[row]) ? 0 : a.es.cnt[row];
   const int e_base = a.es.off[row];
   const bool has_r = a.es.rhat != nullptr && a.U != nullptr;
   AttnState st;
@@ -696,6 +696,8 @@ __global__ __launch_bounds__(NT) void k_occupancy(OccupancyArgs a) {
 // launches (K = 1961) over 16 CUs.  One workgroup (256 threads) per scene; pack = packing.pack_mlp_layer layout.
 __global__ __launch_bounds__(NT) void k_occupancy_embed(OccEmbedArgs a) {
   __shared__ unsigned char occ_b[2048];
+  __shared__ unsigned short cells[2048];
+  __shared__ int n_cells;
   __shared__ float hv[128];
   __shared__ float red[8];
   const SceneState& st = a.st;
@@ -711,6 +713,21 @@ __global__ __launch_bounds__(NT) void k_occupancy_embed(OccEmbedArgs a) {
   }
   __syncthreads();
   for (int g = tid; g < G; g += NT) o[g] = occ_b[g] ? 1.f : 0.f;
+  if (a.active && !a.active[s]) return;             // (uniform over the workgroup)
+  // the occupied cells in ascending order (wave 0: ballot + prefix count per 64 cells): the sum below keeps the order of the
+  // dense product and touches only the ~A occupied columns
+  if (tid < 64) {
+    int base = 0;
+    for (int g0 = 0; g0 < G; g0 += 64) {
+      const int g = g0 + tid;
+      const bool f = g < G && occ_b[g];
+      const unsigned long long m = __ballot(f);
+      if (f) cells[base + __popcll(m & ((1ull << tid) - 1ull))] = (unsigned short)g;
+      base += __popcll(m);
+    }
+    if (tid == 0) n_cells = base;
+  }
+  __syncthreads();
   const int k0p = (G + 7) / 8 * 8;
   const float* W0 = a.pack;                         // P(k0p, 128): element (k, n) at ((k >> 3) * 128 + n) * 8 + (k & 7)
   const float* b0 = a.pack + (size_t)k0p * 128;
@@ -720,8 +737,11 @@ __global__ __launch_bounds__(NT) void k_occupancy_embed(OccEmbedArgs a) {
   const float* b3 = W3 + 128 * 128;
   float h = 0.f;
   if (tid < 128) {
-    for (int g = 0; g < G; ++g)
-      if (occ_b[g]) h += W0[((size_t)(g >> 3) * 128 + tid) * 8 + (g & 7)];
+    const int n = n_cells;
+    for (int i = 0; i < n; ++i) {
+      const int g = cells[i];
+      h += W0[((size_t)(g >> 3) * 128 + tid) * 8 + (g & 7)];
+    }
     h += b0[tid];
   }
   // LayerNorm over the 128 values (threads 0..127 = waves 0, 1), biased variance, eps 1e-5

@@ -56,6 +56,7 @@ struct EdgeAttnArgs {
   float* SIG;                        // [rows][8]    sum_e attn
   const float* wkr;                  // unused (kept for layout stability)
   const int* n_agents; int A_cap, margin;   // optional (k_edge_attn): rows at or beyond n_agents[s] + margin of their scene are skipped
+  const int* row_mask;               // optional (k_edge_attn_wide): rows with row_mask[row] == 0 are treated as edgeless
 };
 
 // k_edge_fused (edge_fused.hip): edge attention of a 16-row tile with the absorbed query and the positional aggregate kept on
@@ -318,7 +319,8 @@ struct InsertCatArgs {
   float* cat_agent; float* shape_all; int* new_local;
 };
 struct OccupancyArgs { SceneState st; int c; int grid_size; float* occ; /* [S][grid_size] */ };
-struct OccEmbedArgs { SceneState st; int c; int grid_size; float* occ; const float* pack; float* emb; /* [S][128] */ };
+struct OccEmbedArgs { SceneState st; int c; int grid_size; float* occ; const float* pack; float* emb; /* [S][128] */
+                      const int* active; /* optional: scenes with active[s] == 0 get the occupancy vector only */ };
 
 struct InsertDecideArgs {
   SceneState st;
