@@ -1008,9 +1008,11 @@ int gather_rows(const float* src, const int* list, const int* mask, int n, int l
   hipLaunchKernelGGL(k_gather_rows, dim3(ceil_div(n * 32, NT)), dim3(NT), 0, (hipStream_t)stream, src, list, mask, n, limit, dst);
   return check_launch("k_gather_rows");
 }
-int scatter_rows(const float* src, const int* list, const int* mask, int n, float* dst, void* stream) {
-  hipLaunchKernelGGL(k_scatter_rows, dim3(ceil_div(n * 32, NT)), dim3(NT), 0, (hipStream_t)stream, src, list, mask, n, dst);
-  return check_launch("k_scatter_rows");
+int scatter_rows2(const float* src0, const float* src1, const int* list, const int* mask, int n, float* dst0, float* dst1,
+                  void* stream) {
+  hipLaunchKernelGGL(k_scatter_rows2, dim3(ceil_div(n * 32, NT)), dim3(NT), 0, (hipStream_t)stream, src0, src1, list, mask, n, dst0,
+                     dst1);
+  return check_launch("k_scatter_rows2");
 }
 // a row without edges has agg = z = sigma = 0: the positional part adds exactly nothing and is skipped
 int edgeless(float* X, int rows, const float* pack, const InfgenInsertion* I, void* stream) {
@@ -1059,8 +1061,7 @@ extern "C" int infgen_insert_seed(const InfgenRollout* r, const InfgenInsertion*
     RET_IF(infgen_attn_post_pre(I->XS, R, I->attn_pt2sa[i], I->AGGS, I->ZS, I->SIGS, 1, I->attn_a2sa[i], I->QS, I->US,
                                 riders ? I->KN : nullptr, riders ? I->VN : nullptr, stream));
     if (riders) {
-      RET_IF(scatter_rows(I->KN + (size_t)S * D, I->prev_row, I->prev_mask, S, I->Ksa[i], stream));
-      RET_IF(scatter_rows(I->VN + (size_t)S * D, I->prev_row, I->prev_mask, S, I->Vsa[i], stream));
+      RET_IF(scatter_rows2(I->KN + (size_t)S * D, I->VN + (size_t)S * D, I->prev_row, I->prev_mask, S, I->Ksa[i], I->Vsa[i], stream));
     }
     RET_IF(infgen_edge_attn_mode(S, I->QS, I->US, I->Ksa[i], I->Vsa[i], I->ea_s.off, I->ea_s.cnt, I->ea_s.src, I->ea_s.rhat, I->AGGS,
                                  I->ZS, I->SIGS, 1, stream));
@@ -1080,9 +1081,13 @@ extern "C" int infgen_insert_seed(const InfgenRollout* r, const InfgenInsertion*
   RET_IF(infgen_insert_decide_topk(r, t, I->force_enter, I->max_new, I->lg_state, I->lg_type, I->shape, I->lg_pos, I->occ, I->active,
                                    I->n_new, I->inserted, I->new_row, I->new_shape, I->new_cell, I->insert_k, uniform, stream));
   // hand-over to the host: did any scene insert, into which rows, which scenes go on?
-  if (hipMemcpyAsync(I->host_dec, I->inserted, S * sizeof(int), hipMemcpyDeviceToHost, hs) != hipSuccess ||
-      hipMemcpyAsync(I->host_dec + S, I->new_row, S * sizeof(int), hipMemcpyDeviceToHost, hs) != hipSuccess ||
-      hipMemcpyAsync(I->host_dec + 2 * S, I->active, S * sizeof(int), hipMemcpyDeviceToHost, hs) != hipSuccess)
+  // (one copy when the caller laid the three arrays out back to back, as infgen_amd/engine.py does)
+  if (I->new_row == I->inserted + S && I->active == I->inserted + 2 * S) {
+    if (hipMemcpyAsync(I->host_dec, I->inserted, 3 * (size_t)S * sizeof(int), hipMemcpyDeviceToHost, hs) != hipSuccess)
+      return fail("infgen_insert_seed", "hand-over copy failed");
+  } else if (hipMemcpyAsync(I->host_dec, I->inserted, S * sizeof(int), hipMemcpyDeviceToHost, hs) != hipSuccess ||
+             hipMemcpyAsync(I->host_dec + S, I->new_row, S * sizeof(int), hipMemcpyDeviceToHost, hs) != hipSuccess ||
+             hipMemcpyAsync(I->host_dec + 2 * S, I->active, S * sizeof(int), hipMemcpyDeviceToHost, hs) != hipSuccess)
     return fail("infgen_insert_seed", "hand-over copy failed");
   return 0;
 }
@@ -1132,8 +1137,7 @@ extern "C" int infgen_insert_heading(const InfgenRollout* r, const InfgenInserti
     RET_IF(infgen_attn_post_pre(I->XS, R, r->attn_m[i], I->AGGS, I->ZS, I->SIGS, 1, r->attn_a[i], I->QS, I->US, riders ? I->KN : nullptr,
                                 riders ? I->VN : nullptr, stream));
     if (riders) {
-      RET_IF(scatter_rows(I->KN + (size_t)S * D, I->pend_row, I->pend_mask, S, I->Kh[i], stream));
-      RET_IF(scatter_rows(I->VN + (size_t)S * D, I->pend_row, I->pend_mask, S, I->Vh[i], stream));
+      RET_IF(scatter_rows2(I->KN + (size_t)S * D, I->VN + (size_t)S * D, I->pend_row, I->pend_mask, S, I->Kh[i], I->Vh[i], stream));
     }
     RET_IF(infgen_edge_attn(S, I->QS, I->US, I->Kh[i], I->Vh[i], I->ea_h.off, I->ea_h.cnt, I->ea_h.src, I->ea_h.rhat, I->AGGS, I->ZS,
                             I->SIGS, stream));
@@ -1150,11 +1154,7 @@ extern "C" int infgen_insert_heading(const InfgenRollout* r, const InfgenInserti
   RET_IF(infgen_insert_finalize(r, c, I->angle_interval, I->inserted, I->new_row, I->lg_heading, I->n_heading, I->offset, I->hv_ovr, stream));
   RET_IF(infgen_raw_feature_rows(r, c, I->new_row, I->inserted, S, stream));
   // the rows of this iteration ride along in the next seed chain / heading stage
-  const size_t nb = (size_t)S * sizeof(int);
-  if (hipMemcpyAsync(I->prev_row, I->new_row, nb, hipMemcpyDeviceToDevice, hs) != hipSuccess ||
-      hipMemcpyAsync(I->prev_mask, I->inserted, nb, hipMemcpyDeviceToDevice, hs) != hipSuccess ||
-      hipMemcpyAsync(I->pend_row, I->new_row, nb, hipMemcpyDeviceToDevice, hs) != hipSuccess ||
-      hipMemcpyAsync(I->pend_mask, I->inserted, nb, hipMemcpyDeviceToDevice, hs) != hipSuccess)
-    return fail("infgen_insert_heading", "copy failed");
-  return 0;
+  hipLaunchKernelGGL(k_note_riders, dim3(ceil_div(S, NT)), dim3(NT), 0, hs, I->new_row, I->inserted, S, I->prev_row, I->prev_mask,
+                     I->pend_row, I->pend_mask);
+  return check_launch("k_note_riders");
 }

@@ -114,6 +114,10 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
   {
     const bool b3 = lane & 8;
     const bool kv_once = a.kv_once != 0;
+    const unsigned lo8 = 8u * (unsigned)lane;
+    auto ld8 = [&](const float* base, bool nt) {
+      return ea_ld(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + lo8), nt);
+    };
     // rows are dealt to the waves through an LDS counter (the agent set's lists vary in length)
     auto take_row = [&]() {
       int r = 0;
@@ -135,21 +139,34 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
       for (int c0 = 0; c0 < E; c0 += 64) {
         const int mc = min(64, E - c0);
         if (c0 > 0) sv = a.es.src[e_base + c0 + min(lane, mc - 1)];        // lists beyond 64 edges: next chunk of indices
-        // G edges per trip: all their K / V / rhat rows are requested at the top of the trip (index clamped at the end of the
-        // list: no branch around the loads, the waits are counted ones) and consumed in turn; nothing is carried in registers
-        // from trip to trip (edge_attn.cuh explains why), the trip's fill latency is hidden by the SIMD's other waves
-        for (int i0 = 0; i0 < mc; i0 += G) {
-          pk2 kb[G], vb[G], rb[G];
+        // G edges per trip: all their K / V / rhat rows are requested at the top of the trip (wave-uniform row base + the lane's
+        // 8-byte offset) and consumed in turn with counted waits; nothing is carried in registers from trip to trip (edge_attn.cuh
+        // explains why), the trip's fill latency is hidden by the SIMD's other waves.  The tail of the list runs a trip of
+        // exactly its length: no dead slots
+        auto trip = [&](auto nn, int i0) {
+          constexpr int N = decltype(nn)::value;
+          pk2 kb[N], vb[N], rb[N];
 #pragma unroll
-          for (int s = 0; s < G; ++s) {
-            const int ic = min(i0 + s, mc - 1);
-            const int sj = __builtin_amdgcn_readlane(sv, ic);
-            kb[s] = ea_ld(a.Ksrc + (size_t)sj * D + 2 * lane, kv_once);
-            vb[s] = ea_ld(a.Vsrc + (size_t)sj * D + 2 * lane, kv_once);
-            rb[s] = ea_ld(a.es.rhat + (size_t)(e_base + c0 + ic) * D + 2 * lane, true);
+          for (int s = 0; s < N; ++s) {
+            const int sj = __builtin_amdgcn_readlane(sv, i0 + s);
+            kb[s] = ld8(a.Ksrc + (size_t)sj * D, kv_once);
+            vb[s] = ld8(a.Vsrc + (size_t)sj * D, kv_once);
+            rb[s] = ld8(a.es.rhat + (size_t)(e_base + c0 + i0 + s) * D, true);
           }
 #pragma unroll
-          for (int s = 0; s < G; ++s) acc.step(kb[s], vb[s], rb[s], i0 + s < mc, b3);
+          for (int s = 0; s < N; ++s) acc.step(kb[s], vb[s], rb[s], b3);
+        };
+        int i0 = 0;
+        for (; i0 + G <= mc; i0 += G) trip(std::integral_constant<int, G>{}, i0);
+        switch (mc - i0) {
+          case 1: trip(std::integral_constant<int, 1>{}, i0); break;
+          case 2: trip(std::integral_constant<int, 2>{}, i0); break;
+          case 3: trip(std::integral_constant<int, 3>{}, i0); break;
+          case 4: if constexpr (G > 4) trip(std::integral_constant<int, 4>{}, i0); break;
+          case 5: if constexpr (G > 5) trip(std::integral_constant<int, 5>{}, i0); break;
+          case 6: if constexpr (G > 6) trip(std::integral_constant<int, 6>{}, i0); break;
+          case 7: if constexpr (G > 7) trip(std::integral_constant<int, 7>{}, i0); break;
+          default: break;
         }
       }
       const float inv = 1.0f / (acc.lsum + 1e-16f);
@@ -311,6 +328,10 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused_p(EdgeFusedArgs a) {
   {
     const bool b3 = lane & 8;
     const bool kv_once = a.kv_once != 0;
+    const unsigned lo8 = 8u * (unsigned)lane;
+    auto ld8 = [&](const float* base, bool nt) {
+      return ea_ld(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + lo8), nt);
+    };
     // rows are dealt to the waves through an LDS counter (the agent set's lists vary in length)
     auto take_row = [&]() {
       int r = 0;
@@ -332,21 +353,34 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused_p(EdgeFusedArgs a) {
       for (int c0 = 0; c0 < E; c0 += 64) {
         const int mc = min(64, E - c0);
         if (c0 > 0) sv = a.es.src[e_base + c0 + min(lane, mc - 1)];        // lists beyond 64 edges: next chunk of indices
-        // G edges per trip: all their K / V / rhat rows are requested at the top of the trip (index clamped at the end of the
-        // list: no branch around the loads, the waits are counted ones) and consumed in turn; nothing is carried in registers
-        // from trip to trip (edge_attn.cuh explains why), the trip's fill latency is hidden by the SIMD's other waves
-        for (int i0 = 0; i0 < mc; i0 += G) {
-          pk2 kb[G], vb[G], rb[G];
+        // G edges per trip: all their K / V / rhat rows are requested at the top of the trip (wave-uniform row base + the lane's
+        // 8-byte offset) and consumed in turn with counted waits; nothing is carried in registers from trip to trip (edge_attn.cuh
+        // explains why), the trip's fill latency is hidden by the SIMD's other waves.  The tail of the list runs a trip of
+        // exactly its length: no dead slots
+        auto trip = [&](auto nn, int i0) {
+          constexpr int N = decltype(nn)::value;
+          pk2 kb[N], vb[N], rb[N];
 #pragma unroll
-          for (int s = 0; s < G; ++s) {
-            const int ic = min(i0 + s, mc - 1);
-            const int sj = __builtin_amdgcn_readlane(sv, ic);
-            kb[s] = ea_ld(a.Ksrc + (size_t)sj * D + 2 * lane, kv_once);
-            vb[s] = ea_ld(a.Vsrc + (size_t)sj * D + 2 * lane, kv_once);
-            rb[s] = ea_ld(a.es.rhat + (size_t)(e_base + c0 + ic) * D + 2 * lane, true);
+          for (int s = 0; s < N; ++s) {
+            const int sj = __builtin_amdgcn_readlane(sv, i0 + s);
+            kb[s] = ld8(a.Ksrc + (size_t)sj * D, kv_once);
+            vb[s] = ld8(a.Vsrc + (size_t)sj * D, kv_once);
+            rb[s] = ld8(a.es.rhat + (size_t)(e_base + c0 + i0 + s) * D, true);
           }
 #pragma unroll
-          for (int s = 0; s < G; ++s) acc.step(kb[s], vb[s], rb[s], i0 + s < mc, b3);
+          for (int s = 0; s < N; ++s) acc.step(kb[s], vb[s], rb[s], b3);
+        };
+        int i0 = 0;
+        for (; i0 + G <= mc; i0 += G) trip(std::integral_constant<int, G>{}, i0);
+        switch (mc - i0) {
+          case 1: trip(std::integral_constant<int, 1>{}, i0); break;
+          case 2: trip(std::integral_constant<int, 2>{}, i0); break;
+          case 3: trip(std::integral_constant<int, 3>{}, i0); break;
+          case 4: if constexpr (G > 4) trip(std::integral_constant<int, 4>{}, i0); break;
+          case 5: if constexpr (G > 5) trip(std::integral_constant<int, 5>{}, i0); break;
+          case 6: if constexpr (G > 6) trip(std::integral_constant<int, 6>{}, i0); break;
+          case 7: if constexpr (G > 7) trip(std::integral_constant<int, 7>{}, i0); break;
+          default: break;
         }
       }
       const float inv = 1.0f / (acc.lsum + 1e-16f);

@@ -574,6 +574,25 @@ __global__ __launch_bounds__(NT) void k_scatter_rows(const float* src, const int
   *reinterpret_cast<float4*>(dst + (size_t)row_list[k] * D + 4 * c4) = *reinterpret_cast<const float4*>(src + (size_t)k * D + 4 * c4);
 }
 
+// the same for two arrays (K and V of the riders) in one launch
+__global__ __launch_bounds__(NT) void k_scatter_rows2(const float* src0, const float* src1, const int* row_list, const int* row_mask,
+                                                      int n, float* dst0, float* dst1) {
+  const int gid = blockIdx.x * NT + threadIdx.x;
+  const int k = gid >> 5, c4 = gid & 31;
+  if (k >= n || !row_mask[k]) return;
+  const size_t o = (size_t)row_list[k] * D + 4 * c4, i = (size_t)k * D + 4 * c4;
+  *reinterpret_cast<float4*>(dst0 + o) = *reinterpret_cast<const float4*>(src0 + i);
+  *reinterpret_cast<float4*>(dst1 + o) = *reinterpret_cast<const float4*>(src1 + i);
+}
+
+// the rows / flags of this iteration become the riders of the next seed chain (prev) and heading stage (pend)
+__global__ __launch_bounds__(NT) void k_note_riders(const int* new_row, const int* inserted, int n, int* prev_row, int* prev_mask,
+                                                    int* pend_row, int* pend_mask) {
+  const int k = blockIdx.x * NT + threadIdx.x;
+  if (k >= n) return;
+  const int r = new_row[k], m = inserted[k];
+  prev_row[k] = r; prev_mask[k] = m; pend_row[k] = r; pend_mask[k] = m;
+}
 
 // k_gather_rows: dst[k] = src[row_list[k]] (128 floats) where row_mask[k] != 0 (null: everywhere), zeros elsewhere; rows clamped
 // to [0, limit).  With row_list == null: dst[k] = src[0] (a broadcast row).

@@ -400,6 +400,10 @@ template <int BT> __global__ void k_build_edges(BuildEdgesArgs a);
 template <int BT> __global__ void k_integrate(IntegrateArgs a);
 __global__ void k_rawfeat_prep(RawFeatArgs a);
 __global__ void k_scatter_rows(const float* src, const int* row_list, const int* row_mask, int n, float* dst);
+__global__ void k_scatter_rows2(const float* src0, const float* src1, const int* row_list, const int* row_mask, int n, float* dst0,
+                                float* dst1);
+__global__ void k_note_riders(const int* new_row, const int* inserted, int n, int* prev_row, int* prev_mask, int* pend_row,
+                              int* pend_mask);
 __global__ void k_gather_rows(const float* src, const int* row_list, const int* row_mask, int n, int limit, float* dst);
 __global__ void k_insert_cat(InsertCatArgs a);
 __global__ void k_map_graph(MapGraphArgs a);

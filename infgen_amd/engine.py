@@ -625,7 +625,7 @@ class RolloutEngine:
             KN=f(2 * S, D), VN=f(2 * S, D),
             ea_s=ebuf(S * A_cap), em_s=ebuf(S * min(M_cap, 2048)), ea_h=ebuf(S * 24), em_h=ebuf(S * 128),
             occ_off=ar.clone(), occ_cnt=torch.ones(S, device=dev, dtype=torch.int32), occ_src=ar.clone(),
-            active=i32(S), n_new=i32(S), inserted=i32(S), new_row=i32(S), new_cell=i32(S), new_shape=f(S, 3),
+            dec3=i32(3 * S), n_new=i32(S), new_cell=i32(S), new_shape=f(S, 3),
             first_new=torch.full((S,), A_cap, device=dev, dtype=torch.int32), hv_ovr=f(S, 2), shape_all=torch.full((rows, 3), INVALID_SHAPE, device=dev),
             scene_base=(ar * A_cap).contiguous(), inserted_rows=[[] for _ in range(S)],
             groups=i32((rows + 15) // 16), n_groups=i32(1),
@@ -634,6 +634,9 @@ class RolloutEngine:
             hid=f(6, S, D), lg_state=f(S, 2), lg_type=f(S, 3), shape=f(S, 3), lg_pos=f(S, G), lg_heading=f(S, int(360.0 / self.cfg.angle_interval)),
             offset=f(S, 2), t1=f(S, D), t2=f(S, D), shp=f(S, D), struct=None,
             host_ev=torch.cuda.Event())
+        # inserted | new_row | active back to back: one device-to-host copy per iteration hands all three over
+        d3 = self.ins['dec3']
+        self.ins['inserted'], self.ins['new_row'], self.ins['active'] = d3[:S], d3[S:2 * S], d3[2 * S:]
         if self.seed_outputs:
             steps = self.cfg.num_decode_steps
             self.seed_out = dict(state=f(S, 11, steps), pos=f(S, 11, steps, G), occ_a=f(S, 11, steps, G), occ_p=f(S, 11, steps, G),
