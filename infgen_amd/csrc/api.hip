@@ -257,12 +257,14 @@ extern "C" int infgen_set_fourier_mode(int mode) {
   return 0;
 }
 
-extern "C" int infgen_fourier_embed(const float* raw, int n, const int* count_dev, int e_cap, const float* pack,
-                                    const float* cat, int ldcat, float* out, int ldo, int normalize, void* stream) {
+// out_r24: rows in the packed 24-bit format of kernels.h (k_fourier_h only; the rollout's private rhat buffers)
+static int fourier_embed_impl(const float* raw, int n, const int* count_dev, int e_cap, const float* pack,
+                              const float* cat, int ldcat, float* out, int ldo, int normalize, int out_r24, void* stream) {
   if (e_cap <= 0) return 0;
   if (n < 1 || n > 4) return fail("infgen_fourier_embed", "n_dims must be in 1..4");
+  if (out_r24 && O().fourier_mode == 0) return fail("infgen_fourier_embed", "packed rows need the split kernel");
   FourierArgs a{raw, n, count_dev, e_cap, pack, cat, ldcat, out, ldo, normalize,
-                (g_prof.mask >> INFGEN_KID_FOURIER) & 1u ? g_prof.rows_dev : nullptr};
+                (g_prof.mask >> INFGEN_KID_FOURIER) & 1u ? g_prof.rows_dev : nullptr, out_r24};
   if (O().fourier_mode == 0) {
     int grid = ceil_div(e_cap, TR);
     if (grid > 2048) grid = 2048;
@@ -276,6 +278,11 @@ extern "C" int infgen_fourier_embed(const float* raw, int n, const int* count_de
     else hipLaunchKernelGGL(k_fourier_h<3>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
   }
   return check_launch("infgen_fourier_embed");
+}
+
+extern "C" int infgen_fourier_embed(const float* raw, int n, const int* count_dev, int e_cap, const float* pack,
+                                    const float* cat, int ldcat, float* out, int ldo, int normalize, void* stream) {
+  return fourier_embed_impl(raw, n, count_dev, e_cap, pack, cat, ldcat, out, ldo, normalize, 0, stream);
 }
 
 // 0: fp32-input MFMA (k_attn_pre / k_attn_post), 1: fp16 three-term split on 64-row tiles (k_attn_h), 3: the same arithmetic on
@@ -398,13 +405,13 @@ extern "C" int infgen_set_edge_loop(int v) {
 // resident workgroups per CU the runtime reports for k_edge_fused<6> (diagnostics; tools/edge_probe.sh)
 extern "C" int infgen_edge_fused_occupancy(void) {
   int n = -1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_edge_fused<6>, 1024, 0) != hipSuccess) return -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_edge_fused<6, false>, 1024, 0) != hipSuccess) return -1;
   return n;
 }
 
 static int edge_fused_launch(int rows, const float* Q, const float* pack, const float* Ksrc, const float* Vsrc,
                              const int* off, const int* cnt, const int* src, const float* rhat, float* AGG,
-                             int rows_per_scene, int kv_once, void* stream) {
+                             int rows_per_scene, int kv_once, void* stream, int r24 = 0) {
   if (rows <= 0) return 0;
   if (!pack || !rhat) return fail("infgen_edge_attn_fused", "needs the layer pack and rhat");
   static const int dbg = getenv("INFGEN_EDGE_DBG") ? atoi(getenv("INFGEN_EDGE_DBG")) : 0;
@@ -420,7 +427,7 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
   if (no_xcd & 2) a.kv_once = 0;
   a.n_virtual = grid;
   static const int persist = getenv("INFGEN_EDGE_P") ? atoi(getenv("INFGEN_EDGE_P")) : 0;
-  if (persist) {
+  if (persist && !r24) {
     const int pg = grid < 256 ? grid : 256;
     ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
     if (persist == 2) hipLaunchKernelGGL(k_edge_fused_p<4>, dim3(pg), dim3(1024), 0, (hipStream_t)stream, a);
@@ -428,9 +435,10 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
     return check_launch("infgen_edge_attn_fused");
   }
   { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
-    if (O().edge_loop == 4) hipLaunchKernelGGL(k_edge_fused<4>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, a);
-    else if (O().edge_loop == 8) hipLaunchKernelGGL(k_edge_fused<8>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_edge_fused<6>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, a); }
+    const int G = O().edge_loop;
+    auto kern = r24 ? (G == 4 ? k_edge_fused<4, true> : G == 8 ? k_edge_fused<8, true> : k_edge_fused<6, true>)
+                    : (G == 4 ? k_edge_fused<4, false> : G == 8 ? k_edge_fused<8, false> : k_edge_fused<6, false>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_edge_attn_fused");
 }
 
@@ -811,31 +819,34 @@ extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless,
   const int rows = r->S * r->A_cap;
   RET_IF(infgen_build_edges(r, c, edgeless, stream));
   const bool overlap = O().overlap && g_side && !edgeless;
+  const bool fuse = O().edge_fuse == 2 || (O().edge_fuse == 1 && rows > 256);      // U / Z / SIG stay on chip inside k_edge_fused
+  // the step's rhat rows never leave the library: packed 24-bit rows (kernels.h) when both ends are the kernels that know them
+  static const int no_r24 = getenv("INFGEN_NO_R24") ? atoi(getenv("INFGEN_NO_R24")) : 0;
+  const int r24 = fuse && O().fourier_mode != 0 && !no_r24;
   if (overlap) {
     hipStream_t ms = (hipStream_t)stream;
     if (hipEventRecord(g_ev_fork, ms) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork, 0) != hipSuccess)
       return fail("infgen_decode_layers", "fork failed");
-    RET_IF(infgen_fourier_embed(r->em.raw, 3, r->em.total, r->em.cap, r->four_m, nullptr, 0, r->em.rhat, 128, 1, g_side));
+    RET_IF(fourier_embed_impl(r->em.raw, 3, r->em.total, r->em.cap, r->four_m, nullptr, 0, r->em.rhat, 128, 1, r24, g_side));
     if (hipEventRecord(g_ev_m, g_side) != hipSuccess) return fail("infgen_decode_layers", "event failed");
-    RET_IF(infgen_fourier_embed(r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, g_side));
+    RET_IF(fourier_embed_impl(r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, r24, g_side));
     if (hipEventRecord(g_ev_a, g_side) != hipSuccess) return fail("infgen_decode_layers", "event failed");
-    RET_IF(infgen_fourier_embed(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, stream));
+    RET_IF(fourier_embed_impl(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, r24, stream));
   } else if (!edgeless) {
-    RET_IF(infgen_fourier_embed(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, stream));
-    RET_IF(infgen_fourier_embed(r->em.raw, 3, r->em.total, r->em.cap, r->four_m, nullptr, 0, r->em.rhat, 128, 1, stream));
-    RET_IF(infgen_fourier_embed(r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, stream));
+    RET_IF(fourier_embed_impl(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, r24, stream));
+    RET_IF(fourier_embed_impl(r->em.raw, 3, r->em.total, r->em.cap, r->four_m, nullptr, 0, r->em.rhat, 128, 1, r24, stream));
+    RET_IF(fourier_embed_impl(r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, r24, stream));
   }
   const size_t slot = (size_t)(c % r->ring) * rows * D;
   const int L = r->num_layers;
   // prologue of the first (temporal) layer; every later layer's prologue is fused into the previous
   // layer's k_attn_post
-  const bool fuse = O().edge_fuse == 2 || (O().edge_fuse == 1 && rows > 256);      // U / Z / SIG stay on chip inside k_edge_fused
   float* U = fuse ? nullptr : r->U;
   const float* Z = fuse ? nullptr : r->Z;
   const float* SIG = fuse ? nullptr : r->SIG;
   const int has_pos = fuse ? 0 : 1;                 // the fused edge kernel already added W'vr z + b' sigma to AGG
   auto edge = [&](const float* pack, const float* Ks, const float* Vs, const InfgenEdgeBuf& e, int kv_once = 0) {
-    return fuse ? edge_fused_launch(rows, r->Q, pack, Ks, Vs, e.off, e.cnt, e.src, e.rhat, r->AGG, r->A_cap, kv_once, stream)
+    return fuse ? edge_fused_launch(rows, r->Q, pack, Ks, Vs, e.off, e.cnt, e.src, e.rhat, r->AGG, r->A_cap, kv_once, stream, r24)
                 : infgen_edge_attn(rows, r->Q, r->U, Ks, Vs, e.off, e.cnt, e.src, e.rhat, r->AGG, r->Z, r->SIG, stream);
   };
   RET_IF(infgen_attn_pre(r->X, rows, r->attn_t[0], 0, r->Q, U, r->ringK[0] + slot, r->ringV[0] + slot, stream));

@@ -32,7 +32,7 @@ constexpr int EF_LDU = H * D + 4;           // row stride of the U / Z tile in f
 constexpr int EF_LDA = D + 4;
 
 // G = edges per trip of the edge loop (their K / V / rhat rows are requested together)
-template <int G>
+template <int G, bool R24>
 __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
   __shared__ __attribute__((aligned(16))) float UZ[EF_ROWS * EF_LDU];
   __shared__ __attribute__((aligned(16))) float AG[EF_ROWS * EF_LDA];     // q tile (phase 1 -> 2), then agg (phase 2 -> 3)
@@ -118,6 +118,13 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
     auto ld8 = [&](const float* base, bool nt) {
       return ea_ld(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + lo8), nt);
     };
+    // packed 24-bit rhat row e (kernels.h): this lane's two columns = one dword of the 16-bit plane + one short of the 8-bit plane
+    auto ld_r24 = [&](size_t e) {
+      const char* rowp = reinterpret_cast<const char*>(a.es.rhat) + e * R24_ROW_BYTES;
+      const unsigned hi = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(rowp + 4 * lane));
+      const unsigned lo = __builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(rowp + R24_LO_PLANE + 2 * lane));
+      return pk2{__uint_as_float((hi << 16) | ((lo & 0xffu) << 8)), __uint_as_float((hi & 0xffff0000u) | (lo & 0xff00u))};
+    };
     // rows are dealt to the waves through an LDS counter (the agent set's lists vary in length)
     auto take_row = [&]() {
       int r = 0;
@@ -151,7 +158,8 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
             const int sj = __builtin_amdgcn_readlane(sv, i0 + s);
             kb[s] = ld8(a.Ksrc + (size_t)sj * D, kv_once);
             vb[s] = ld8(a.Vsrc + (size_t)sj * D, kv_once);
-            rb[s] = ld8(a.es.rhat + (size_t)(e_base + c0 + i0 + s) * D, true);
+            if constexpr (R24) rb[s] = ld_r24((size_t)(e_base + c0 + i0 + s));
+            else rb[s] = ld8(a.es.rhat + (size_t)(e_base + c0 + i0 + s) * D, true);
           }
 #pragma unroll
           for (int s = 0; s < N; ++s) acc.step(kb[s], vb[s], rb[s], b3);
@@ -438,9 +446,12 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused_p(EdgeFusedArgs a) {
   }   // tile slots of this workgroup
 }
 
-template __global__ void k_edge_fused<4>(EdgeFusedArgs);
-template __global__ void k_edge_fused<6>(EdgeFusedArgs);
-template __global__ void k_edge_fused<8>(EdgeFusedArgs);
+template __global__ void k_edge_fused<4, false>(EdgeFusedArgs);
+template __global__ void k_edge_fused<6, false>(EdgeFusedArgs);
+template __global__ void k_edge_fused<8, false>(EdgeFusedArgs);
+template __global__ void k_edge_fused<4, true>(EdgeFusedArgs);
+template __global__ void k_edge_fused<6, true>(EdgeFusedArgs);
+template __global__ void k_edge_fused<8, true>(EdgeFusedArgs);
 template __global__ void k_edge_fused_p<6>(EdgeFusedArgs);
 template __global__ void k_edge_fused_p<4>(EdgeFusedArgs);
 

@@ -171,7 +171,22 @@ __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
       acc3[t] = fma4(acc3[t], splat4(inv3), lds4(tail + FHT_B3 + 16 * t + 4 * rg));
     }
     if (a.normalize) ln_regs<false, false>(acc3, nullptr, nullptr, rg);
-    if (valid) {
+    if (valid && a.out_r24) {
+      // packed 24-bit rows (kernels.h: R24_ROW_BYTES): this lane's four columns of every feature tile
+      char* o = reinterpret_cast<char*>(a.out) + (size_t)e * R24_ROW_BYTES;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        unsigned u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned b = __float_as_uint(acc3[t][k]);
+          u[k] = b + 0x7fu + ((b >> 8) & 1u);                        // round to nearest even at bit 8
+        }
+        *reinterpret_cast<uint2*>(o + 2 * (16 * t + 4 * rg)) = make_uint2((u[0] >> 16) | (u[1] & 0xffff0000u), (u[2] >> 16) | (u[3] & 0xffff0000u));
+        *reinterpret_cast<unsigned*>(o + R24_LO_PLANE + 16 * t + 4 * rg) =
+            ((u[0] >> 8) & 0xffu) | (u[1] & 0xff00u) | ((u[2] << 8) & 0xff0000u) | ((u[3] << 16) & 0xff000000u);
+      }
+    } else if (valid) {
       float* o = a.out + (size_t)e * a.ldo;
 #pragma unroll
       for (int t = 0; t < 8; ++t)

@@ -27,7 +27,15 @@ struct FourierArgs {
   float* out; int ldo;
   int normalize;
   unsigned long long* prof_rows;   // optional [8]: rows processed, indexed by n (profiling only)
+  int out_r24;             // k_fourier_h only: rows in the packed 24-bit format (R24_ROW_BYTES per row, below) instead of fp32
 };
+
+// Packed 24-bit rows of the normalised relative-position embedding (the rollout's private edge buffers; k_fourier_h writes,
+// k_edge_fused reads): the upper 24 bits of every fp32 value (sign, exponent, 15 mantissa bits, round to nearest even) as two
+// planes per row - 128 x 16 bit (bits 31..16) then 128 x 8 bit (bits 15..8): 384 B instead of 512.  The values are O(1)
+// (affine-free LayerNorm output): relative error 2^-17, 32 x below fp16; the edge loop is bound by the bytes it gathers.
+constexpr int R24_ROW_BYTES = 384;
+constexpr int R24_LO_PLANE = 256;
 
 // One edge set in CSR-by-destination form (built on the device every decode step).
 struct EdgeSet {
@@ -391,7 +399,7 @@ template <int WAVES, int TERMS> __global__ void k_attn_h(AttnHArgs a);
 template <int TERMS> __global__ void k_attn_hs(AttnHArgs a);             // attn_hs.hip: the same for few rows (one 16-row group per workgroup)   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);
-template <int G> __global__ void k_edge_fused(EdgeFusedArgs a);        // edge_fused.hip
+template <int G, bool R24> __global__ void k_edge_fused(EdgeFusedArgs a);        // edge_fused.hip (R24: rhat rows in the packed format)
 template <int G> __global__ void k_edge_fused_p(EdgeFusedArgs a);      // persistent workgroups, decoupled halves
 __global__ void k_edge_attn_wide(EdgeAttnArgs a);
 __global__ void k_attn_post(AttnPostArgs a);
