@@ -341,8 +341,8 @@ def main():
         rows_t = rows_dec * args.steps
         nbytes = L * KV_ROW_BYTES * (ed['temporal'] + ed['map'] + rows_t)
         nflop = 2.0 * L * EDGE_MAC_PER_LAYER * (ed['temporal'] + ed['map'] + ed['agent'])
-        # what this design has to move for the same launches: + 512 B of rhat per edge, + q in / agg out per row
-        model = nbytes + L * 512.0 * (ed['temporal'] + ed['map'] + ed['agent']) + 3 * L * 1024.0 * rows_t
+        # what this design has to move for the same launches: + 384 B of rhat per edge (24-bit rows), + q in / agg out per row
+        model = nbytes + L * 384.0 * (ed['temporal'] + ed['map'] + ed['agent']) + 3 * L * 1024.0 * rows_t
         secs = dom['ms'] * 1e-3
         hbm_frac = nbytes / secs / (HBM_PEAK_GBS * 1e9)
         mfma_frac = nflop / secs / (F16_SPLIT_PEAK_TFLOPS * 1e12)
