@@ -2,7 +2,6 @@
 // the fused tile kernel k_edge_fused (edge_fused.hip): one wavefront per destination row, single pass over the row's
 // incoming edges with an online (running-max) softmax; every global access is a coalesced 512-byte row.
 #pragma once
-#include <type_traits>
 #include "kernels.h"
 
 namespace ig {
@@ -30,7 +29,7 @@ struct AttnState {
 //     exp(s - max) / (sum + 1e-16) is reproduced to rounding (the epsilon only matters for rows without edges: exact 0);
 //   * the eight u_h . rhat partial products are formed for two heads at a time (v_pk_mul / v_pk_fma);
 //   * source indices of up to 64 edges sit in one register (v_readlane per edge instead of a dependent scalar load), and
-//     the K / V / rhat rows of PF edges are requested together; the tail of a list runs a trip of exactly its length.
+//     the K / V / rhat rows of PF edges are requested together.
 typedef float pk2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pk2 pk_fma(pk2 a, pk2 b, pk2 c) { return __builtin_elementwise_fma(a, b, c); }
 constexpr float EA_LOG2E = 1.44269504088896340736f;
@@ -61,8 +60,9 @@ struct EdgeAcc {
       uy[i] = pk2{u0.y, u1.y};
     }
   }
-  // one edge
-  __device__ __forceinline__ void step(pk2 k2, pk2 v2, pk2 r2, bool b3) {
+  // one edge; live = false (a slot beyond the end of the list in an unrolled tail): the score is -inf and the edge contributes
+  // exactly nothing - cheaper than a branch around the accumulator updates, whose join makes hipcc copy all of them
+  __device__ __forceinline__ void step(pk2 k2, pk2 v2, pk2 r2, bool live, bool b3) {
     float val = fmaf(q.y, k2[1], q.x * k2[0]);
     if constexpr (HASR) {
       pk2 pp[H / 2];
@@ -88,8 +88,9 @@ struct EdgeAcc {
       const float keep = b3 ? k2v[1] : k2v[0];
       val += keep + dpp_xor8(send);
     }
-    // log2-domain score of head (lane >> 3), uniform over its 8 lanes
-    val = sum8(val) * EA_LOG2E;
+    // log2-domain score of head (lane >> 3), uniform over its 8 lanes (the dead-slot select is on the constant so that the
+    // score - and with it the K row's load - cannot be sunk into a branch on `live`)
+    val = fminf(sum8(val) * EA_LOG2E, live ? INFINITY : -INFINITY);
     const bool grow = val > m + EA_TAU;                // first edge: m = -inf
     if (__any(grow)) {
       const float mn = grow ? val : m;
@@ -136,44 +137,27 @@ __device__ __forceinline__ void edge_attn_wave2(const EdgeAttnArgs& a, int row, 
   else if constexpr (HASR) acc.load_u(a.U + (size_t)row * (H * D), lane);
   acc.reset();
   const int n = E > e_first ? (E - e_first + e_step - 1) / e_step : 0;      // edges of this wave
-  // one trip = N edges: all their K / V / rhat rows are requested at the top (the row bases are wave-uniform: scalar base +
-  // the lane's 8-byte offset, no vector address arithmetic) and consumed in turn with counted waits.  Nothing is carried in
-  // registers from trip to trip on purpose: hipcc pipelines loop-carried load destinations through staging registers and
-  // rotates them with copies at the back edge, and a copy of a pending load's destination is a full wait (measured: 2, 3 or 5
-  // edges carried in flight, same time) - the trip's fill latency is hidden by the other waves of the SIMD instead.
-  const unsigned lo8 = 8u * (unsigned)lane;
-  auto ld = [&](const float* base, bool nt) {
-    return ea_ld(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + lo8), nt);
-  };
   for (int c0 = 0; c0 < n; c0 += 64) {
     const int mc = min(64, n - c0);
     const int srcv = a.es.src[e_base + e_first + (c0 + min(lane, mc - 1)) * e_step];
-    auto trip = [&](auto nn, int i0) {
-      constexpr int N = decltype(nn)::value;
-      pk2 kb[N], vb[N], rb[N];
+    // PF edges per trip: all their K / V / rhat rows are requested at the top of the trip (index clamped at the end of the
+    // list: no branch around the loads, the waits are counted ones) and consumed in turn.  Nothing is carried in registers
+    // from trip to trip on purpose: hipcc pipelines loop-carried load destinations through staging registers and rotates
+    // them with copies at the back edge, and a copy of a pending load's destination is a full wait (measured: 2, 3 or 5
+    // edges carried in flight, same time) - the trip's fill latency is hidden by the other waves of the SIMD instead.
+    for (int i0 = 0; i0 < mc; i0 += PF) {
+      pk2 kb[PF], vb[PF], rb[PF];
 #pragma unroll
-      for (int s = 0; s < N; ++s) {
-        const int sj = __builtin_amdgcn_readlane(srcv, i0 + s);
-        const size_t e = (size_t)(e_base + e_first + (c0 + i0 + s) * e_step);
-        kb[s] = ld(a.Ksrc + (size_t)sj * D, kv_once);
-        vb[s] = ld(a.Vsrc + (size_t)sj * D, kv_once);
-        if constexpr (HASR) rb[s] = ld(a.es.rhat + e * D, true);
+      for (int s = 0; s < PF; ++s) {
+        const int ic = min(i0 + s, mc - 1);
+        const int sj = __builtin_amdgcn_readlane(srcv, ic);
+        const size_t e = (size_t)(e_base + e_first + (c0 + ic) * e_step);
+        kb[s] = ea_ld(a.Ksrc + (size_t)sj * D + 2 * lane, kv_once);
+        vb[s] = ea_ld(a.Vsrc + (size_t)sj * D + 2 * lane, kv_once);
+        if constexpr (HASR) rb[s] = __builtin_nontemporal_load(reinterpret_cast<const pk2*>(a.es.rhat + e * D + 2 * lane));
       }
 #pragma unroll
-      for (int s = 0; s < N; ++s) acc.step(kb[s], vb[s], HASR ? rb[s] : pk2{0.f, 0.f}, b3);
-    };
-    int i0 = 0;
-    for (; i0 + PF <= mc; i0 += PF) trip(std::integral_constant<int, PF>{}, i0);
-    // the tail of the list: a trip of exactly the remaining edges (no dead slots)
-    switch (mc - i0) {
-      case 1: trip(std::integral_constant<int, 1>{}, i0); break;
-      case 2: trip(std::integral_constant<int, 2>{}, i0); break;
-      case 3: trip(std::integral_constant<int, 3>{}, i0); break;
-      case 4: if constexpr (PF > 4) trip(std::integral_constant<int, 4>{}, i0); break;
-      case 5: if constexpr (PF > 5) trip(std::integral_constant<int, 5>{}, i0); break;
-      case 6: if constexpr (PF > 6) trip(std::integral_constant<int, 6>{}, i0); break;
-      case 7: if constexpr (PF > 7) trip(std::integral_constant<int, 7>{}, i0); break;
-      default: break;
+      for (int s = 0; s < PF; ++s) acc.step(kb[s], vb[s], HASR ? rb[s] : pk2{0.f, 0.f}, i0 + s < mc, b3);
     }
   }
 #pragma unroll

@@ -146,35 +146,24 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
       for (int c0 = 0; c0 < E; c0 += 64) {
         const int mc = min(64, E - c0);
         if (c0 > 0) sv = a.es.src[e_base + c0 + min(lane, mc - 1)];        // lists beyond 64 edges: next chunk of indices
-        // G edges per trip: all their K / V / rhat rows are requested at the top of the trip (wave-uniform row base + the lane's
-        // 8-byte offset) and consumed in turn with counted waits; nothing is carried in registers from trip to trip (edge_attn.cuh
-        // explains why), the trip's fill latency is hidden by the SIMD's other waves.  The tail of the list runs a trip of
-        // exactly its length: no dead slots
-        auto trip = [&](auto nn, int i0) {
-          constexpr int N = decltype(nn)::value;
-          pk2 kb[N], vb[N], rb[N];
+        // G edges per trip: all their K / V / rhat rows are requested at the top of the trip (index clamped at the end of the
+        // list: no branch around the loads, the waits are counted ones) and consumed in turn; nothing is carried in registers
+        // from trip to trip (edge_attn.cuh explains why), the trip's fill latency is hidden by the SIMD's other waves.  (A
+        // tail trip of exactly the remaining length was tried: same time on lists of any raggedness - the loop is bound by
+        // its gathers, DESIGN.md section 9 - and ten spilled registers.)
+        for (int i0 = 0; i0 < mc; i0 += G) {
+          pk2 kb[G], vb[G], rb[G];
 #pragma unroll
-          for (int s = 0; s < N; ++s) {
-            const int sj = __builtin_amdgcn_readlane(sv, i0 + s);
+          for (int s = 0; s < G; ++s) {
+            const int ic = min(i0 + s, mc - 1);
+            const int sj = __builtin_amdgcn_readlane(sv, ic);
             kb[s] = ld8(a.Ksrc + (size_t)sj * D, kv_once);
             vb[s] = ld8(a.Vsrc + (size_t)sj * D, kv_once);
-            if constexpr (R24) rb[s] = ld_r24((size_t)(e_base + c0 + i0 + s));
-            else rb[s] = ld8(a.es.rhat + (size_t)(e_base + c0 + i0 + s) * D, true);
+            if constexpr (R24) rb[s] = ld_r24((size_t)(e_base + c0 + ic));
+            else rb[s] = ld8(a.es.rhat + (size_t)(e_base + c0 + ic) * D, true);
           }
 #pragma unroll
-          for (int s = 0; s < N; ++s) acc.step(kb[s], vb[s], rb[s], b3);
-        };
-        int i0 = 0;
-        for (; i0 + G <= mc; i0 += G) trip(std::integral_constant<int, G>{}, i0);
-        switch (mc - i0) {
-          case 1: trip(std::integral_constant<int, 1>{}, i0); break;
-          case 2: trip(std::integral_constant<int, 2>{}, i0); break;
-          case 3: trip(std::integral_constant<int, 3>{}, i0); break;
-          case 4: if constexpr (G > 4) trip(std::integral_constant<int, 4>{}, i0); break;
-          case 5: if constexpr (G > 5) trip(std::integral_constant<int, 5>{}, i0); break;
-          case 6: if constexpr (G > 6) trip(std::integral_constant<int, 6>{}, i0); break;
-          case 7: if constexpr (G > 7) trip(std::integral_constant<int, 7>{}, i0); break;
-          default: break;
+          for (int s = 0; s < G; ++s) acc.step(kb[s], vb[s], rb[s], i0 + s < mc, b3);
         }
       }
       const float inv = 1.0f / (acc.lsum + 1e-16f);
@@ -361,34 +350,23 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused_p(EdgeFusedArgs a) {
       for (int c0 = 0; c0 < E; c0 += 64) {
         const int mc = min(64, E - c0);
         if (c0 > 0) sv = a.es.src[e_base + c0 + min(lane, mc - 1)];        // lists beyond 64 edges: next chunk of indices
-        // G edges per trip: all their K / V / rhat rows are requested at the top of the trip (wave-uniform row base + the lane's
-        // 8-byte offset) and consumed in turn with counted waits; nothing is carried in registers from trip to trip (edge_attn.cuh
-        // explains why), the trip's fill latency is hidden by the SIMD's other waves.  The tail of the list runs a trip of
-        // exactly its length: no dead slots
-        auto trip = [&](auto nn, int i0) {
-          constexpr int N = decltype(nn)::value;
-          pk2 kb[N], vb[N], rb[N];
+        // G edges per trip: all their K / V / rhat rows are requested at the top of the trip (index clamped at the end of the
+        // list: no branch around the loads, the waits are counted ones) and consumed in turn; nothing is carried in registers
+        // from trip to trip (edge_attn.cuh explains why), the trip's fill latency is hidden by the SIMD's other waves.  (A
+        // tail trip of exactly the remaining length was tried: same time on lists of any raggedness - the loop is bound by
+        // its gathers, DESIGN.md section 9 - and ten spilled registers.)
+        for (int i0 = 0; i0 < mc; i0 += G) {
+          pk2 kb[G], vb[G], rb[G];
 #pragma unroll
-          for (int s = 0; s < N; ++s) {
-            const int sj = __builtin_amdgcn_readlane(sv, i0 + s);
+          for (int s = 0; s < G; ++s) {
+            const int ic = min(i0 + s, mc - 1);
+            const int sj = __builtin_amdgcn_readlane(sv, ic);
             kb[s] = ld8(a.Ksrc + (size_t)sj * D, kv_once);
             vb[s] = ld8(a.Vsrc + (size_t)sj * D, kv_once);
-            rb[s] = ld8(a.es.rhat + (size_t)(e_base + c0 + i0 + s) * D, true);
+            rb[s] = ld8(a.es.rhat + (size_t)(e_base + c0 + ic) * D, true);
           }
 #pragma unroll
-          for (int s = 0; s < N; ++s) acc.step(kb[s], vb[s], rb[s], b3);
-        };
-        int i0 = 0;
-        for (; i0 + G <= mc; i0 += G) trip(std::integral_constant<int, G>{}, i0);
-        switch (mc - i0) {
-          case 1: trip(std::integral_constant<int, 1>{}, i0); break;
-          case 2: trip(std::integral_constant<int, 2>{}, i0); break;
-          case 3: trip(std::integral_constant<int, 3>{}, i0); break;
-          case 4: if constexpr (G > 4) trip(std::integral_constant<int, 4>{}, i0); break;
-          case 5: if constexpr (G > 5) trip(std::integral_constant<int, 5>{}, i0); break;
-          case 6: if constexpr (G > 6) trip(std::integral_constant<int, 6>{}, i0); break;
-          case 7: if constexpr (G > 7) trip(std::integral_constant<int, 7>{}, i0); break;
-          default: break;
+          for (int s = 0; s < G; ++s) acc.step(kb[s], vb[s], rb[s], i0 + s < mc, b3);
         }
       }
       const float inv = 1.0f / (acc.lsum + 1e-16f);

@@ -11,8 +11,9 @@ def load(path, col):
     for line in list(open(path))[1:]:
         kernel, disp, val = line.rstrip('\n').rsplit(',', 2)      # (kernel names contain commas: k_attn_h<4, 3>)
         for k, (kid, fac) in names.items():
-            if k in kernel:
-                out[kid] = (float(val) * 1024.0, int(disp), fac)
+            if k in kernel:                                          # (template variants of one kernel add up: k_edge_fused<6, true | false>)
+                b, n, _ = out.get(kid, (0.0, 0, fac))
+                out[kid] = (b + float(val) * 1024.0, n + int(disp), fac)
     return out
 
 
