@@ -405,7 +405,7 @@ extern "C" int infgen_set_edge_loop(int v) {
 // resident workgroups per CU the runtime reports for k_edge_fused<6> (diagnostics; tools/edge_probe.sh)
 extern "C" int infgen_edge_fused_occupancy(void) {
   int n = -1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_edge_fused<6, false>, 1024, 0) != hipSuccess) return -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_edge_fused<6, false, 2>, 1024, 0) != hipSuccess) return -1;
   return n;
 }
 
@@ -416,17 +416,22 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
   if (!pack || !rhat) return fail("infgen_edge_attn_fused", "needs the layer pack and rhat");
   static const int dbg = getenv("INFGEN_EDGE_DBG") ? atoi(getenv("INFGEN_EDGE_DBG")) : 0;
   static const int no_xcd = getenv("INFGEN_EDGE_NOXCD") ? atoi(getenv("INFGEN_EDGE_NOXCD")) : 0;
+  static const int persist = getenv("INFGEN_EDGE_P") ? atoi(getenv("INFGEN_EDGE_P")) : 0;
+  static const int small_max = getenv("INFGEN_EDGE_SMALL") ? atoi(getenv("INFGEN_EDGE_SMALL")) : 4096;
+  const int G = O().edge_loop;
+  // small launches: one 16-row group per workgroup (edge_fused.hip), twice the workgroups for the same rows
+  const bool small = rows <= small_max && G == 6 && !persist;
+  const int tr = small ? 16 : 32;          // rows per tile
   EdgeFusedArgs a{rows, Q, pack, Ksrc, Vsrc, EdgeSet{off, cnt, src, rhat}, AGG, nullptr, nullptr, dbg, 0, kv_once};
-  int grid = ceil_div(rows, 32);           // 32-row tiles (two 16-row groups); with a group list at most that many
+  int grid = ceil_div(rows, tr);           // with a group list at most that many
   if (O().row_groups && rows == group_rows()) { a.groups = O().row_groups; a.n_groups = O().n_row_groups; }
-  else if (rows_per_scene > 32 && rows_per_scene % 32 == 0 && !(no_xcd & 1)) {
-    a.tiles_per_scene = rows_per_scene / 32;
+  else if (rows_per_scene > tr && rows_per_scene % tr == 0 && !(no_xcd & 1)) {
+    a.tiles_per_scene = rows_per_scene / tr;
     const int grp = 8 * a.tiles_per_scene;
     grid = ceil_div(grid, grp) * grp;
   }
   if (no_xcd & 2) a.kv_once = 0;
   a.n_virtual = grid;
-  static const int persist = getenv("INFGEN_EDGE_P") ? atoi(getenv("INFGEN_EDGE_P")) : 0;
   if (persist && !r24) {
     const int pg = grid < 256 ? grid : 256;
     ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
@@ -435,9 +440,9 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
     return check_launch("infgen_edge_attn_fused");
   }
   { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
-    const int G = O().edge_loop;
-    auto kern = r24 ? (G == 4 ? k_edge_fused<4, true> : G == 8 ? k_edge_fused<8, true> : k_edge_fused<6, true>)
-                    : (G == 4 ? k_edge_fused<4, false> : G == 8 ? k_edge_fused<8, false> : k_edge_fused<6, false>);
+    auto kern = small ? (r24 ? k_edge_fused<6, true, 1> : k_edge_fused<6, false, 1>)
+              : r24 ? (G == 4 ? k_edge_fused<4, true, 2> : G == 8 ? k_edge_fused<8, true, 2> : k_edge_fused<6, true, 2>)
+                    : (G == 4 ? k_edge_fused<4, false, 2> : G == 8 ? k_edge_fused<8, false, 2> : k_edge_fused<6, false, 2>);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_edge_attn_fused");
 }
@@ -821,8 +826,9 @@ extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless,
   const bool overlap = O().overlap && g_side && !edgeless;
   const bool fuse = O().edge_fuse == 2 || (O().edge_fuse == 1 && rows > 256);      // U / Z / SIG stay on chip inside k_edge_fused
   // the step's rhat rows never leave the library: packed 24-bit rows (kernels.h) when both ends are the kernels that know them
-  static const int no_r24 = getenv("INFGEN_NO_R24") ? atoi(getenv("INFGEN_NO_R24")) : 0;
-  const int r24 = fuse && O().fourier_mode != 0 && !no_r24;
+  // (INFGEN_NO_R24=1, read per call: fp32 rows instead - tests/test_rollout_gpu.py compares the two)
+  const char* no_r24 = getenv("INFGEN_NO_R24");
+  const int r24 = fuse && O().fourier_mode != 0 && !(no_r24 && atoi(no_r24));
   if (overlap) {
     hipStream_t ms = (hipStream_t)stream;
     if (hipEventRecord(g_ev_fork, ms) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork, 0) != hipSuccess)

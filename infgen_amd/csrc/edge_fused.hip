@@ -31,15 +31,19 @@ constexpr int EF_ROWS = 16 * EF_HALVES;
 constexpr int EF_LDU = H * D + 4;           // row stride of the U / Z tile in floats (+4: conflict-free b128 column writes)
 constexpr int EF_LDA = D + 4;
 
-// G = edges per trip of the edge loop (their K / V / rhat rows are requested together)
-template <int G, bool R24>
+// G = edges per trip of the edge loop (their K / V / rhat rows are requested together); R24: rhat rows in the packed 24-bit
+// format (kernels.h); HALVES = 16-row groups per workgroup: 2 when the launch fills the chip, 1 for small launches (up to 256
+// groups = 4 k rows: twice the workgroups, and the 16 waves take ONE row each in the edge loop instead of two - the loop of a
+// small launch is the latency of its longest rows; the 8 waves without a (head, half) idle in the matrix phases)
+template <int G, bool R24, int HALVES>
 __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
-  __shared__ __attribute__((aligned(16))) float UZ[EF_ROWS * EF_LDU];
-  __shared__ __attribute__((aligned(16))) float AG[EF_ROWS * EF_LDA];     // q tile (phase 1 -> 2), then agg (phase 2 -> 3)
-  __shared__ float SG[EF_ROWS * H];
+  constexpr int ROWS = 16 * HALVES;
+  __shared__ __attribute__((aligned(16))) float UZ[ROWS * EF_LDU];
+  __shared__ __attribute__((aligned(16))) float AG[ROWS * EF_LDA];     // q tile (phase 1 -> 2), then agg (phase 2 -> 3)
+  __shared__ float SG[ROWS * H];
   __shared__ int next_row;
-  const int ngroups = a.groups ? *a.n_groups : (a.rows + 15) / 16;        // 16-row groups; a tile takes two of them
-  const int ntiles = (ngroups + EF_HALVES - 1) / EF_HALVES;
+  const int ngroups = a.groups ? *a.n_groups : (a.rows + 15) / 16;        // 16-row groups; a tile takes HALVES of them
+  const int ntiles = (ngroups + HALVES - 1) / HALVES;
   // XCD-aware tile order: consecutive workgroups go to consecutive XCDs (b % 8), each with its own L2.  With tps tiles per
   // scene, workgroups b, b + 8, ..., b + 8 (tps - 1) - one XCD - take the tiles of ONE scene, so that the scene's K / V rows
   // (agent set: read by every row of the scene) are fetched into one L2 instead of tps of them.
@@ -55,21 +59,22 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
   const int j = lane & 15, g = lane >> 4;
   const int h = w & 7, half = w >> 3, hp = h >> 1, hh = h & 1;
   // first row of each half (-1: no such group)
-  int r0h[EF_HALVES];
+  int r0h[HALVES];
 #pragma unroll
-  for (int b = 0; b < EF_HALVES; ++b) {
-    const int gi = EF_HALVES * tile + b;
+  for (int b = 0; b < HALVES; ++b) {
+    const int gi = HALVES * tile + b;
     r0h[b] = gi < ngroups ? 16 * (a.groups ? a.groups[gi] : gi) : -1;
   }
-  const int r0 = half ? r0h[1] : r0h[0];
+  const bool mat = half < HALVES;                  // this wave has a (head, half) of the matrix phases
+  const int r0 = (HALVES > 1 && half) ? r0h[HALVES - 1] : r0h[0];
   const int jl = 16 * half + j;                    // this lane's row of the LDS tiles in the matrix phases
   const int row = r0 + j;
-  const bool valid = r0 >= 0 && row < a.rows;
+  const bool valid = mat && r0 >= 0 && row < a.rows;
   const float* hdr = a.pack + AH_HDR;
   if (threadIdx.x == 0) next_row = 0;
 
   // ---- phase 1: u_h = q_h W'_kr,h (K = 16: v_mfma_f32_16x16x16_f16; B fragment = the head's 16 query values of row j)
-  {
+  if (mat) {
     float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) qv = *reinterpret_cast<const float4*>(a.Q + (size_t)row * D + DH * h + 4 * g);
     const unsigned short* Wk = reinterpret_cast<const unsigned short*>(a.pack + AH_PRE) + (size_t)(4 + hp) * QUARTER +
@@ -131,8 +136,8 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
       if (lane == 0) r = atomicAdd(&next_row, 1);
       return __builtin_amdgcn_readfirstlane(r);
     };
-    for (int rl = take_row(); rl < EF_ROWS; rl = take_row()) {
-      const int rbase = (rl >> 4) ? r0h[1] : r0h[0];
+    for (int rl = take_row(); rl < ROWS; rl = take_row()) {
+      const int rbase = (HALVES > 1 && (rl >> 4)) ? r0h[HALVES - 1] : r0h[0];
       const int drow = rbase + (rl & 15);
       const bool live = rbase >= 0 && drow < a.rows && !(a.dbg & 1);
       const int E = live ? __builtin_amdgcn_readfirstlane(a.es.cnt[drow]) : 0;
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
   __syncthreads();
 
   // ---- phase 3: agg' = agg + W'_vr,h z_h + b'_h sigma_h  (k_attn_h's z-GEMM: |z| <= sqrt(127), static prescale 1024)
-  {
+  if (mat) {
     const float* zrow = UZ + jl * EF_LDU + h * D + 8 * g;
     const unsigned short* Wv = reinterpret_cast<const unsigned short*>(a.pack + AH_POST) + (size_t)hp * QUARTER +
                                (size_t)(hh * 4) * 2 * 512 + lane * 8;
@@ -424,12 +429,14 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused_p(EdgeFusedArgs a) {
   }   // tile slots of this workgroup
 }
 
-template __global__ void k_edge_fused<4, false>(EdgeFusedArgs);
-template __global__ void k_edge_fused<6, false>(EdgeFusedArgs);
-template __global__ void k_edge_fused<8, false>(EdgeFusedArgs);
-template __global__ void k_edge_fused<4, true>(EdgeFusedArgs);
-template __global__ void k_edge_fused<6, true>(EdgeFusedArgs);
-template __global__ void k_edge_fused<8, true>(EdgeFusedArgs);
+template __global__ void k_edge_fused<4, false, 2>(EdgeFusedArgs);
+template __global__ void k_edge_fused<6, false, 2>(EdgeFusedArgs);
+template __global__ void k_edge_fused<8, false, 2>(EdgeFusedArgs);
+template __global__ void k_edge_fused<4, true, 2>(EdgeFusedArgs);
+template __global__ void k_edge_fused<6, true, 2>(EdgeFusedArgs);
+template __global__ void k_edge_fused<8, true, 2>(EdgeFusedArgs);
+template __global__ void k_edge_fused<6, false, 1>(EdgeFusedArgs);
+template __global__ void k_edge_fused<6, true, 1>(EdgeFusedArgs);
 template __global__ void k_edge_fused_p<6>(EdgeFusedArgs);
 template __global__ void k_edge_fused_p<4>(EdgeFusedArgs);
 

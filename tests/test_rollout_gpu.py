@@ -540,6 +540,35 @@ def test_fused_edge_attention_rollout_matches_default():
         assert np.abs(a['logits'] - b['logits']).max() <= 2e-4
 
 
+def test_packed_rhat_rows_match_fp32_rows():
+    """the rollout keeps the normalised relative-position embeddings of its own edge sets as packed 24-bit rows (kernels.h
+    R24_ROW_BYTES: k_fourier_h writes, k_edge_fused reads; relative error 2^-17) - against the same rollout with fp32 rows
+    (INFGEN_NO_R24=1): tokens identical, logits within 5e-5"""
+    import os
+    from infgen_amd import engine, synth, _lib
+    c = load_case('c2_a32_m512')
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], c['cfg'], dev)
+    scenes = [synth.make_scene(700 + i, 24 + i, 300, c['cfg'], vocab=c['vocab'], grid=c['grid'], slip=0.2) for i in range(12)]
+    outs = []
+    lib = _lib.load()
+    try:
+        _lib.check(lib.infgen_set_edge_fuse(2))
+        for no_r24 in ('1', '0'):
+            os.environ['INFGEN_NO_R24'] = no_r24
+            eng = engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=True)
+            eng.rollout()
+            outs.append(eng.outputs())
+    finally:
+        os.environ.pop('INFGEN_NO_R24', None)
+        _lib.check(lib.infgen_set_edge_fuse(1))
+    worst = 0.0
+    for a, b in zip(*outs):
+        assert np.array_equal(a['next_token_idx'], b['next_token_idx'])
+        worst = max(worst, float(np.abs(a['logits'] - b['logits']).max()))
+    assert 0.0 < worst <= 5e-5, worst          # (> 0: the packed path really ran)
+
+
 def test_bench_size_batch_properties():
     """BASELINE C3 shapes at the bench's full size (512 scenes x 64 agents x 1024 map tokens, R = 80), checked through
     size-independent properties: a second rollout of the same batch is bitwise identical; scenes are independent units,
