@@ -694,8 +694,8 @@ extern "C" int infgen_build_edges(const InfgenRollout* r, int c, int edgeless, v
   a.rows = r->S * r->A_cap; a.t = ebuf(r->et); a.m = ebuf(r->em); a.a = ebuf(r->ea);
   a.prof = (g_prof.mask & ((1u << INFGEN_KID_EDGE_ATTN) | (1u << INFGEN_KID_BUILD_EDGES))) ? g_prof.rows_dev : nullptr;
   { ProfScope _ps(INFGEN_KID_BUILD_EDGES, stream);
-    if (r->A_cap <= 256) hipLaunchKernelGGL(k_build_edges<256>, dim3(r->S), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_build_edges<1024>, dim3(r->S), dim3(1024), 0, s, a); }
+    if (r->A_cap <= 256) hipLaunchKernelGGL(k_build_edges<256>, dim3(r->S, 3), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_build_edges<1024>, dim3(r->S, 3), dim3(1024), 0, s, a); }
   return check_launch("infgen_build_edges");
 }
 

@@ -145,8 +145,9 @@ __global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
   const int c = a.c;
   const int rows_total = a.rows;
   const int row = s * st.A_cap + t;
+  const int part = blockIdx.y;        // the three sets of a scene are built by three workgroups (grid S x 3): independent lists
   if (a.edgeless) {
-    if (t < st.A_cap) {
+    if (part == 0 && t < st.A_cap) {
       a.t.off[row] = 0; a.t.cnt[row] = 0;
       a.m.off[row] = 0; a.m.cnt[row] = 0;
       a.a.off[row] = 0; a.a.cnt[row] = 0;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
 
   // ---------------- temporal (window <= 16 columns: every slot of the row is fetched up front, the
   // loads are independent and overlap)
-  {
+  if (part == 0) {
     constexpr int WMAX = 16;
     int cnt = 0;
     const int lo = max(c - st.W, 0);
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
   }
 
   // ---------------- map -> agent (first 5 within radius, ascending index): one wave per agent
-  {
+  if (part == 1) {
     const int M = st.n_map[s];
     const float r2 = a.r_map * a.r_map;
     const float* mp = st.map_pos + (size_t)s * st.M_cap * 2;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
   }
 
   // ---------------- agent <-> agent
-  {
+  if (part == 2) {
     const float r2 = a.r_agent * a.r_agent;
     int cnt = 0;
     const bool dst_ok = (t < A) && im[t];
