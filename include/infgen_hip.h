@@ -82,7 +82,9 @@ typedef struct InfgenEdgeBuf {
   int* cnt;      /* [rows] */
   int* src;      /* [cap] */
   float* raw;    /* [cap][4] */
-  float* rhat;   /* [cap][128] */
+  float* rhat;   /* [cap][128] fp32 as written by infgen_fourier_embed.  The three sets of an InfgenRollout (et / em / ea) are scratch of
+                  * infgen_decode_layers: between its Fourier and edge launches it may keep the rows in a packed 24-bit form (384 B
+                  * per row in the same buffer) - do not read them back */
   int* total;    /* [1] */
   int cap;
   int _pad;
