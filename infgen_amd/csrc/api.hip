@@ -434,9 +434,39 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
   a.n_virtual = grid;
   if (persist && !r24) {
     const int pg = grid < 256 ? grid : 256;
-    ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
-    if (persist == 2) hipLaunchKernelGGL(k_edge_fused_p<4>, dim3(pg), dim3(1024), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_edge_fused_p<6>, dim3(pg), dim3(1024), 0, (hipStream_t)stream, a);
+    // INFGEN_EDGE_DBG bit 3 (diagnostic, synchronous): checksums of what each phase hands to the next, compared between the
+    // launches n and n - 3 (the map encoder's three sublayers repeat with identical inputs from one prologue to the next)
+    static unsigned* dbuf[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    static long n_launch = 0;
+    const int slot = (int)(n_launch % 3), gen = (int)((n_launch / 3) & 1);
+    const size_t nb = (size_t)rows * 12 * sizeof(unsigned);
+    if (dbg & 8) {
+      if (!dbuf[slot][gen] && hipMalloc(&dbuf[slot][gen], nb) != hipSuccess) return fail("infgen_edge_attn_fused", "debug buffer");
+      hipMemsetAsync(dbuf[slot][gen], 0, nb, (hipStream_t)stream);
+      a.dbgbuf = dbuf[slot][gen];
+    }
+    { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
+      if (persist == 2) hipLaunchKernelGGL(k_edge_fused_p<4>, dim3(pg), dim3(1024), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL(k_edge_fused_p<6>, dim3(pg), dim3(1024), 0, (hipStream_t)stream, a); }
+    if ((dbg & 8) && n_launch >= 3 && dbuf[slot][gen ^ 1]) {
+      std::vector<unsigned> x((size_t)rows * 12), y((size_t)rows * 12);
+      hipStreamSynchronize((hipStream_t)stream);
+      hipMemcpy(x.data(), dbuf[slot][gen], nb, hipMemcpyDeviceToHost);
+      hipMemcpy(y.data(), dbuf[slot][gen ^ 1], nb, hipMemcpyDeviceToHost);
+      long du = 0, dq = 0, dz = 0, dr = 0, dr_only = 0, dl = 0, dz_only = 0;
+      for (int r_ = 0; r_ < rows; ++r_) {
+        const unsigned* p = &x[(size_t)r_ * 12]; const unsigned* q = &y[(size_t)r_ * 12];
+        const bool bu = p[0] != q[0], bq = p[1] != q[1], bz = p[2] != q[2];
+        dl += p[3] != q[3]; dz_only += bz && p[3] == q[3];
+        bool br = false;
+        for (int k = 4; k < 12; ++k) br |= p[k] != q[k];
+        du += bu; dq += bq; dz += bz; dr += br; dr_only += br && !bz;
+      }
+      fprintf(stderr, "[edge_p dbg] launch %ld (sublayer %d): rows %d, differ vs previous prologue: u-read %ld, q-read %ld, loaded K/V/rhat %ld, "
+                      "loop result %ld (with identical loads %ld), z read by phase 3 %ld (with identical loop result %ld)\n",
+              n_launch, slot, rows, du, dq, dl, dz, dz_only, dr, dr_only);
+    }
+    ++n_launch;
     return check_launch("infgen_edge_attn_fused");
   }
   { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);

@@ -250,6 +250,12 @@ __device__ __forceinline__ void half_barrier(int* ctr, int& epoch, int lane) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+__device__ __forceinline__ unsigned wave_xor(unsigned v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v ^= (unsigned)__shfl_xor((int)v, o, 64);
+  return v;
+}
+
 template <int G>
 __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused_p(EdgeFusedArgs a) {
   __shared__ __attribute__((aligned(16))) float UZ[EF_ROWS * EF_LDU];
@@ -352,6 +358,16 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused_p(EdgeFusedArgs a) {
       acc.q = *reinterpret_cast<const float2*>(AG + rl * EF_LDA + 2 * lane);
       acc.load_u(uz, lane);
       acc.reset();
+      unsigned cld = 0;
+      if (a.dbgbuf && live) {                    // what this wave read of the row's u tile and q (written by the matrix phase)
+        unsigned cu = 0;
+#pragma unroll
+        for (int i = 0; i < H / 2; ++i)
+          cu ^= __float_as_uint(acc.ux[i][0]) ^ (__float_as_uint(acc.ux[i][1]) * 3u) ^ (__float_as_uint(acc.uy[i][0]) * 5u) ^ (__float_as_uint(acc.uy[i][1]) * 7u);
+        cu = wave_xor(cu * (2u * lane + 1u));
+        const unsigned cq_ = wave_xor((__float_as_uint(acc.q.x) ^ (__float_as_uint(acc.q.y) * 3u)) * (2u * lane + 1u));
+        if (lane == 0) { a.dbgbuf[(size_t)drow * 12 + 0] = cu; a.dbgbuf[(size_t)drow * 12 + 1] = cq_; }
+      }
       for (int c0 = 0; c0 < E; c0 += 64) {
         const int mc = min(64, E - c0);
         if (c0 > 0) sv = a.es.src[e_base + c0 + min(lane, mc - 1)];        // lists beyond 64 edges: next chunk of indices
@@ -370,11 +386,28 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused_p(EdgeFusedArgs a) {
             vb[s] = ld8(a.Vsrc + (size_t)sj * D, kv_once);
             rb[s] = ld8(a.es.rhat + (size_t)(e_base + c0 + ic) * D, true);
           }
+          if (a.dbgbuf) {                          // the values the loads of this trip delivered (live slots)
+#pragma unroll
+            for (int s = 0; s < G; ++s)
+              if (i0 + s < mc) {
+                const unsigned wgt = 2u * (unsigned)(c0 + i0 + s) + 1u;
+                cld ^= (__float_as_uint(kb[s][0]) ^ (__float_as_uint(kb[s][1]) * 3u) ^ (__float_as_uint(vb[s][0]) * 5u) ^
+                        (__float_as_uint(vb[s][1]) * 7u) ^ (__float_as_uint(rb[s][0]) * 9u) ^ (__float_as_uint(rb[s][1]) * 11u)) * wgt;
+              }
+          }
 #pragma unroll
           for (int s = 0; s < G; ++s) acc.step(kb[s], vb[s], rb[s], i0 + s < mc, b3);
         }
       }
+      if (a.dbgbuf && live) { cld = wave_xor(cld * (2u * lane + 1u)); if (lane == 0) a.dbgbuf[(size_t)drow * 12 + 3] = cld; }
       const float inv = 1.0f / (acc.lsum + 1e-16f);
+      if (a.dbgbuf && live) {                    // the loop's result in registers
+        unsigned cz = __float_as_uint(acc.ag[0]) ^ (__float_as_uint(acc.ag[1]) * 3u) ^ (__float_as_uint(acc.lsum) * 5u);
+#pragma unroll
+        for (int hd = 0; hd < H; ++hd) cz ^= (__float_as_uint(acc.zz[hd][0]) * (2u * hd + 7u)) ^ (__float_as_uint(acc.zz[hd][1]) * (2u * hd + 9u));
+        cz = wave_xor(cz * (2u * lane + 1u));
+        if (lane == 0) a.dbgbuf[(size_t)drow * 12 + 2] = cz;
+      }
       *reinterpret_cast<float2*>(AG + rl * EF_LDA + 2 * lane) = make_float2(acc.ag[0] * inv, acc.ag[1] * inv);
 #pragma unroll
       for (int hd = 0; hd < H; ++hd) {
@@ -398,11 +431,14 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused_p(EdgeFusedArgs a) {
       al[s] = *reinterpret_cast<const v8h*>(Wv + (s * 2 + 1) * 512);
     }
     const float zs = 1024.0f, zinv = hdr[4] * (1.0f / 1024.0f);
+    unsigned czr = 0;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const float4 z0 = *reinterpret_cast<const float4*>(zrow + 32 * s);
       const float4 z1 = *reinterpret_cast<const float4*>(zrow + 32 * s + 4);
+      czr ^= (__float_as_uint(z0.x) ^ (__float_as_uint(z0.y) * 3u) ^ (__float_as_uint(z0.z) * 5u) ^ (__float_as_uint(z0.w) * 7u) ^
+              (__float_as_uint(z1.x) * 9u) ^ (__float_as_uint(z1.y) * 11u) ^ (__float_as_uint(z1.z) * 13u) ^ (__float_as_uint(z1.w) * 15u)) * (2u * s + 1u);
       u32x4 bh, bl;
       unsigned hi, lo;
       split_pair(z0.x * zs, z0.y * zs, hi, lo); bh[0] = hi; bl[0] = lo;
@@ -413,6 +449,12 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused_p(EdgeFusedArgs a) {
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], vbh, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], vbl, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s], vbh, acc, 0, 0, 0);
+    }
+    if (a.dbgbuf) {                              // what the matrix phase read of z (row j, head h), its agg slice and sigma
+      unsigned c = czr * (2u * g + 1u);
+      c ^= (unsigned)__shfl_xor((int)c, 16, 64);
+      c ^= (unsigned)__shfl_xor((int)c, 32, 64);
+      if (valid && g == 0) a.dbgbuf[(size_t)row * 12 + 4 + h] = c;
     }
     if (valid) {
       const float sg = SG[jl * H + h];

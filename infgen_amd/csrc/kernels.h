@@ -81,6 +81,7 @@ struct EdgeFusedArgs {
   int tiles_per_scene;               // > 1: XCD-aware tile order (rows of a scene are A_cap = 32 * tiles_per_scene consecutive rows)
   int kv_once;                       // 1: every K / V source row is read once (temporal ring): non-temporal loads
   int n_virtual;                     // tile slots to visit (tiles rounded up to whole XCD groups)
+  unsigned* dbgbuf;                  // k_edge_fused_p only (INFGEN_EDGE_DBG bit 3): [rows][12] checksums of the hand-offs between the phases
 };
 
 struct AttnPostArgs {
