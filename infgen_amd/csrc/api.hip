@@ -739,8 +739,9 @@ extern "C" int infgen_integrate(const InfgenRollout* r, int t, void* stream) {
   a.vocab = r->vocab; a.token_size = r->token_size; a.grid_xy = r->grid_xy; a.grid_size = r->grid_size;
   a.pred_traj = r->pred_traj; a.pred_head = r->pred_head; a.pred_state = r->pred_state;
   { ProfScope _ps(INFGEN_KID_INTEGRATE, stream);
-    if (r->A_cap <= 256) hipLaunchKernelGGL(k_integrate<256>, dim3(r->S), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_integrate<1024>, dim3(r->S), dim3(1024), 0, (hipStream_t)stream, a); }
+    // 16 waves per scene whatever A_cap: the grid-cell search is one wave per agent (4 instead of 16 agents per wave with 256
+    // threads: 0.95 -> 0.56 ms per rollout at 8 scenes, 1.23 -> 0.98 at 512)
+    hipLaunchKernelGGL(k_integrate<1024>, dim3(r->S), dim3(1024), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_integrate");
 }
 

@@ -511,7 +511,6 @@ __global__ __launch_bounds__(BT) void k_integrate(IntegrateArgs a) {
     }
   }
 }
-template __global__ void k_integrate<256>(IntegrateArgs);
 template __global__ void k_integrate<1024>(IntegrateArgs);
 
 // ------------------------------------------------------------------------------------------
