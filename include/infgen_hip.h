@@ -189,6 +189,13 @@ int infgen_edge_attn(int rows, const float* Q, const float* U, const float* Ksrc
 int infgen_edge_attn_fused(int rows, const float* Q, const float* pack, const float* Ksrc, const float* Vsrc,
                            const int* off, const int* cnt, const int* src, const float* rhat,
                            float* AGG, void* stream);
+/* The same two operators with the normalised relative-position rows in a packed 24-bit form: per row 128 x 16 bit (bits 31..16 of
+ * the fp32 values) followed by 128 x 8 bit (bits 15..8), 384 bytes, values rounded to nearest even at bit 8 (relative error 2^-17).
+ * infgen_fourier_embed_r24 (normalize = 1, no categorical sum; split Fourier kernel only, i.e. infgen_set_fourier_mode != 0) writes
+ * e_cap rows of 384 bytes to `out`; infgen_edge_attn_fused_r24 reads them.  infgen_decode_layers uses the form for its own sets. */
+int infgen_fourier_embed_r24(const float* raw, int n_dims, const int* count_dev, int e_cap, const float* pack, void* out, void* stream);
+int infgen_edge_attn_fused_r24(int rows, const float* Q, const float* pack, const float* Ksrc, const float* Vsrc,
+                               const int* off, const int* cnt, const int* src, const void* rhat24, float* AGG, void* stream);
 int infgen_set_edge_fuse(int mode);
 /* the process-wide defaults (what the infgen_set_* functions edited so far), e.g. to seed a context's own InfgenOptions */
 int infgen_get_options(InfgenOptions* out);

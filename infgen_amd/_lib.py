@@ -115,6 +115,8 @@ SYMBOLS = {
     'infgen_debug_stream_read': (_i, [_p, C.c_ulonglong, _i, _p, _p]),
     'infgen_set_overlap': (_i, [_i]),
     'infgen_edge_attn_fused': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'infgen_edge_attn_fused_r24': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'infgen_fourier_embed_r24': (_i, [_p, _i, _p, _i, _p, _p, _p]),
     'infgen_distance_to_nearest_object': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_float, _p, _p, _p]),
     'infgen_kinematic_features': (_i, [_p, _p, _p, _p, _i, _i, C.c_float, _p, _p, _p, _p, _p]),
     'infgen_time_to_collision': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),

@@ -483,6 +483,19 @@ extern "C" int infgen_edge_attn_fused(int rows, const float* Q, const float* pac
   return edge_fused_launch(rows, Q, pack, Ksrc, Vsrc, off, cnt, src, rhat, AGG, 0, 0, stream);
 }
 
+// the same pair of operators with the rows of rhat in the packed 24-bit form (include/infgen_hip.h): what infgen_decode_layers does
+// for its own edge sets, for callers that own the buffer between the two calls (the map encoder of infgen_amd/engine.py)
+extern "C" int infgen_fourier_embed_r24(const float* raw, int n, const int* count_dev, int e_cap, const float* pack, void* out,
+                                        void* stream) {
+  return fourier_embed_impl(raw, n, count_dev, e_cap, pack, nullptr, 0, static_cast<float*>(out), 128, 1, 1, stream);
+}
+
+extern "C" int infgen_edge_attn_fused_r24(int rows, const float* Q, const float* pack, const float* Ksrc, const float* Vsrc,
+                                          const int* off, const int* cnt, const int* src, const void* rhat24,
+                                          float* AGG, void* stream) {
+  return edge_fused_launch(rows, Q, pack, Ksrc, Vsrc, off, cnt, src, static_cast<const float*>(rhat24), AGG, 0, 0, stream, 1);
+}
+
 // one wave per destination; few destinations (<= 256 rows) get the 8-wave split so that the chip is not idle
 extern "C" int infgen_edge_attn(int rows, const float* Q, const float* U, const float* Ksrc, const float* Vsrc,
                                 const int* off, const int* cnt, const int* src, const float* rhat,

@@ -478,6 +478,13 @@ class RolloutEngine:
             map_tok=np.asarray(pt['token_idx']).astype(np.int64), map_type=np.asarray(pt['type']).astype(np.int64),
             map_pl=np.asarray(pt['pl_type']).astype(np.int64), map_light=light)
 
+    def _fourier_split(self) -> bool:
+        """is the Fourier embedding of the operator-level entries the split kernel (infgen_set_fourier_mode != 0)?  (they read
+        the process-wide switches, like every call of the map encoder)"""
+        o = _lib.Options()
+        _lib.check(self.lib.infgen_get_options(C.byref(o)), 'infgen_get_options')
+        return o.fourier_mode != 0
+
     # ------------------------------------------------------------------ prologue (once per rollout)
     def reset(self):
         """restore the scene state to the rollout's initial condition (device-to-device copies)"""
@@ -538,9 +545,16 @@ class RolloutEngine:
                 self._mg = None
                 return self.prologue(map_only=map_only)
             self._mg_checked = True
-        ops.fourier(g['raw'], 3, w.four_pt, g['rhat'], count_dev=g['total'], rows=g['cap'], normalize=True)
+        fused = os.environ.get('INFGEN_MAP_FUSE', '1') != '0'
+        # rhat rows of the pt <-> pt edges in the packed 24-bit form when both ends know it (split Fourier kernel -> k_edge_fused)
+        r24 = fused and os.environ.get('INFGEN_NO_R24', '0') != '1' and self._fourier_split()
+        if r24:
+            _lib.check(self.lib.infgen_fourier_embed_r24(_lib.ptr(g['raw']), 3, _lib.ptr(g['total']), g['cap'], _lib.ptr(w.four_pt),
+                                                         g['rhat'].data_ptr(), ops.stream), 'infgen_fourier_embed_r24')
+        else:
+            ops.fourier(g['raw'], 3, w.four_pt, g['rhat'], count_dev=g['total'], rows=g['cap'], normalize=True)
         for i in range(cfg.num_map_layers):
-            if os.environ.get('INFGEN_MAP_FUSE', '1') == '0':       # the unfused sequence (comparison)
+            if not fused:                                           # the unfused sequence (comparison)
                 if 'U' not in g:
                     g.update(U=torch.empty(mrows, 8 * D, device=dev), Z=torch.empty(mrows, 8 * D, device=dev),
                              SIG=torch.empty(mrows, 8, device=dev))
@@ -551,8 +565,14 @@ class RolloutEngine:
                 continue
             # edge side with k_edge_fused: the absorbed query and the positional aggregate stay on chip (no U / Z arrays)
             ops.attn_pre(x_pt, w.attn_pt[i], q=g['Q'], k=g['K'], v=g['V'])
-            ops.edge_attn(mrows, g['Q'], w.attn_pt[i], g['K'], g['V'], g['off'], g['cnt'], g['src'], g['rhat'],
-                          g['AGG'], None, None, wide='fused')
+            if r24:
+                _lib.check(self.lib.infgen_edge_attn_fused_r24(mrows, _lib.ptr(g['Q']), _lib.ptr(w.attn_pt[i]), _lib.ptr(g['K']),
+                                                               _lib.ptr(g['V']), _lib.ptr(g['off']), _lib.ptr(g['cnt']),
+                                                               _lib.ptr(g['src']), g['rhat'].data_ptr(), _lib.ptr(g['AGG']),
+                                                               ops.stream), 'infgen_edge_attn_fused_r24')
+            else:
+                ops.edge_attn(mrows, g['Q'], w.attn_pt[i], g['K'], g['V'], g['off'], g['cnt'], g['src'], g['rhat'],
+                              g['AGG'], None, None, wide='fused')
             ops.attn_post(x_pt, w.attn_pt[i], g['AGG'], None, None, has_pos=False)
         if map_only:
             return
