@@ -355,8 +355,11 @@ __global__ __launch_bounds__(NT) void k_map_graph(MapGraphArgs a) {
   float cx = 0.f, cy = 0.f, co = 0.f;
   if (centre) { cx = mp[2 * i]; cy = mp[2 * i + 1]; co = mo[i]; }
   const float r2 = a.radius * a.radius;
-  // pass 1: count kept neighbours (self excluded)
+  // pass 1: count kept neighbours (self excluded); every lane remembers in which 64-token chunks it emits (bit per chunk: up to
+  // 4096 tokens per scene), so that pass 2 neither reloads nor re-tests the tokens that are not emitted
   int found = 0, kept = 0;
+  unsigned long long emit_chunks = 0;
+  const bool masks_ok = M <= 4096;
   if (centre) {
     for (int m0 = 0; m0 < M && found < a.max_nbr + 1; m0 += 64) {
       const int m = m0 + lane;
@@ -368,6 +371,7 @@ __global__ __launch_bounds__(NT) void k_map_graph(MapGraphArgs a) {
       const unsigned long long bal = __ballot(in);
       const int before = __popcll(bal & ((1ull << lane) - 1ull));
       const bool emit = in && (found + before < a.max_nbr + 1) && (m != i);
+      if (emit && masks_ok) emit_chunks |= 1ull << (m0 >> 6);
       kept += (int)__popcll(__ballot(emit));
       found += (int)__popcll(bal);
     }
@@ -387,16 +391,22 @@ __global__ __launch_bounds__(NT) void k_map_graph(MapGraphArgs a) {
   const float ocs = cosf(co), osn = sinf(co);
   found = 0;
   int written = 0;
-  for (int m0 = 0; m0 < M && found < a.max_nbr + 1; m0 += 64) {
+  for (int m0 = 0; m0 < M && (masks_ok ? written < kept : found < a.max_nbr + 1); m0 += 64) {
     const int m = m0 + lane;
-    bool in = false;
-    if (m < M) {
-      const float dx = cx - mp[2 * m], dy = cy - mp[2 * m + 1];
-      in = (dx * dx + dy * dy) < r2;
+    bool emit;
+    if (masks_ok) {
+      emit = (emit_chunks >> (m0 >> 6)) & 1ull;
+    } else {
+      bool in = false;
+      if (m < M) {
+        const float dx = cx - mp[2 * m], dy = cy - mp[2 * m + 1];
+        in = (dx * dx + dy * dy) < r2;
+      }
+      const unsigned long long bal = __ballot(in);
+      const int before = __popcll(bal & ((1ull << lane) - 1ull));
+      emit = in && (found + before < a.max_nbr + 1) && (m != i);
+      found += (int)__popcll(bal);
     }
-    const unsigned long long bal = __ballot(in);
-    const int before = __popcll(bal & ((1ull << lane) - 1ull));
-    const bool emit = in && (found + before < a.max_nbr + 1) && (m != i);
     const unsigned long long ebal = __ballot(emit);
     const int ebefore = __popcll(ebal & ((1ull << lane) - 1ull));
     if (emit) {
@@ -407,7 +417,6 @@ __global__ __launch_bounds__(NT) void k_map_graph(MapGraphArgs a) {
           make_float4(norm2(dx, dy), angle_between(ocs, osn, dx, dy), wrap_angle(mo[m] - co), 0.f);
     }
     written += (int)__popcll(ebal);
-    found += (int)__popcll(bal);
   }
 }
 
