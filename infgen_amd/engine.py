@@ -563,8 +563,10 @@ class RolloutEngine:
                               g['AGG'], g['Z'], g['SIG'])
                 ops.attn_post(x_pt, w.attn_pt[i], g['AGG'], g['Z'], g['SIG'])
                 continue
-            # edge side with k_edge_fused: the absorbed query and the positional aggregate stay on chip (no U / Z arrays)
-            ops.attn_pre(x_pt, w.attn_pt[i], q=g['Q'], k=g['K'], v=g['V'])
+            # edge side with k_edge_fused: the absorbed query and the positional aggregate stay on chip (no U / Z arrays); the pre
+            # part of layer i + 1 rides in the post launch of layer i (as in the agent layers)
+            if i == 0:
+                ops.attn_pre(x_pt, w.attn_pt[0], q=g['Q'], k=g['K'], v=g['V'])
             if r24:
                 _lib.check(self.lib.infgen_edge_attn_fused_r24(mrows, _lib.ptr(g['Q']), _lib.ptr(w.attn_pt[i]), _lib.ptr(g['K']),
                                                                _lib.ptr(g['V']), _lib.ptr(g['off']), _lib.ptr(g['cnt']),
@@ -573,7 +575,11 @@ class RolloutEngine:
             else:
                 ops.edge_attn(mrows, g['Q'], w.attn_pt[i], g['K'], g['V'], g['off'], g['cnt'], g['src'], g['rhat'],
                               g['AGG'], None, None, wide='fused')
-            ops.attn_post(x_pt, w.attn_pt[i], g['AGG'], None, None, has_pos=False)
+            if i + 1 < cfg.num_map_layers:
+                ops.attn_post_pre(x_pt, w.attn_pt[i], g['AGG'], None, None, w.attn_pt[i + 1], has_pos=False,
+                                  q=g['Q'], k=g['K'], v=g['V'])
+            else:
+                ops.attn_post(x_pt, w.attn_pt[i], g['AGG'], None, None, has_pos=False)
         if map_only:
             return
         self._finish_prologue()
