@@ -149,6 +149,10 @@ typedef struct InfgenRollout {
    * computed).  Long teacher-forced comparisons use it where a pose sits on a cell border (arg-min of encode_pos flips with
    * the last bits of the pose) */
   const int* teacher_grid;
+  /* optional [32][128], written by infgen_fourier_last_dim_table(four_t, 4, ..) under the arithmetic (infgen_set_gemm_terms /
+   * opts.gemm_terms) the context runs with: the temporal edges' time-gap input takes the values -1 .. -16 only, so its branch
+   * of r_t_emb (layers.py:150-153, mlps[3]) is looked up instead of evaluated per edge.  NULL: evaluated per edge. */
+  const float* four_t_dt;
 } InfgenRollout;
 
 int infgen_linear(const float* X, int ldx, const int* gather, int rows, int K,
@@ -169,6 +173,13 @@ int infgen_linear_multi(const InfgenLinearDesc* desc, int n, void* stream);
 int infgen_layernorm(const float* X, int rows, const float* gamma, const float* beta, float* Y, void* stream);
 int infgen_fourier_embed(const float* raw, int n_dims, const int* count_dev, int e_cap, const float* pack,
                          const float* cat, int ldcat, float* out, int ldo, int normalize, void* stream);
+/* FourierEmbedding whose LAST continuous input only takes the values 0, -1, .., -31 (the time gap of the temporal edges):
+ * infgen_fourier_last_dim_table writes table[32][128], row k = mlps[n-1](-k) without its bias, with the arithmetic of the
+ * current gemm_terms; infgen_fourier_embed_tab evaluates dims 0 .. n-2 per row and adds row (int)(-raw[e][n-1]) of the table
+ * (same result as infgen_fourier_embed up to the fp32 summation order of the per-dim branches).  Split kernel only. */
+int infgen_fourier_last_dim_table(const float* pack, int n_dims, float* table, void* stream);
+int infgen_fourier_embed_tab(const float* raw, int n_dims, const int* count_dev, int e_cap, const float* pack,
+                             const float* table, float* out, int ldo, int normalize, void* stream);
 /* arithmetic of infgen_fourier_embed: 1 (default) = fp16 MFMA with a three-term hi/lo split of both operands and fp32
  * accumulation (2^-21 relative error per product, 5.3x the fp32 matrix rate), 0 = fp32-input MFMA.  Process-wide. */
 int infgen_set_fourier_mode(int mode);

@@ -91,6 +91,7 @@ class Rollout(C.Structure):
         ('sample_k', _i), ('_pad1', _i), ('sample_u', _p), ('logits_scratch', _p),
         ('opts', Options),
         ('teacher_grid', _p),
+        ('four_t_dt', _p),
     ]
 
 
@@ -117,6 +118,8 @@ SYMBOLS = {
     'infgen_edge_attn_fused': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'infgen_edge_attn_fused_r24': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'infgen_fourier_embed_r24': (_i, [_p, _i, _p, _i, _p, _p, _p]),
+    'infgen_fourier_last_dim_table': (_i, [_p, _i, _p, _p]),
+    'infgen_fourier_embed_tab': (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _p]),
     'infgen_distance_to_nearest_object': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_float, _p, _p, _p]),
     'infgen_kinematic_features': (_i, [_p, _p, _p, _p, _i, _i, C.c_float, _p, _p, _p, _p, _p]),
     'infgen_time_to_collision': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),

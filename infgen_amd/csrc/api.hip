@@ -259,12 +259,15 @@ extern "C" int infgen_set_fourier_mode(int mode) {
 
 // out_r24: rows in the packed 24-bit format of kernels.h (k_fourier_h only; the rollout's private rhat buffers)
 static int fourier_embed_impl(const float* raw, int n, const int* count_dev, int e_cap, const float* pack,
-                              const float* cat, int ldcat, float* out, int ldo, int normalize, int out_r24, void* stream) {
+                              const float* cat, int ldcat, float* out, int ldo, int normalize, int out_r24, void* stream,
+                              const float* dt_tab = nullptr, int dt_mode = 0) {
   if (e_cap <= 0) return 0;
   if (n < 1 || n > 4) return fail("infgen_fourier_embed", "n_dims must be in 1..4");
   if (out_r24 && O().fourier_mode == 0) return fail("infgen_fourier_embed", "packed rows need the split kernel");
+  if (dt_mode && (O().fourier_mode == 0 || n < 2 || (dt_mode == 1 && !dt_tab)))
+    return fail("infgen_fourier_embed", "the last-dim table needs the split kernel, n_dims >= 2 and a table");
   FourierArgs a{raw, n, count_dev, e_cap, pack, cat, ldcat, out, ldo, normalize,
-                (g_prof.mask >> INFGEN_KID_FOURIER) & 1u ? g_prof.rows_dev : nullptr, out_r24};
+                (g_prof.mask >> INFGEN_KID_FOURIER) & 1u && dt_mode != 2 ? g_prof.rows_dev : nullptr, out_r24, dt_tab, dt_mode};
   if (O().fourier_mode == 0) {
     int grid = ceil_div(e_cap, TR);
     if (grid > 2048) grid = 2048;
@@ -283,6 +286,15 @@ static int fourier_embed_impl(const float* raw, int n, const int* count_dev, int
 extern "C" int infgen_fourier_embed(const float* raw, int n, const int* count_dev, int e_cap, const float* pack,
                                     const float* cat, int ldcat, float* out, int ldo, int normalize, void* stream) {
   return fourier_embed_impl(raw, n, count_dev, e_cap, pack, cat, ldcat, out, ldo, normalize, 0, stream);
+}
+
+// The last input dim of a FourierEmbedding as a lookup (include/infgen_hip.h): table of its branch at the values 0, -1, ..
+extern "C" int infgen_fourier_last_dim_table(const float* pack, int n, float* table, void* stream) {
+  return fourier_embed_impl(nullptr, n, nullptr, DT_TAB_ROWS, pack, nullptr, 0, table, 128, 0, 0, stream, nullptr, 2);
+}
+extern "C" int infgen_fourier_embed_tab(const float* raw, int n, const int* count_dev, int e_cap, const float* pack,
+                                        const float* table, float* out, int ldo, int normalize, void* stream) {
+  return fourier_embed_impl(raw, n, count_dev, e_cap, pack, nullptr, 0, out, ldo, normalize, 0, stream, table, 1);
 }
 
 // 0: fp32-input MFMA (k_attn_pre / k_attn_post), 1: fp16 three-term split on 64-row tiles (k_attn_h), 3: the same arithmetic on
@@ -873,6 +885,8 @@ extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless,
   // (INFGEN_NO_R24=1, read per call: fp32 rows instead - tests/test_rollout_gpu.py compares the two)
   const char* no_r24 = getenv("INFGEN_NO_R24");
   const int r24 = fuse && O().fourier_mode != 0 && !(no_r24 && atoi(no_r24));
+  // the temporal set's fourth input (the time gap, one of -1 .. -16) as a lookup of its branch (kernels.h: dt_mode)
+  const float* dt = O().fourier_mode != 0 ? r->four_t_dt : nullptr;
   if (overlap) {
     hipStream_t ms = (hipStream_t)stream;
     if (hipEventRecord(g_ev_fork, ms) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork, 0) != hipSuccess)
@@ -881,9 +895,9 @@ extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless,
     if (hipEventRecord(g_ev_m, g_side) != hipSuccess) return fail("infgen_decode_layers", "event failed");
     RET_IF(fourier_embed_impl(r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, r24, g_side));
     if (hipEventRecord(g_ev_a, g_side) != hipSuccess) return fail("infgen_decode_layers", "event failed");
-    RET_IF(fourier_embed_impl(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, r24, stream));
+    RET_IF(fourier_embed_impl(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, r24, stream, dt, dt != nullptr));
   } else if (!edgeless) {
-    RET_IF(fourier_embed_impl(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, r24, stream));
+    RET_IF(fourier_embed_impl(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, r24, stream, dt, dt != nullptr));
     RET_IF(fourier_embed_impl(r->em.raw, 3, r->em.total, r->em.cap, r->four_m, nullptr, 0, r->em.rhat, 128, 1, r24, stream));
     RET_IF(fourier_embed_impl(r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, r24, stream));
   }

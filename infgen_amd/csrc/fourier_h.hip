@@ -87,13 +87,20 @@ __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
   if (a.prof_rows && blockIdx.x == 0 && tid == 0) atomicAdd(a.prof_rows + a.n, (unsigned long long)E);
   const float* vec = a.pack + fourier_pack_size_f32(a.n);
   const unsigned short* wg = reinterpret_cast<const unsigned short*>(vec + FH_VEC_SIZE);
-  __shared__ const unsigned short* seg_ptr[1];
-  __shared__ int seg_n[1];
-  if (tid == 0) { seg_ptr[0] = wg; seg_n[0] = 4 * (2 * a.n + 1); }   // quarter-matrices per tile, consumed in storage order
+  __shared__ const unsigned short* seg_ptr[2];
+  __shared__ int seg_n[2];
+  // quarter-matrices per tile, consumed in storage order (W1_i W2_i per dim, then W3); the table modes skip the last dim's
+  // eight quarters (1) or stage nothing else (2)
+  const int mode = a.dt_mode;
+  const int i_lo = mode == 2 ? a.n - 1 : 0, i_hi = mode == 1 ? a.n - 1 : a.n;
+  if (tid == 0) {
+    seg_ptr[0] = wg + (size_t)8 * i_lo * QUARTER; seg_n[0] = mode == 0 ? 4 * (2 * a.n + 1) : 8 * (i_hi - i_lo);
+    seg_ptr[1] = wg + (size_t)8 * a.n * QUARTER; seg_n[1] = 4;
+  }
   for (int i = tid; i < FH_VEC_SIZE; i += FH_NT) Vt[i] = vec[i];
   __syncthreads();
   QuarterStream<FH_NT, RING> qs;
-  qs.init(seg_ptr, seg_n, 1, (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x, Wb, tid);
+  qs.init(seg_ptr, seg_n, mode == 1 ? 2 : 1, (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x, Wb, tid);
   auto take = [&]() { return qs.take(); };
   const float inv2 = Vt[FH_HDR + 4], inv3 = Vt[FH_HDR + 5], fscale = Vt[FH_HDR + 6];
   const float* tail = Vt + FH_TAIL;
@@ -102,13 +109,14 @@ __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
     const int e = tile * FH_TILE + w * 16 + j;
     const bool valid = e < E;
     float4 rawv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) rawv = *reinterpret_cast<const float4*>(a.raw + 4 * (size_t)e);
+    if (valid && mode != 2) rawv = *reinterpret_cast<const float4*>(a.raw + 4 * (size_t)e);
+    if (mode == 2) rawv = make_float4(-(float)e, -(float)e, -(float)e, -(float)e);
     u32x4 Bh[4], Bl[4];
     f32x4 acc2[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int i = 0; i < a.n; ++i) {
+    for (int i = i_lo; i < i_hi; ++i) {
       const float x = (i == 0) ? rawv.x : (i == 1) ? rawv.y : (i == 2) ? rawv.z : rawv.w;
       const float* fq = Vt + FH_FREQ + i * 64;
       const float* dv = Vt + FH_DIM0 + i * FHD_SIZE;
@@ -152,11 +160,28 @@ __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) gemm_quarter<TERMS>(acc2, take(), Bh[s], Bl[s], lane);
     }
+    if (mode == 2) {
+      if (valid) {
+        float* o = a.out + (size_t)e * a.ldo;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const f32x4 v = acc2[t] * splat4(inv2);
+          *reinterpret_cast<float4*>(o + 16 * t + 4 * rg) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+      continue;
+    }
+    const float* dtrow = nullptr;
+    if (mode == 1 && valid) {
+      const float g = a.n == 4 ? rawv.w : a.n == 3 ? rawv.z : a.n == 2 ? rawv.y : rawv.x;
+      dtrow = a.dt_tab + 128 * min(max((int)(-g), 0), DT_TAB_ROWS - 1);
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int f = 16 * t + 4 * rg;
       f32x4 c = lds4(tail + FHT_B2SUM + f);
       if (a.cat && valid) c += lds4(a.cat + (size_t)e * a.ldcat + f);
+      if (dtrow) c += lds4(dtrow + f);
       acc2[t] = fma4(acc2[t], splat4(inv2), c);
     }
     ln_regs<true, true>(acc2, tail + FHT_G2, tail + FHT_BE2, rg);

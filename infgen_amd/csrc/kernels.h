@@ -28,7 +28,13 @@ struct FourierArgs {
   int normalize;
   unsigned long long* prof_rows;   // optional [8]: rows processed, indexed by n (profiling only)
   int out_r24;             // k_fourier_h only: rows in the packed 24-bit format (R24_ROW_BYTES per row, below) instead of fp32
+  // k_fourier_h only - the LAST input dim as a lookup (temporal edges: the time gap j - c is one of -1 .. -16, edge_kernels.hip):
+  // dt_mode 1: dims 0 .. n - 2 are evaluated, row (int)(-raw[e][n - 1]) of dt_tab [DT_TAB_ROWS][128] is added to their sum
+  //            (8 of the 4 (2 n + 1) weight quarters per tile are never staged);
+  // dt_mode 2: writes that table - row e = the last dim's branch mlps[n - 1](-e) without its bias (the bias sum stays in the pack)
+  const float* dt_tab; int dt_mode;
 };
+constexpr int DT_TAB_ROWS = 32;
 
 // Packed 24-bit rows of the normalised relative-position embedding (the rollout's private edge buffers; k_fourier_h writes,
 // k_edge_fused reads): the upper 24 bits of every fp32 value (sign, exponent, 15 mantissa bits, round to nearest even) as two

@@ -61,6 +61,7 @@ class PackedWeights:
         self.attn_pt = [dev(packing.pack_attention_layer(sd, f'{mp}.pt2pt_layers.{i}'))
                         for i in range(cfg.num_map_layers)]
         self.four_t = dev(packing.pack_fourier(sd, f'{ap}.r_t_emb', 4))
+        self._time_gap_tables = {}
         self.four_m = dev(packing.pack_fourier(sd, f'{ap}.r_pt2a_emb', 3))
         self.four_a = dev(packing.pack_fourier(sd, f'{ap}.r_a2a_emb', 3))
         self.four_xa = dev(packing.pack_fourier(sd, f'{ap}.x_a_emb', 2))
@@ -94,6 +95,26 @@ class PackedWeights:
                        'seed_offset_xy_predict_head', 'seed_agent_occ_embed')}
         self._tables = None
         self._tables_key = None
+
+    def time_gap_table(self, lib, terms: int, stream):
+        """[32][128] table of r_t_emb's fourth branch (the time gap of a temporal edge is one of -1 .. -16, agent_decoder.py:586-600)
+        under the arithmetic ``terms`` (infgen_fourier_last_dim_table), cached per pack"""
+        tab = self._time_gap_tables.get(terms)
+        if tab is None:
+            o = _lib.Options()
+            _lib.check(lib.infgen_get_options(C.byref(o)), 'infgen_get_options')
+            tab = torch.zeros(32, D, device=self.four_t.device)
+            if o.gemm_terms != terms:
+                _lib.check(lib.infgen_set_gemm_terms(terms), 'infgen_set_gemm_terms')
+            try:
+                _lib.check(lib.infgen_fourier_last_dim_table(_lib.ptr(self.four_t), 4, _lib.ptr(tab), stream),
+                           'infgen_fourier_last_dim_table')
+            finally:
+                if o.gemm_terms != terms:
+                    _lib.check(lib.infgen_set_gemm_terms(int(o.gemm_terms)), 'infgen_set_gemm_terms')
+            torch.cuda.synchronize(tab.device)
+            self._time_gap_tables[terms] = tab
+        return tab
 
     def tables(self, ops: 'Ops', vocab_dev: torch.Tensor, grid_dev: torch.Tensor, map_vocab_dev: torch.Tensor):
         """Per-checkpoint constants (the reference recomputes them in every inference call,
@@ -809,6 +830,11 @@ class RolloutEngine:
         for k, v in (self.options or {}).items():
             setattr(o, k, int(v))
         o.use = 1
+        # the temporal edges' time-gap input as a lookup of its r_t_emb branch (include/infgen_hip.h: four_t_dt), built once per
+        # weight pack and arithmetic; INFGEN_NO_DT_TAB=1: evaluated per edge as before
+        self._ctx.four_t_dt = None
+        if o.fourier_mode != 0 and os.environ.get('INFGEN_NO_DT_TAB', '0') != '1':
+            self._ctx.four_t_dt = _lib.ptr(self.w.time_gap_table(self.lib, int(o.gemm_terms), self.ops.stream))
         o.row_groups = o.n_row_groups = None
         o.row_group_margin = 0
         if groups and self.insertion and self.ins is not None and os.environ.get('INFGEN_ROW_GROUPS', '1') != '0':

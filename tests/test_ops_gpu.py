@@ -98,6 +98,47 @@ def _fourier_case(env, n, prefix, E):
     assert np.abs(out2.cpu().numpy() - ref2.numpy()).max() <= 2e-4
 
 
+@pytest.mark.parametrize('terms', [3, 1])
+def test_fourier_time_gap_table(env, terms):
+    """the temporal edges' fourth input (time gap -1 .. -16) as a lookup of its branch (infgen_fourier_last_dim_table /
+    infgen_fourier_embed_tab) against the oracle (layers.py:142-160) and against the per-edge evaluation of the same kernel"""
+    from oracle import rollout_oracle as ro
+    from infgen_amd import _lib
+    lib, dev = env['lib'], env['dev']
+    E, prefix = 40003, 'agent_encoder.r_t_emb'
+    rng = np.random.default_rng(44)
+    raw = np.zeros((E, 4), np.float32)
+    raw[:, 0] = rng.uniform(0, 60, E)
+    raw[:, 1:3] = rng.uniform(-np.pi, np.pi, (E, 2))
+    raw[:, 3] = -rng.integers(1, 17, E)
+    pack = _dev(env['packing'].pack_fourier(env['sd'], prefix, 4), dev)
+    rawd = _dev(raw, dev)
+    _lib.check(lib.infgen_set_gemm_terms(terms))
+    try:
+        tab = torch.zeros(32, 128, device=dev)
+        _lib.check(lib.infgen_fourier_last_dim_table(_lib.ptr(pack), 4, _lib.ptr(tab), env['ops'].stream))
+        outs = []
+        for normalize in (0, 1):
+            a, b = torch.empty(E, 128, device=dev), torch.empty(E, 128, device=dev)
+            _lib.check(lib.infgen_fourier_embed_tab(_lib.ptr(rawd), 4, None, E, _lib.ptr(pack), _lib.ptr(tab), a.data_ptr(), 128,
+                                                    normalize, env['ops'].stream))
+            env['ops'].fourier(rawd, 4, pack, b, normalize=bool(normalize))
+            outs.append((a.cpu().numpy(), b.cpu().numpy()))
+    finally:
+        _lib.check(lib.infgen_set_gemm_terms(3))
+    with torch.no_grad():
+        ref = ro.fourier_embedding(env['tsd'], prefix, torch.from_numpy(raw), None)
+    ref2 = torch.nn.functional.layer_norm(ref, (128,)).numpy()
+    (a0, b0), (a1, b1) = outs
+    # three-term split: only the fp32 summation order of the branches differs; plain fp16 operands: a last-bit change of the sum
+    # can move the fp16 rounding of an activation (2^-11), the mode's own error level
+    assert np.abs(a0 - b0).max() <= (2e-6 if terms == 3 else 2e-3) * max(1.0, np.abs(b0).max())
+    assert np.abs(a1 - b1).max() <= (1e-5 if terms == 3 else 5e-3)
+    if terms == 3:
+        assert np.abs(a0 - ref.numpy()).max() <= 5e-5
+        assert np.abs(a1 - ref2).max() <= 2e-4
+
+
 def test_fourier_split_is_deterministic(env):
     """350k rows (every CU busy for ~10 tiles), four launches: bitwise identical, and equal to the fp32-MFMA kernel
     within the split's accuracy.  Guards the one-workgroup-per-CU placement of k_fourier_h (csrc/fourier_h.hip)."""
