@@ -326,6 +326,7 @@ def main():
                  'mfma_fraction': f_alg / t_roll / (F16_SPLIT_PEAK_TFLOPS * 1e12),
                  'mfma_fraction_vs_fp32_matrix_peak': f_alg / t_roll / (FP32_MATRIX_PEAK_TFLOPS * 1e12),
                  'algorithmic_gbytes_per_rollout': b_alg / 1e9, 'algorithmic_gflop_per_rollout': f_alg / 1e9,
+                 'edges_built_per_rollout': {k: float(ed1[k]) for k in ('temporal', 'map', 'agent')},
                  'note': 'SURVEY 8d figures (windowed K/V, every datum moved once; reference per-edge FLOPs) over the measured '
                          'rollout time incl. the map-encoder prologue'}
 
