@@ -569,6 +569,33 @@ def test_packed_rhat_rows_match_fp32_rows():
     assert 0.0 < worst <= 5e-5, worst          # (> 0: the packed path really ran)
 
 
+def test_time_gap_lookup_matches_per_edge_evaluation():
+    """the temporal edges' time-gap branch of r_t_emb looked up (InfgenRollout.four_t_dt) against the same rollout with
+    the branch evaluated per edge (INFGEN_NO_DT_TAB=1): tokens identical, logits within 2e-5 (fp32 summation order only) - and
+    different at all, i.e. the lookup really ran"""
+    import os
+    from infgen_amd import engine, synth
+    c = load_case('c2_a32_m512')
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], c['cfg'], dev)
+    scenes = [synth.make_scene(900 + i, 20 + i, 300, c['cfg'], vocab=c['vocab'], grid=c['grid'], slip=0.2) for i in range(12)]
+    outs = []
+    try:
+        for off in ('1', '0'):
+            os.environ['INFGEN_NO_DT_TAB'] = off
+            eng = engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=True)
+            eng.rollout()
+            assert bool(eng._ctx.four_t_dt) == (off == '0')
+            outs.append(eng.outputs())
+    finally:
+        os.environ.pop('INFGEN_NO_DT_TAB', None)
+    worst = 0.0
+    for a, b in zip(*outs):
+        assert np.array_equal(a['next_token_idx'], b['next_token_idx'])
+        worst = max(worst, float(np.abs(a['logits'] - b['logits']).max()))
+    assert 0.0 < worst <= 2e-5, worst
+
+
 def test_bench_size_batch_properties():
     """BASELINE C3 shapes at the bench's full size (512 scenes x 64 agents x 1024 map tokens, R = 80), checked through
     size-independent properties: a second rollout of the same batch is bitwise identical; scenes are independent units,
