@@ -277,11 +277,7 @@ static int fourier_embed_impl(const float* raw, int n, const int* count_dev, int
     int grid = ceil_div(e_cap, 128);     // 128-row tiles (8 waves x 16 rows), persistent
     if (grid > 256) grid = 256;          // one workgroup per CU (fourier_h.hip explains why)
     ProfScope _ps(INFGEN_KID_FOURIER, stream);
-    static const int u2 = getenv("INFGEN_FOURIER_U2") ? atoi(getenv("INFGEN_FOURIER_U2")) : 0;
-    if (u2) {
-      if (O().gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h2<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-      else hipLaunchKernelGGL(k_fourier_h2<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    } else if (O().gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h<1>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    if (O().gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h<1>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_fourier_h<3>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
   }
   return check_launch("infgen_fourier_embed");

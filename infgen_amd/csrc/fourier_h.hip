@@ -223,213 +223,4 @@ __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
 template __global__ void k_fourier_h<3>(FourierArgs);
 template __global__ void k_fourier_h<1>(FourierArgs);
 
-// k_fourier_h2: the same computation with TWO 16-edge groups per wave (4 waves x 32 edges, one wave per SIMD, up to 512
-// registers): every A fragment read from LDS feeds the MFMAs of both groups - half the LDS reads and half the barriers per edge.
-// Selected by INFGEN_FOURIER_U2=1 (api.hip); results are bitwise those of k_fourier_h (same operations per edge).
-constexpr int FH2_WAVES = 4;
-constexpr int FH2_NT = 64 * FH2_WAVES;
-constexpr int FH2_TILE = 32 * FH2_WAVES;
-
-template <int TERMS>
-__device__ __forceinline__ void gemm_quarter2(f32x4 (&acc0)[8], f32x4 (&acc1)[8], const unsigned short* Wl, u32x4 Bh0, u32x4 Bl0,
-                                              u32x4 Bh1, u32x4 Bl1, int lane) {
-  const v8h bh0 = __builtin_bit_cast(v8h, Bh0), bl0 = __builtin_bit_cast(v8h, Bl0);
-  const v8h bh1 = __builtin_bit_cast(v8h, Bh1), bl1 = __builtin_bit_cast(v8h, Bl1);
-  const unsigned short* p = Wl + lane * 8;
-#pragma unroll
-  for (int g = 0; g < 8; g += 4) {
-    v8h ah[4], al[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      ah[t] = *reinterpret_cast<const v8h*>(p + (g + t) * 1024);
-      if constexpr (TERMS == 3) al[t] = *reinterpret_cast<const v8h*>(p + (g + t) * 1024 + 512);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc0[g + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh0, acc0[g + t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc1[g + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh1, acc1[g + t], 0, 0, 0);
-    if constexpr (TERMS == 3) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc0[g + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl0, acc0[g + t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc1[g + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl1, acc1[g + t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc0[g + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh0, acc0[g + t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc1[g + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh1, acc1[g + t], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-template <int TERMS>
-__global__ __launch_bounds__(FH2_NT, 1) void k_fourier_h2(FourierArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned short Wb[RING][QUARTER];
-  __shared__ __attribute__((aligned(16))) float Vt[FH_VEC_SIZE];
-  const int E = a.count_dev ? min(*a.count_dev, a.e_cap) : a.e_cap;
-  const int ntiles = (E + FH2_TILE - 1) / FH2_TILE;
-  if ((int)blockIdx.x >= ntiles) return;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, w = tid >> 6;
-  const int j = lane & 15, rg = lane >> 4;
-  if (a.prof_rows && blockIdx.x == 0 && tid == 0) atomicAdd(a.prof_rows + a.n, (unsigned long long)E);
-  const float* vec = a.pack + fourier_pack_size_f32(a.n);
-  const unsigned short* wg = reinterpret_cast<const unsigned short*>(vec + FH_VEC_SIZE);
-  __shared__ const unsigned short* seg_ptr[2];
-  __shared__ int seg_n[2];
-  const int mode = a.dt_mode;
-  const int i_lo = mode == 2 ? a.n - 1 : 0, i_hi = mode == 1 ? a.n - 1 : a.n;
-  if (tid == 0) {
-    seg_ptr[0] = wg + (size_t)8 * i_lo * QUARTER; seg_n[0] = mode == 0 ? 4 * (2 * a.n + 1) : 8 * (i_hi - i_lo);
-    seg_ptr[1] = wg + (size_t)8 * a.n * QUARTER; seg_n[1] = 4;
-  }
-  for (int i = tid; i < FH_VEC_SIZE; i += FH2_NT) Vt[i] = vec[i];
-  __syncthreads();
-  QuarterStream<FH2_NT, RING> qs;
-  qs.init(seg_ptr, seg_n, mode == 1 ? 2 : 1, (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x, Wb, tid);
-  const float inv2 = Vt[FH_HDR + 4], inv3 = Vt[FH_HDR + 5], fscale = Vt[FH_HDR + 6];
-  const float* tail = Vt + FH_TAIL;
-
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    int e[2];
-    bool valid[2];
-    float4 rawv[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      e[u] = tile * FH2_TILE + w * 32 + u * 16 + j;
-      valid[u] = e[u] < E;
-      rawv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (valid[u] && mode != 2) rawv[u] = *reinterpret_cast<const float4*>(a.raw + 4 * (size_t)e[u]);
-      if (mode == 2) rawv[u] = make_float4(-(float)e[u], -(float)e[u], -(float)e[u], -(float)e[u]);
-    }
-    u32x4 Bh[2][4], Bl[2][4];
-    f32x4 acc2[2][8];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int t = 0; t < 8; ++t) acc2[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int i = i_lo; i < i_hi; ++i) {
-      const float* fq = Vt + FH_FREQ + i * 64;
-      const float* dv = Vt + FH_DIM0 + i * FHD_SIZE;
-      float xs[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const float x = (i == 0) ? rawv[u].x : (i == 1) ? rawv[u].y : (i == 2) ? rawv[u].z : rawv[u].w;
-        xs[u] = x;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const float4 f0 = *reinterpret_cast<const float4*>(fq + 32 * s + 8 * rg);
-          const float4 f1 = *reinterpret_cast<const float4*>(fq + 32 * s + 8 * rg + 4);
-          const float fr[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-          float cs[8], sn[8];
-#pragma unroll
-          for (int p = 0; p < 8; ++p) {
-            const float z = x * fr[p] * 2.0f * PI_F;
-            sincos_fast(z, sn[p], cs[p]);
-            cs[p] *= fscale; sn[p] *= fscale;
-          }
-#pragma unroll
-          for (int wd = 0; wd < 4; ++wd) {
-            unsigned hi, lo;
-            split_pair(cs[2 * wd], cs[2 * wd + 1], hi, lo);
-            Bh[u][s][wd] = hi; Bl[u][s][wd] = lo;
-            split_pair(sn[2 * wd], sn[2 * wd + 1], hi, lo);
-            Bh[u][s + 2][wd] = hi; Bl[u][s + 2][wd] = lo;
-          }
-        }
-      }
-      f32x4 acc1[2][8];
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) acc1[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) gemm_quarter2<TERMS>(acc1[0], acc1[1], qs.take(), Bh[0][s], Bl[0][s], Bh[1][s], Bl[1][s], lane);
-      const float inv1 = Vt[FH_HDR + i];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          acc1[u][t] = fma4(acc1[u][t], splat4(inv1),
-                            fma4(splat4(xs[u]), lds4(dv + FHD_WX + 16 * t + 4 * rg), lds4(dv + FHD_B1 + 16 * t + 4 * rg)));
-        }
-        ln_regs<true, true>(acc1[u], dv + FHD_G1, dv + FHD_BE1, rg);
-        regs_to_frags(acc1[u], Bh[u], Bl[u]);
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) gemm_quarter2<TERMS>(acc2[0], acc2[1], qs.take(), Bh[0][s], Bl[0][s], Bh[1][s], Bl[1][s], lane);
-    }
-    if (mode == 2) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-        if (valid[u]) {
-          float* o = a.out + (size_t)e[u] * a.ldo;
-#pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            const f32x4 v = acc2[u][t] * splat4(inv2);
-            *reinterpret_cast<float4*>(o + 16 * t + 4 * rg) = make_float4(v[0], v[1], v[2], v[3]);
-          }
-        }
-      continue;
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const float* dtrow = nullptr;
-      if (mode == 1 && valid[u]) {
-        const float g = a.n == 4 ? rawv[u].w : a.n == 3 ? rawv[u].z : a.n == 2 ? rawv[u].y : rawv[u].x;
-        dtrow = a.dt_tab + 128 * min(max((int)(-g), 0), DT_TAB_ROWS - 1);
-      }
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int f = 16 * t + 4 * rg;
-        f32x4 c = lds4(tail + FHT_B2SUM + f);
-        if (a.cat && valid[u]) c += lds4(a.cat + (size_t)e[u] * a.ldcat + f);
-        if (dtrow) c += lds4(dtrow + f);
-        acc2[u][t] = fma4(acc2[u][t], splat4(inv2), c);
-      }
-      ln_regs<true, true>(acc2[u], tail + FHT_G2, tail + FHT_BE2, rg);
-      regs_to_frags(acc2[u], Bh[u], Bl[u]);
-    }
-    f32x4 acc3[2][8];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int t = 0; t < 8; ++t) acc3[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 4; ++s) gemm_quarter2<TERMS>(acc3[0], acc3[1], qs.take(), Bh[0][s], Bl[0][s], Bh[1][s], Bl[1][s], lane);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) acc3[u][t] = fma4(acc3[u][t], splat4(inv3), lds4(tail + FHT_B3 + 16 * t + 4 * rg));
-      if (a.normalize) ln_regs<false, false>(acc3[u], nullptr, nullptr, rg);
-      if (valid[u] && a.out_r24) {
-        char* o = reinterpret_cast<char*>(a.out) + (size_t)e[u] * R24_ROW_BYTES;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          unsigned q[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const unsigned b = __float_as_uint(acc3[u][t][k]);
-            q[k] = b + 0x7fu + ((b >> 8) & 1u);
-          }
-          *reinterpret_cast<uint2*>(o + 2 * (16 * t + 4 * rg)) = make_uint2((q[0] >> 16) | (q[1] & 0xffff0000u), (q[2] >> 16) | (q[3] & 0xffff0000u));
-          *reinterpret_cast<unsigned*>(o + R24_LO_PLANE + 16 * t + 4 * rg) =
-              ((q[0] >> 8) & 0xffu) | (q[1] & 0xff00u) | ((q[2] << 8) & 0xff0000u) | ((q[3] << 16) & 0xff000000u);
-        }
-      } else if (valid[u]) {
-        float* o = a.out + (size_t)e[u] * a.ldo;
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-          *reinterpret_cast<float4*>(o + 16 * t + 4 * rg) = make_float4(acc3[u][t][0], acc3[u][t][1], acc3[u][t][2], acc3[u][t][3]);
-      }
-    }
-  }
-}
-
-template __global__ void k_fourier_h2<3>(FourierArgs);
-template __global__ void k_fourier_h2<1>(FourierArgs);
-
-
 }  // namespace ig

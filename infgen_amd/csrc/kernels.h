@@ -386,7 +386,6 @@ __global__ void k_linear(LinearArgs a);
 __global__ void k_linear_multi(LinearMultiArgs m);
 __global__ void k_fourier(FourierArgs a);
 template <int TERMS> __global__ void k_fourier_h(FourierArgs a);
-template <int TERMS> __global__ void k_fourier_h2(FourierArgs a);   // two 16-edge groups per wave (INFGEN_FOURIER_U2=1)
 __global__ void k_match_tokens(MatchTokensArgs a);   // token_kernels.hip
 template <int TERMS> __global__ void k_mlpemb_h(MlpEmbHArgs a);           // mlp_h.hip
 __global__ void k_box_corners(NearestArgs a);        // metric_kernels.hip
