@@ -454,7 +454,7 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
     const size_t nb = (size_t)rows * 12 * sizeof(unsigned);
     if (dbg & 8) {
       if (!dbuf[slot][gen] && hipMalloc(&dbuf[slot][gen], nb) != hipSuccess) return fail("infgen_edge_attn_fused", "debug buffer");
-      hipMemsetAsync(dbuf[slot][gen], 0, nb, (hipStream_t)stream);
+      (void)hipMemsetAsync(dbuf[slot][gen], 0, nb, (hipStream_t)stream);
       a.dbgbuf = dbuf[slot][gen];
     }
     { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
@@ -462,9 +462,9 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
       else hipLaunchKernelGGL(k_edge_fused_p<6>, dim3(pg), dim3(1024), 0, (hipStream_t)stream, a); }
     if ((dbg & 8) && n_launch >= 3 && dbuf[slot][gen ^ 1]) {
       std::vector<unsigned> x((size_t)rows * 12), y((size_t)rows * 12);
-      hipStreamSynchronize((hipStream_t)stream);
-      hipMemcpy(x.data(), dbuf[slot][gen], nb, hipMemcpyDeviceToHost);
-      hipMemcpy(y.data(), dbuf[slot][gen ^ 1], nb, hipMemcpyDeviceToHost);
+      (void)hipStreamSynchronize((hipStream_t)stream);
+      (void)hipMemcpy(x.data(), dbuf[slot][gen], nb, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(y.data(), dbuf[slot][gen ^ 1], nb, hipMemcpyDeviceToHost);
       long du = 0, dq = 0, dz = 0, dr = 0, dr_only = 0, dl = 0, dz_only = 0;
       for (int r_ = 0; r_ < rows; ++r_) {
         const unsigned* p = &x[(size_t)r_ * 12]; const unsigned* q = &y[(size_t)r_ * 12];
