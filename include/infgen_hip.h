@@ -231,6 +231,12 @@ int infgen_attn_post_pre(float* X, int rows, const float* pack, const float* AGG
                          int has_pos, const float* next_pack, float* nQ, float* nU, float* nK, float* nV, void* stream);
 int infgen_heads(const float* X, int rows, const float* tok_pack, const float* st_pack, int token_size,
                  float* logits, int* next_token, int* next_state, void* stream);
+/* out[k][:] = tab0[idx0[k]] + ((tab1[idx1[k]] + tab2[idx2[k]]) + tab3[idx3[k]]), rows of 128 floats, int64 indices (clamped to
+ * the table sizes n0 .. n3): the map-token embedding plus the sum of its three nn.Embedding rows in one pass
+ * (infgen/modules/map_decoder.py:87-89 and the token table of :70-86), in torch's summation order */
+int infgen_embedding_sum4(const float* tab0, const long long* idx0, int n0, const float* tab1, const long long* idx1, int n1,
+                          const float* tab2, const long long* idx2, int n2, const float* tab3, const long long* idx3, int n3,
+                          int rows, float* out, void* stream);
 /* compacted CSR: `total` (device int) receives the edge count; rows whose edges would exceed `cap`
  * get cnt = 0 and the caller must retry with a larger buffer when *total > cap */
 int infgen_map_graph(int S, int M_cap, const int* n_map, const float* pos, const float* orient, float radius,

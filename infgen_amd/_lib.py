@@ -118,6 +118,7 @@ SYMBOLS = {
     'infgen_edge_attn_fused': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'infgen_edge_attn_fused_r24': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'infgen_fourier_embed_r24': (_i, [_p, _i, _p, _i, _p, _p, _p]),
+    'infgen_embedding_sum4': (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _p, _p]),
     'infgen_fourier_last_dim_table': (_i, [_p, _i, _p, _p]),
     'infgen_fourier_embed_tab': (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _p]),
     'infgen_distance_to_nearest_object': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_float, _p, _p, _p]),

@@ -699,6 +699,17 @@ extern "C" int infgen_heads(const float* X, int rows, const float* tok_pack, con
   return check_launch("infgen_heads");
 }
 
+extern "C" int infgen_embedding_sum4(const float* tab0, const long long* idx0, int n0, const float* tab1, const long long* idx1, int n1,
+                                     const float* tab2, const long long* idx2, int n2, const float* tab3, const long long* idx3, int n3,
+                                     int rows, float* out, void* stream) {
+  if (rows <= 0) return 0;
+  if (!tab0 || !tab1 || !tab2 || !tab3 || !idx0 || !idx1 || !idx2 || !idx3 || !out || n0 < 1 || n1 < 1 || n2 < 1 || n3 < 1)
+    return fail("infgen_embedding_sum4", "null table / index array or empty table");
+  EmbedSum4Args a{{tab0, tab1, tab2, tab3}, {idx0, idx1, idx2, idx3}, {n0, n1, n2, n3}, rows, out};
+  hipLaunchKernelGGL(k_embedding_sum4, dim3((unsigned)(((long long)rows * 32 + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, a);
+  return check_launch("infgen_embedding_sum4");
+}
+
 extern "C" int infgen_map_graph(int S, int M_cap, const int* n_map, const float* pos, const float* orient,
                                 float radius, int max_nbr, int* off, int* cnt, int* src, float* raw, int* total,
                                 int cap, void* stream) {

@@ -619,6 +619,27 @@ __global__ __launch_bounds__(NT) void k_gather_rows(const float* src, const int*
   *reinterpret_cast<float4*>(dst + (size_t)k * D + 4 * c4) = v;
 }
 
+// k_embedding_sum4: out[k] = tab0[i0[k]] + ((tab1[i1[k]] + tab2[i2[k]]) + tab3[i3[k]]) - the map-token table row plus its three
+// categorical embeddings (map_decoder.py:87-89) in one pass over the rows instead of four gathers and three adds.  32 threads
+// per row, one float4 each.
+__global__ __launch_bounds__(NT) void k_embedding_sum4(EmbedSum4Args a) {
+  const int gid = blockIdx.x * NT + threadIdx.x;
+  const int k = gid >> 5, c4 = gid & 31;
+  if (k >= a.rows) return;
+  float4 v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long r = min(max(a.idx[i][k], 0ll), (long long)a.n[i] - 1);
+    v[i] = *reinterpret_cast<const float4*>(a.tab[i] + (size_t)r * D + 4 * c4);
+  }
+  float4 o;
+  o.x = v[0].x + ((v[1].x + v[2].x) + v[3].x);
+  o.y = v[0].y + ((v[1].y + v[2].y) + v[3].y);
+  o.z = v[0].z + ((v[1].z + v[2].z) + v[3].z);
+  o.w = v[0].w + ((v[1].w + v[2].w) + v[3].w);
+  *reinterpret_cast<float4*>(a.out + (size_t)k * D + 4 * c4) = o;
+}
+
 // k_insert_cat: categorical embedding / shape of the rows a sub-loop iteration appended (agent_decoder.py:1949-1950, :1993):
 // cat_agent[new_row] = type_a_emb[type[new_row]] + shape_emb(new_shape)[s], shape_all[new_row] = new_shape[s]; and the new
 // row's index inside its scene (the centre of the heading stage's edge search).  32 threads per scene.

@@ -419,6 +419,11 @@ __global__ void k_scatter_rows2(const float* src0, const float* src1, const int*
                                 float* dst1);
 __global__ void k_note_riders(const int* new_row, const int* inserted, int n, int* prev_row, int* prev_mask, int* pend_row,
                               int* pend_mask);
+struct EmbedSum4Args {
+  const float* tab[4]; const long long* idx[4]; int n[4];
+  int rows; float* out;
+};
+__global__ void k_embedding_sum4(EmbedSum4Args a);
 __global__ void k_gather_rows(const float* src, const int* row_list, const int* row_mask, int n, int limit, float* dst);
 __global__ void k_insert_cat(InsertCatArgs a);
 __global__ void k_map_graph(MapGraphArgs a);

@@ -539,11 +539,15 @@ class RolloutEngine:
         # ---- map encoder
         mrows = S * M_cap
         mtok, mtype, mpl, mlight = self._map_cat
-        x_pt = tabs['map_tab'][mtok.reshape(-1)]
-        cat = (w.type_pt_emb[mtype.reshape(-1)] + w.polygon_type_emb[mpl.reshape(-1)]) + w.light_pl_emb[mlight.reshape(-1)]
         if self.x_pt is None:
             self.x_pt = torch.empty(mrows, D, device=dev)
-        torch.add(x_pt, cat, out=self.x_pt)
+        # token-table row + (type + polygon type) + light embedding (map_decoder.py:87-89) in one pass over the rows
+        mt = tabs['map_tab']
+        _lib.check(self.lib.infgen_embedding_sum4(_lib.ptr(mt), _lib.ptr(mtok), mt.shape[0], _lib.ptr(w.type_pt_emb), _lib.ptr(mtype),
+                                                  w.type_pt_emb.shape[0], _lib.ptr(w.polygon_type_emb), _lib.ptr(mpl),
+                                                  w.polygon_type_emb.shape[0], _lib.ptr(w.light_pl_emb), _lib.ptr(mlight),
+                                                  w.light_pl_emb.shape[0], mrows, _lib.ptr(self.x_pt), ops.stream),
+                   'infgen_embedding_sum4')
         x_pt = self.x_pt
         K = 100
         if self._mg is None:

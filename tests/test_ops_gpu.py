@@ -98,6 +98,30 @@ def _fourier_case(env, n, prefix, E):
     assert np.abs(out2.cpu().numpy() - ref2.numpy()).max() <= 2e-4
 
 
+def test_embedding_sum4_is_torch_indexing(env):
+    """infgen_embedding_sum4 (the map-token embedding + its three nn.Embedding rows, map_decoder.py:87-89) bitwise against the
+    torch expression it replaces; out-of-range indices are clamped"""
+    from infgen_amd import _lib
+    dev = env['dev']
+    g = torch.Generator().manual_seed(5)
+    tabs = [torch.randn(n, 128, generator=g).to(dev) for n in (1024, 17, 4, 4)]
+    rows = 70001
+    idx = [torch.randint(0, t.shape[0], (rows,), generator=g).to(dev) for t in tabs]
+    out = torch.empty(rows, 128, device=dev)
+    args = []
+    for t, i in zip(tabs, idx):
+        args += [_lib.ptr(t), _lib.ptr(i), t.shape[0]]
+    _lib.check(env['lib'].infgen_embedding_sum4(*args, rows, _lib.ptr(out), env['ops'].stream))
+    ref = tabs[0][idx[0]] + ((tabs[1][idx[1]] + tabs[2][idx[2]]) + tabs[3][idx[3]])
+    assert torch.equal(out, ref)
+    bad = idx[1].clone()
+    bad[:5] = torch.tensor([-3, 17, 99, 16, 0], device=dev)
+    args[4] = _lib.ptr(bad)
+    _lib.check(env['lib'].infgen_embedding_sum4(*args, rows, _lib.ptr(out), env['ops'].stream))
+    ref = tabs[0][idx[0]] + ((tabs[1][bad.clamp(0, 16)] + tabs[2][idx[2]]) + tabs[3][idx[3]])
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize('terms', [3, 1])
 def test_fourier_time_gap_table(env, terms):
     """the temporal edges' fourth input (time gap -1 .. -16) as a lookup of its branch (infgen_fourier_last_dim_table /
