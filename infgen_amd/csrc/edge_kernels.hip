@@ -283,38 +283,34 @@ __global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
   // ---------------- agent <-> agent
   if (part == 2) {
     const float r2 = a.r_agent * a.r_agent;
-    int cnt = 0;
-    const bool dst_ok = (t < A) && im[t];
     // radius_graph(..., loop=False, max_num_neighbors=300) over ALL rows of the column, masked ones included, and only then
     // subgraph(mask) (agent_decoder.py:632-634): per destination the first 300 + 1 rows in ascending index within the radius
-    // (itself among them) are candidates; the self pair and the masked sources are dropped afterwards
-    if (dst_ok) {
-      int found = 0;
-      for (int j = 0; j < A && found < A2A_MAX_NBR + 1; ++j) {
-        const float dx = px[t] - px[j], dy = py[t] - py[j];
-        if (!(dx * dx + dy * dy < r2)) continue;
-        ++found;
-        if (j != t && im[j]) ++cnt;
-      }
-    }
-    int tot;
-    const int excl = block_excl_scan<BT>(cnt, scan, &tot);
-    if (t == 0) { base_a = atomicAdd(a.a.total, tot); if (a.prof) atomicAdd(a.prof + 10, (unsigned long long)tot); }
-    __syncthreads();
-    if (t < st.A_cap) {
-      int e = base_a + excl;
-      a.a.off[row] = e;
-      a.a.cnt[row] = cnt;
-      if (cnt > 0) {
-        const bool d_inv = stt[t] == INVALID;
-        int found = 0;
-        for (int j = 0; j < A && found < A2A_MAX_NBR + 1; ++j) {
-          const float ddx = px[t] - px[j], ddy = py[t] - py[j];
-          if (!(ddx * ddx + ddy * ddy < r2)) continue;
-          ++found;
-          if (j == t || !im[j]) continue;
-          float dx = px[j] - px[t], dy = py[j] - py[t];
-          float dth = wrap_angle(hd[j] - hd[t]);
+    // (itself among them) are candidates; the self pair and the masked sources are dropped afterwards.
+    // One wave per destination, the sources across the lanes (64 per trip): ballots give the candidate rank and the slot of
+    // every emitted edge, so a list is written by consecutive lanes in ascending source index.
+    const int lane = lane_id();
+    int* acnt = mapcnt;      // (the map part's arrays are free in this workgroup)
+    int* aoff = mapidx;
+    auto scan_sources = [&](int ag, int e0, bool emit) {
+      int found = 0, cnt = 0;
+      const float ax = px[ag], ay = py[ag];
+      const bool d_inv = stt[ag] == INVALID;
+      for (int j0 = 0; j0 < A && found < A2A_MAX_NBR + 1; j0 += 64) {
+        const int j = j0 + lane;
+        bool in = false;
+        if (j < A) {
+          const float ddx = ax - px[j], ddy = ay - py[j];
+          in = ddx * ddx + ddy * ddy < r2;
+        }
+        const unsigned long long bal = __ballot(in);
+        const unsigned long long lower = (1ull << lane) - 1ull;
+        const bool cand = in && found + (int)__popcll(bal & lower) < A2A_MAX_NBR + 1;
+        const bool out = cand && j != ag && im[j];
+        const unsigned long long obal = __ballot(out);
+        if (emit && out) {
+          const int e = e0 + cnt + (int)__popcll(obal & lower);
+          float dx = px[j] - ax, dy = py[j] - ay;
+          float dth = wrap_angle(hd[j] - hd[ag]);
           const bool s_inv = stt[j] == INVALID;
           if (s_inv && !d_inv) { dx = -MOTION_GAP; dy = -MOTION_GAP; dth = -HEADING_GAP; }
           if (!s_inv && d_inv) { dx = MOTION_GAP; dy = MOTION_GAP; }      // :650 is a no-op
@@ -322,12 +318,32 @@ __global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
           if (e < a.a.cap) {
             a.a.src[e] = s * st.A_cap + j;
             *reinterpret_cast<float4*>(a.a.raw + 4 * (size_t)e) =
-                make_float4(norm2(dx, dy), angle_between(hc[t], hs[t], dx, dy), dth, 0.f);
+                make_float4(norm2(dx, dy), angle_between(hc[ag], hs[ag], dx, dy), dth, 0.f);
           }
-          ++e;
         }
+        cnt += (int)__popcll(obal);
+        found += (int)__popcll(bal);
       }
+      return cnt;
+    };
+    for (int ag = wave_id(); ag < st.A_cap; ag += BT / 64) {
+      const int cnt = (ag < A && im[ag]) ? scan_sources(ag, 0, false) : 0;
+      if (lane == 0) acnt[ag] = cnt;
     }
+    __syncthreads();
+    const int cnt = (t < st.A_cap) ? acnt[t] : 0;
+    int tot;
+    const int excl = block_excl_scan<BT>(cnt, scan, &tot);
+    if (t == 0) { base_a = atomicAdd(a.a.total, tot); if (a.prof) atomicAdd(a.prof + 10, (unsigned long long)tot); }
+    __syncthreads();
+    if (t < st.A_cap) {
+      aoff[t] = base_a + excl;
+      a.a.off[row] = base_a + excl;
+      a.a.cnt[row] = cnt;
+    }
+    __syncthreads();
+    for (int ag = wave_id(); ag < st.A_cap; ag += BT / 64)
+      if (acnt[ag] > 0) scan_sources(ag, aoff[ag], true);
   }
 }
 template __global__ void k_build_edges<256>(BuildEdgesArgs);
