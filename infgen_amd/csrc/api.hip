@@ -750,9 +750,11 @@ extern "C" int infgen_build_edges(const InfgenRollout* r, int c, int edgeless, v
   OptScope _opts(r);
   hipStream_t s = (hipStream_t)stream;
   if (!edgeless) {
-    if (hipMemsetAsync(r->et.total, 0, sizeof(int), s) != hipSuccess ||
-        hipMemsetAsync(r->em.total, 0, sizeof(int), s) != hipSuccess ||
-        hipMemsetAsync(r->ea.total, 0, sizeof(int), s) != hipSuccess)
+    if (r->em.total == r->et.total + 1 && r->ea.total == r->et.total + 2) {      // laid out back to back: one fill
+      if (hipMemsetAsync(r->et.total, 0, 3 * sizeof(int), s) != hipSuccess) return fail("infgen_build_edges", "memset failed");
+    } else if (hipMemsetAsync(r->et.total, 0, sizeof(int), s) != hipSuccess ||
+               hipMemsetAsync(r->em.total, 0, sizeof(int), s) != hipSuccess ||
+               hipMemsetAsync(r->ea.total, 0, sizeof(int), s) != hipSuccess)
       return fail("infgen_build_edges", "memset failed");
   }
   BuildEdgesArgs a;
@@ -760,8 +762,10 @@ extern "C" int infgen_build_edges(const InfgenRollout* r, int c, int edgeless, v
   a.rows = r->S * r->A_cap; a.t = ebuf(r->et); a.m = ebuf(r->em); a.a = ebuf(r->ea);
   a.prof = (g_prof.mask & ((1u << INFGEN_KID_EDGE_ATTN) | (1u << INFGEN_KID_BUILD_EDGES))) ? g_prof.rows_dev : nullptr;
   { ProfScope _ps(INFGEN_KID_BUILD_EDGES, stream);
-    if (r->A_cap <= 256) hipLaunchKernelGGL(k_build_edges<256>, dim3(r->S, 3), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_build_edges<1024>, dim3(r->S, 3), dim3(1024), 0, s, a); }
+    a.map_lds = r->M_cap < 4096 ? r->M_cap : 4096;
+    const size_t lds = (size_t)a.map_lds * 8;
+    if (r->A_cap <= 256) hipLaunchKernelGGL(k_build_edges<256>, dim3(r->S, 3), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(k_build_edges<1024>, dim3(r->S, 3), dim3(1024), lds, s, a); }
   return check_launch("infgen_build_edges");
 }
 

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
   __shared__ int mapidx[BT * 5];
   __shared__ int mapcnt[BT];
   __shared__ int base_t, base_m, base_a;
-  __shared__ __attribute__((aligned(8))) float2 mxy[MAP_LDS];
+  extern __shared__ __attribute__((aligned(8))) float2 mxy[];   // min(M_cap, MAP_LDS) slots: sized at launch so that short maps leave room for more workgroups per CU
   const SceneState& st = a.st;
   const int s = blockIdx.x;
   const int t = threadIdx.x;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
     const float r2 = a.r_map * a.r_map;
     const float* mp = st.map_pos + (size_t)s * st.M_cap * 2;
     const int lane = lane_id();
-    const bool map_in_lds = M <= MAP_LDS;
+    const bool map_in_lds = M <= a.map_lds;
     if (map_in_lds) {
       for (int m = t; m < M; m += BT) mxy[m] = *reinterpret_cast<const float2*>(mp + 2 * m);
       __syncthreads();

@@ -278,6 +278,7 @@ struct BuildEdgesArgs {
   int rows;                         // S * A_cap
   EdgeBuf t, m, a;
   unsigned long long* prof;         // optional profiling counters (api.hip Prof::rows_dev): [8 + kind] += edges of the scene
+  int map_lds;                      // float2 slots of dynamic LDS for the scene's map-token positions (0 .. 4096)
 };
 
 struct IntegrateArgs {

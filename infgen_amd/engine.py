@@ -410,10 +410,11 @@ class RolloutEngine:
         self.mapK = [f(S * M_cap, D) for _ in range(L)]
         self.mapV = [f(S * M_cap, D) for _ in range(L)]
         self.edges = {}
-        for name, cap in (('t', rows * self.W), ('m', rows * 5), ('a', rows * (A_cap - 1))):
+        totals = i32(3)        # the three edge totals back to back: infgen_build_edges clears them with one memset
+        for k, (name, cap) in enumerate((('t', rows * self.W), ('m', rows * 5), ('a', rows * (A_cap - 1)))):
             cap = max(cap, 32)
             self.edges[name] = dict(off=i32(rows), cnt=i32(rows), src=i32(cap), raw=f(cap, 4), rhat=f(cap, D),
-                                    total=i32(1), cap=cap)
+                                    total=totals[k:k + 1], cap=cap)
         self.raw2, self.cat, self.fus_in = f(rows, 4), f(rows, D), f(rows, 4 * D)
         self.tmp1, self.tmp2 = f(rows, D), f(rows, D)
         self.next_token, self.next_state = i32(rows), i32(rows)
