@@ -682,11 +682,27 @@ extern "C" int infgen_match_map_tokens(const float* traj_pos, const float* theta
   return check_launch("infgen_match_map_tokens");
 }
 
-extern "C" int infgen_heads(const float* X, int rows, const float* tok_pack, const float* st_pack, int token_size,
-                            float* logits, int* next_token, int* next_state, void* stream) {
+// scratch: optional rows x 8 bytes - with it, launches of few row tiles deal the logit chunks to several workgroups per tile
+static int heads_impl(const float* X, int rows, const float* tok_pack, const float* st_pack, int token_size,
+                      float* logits, int* next_token, int* next_state, unsigned long long* scratch, void* stream) {
   if (rows <= 0) return 0;
   if (token_size % 128) return fail("infgen_heads", "token_size must be a multiple of 128");
-  HeadsArgs a{X, rows, tok_pack, st_pack, token_size, logits, next_token, next_state};
+  HeadsArgs a{X, rows, tok_pack, st_pack, token_size, logits, next_token, next_state, nullptr, 1};
+  if (scratch && !attn_split(rows)) {
+    static const int no_split = getenv("INFGEN_HEADS_NOSPLIT") ? atoi(getenv("INFGEN_HEADS_NOSPLIT")) : 0;
+    const int tiles = ceil_div(rows, TR), nchunk = token_size / 128;
+    int ns = 1;
+    while (!no_split && 2 * ns <= nchunk && nchunk % (2 * ns) == 0 && tiles * 2 * ns <= 512) ns *= 2;
+    if (ns > 1) {
+      if (hipMemsetAsync(scratch, 0, (size_t)rows * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess)
+        return fail("infgen_heads", "memset failed");
+      a.part = scratch; a.nsplit = ns;
+      { ProfScope _ps(INFGEN_KID_HEADS, stream, (double)rows * (2 * 16384.0 + 128.0 * token_size + 384.0));
+        hipLaunchKernelGGL(k_heads, dim3(tiles, ns), dim3(NT), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(k_heads_finish, dim3(ceil_div(rows, NT)), dim3(NT), 0, (hipStream_t)stream, scratch, rows, next_token); }
+      return check_launch("infgen_heads");
+    }
+  }
   { ProfScope _ps(INFGEN_KID_HEADS, stream, (double)rows * (2 * 16384.0 + 128.0 * token_size + 384.0));
     if (attn_split(rows)) {
       int grid = ceil_div(rows, 64);
@@ -697,6 +713,11 @@ extern "C" int infgen_heads(const float* X, int rows, const float* tok_pack, con
       hipLaunchKernelGGL(k_heads, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a);
     } }
   return check_launch("infgen_heads");
+}
+
+extern "C" int infgen_heads(const float* X, int rows, const float* tok_pack, const float* st_pack, int token_size,
+                            float* logits, int* next_token, int* next_state, void* stream) {
+  return heads_impl(X, rows, tok_pack, st_pack, token_size, logits, next_token, next_state, nullptr, stream);
 }
 
 extern "C" int infgen_embedding_sum4(const float* tab0, const long long* idx0, int n0, const float* tab1, const long long* idx1, int n1,
@@ -964,8 +985,9 @@ extern "C" int infgen_decode_step(const InfgenRollout* r, int t, void* stream) {
   float* lg = (r->store_logits && r->logits) ? r->logits + (size_t)t * rows * r->token_size : nullptr;
   const bool sample = r->sample_k > 1 && r->sample_u && (lg || r->logits_scratch);
   if (sample && !lg) lg = r->logits_scratch;
-  RET_IF(infgen_heads(r->X, rows, r->tok_head_pack, r->st_head_pack, r->token_size, lg, r->next_token,
-                      r->next_state, stream));
+  // (tmp2 is scratch of the raw-feature stage, free here: the per-row keys of the split arg-max)
+  RET_IF(heads_impl(r->X, rows, r->tok_head_pack, r->st_head_pack, r->token_size, lg, r->next_token,
+                    r->next_state, reinterpret_cast<unsigned long long*>(r->tmp2), stream));
   if (sample)
     RET_IF(infgen_sample_topk(lg, rows, r->token_size, r->sample_k, r->sample_u + (size_t)t * rows, r->next_token, stream));
   RET_IF(infgen_integrate(r, t, stream));

@@ -221,7 +221,11 @@ struct HeadsArgs {
   float* logits;            // optional [rows][token_size]
   int* next_token;          // [rows]
   int* next_state;          // [rows] raw argmax in {0,1,2}
+  // k_heads only, few rows: the token_size / 128 logit chunks dealt to gridDim.y = nsplit workgroups per row tile; each merges its
+  // (max, first index) into part[row] as an ordered 64-bit key (atomicMax; zeroed by the caller), k_heads_finish decodes them
+  unsigned long long* part; int nsplit;
 };
+__global__ void k_heads_finish(const unsigned long long* part, int rows, int* next_token);
 
 // ---- per-scene state (column-major per scene: [S][T][A_cap]) -----------------------------------
 struct SceneState {

@@ -266,7 +266,9 @@ __global__ __launch_bounds__(NT, 2) void k_heads(HeadsArgs a) {
     const float* P = a.tok_pack;
     f32x16 acc = zero16();
     const float* W3p = P + 16768;
-    gemm128(acc, Xs, LDT, P, 128, n0, cur, [&] { return b_load_half(W3p, a.token_size, n0, 0); });
+    const int nchunk = a.token_size / 128, ns = a.nsplit > 1 ? a.nsplit : 1, sp = blockIdx.y;
+    const int p0 = nchunk * sp / ns, p1 = nchunk * (sp + 1) / ns;       // this workgroup's logit chunks
+    gemm128(acc, Xs, LDT, P, 128, n0, cur, [&] { return b_load_half(W3p, a.token_size, 128 * p0 + n0, 0); });
     acc_to_lds(acc, Hs, LDT, n0, P + 16384);
     __syncthreads();
     ln_tile(Hs, LDT, Hs, LDT, P + 16512, P + 16640, true);
@@ -277,10 +279,10 @@ __global__ __launch_bounds__(NT, 2) void k_heads(HeadsArgs a) {
     int bi[16];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) { bv[reg] = -INFINITY; bi[reg] = 0; }
-    for (int p = 0; p < a.token_size / 128; ++p) {
+    for (int p = p0; p < p1; ++p) {
       const int c0 = 128 * p + n0;
       f32x16 acc2 = zero16();
-      const bool last = p + 1 >= a.token_size / 128;
+      const bool last = p + 1 >= p1;
       gemm128(acc2, Hs, LDT, W3, a.token_size, c0, cur, [&] {
         return last ? b_load_half(a.st_pack, 128, n0, 0) : b_load_half(W3, a.token_size, c0 + 128, 0);
       });
@@ -317,8 +319,15 @@ __global__ __launch_bounds__(NT, 2) void k_heads(HeadsArgs a) {
         const int oi = red_i[ww][r];
         if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
       }
-      a.next_token[row0 + r] = i;
+      if (ns == 1) a.next_token[row0 + r] = i;
+      else {
+        // ordered key: larger value first, then the smaller index (torch.argmax: first maximum); -0 counts as +0
+        unsigned u = __float_as_uint(v + 0.0f);
+        u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+        atomicMax(a.part + row0 + r, ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)i));
+      }
     }
+    if (sp != 0) return;                 // the state head is the first split's
   }
   __syncthreads();
   {
@@ -344,6 +353,11 @@ __global__ __launch_bounds__(NT, 2) void k_heads(HeadsArgs a) {
       a.next_state[row0 + r] = bi;
     }
   }
+}
+
+__global__ __launch_bounds__(NT) void k_heads_finish(const unsigned long long* part, int rows, int* next_token) {
+  const int r = blockIdx.x * NT + threadIdx.x;
+  if (r < rows) next_token[r] = (int)(0xffffffffu - (unsigned)(part[r] & 0xffffffffull));
 }
 
 }  // namespace ig
