@@ -910,6 +910,11 @@ extern "C" int infgen_set_overlap(int mode) {
   return 0;
 }
 
+static int fourier_nomulti() {
+  static const int v = getenv("INFGEN_FOURIER_NOMULTI") ? atoi(getenv("INFGEN_FOURIER_NOMULTI")) : 0;
+  return v;
+}
+
 extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless, void* stream) {
   RET_IF(validate(r, "infgen_decode_layers"));
   OptScope _opts(r);
@@ -932,6 +937,21 @@ extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless,
     RET_IF(fourier_embed_impl(r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, r24, g_side));
     if (hipEventRecord(g_ev_a, g_side) != hipSuccess) return fail("infgen_decode_layers", "event failed");
     RET_IF(fourier_embed_impl(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, r24, stream, dt, dt != nullptr));
+  } else if (!edgeless && O().fourier_mode != 0 && rows <= 10240 && !fourier_nomulti()) {
+    // few rows: the three sets side by side in one launch (each is a handful of 128-edge tiles of 35 - 45 us)
+    unsigned long long* pr = (g_prof.mask >> INFGEN_KID_FOURIER) & 1u ? g_prof.rows_dev : nullptr;
+    FourierMultiArgs m;
+    m.set[0] = FourierArgs{r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, pr, r24, dt, dt != nullptr};
+    m.set[1] = FourierArgs{r->em.raw, 3, r->em.total, r->em.cap, r->four_m, nullptr, 0, r->em.rhat, 128, 1, pr, r24, nullptr, 0};
+    m.set[2] = FourierArgs{r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, pr, r24, nullptr, 0};
+    int cap = r->et.cap > r->em.cap ? r->et.cap : r->em.cap;
+    if (r->ea.cap > cap) cap = r->ea.cap;
+    int grid = ceil_div(cap, 128);
+    if (grid > 256) grid = 256;
+    { ProfScope _ps(INFGEN_KID_FOURIER, stream);
+      if (O().gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h_multi<1>, dim3(grid, 3), dim3(512), 0, (hipStream_t)stream, m);
+      else hipLaunchKernelGGL(k_fourier_h_multi<3>, dim3(grid, 3), dim3(512), 0, (hipStream_t)stream, m); }
+    RET_IF(check_launch("infgen_decode_layers(fourier)"));
   } else if (!edgeless) {
     RET_IF(fourier_embed_impl(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, r24, stream, dt, dt != nullptr));
     RET_IF(fourier_embed_impl(r->em.raw, 3, r->em.total, r->em.cap, r->four_m, nullptr, 0, r->em.rhat, 128, 1, r24, stream));

@@ -75,7 +75,7 @@ __device__ __forceinline__ void sincos_fast(float z, float& s, float& c) {
 }
 
 template <int TERMS>
-__global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
+__device__ __forceinline__ void fourier_h_body(const FourierArgs& a) {
   __shared__ __attribute__((aligned(16))) unsigned short Wb[RING][QUARTER];    // 80 KB: also keeps the CU to ONE workgroup
   __shared__ __attribute__((aligned(16))) float Vt[FH_VEC_SIZE];
   const int E = a.count_dev ? min(*a.count_dev, a.e_cap) : a.e_cap;
@@ -220,6 +220,16 @@ __global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
   }
 }
 
+template <int TERMS>
+__global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) { fourier_h_body<TERMS>(a); }
+
+// up to three independent edge sets in one launch (gridDim.y = sets): the three Fourier embeddings of a decode step side by
+// side when the sets are too small to fill the chip one after the other (a single tile costs 28 - 36 quarters = 35 - 45 us)
+template <int TERMS>
+__global__ __launch_bounds__(FH_NT, 1) void k_fourier_h_multi(FourierMultiArgs m) { fourier_h_body<TERMS>(m.set[blockIdx.y]); }
+
+template __global__ void k_fourier_h_multi<3>(FourierMultiArgs);
+template __global__ void k_fourier_h_multi<1>(FourierMultiArgs);
 template __global__ void k_fourier_h<3>(FourierArgs);
 template __global__ void k_fourier_h<1>(FourierArgs);
 

@@ -35,6 +35,7 @@ struct FourierArgs {
   const float* dt_tab; int dt_mode;
 };
 constexpr int DT_TAB_ROWS = 32;
+struct FourierMultiArgs { FourierArgs set[3]; };
 
 // Packed 24-bit rows of the normalised relative-position embedding (the rollout's private edge buffers; k_fourier_h writes,
 // k_edge_fused reads): the upper 24 bits of every fp32 value (sign, exponent, 15 mantissa bits, round to nearest even) as two
@@ -391,6 +392,7 @@ __global__ void k_linear(LinearArgs a);
 __global__ void k_linear_multi(LinearMultiArgs m);
 __global__ void k_fourier(FourierArgs a);
 template <int TERMS> __global__ void k_fourier_h(FourierArgs a);
+template <int TERMS> __global__ void k_fourier_h_multi(FourierMultiArgs m);
 __global__ void k_match_tokens(MatchTokensArgs a);   // token_kernels.hip
 template <int TERMS> __global__ void k_mlpemb_h(MlpEmbHArgs a);           // mlp_h.hip
 __global__ void k_box_corners(NearestArgs a);        // metric_kernels.hip
