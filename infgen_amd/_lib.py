@@ -66,6 +66,9 @@ class Options(C.Structure):
                 ('overlap', _i), ('row_group_margin', _i), ('row_groups', _p), ('n_row_groups', _p)]
 
 
+OPTIONS_VALUE_BYTES = C.sizeof(_i) * 8        # the eight integer switches of Options (the two pointers follow)
+
+
 class Rollout(C.Structure):
     _fields_ = [
         ('S', _i), ('A_cap', _i), ('T', _i), ('M_cap', _i), ('W', _i), ('ring', _i), ('R', _i),
@@ -210,8 +213,18 @@ def ptr(t) -> Optional[int]:
     return t.data_ptr()
 
 
+_prof_mask = 0
+
+
 def prof_enable(mask: int, max_launches: int = 20000) -> None:
+    global _prof_mask
     check(load().infgen_prof_enable(mask, max_launches), 'infgen_prof_enable')
+    _prof_mask = int(mask)
+
+
+def prof_active() -> bool:
+    """per-kernel HIP-event profiling is on (bench.py's roofline legs): launches must be issued eagerly, not replayed"""
+    return _prof_mask != 0
 
 
 def prof_collect():

@@ -13,6 +13,7 @@ map_decoder.py:70-130, agent_decoder.py:1605-2389), greedy decoding, insertion d
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 import os
 from typing import Dict, List, Mapping, Optional, Sequence
 
@@ -116,14 +117,14 @@ class PackedWeights:
             self._time_gap_tables[terms] = tab
         return tab
 
-    def tables(self, ops: 'Ops', vocab_dev: torch.Tensor, grid_dev: torch.Tensor, map_vocab_dev: torch.Tensor):
+    def tables(self, ops: 'Ops', vocab_dev: torch.Tensor, grid_dev: torch.Tensor, map_vocab_dev: torch.Tensor, key: bytes):
         """Per-checkpoint constants (the reference recomputes them in every inference call,
         agent_decoder.py:347-373, map_decoder.py:77-78): token-embedding tables with the bos /
         no_token rows appended, the grid-embedding table with the invalid row, the seed
-        categorical embedding and the map-token embedding table."""
-        key = (vocab_dev.data_ptr(), grid_dev.data_ptr(), map_vocab_dev.data_ptr(), tuple(vocab_dev.shape), tuple(grid_dev.shape))
-        if self._tables is not None and (self._tables_key == key or self._tables_src_equal(vocab_dev, grid_dev, map_vocab_dev)):
-            self._tables_key = key
+        categorical embedding and the map-token embedding table.  ``key``: a content hash of the vocabularies / grid the
+        caller computed on the host before the upload (``tables_key``) - device addresses say nothing about contents, the
+        caching allocator hands a freed engine's addresses to the next one."""
+        if self._tables is not None and self._tables_key == key:
             return self._tables
         dev, ts, G = self.device, self.cfg.token_size, grid_dev.shape[0]
         tok_tab = torch.empty(3, ts + 2, D, device=dev)
@@ -147,13 +148,16 @@ class PackedWeights:
         f_seed = ops.mlp_embedding(fus, self.fusion, 4 * D)
         self._tables = dict(tok_tab=tok_tab, grid_tab=grid_tab, cat_seed=cat_seed, map_tab=map_tab, f_seed=f_seed)
         self._tables_key = key
-        self._tables_src = (vocab_dev.clone(), grid_dev.clone(), map_vocab_dev.clone())
         return self._tables
 
-    def _tables_src_equal(self, vocab_dev, grid_dev, map_vocab_dev) -> bool:
-        """the cached tables were computed from these very vocabularies / this grid (other engines upload their own copies)"""
-        a = self._tables_src
-        return all(x.shape == y.shape and bool(torch.equal(x, y)) for x, y in zip(a, (vocab_dev, grid_dev, map_vocab_dev)))
+    @staticmethod
+    def tables_key(*arrays: np.ndarray) -> bytes:
+        h = hashlib.blake2b(digest_size=16)
+        for a in arrays:
+            a = np.ascontiguousarray(a)
+            h.update(str((a.shape, a.dtype.str)).encode())
+            h.update(a.tobytes())
+        return h.digest()
 
 
 class Ops:
@@ -296,7 +300,7 @@ class RolloutEngine:
                  force_enter: bool = False, insert_headroom: Optional[int] = None,
                  sample_k: int = 1, sample_uniforms: Optional[np.ndarray] = None, options: Optional[Mapping[str, int]] = None,
                  insert_k: int = 1, insert_uniforms: Optional[np.ndarray] = None, seed_outputs: bool = False,
-                 use_graph: bool = False):
+                 use_graph: Optional[bool] = None):
         self.w = weights
         self.options = dict(options) if options else None      # per-engine kernel switches (fields of InfgenOptions)
         self.cfg = cfg = weights.cfg
@@ -324,8 +328,10 @@ class RolloutEngine:
         self.seed_out = None
         # capture the decode steps of a rollout (no insertion: ~47 launches per step, all shapes static) in a HIP graph at the
         # first run and replay it afterwards
+        self._use_graph_arg = use_graph              # None: by size (set below, once the row count is known)
         self.use_graph = bool(use_graph)
         self._graph = None
+        self._graph_opts = None
         if self.insert_k > 1:
             assert insert_uniforms is not None, 'cell sampling needs caller-supplied uniforms [steps][10][S]'
             self._insert_u = torch.from_numpy(np.ascontiguousarray(insert_uniforms, dtype=np.float32)).to(weights.device)
@@ -339,6 +345,7 @@ class RolloutEngine:
         self.hosts = hosts
         amax = max(h['A'] for h in hosts)
         mmax = max(h['M'] for h in hosts)
+        self._amax0 = amax
         head = 0
         if self.insertion:
             head = insert_headroom if insert_headroom is not None else min(10 * cfg.num_decode_steps, 96)
@@ -347,42 +354,22 @@ class RolloutEngine:
         assert amax <= A_cap <= self.lib.infgen_layout_query(_lib.Q_MAX_AGENTS) and A_cap % 32 == 0
         assert mmax <= M_cap
         self.rows = rows = S * A_cap
+        if self._use_graph_arg is None:
+            # batches of up to 64 scenes of 64 rows are launch-to-launch latency bound: +6-7 % from the replay
+            # (INFGEN_GRAPH=0 / 1 overrides)
+            env = os.environ.get('INFGEN_GRAPH')
+            self.use_graph = (rows <= 4096 and not self.insertion) if env is None else env == '1'
 
-        def zeros(shape, dtype):
-            return np.zeros(shape, dtype=dtype)
-        pos = zeros((S, T, A_cap, 2), np.float32); head = zeros((S, T, A_cap), np.float32)
-        state = zeros((S, T, A_cap), np.int32); token = np.full((S, T, A_cap), -1, np.int32)
-        gridtok = np.full((S, T, A_cap), -1, np.int32)
-        tmask = zeros((S, T, A_cap), np.uint8); imask = zeros((S, T, A_cap), np.uint8)
-        catflag = zeros((S, T, A_cap), np.uint8)
-        atype = zeros((S, A_cap), np.int32); bos = zeros((S, A_cap), np.int32)
-        shape10 = np.full((S, A_cap, 3), INVALID_SHAPE, np.float32)
-        n_agents = zeros((S,), np.int32); n_map = zeros((S,), np.int32); av = zeros((S,), np.int32)
-        map_pos = zeros((S, M_cap, 2), np.float32); map_orient = zeros((S, M_cap), np.float32)
-        map_tok = zeros((S, M_cap), np.int64); map_type = zeros((S, M_cap), np.int64)
-        map_pl = zeros((S, M_cap), np.int64); map_light = zeros((S, M_cap), np.int64)
-        for s, h in enumerate(hosts):
-            A, M = h['A'], h['M']
-            n_agents[s], n_map[s], av[s] = A, M, h['av']
-            pos[s, :, :A] = h['pos'].transpose(1, 0, 2); head[s, :, :A] = h['head'].T
-            state[s, :, :A] = h['state'].T; token[s, :, :A] = h['token'].T; gridtok[s, :, :A] = h['grid'].T
-            tmask[s, :, :A] = h['tmask'].T; imask[s, :, :A] = h['imask'].T; catflag[s, :, :A] = h['catflag'].T
-            atype[s, :A] = h['type']; bos[s, :A] = h['bos']; shape10[s, :A] = h['shape10']
-            map_pos[s, :M] = h['map_pos']; map_orient[s, :M] = h['map_orient']
-            map_tok[s, :M] = h['map_tok']; map_type[s, :M] = h['map_type']
-            map_pl[s, :M] = h['map_pl']; map_light[s, :M] = h['map_light']
-
+        arr = self._scene_arrays(hosts)
         t = lambda a: torch.from_numpy(a).to(dev)
-        self.pos, self.head, self.state, self.token, self.gridtok = t(pos), t(head), t(state), t(token), t(gridtok)
-        self.tmask, self.imask, self.catflag = t(tmask), t(imask), t(catflag)
-        self.atype, self.bos = t(atype), t(bos)
-        self.n_agents, self.n_map, self.av = t(n_agents), t(n_map), t(av)
-        self.map_pos, self.map_orient = t(map_pos), t(map_orient)
-        self._map_cat = (t(map_tok), t(map_type), t(map_pl), t(map_light))
-        self._shape10 = t(shape10)
-        self.vocab = t(np.stack([vocab[k] for k in ('veh', 'ped', 'cyc')]).astype(np.float32))
-        self._map_vocab = t(np.asarray(map_vocab, dtype=np.float32).reshape(map_vocab.shape[0], -1))
-        self.grid_xy = t(np.asarray(grid, dtype=np.float32))
+        for k in self._SCENE_ARRAYS:
+            setattr(self, k, t(arr[k]))
+        self._map_cat = tuple(t(arr[k]) for k in ('map_tok', 'map_type', 'map_pl', 'map_light'))
+        vocab_np = np.stack([vocab[k] for k in ('veh', 'ped', 'cyc')]).astype(np.float32)
+        map_vocab_np = np.asarray(map_vocab, dtype=np.float32).reshape(map_vocab.shape[0], -1)
+        grid_np = np.asarray(grid, dtype=np.float32)
+        self._tables_key = PackedWeights.tables_key(vocab_np, grid_np, map_vocab_np)
+        self.vocab, self._map_vocab, self.grid_xy = t(vocab_np), t(map_vocab_np), t(grid_np)
         self.G = int(grid.shape[0])
         self.teacher_token = self.teacher_state = None
         self.teacher_grid = None
@@ -424,10 +411,7 @@ class RolloutEngine:
         self.sample_u = self.logits_scratch = None
         if self.sample_k > 1:
             assert sample_uniforms is not None, 'top-k sampling needs caller-supplied uniforms'
-            u = np.zeros((steps, S, A_cap), np.float32)
-            su = np.asarray(sample_uniforms, dtype=np.float32)
-            u[:, :, :min(A_cap, su.shape[2])] = su[:, :, :A_cap]
-            self.sample_u = torch.from_numpy(u.reshape(steps, rows)).to(dev)
+            self.sample_u = torch.from_numpy(self._uniform_rows(sample_uniforms, amax)).to(dev)
             if self.logits is None:
                 self.logits_scratch = f(rows, cfg.token_size)
         self.tok_tab = self.grid_tab = self.cat_agent = self.cat_seed = None
@@ -440,6 +424,83 @@ class RolloutEngine:
         self._map_nbr_cap = 40          # compacted pt<->pt edges per map token (grown on overflow)
         self._prologue_done = False
         self._decoded_rows = torch.zeros((), device=dev, dtype=torch.int64)
+
+    # ------------------------------------------------------------------ scene arrays (host -> device)
+    _SCENE_ARRAYS = ('pos', 'head', 'state', 'token', 'gridtok', 'tmask', 'imask', 'catflag', 'atype', 'bos', 'n_agents', 'n_map',
+                     'av', 'map_pos', 'map_orient', '_shape10')
+
+    def _scene_arrays(self, hosts) -> Dict[str, np.ndarray]:
+        """the padded [S][T][A_cap] / [S][M_cap] arrays of a batch (section 4 of DESIGN.md) from the per-scene host dicts"""
+        S, T, A_cap, M_cap = self.S, self.T, self.A_cap, self.M_cap
+
+        def zeros(shape, dtype):
+            return np.zeros(shape, dtype=dtype)
+        a = dict(pos=zeros((S, T, A_cap, 2), np.float32), head=zeros((S, T, A_cap), np.float32),
+                 state=zeros((S, T, A_cap), np.int32), token=np.full((S, T, A_cap), -1, np.int32),
+                 gridtok=np.full((S, T, A_cap), -1, np.int32), tmask=zeros((S, T, A_cap), np.uint8),
+                 imask=zeros((S, T, A_cap), np.uint8), catflag=zeros((S, T, A_cap), np.uint8),
+                 atype=zeros((S, A_cap), np.int32), bos=zeros((S, A_cap), np.int32),
+                 _shape10=np.full((S, A_cap, 3), INVALID_SHAPE, np.float32),
+                 n_agents=zeros((S,), np.int32), n_map=zeros((S,), np.int32), av=zeros((S,), np.int32),
+                 map_pos=zeros((S, M_cap, 2), np.float32), map_orient=zeros((S, M_cap), np.float32),
+                 map_tok=zeros((S, M_cap), np.int64), map_type=zeros((S, M_cap), np.int64),
+                 map_pl=zeros((S, M_cap), np.int64), map_light=zeros((S, M_cap), np.int64))
+        for s, h in enumerate(hosts):
+            A, M = h['A'], h['M']
+            a['n_agents'][s], a['n_map'][s], a['av'][s] = A, M, h['av']
+            a['pos'][s, :, :A] = h['pos'].transpose(1, 0, 2); a['head'][s, :, :A] = h['head'].T
+            a['state'][s, :, :A] = h['state'].T; a['token'][s, :, :A] = h['token'].T; a['gridtok'][s, :, :A] = h['grid'].T
+            a['tmask'][s, :, :A] = h['tmask'].T; a['imask'][s, :, :A] = h['imask'].T; a['catflag'][s, :, :A] = h['catflag'].T
+            a['atype'][s, :A] = h['type']; a['bos'][s, :A] = h['bos']; a['_shape10'][s, :A] = h['shape10']
+            a['map_pos'][s, :M] = h['map_pos']; a['map_orient'][s, :M] = h['map_orient']
+            a['map_tok'][s, :M] = h['map_tok']; a['map_type'][s, :M] = h['map_type']
+            a['map_pl'][s, :M] = h['map_pl']; a['map_light'][s, :M] = h['map_light']
+        return a
+
+    def fits(self, scenes: Sequence[Mapping]) -> bool:
+        """can ``reload`` take this batch? (same scene count, agents + insertion head-room and map tokens inside the rows this
+        engine allocated)"""
+        if len(scenes) != self.S or self.teacher_token is not None:
+            return False
+        amax = max(int((np.asarray(sc['agent']['state_idx'])[:, self.hc - 1] != INVALID).sum()) for sc in scenes)
+        mmax = max(int(np.asarray(sc['pt_token']['position']).shape[0]) for sc in scenes)
+        head = (self.A_cap - self._amax0) if self.insertion else 0
+        return amax + head <= self.A_cap and mmax <= self.M_cap
+
+    def reload(self, scenes: Sequence[Mapping], sample_uniforms: Optional[np.ndarray] = None,
+               insert_uniforms: Optional[np.ndarray] = None, x_pt_override: Optional[Sequence] = None):
+        """a new batch of scenes of the same layout into this engine's device buffers: one upload per array, no allocation, the
+        context block / captured graph / scratch stay (the drop-in entry keeps one engine per layout across calls)"""
+        assert self.fits(scenes), 'batch does not fit this engine (RolloutEngine.fits)'
+        self.scenes = scenes
+        self.hosts = hosts = [self._setup_scene(sc) for sc in scenes]
+        arr = self._scene_arrays(hosts)
+        for k in self._SCENE_ARRAYS:
+            getattr(self, k).copy_(torch.from_numpy(arr[k]), non_blocking=False)
+        for dst, k in zip(self._map_cat, ('map_tok', 'map_type', 'map_pl', 'map_light')):
+            dst.copy_(torch.from_numpy(arr[k]))
+        if self.sample_k > 1:
+            assert sample_uniforms is not None, 'top-k sampling needs caller-supplied uniforms'
+            self.sample_u.copy_(torch.from_numpy(self._uniform_rows(sample_uniforms, max(h['A'] for h in hosts))))
+        if self.insert_k > 1:
+            assert insert_uniforms is not None, 'cell sampling needs caller-supplied uniforms [steps][10][S]'
+            self._insert_u.copy_(torch.from_numpy(np.ascontiguousarray(insert_uniforms, dtype=np.float32)))
+        self._x_pt_override = x_pt_override
+        self._init = None                  # reset() snapshots the new initial state
+        self._epi = None
+        self._mg_checked = False           # the new map may hold more pt <-> pt edges than the buffers
+        self._prologue_done = False
+
+    def _uniform_rows(self, sample_uniforms, amax) -> np.ndarray:
+        steps, S, A_cap = self.cfg.num_decode_steps, self.S, self.A_cap
+        su = np.asarray(sample_uniforms, dtype=np.float32)
+        # a missing column would sample with u = 0, i.e. greedily - never fill in silently
+        need = A_cap if self.insertion else amax
+        assert su.ndim == 3 and su.shape[0] >= steps and su.shape[1] >= S and su.shape[2] >= need, \
+            f'sample_uniforms {su.shape} does not cover [steps={steps}][S={S}][rows={need}]'
+        u = np.zeros((steps, S, A_cap), np.float32)
+        u[:, :, :min(A_cap, su.shape[2])] = su[:steps, :S, :A_cap]
+        return u.reshape(steps, S * A_cap)
 
     # ------------------------------------------------------------------ host setup of one scene
     def _setup_scene(self, scene) -> Dict[str, np.ndarray]:
@@ -526,7 +587,7 @@ class RolloutEngine:
         (SURVEY a-Q3) and column 1's raw feature."""
         ops, w, cfg, dev = self.ops, self.w, self.cfg, self.device
         S, A_cap, M_cap, rows = self.S, self.A_cap, self.M_cap, self.rows
-        tabs = w.tables(ops, self.vocab, self.grid_xy, self._map_vocab)
+        tabs = w.tables(ops, self.vocab, self.grid_xy, self._map_vocab, self._tables_key)
         self.tok_tab, self.grid_tab, self.cat_seed = tabs['tok_tab'], tabs['grid_tab'], tabs['cat_seed']
         self.reset()
         # categorical embedding rows (agent_decoder.py:376-380,492)
@@ -861,7 +922,12 @@ class RolloutEngine:
         t1 = self.cfg.num_decode_steps if t1 is None else t1
         self._refresh_opts(groups=True)        # (the group list is rebuilt on the device at every decode step below)
         if not self.insertion:
-            if self.use_graph and (t0, t1) == (0, self.cfg.num_decode_steps):
+            # a replay runs what was captured: fall back to the eager sequence while per-kernel profiling is on (events are not
+            # part of the graph) and re-capture when the context's kernel switches changed since the capture
+            if self.use_graph and (t0, t1) == (0, self.cfg.num_decode_steps) and not _lib.prof_active():
+                snap = bytes(self._ctx.opts)[:_lib.OPTIONS_VALUE_BYTES] + bytes([self._ctx.four_t_dt is not None])
+                if self._graph is not None and snap != self._graph_opts:
+                    self._graph = None
                 if self._graph is None and not getattr(self, '_graph_warm', False):
                     # the first rollout runs eagerly: kernels are loaded lazily at their first launch, which must not happen
                     # inside a capture
@@ -873,6 +939,7 @@ class RolloutEngine:
                     with torch.cuda.graph(g):
                         _lib.check(self.lib.infgen_rollout_run(C.byref(self._ctx), t0, t1, self.ops.stream), 'infgen_rollout_run')
                     self._graph = g
+                    self._graph_opts = snap
                 self._graph.replay()
                 return
             _lib.check(self.lib.infgen_rollout_run(C.byref(self._ctx), t0, t1, self.ops.stream), 'infgen_rollout_run')
@@ -900,6 +967,13 @@ class RolloutEngine:
 
     def step(self, t: int):
         _lib.check(self.lib.infgen_decode_step(C.byref(self._ctx), t, self.ops.stream), 'infgen_decode_step')
+
+    def ctx_tensor(self) -> torch.Tensor:
+        """the bytes of this engine's InfgenRollout block (after ``prologue``) - the state handle of
+        ``torch.ops.infgen_hip.decode_step``"""
+        assert self._ctx is not None, 'run prologue() first'
+        self._refresh_opts(groups=True)
+        return torch.frombuffer(bytearray(bytes(self._ctx)), dtype=torch.uint8)
 
     # ------------------------------------------------------------------ outputs (reference :2303-2389)
     def outputs(self) -> List[Dict[str, np.ndarray]]:
@@ -985,9 +1059,13 @@ class RolloutEngine:
             outs.append(o)
         return outs
 
-    def outputs_device(self) -> List[Dict[str, torch.Tensor]]:
+    def outputs_device(self, detach: bool = False) -> List[Dict[str, torch.Tensor]]:
         """``outputs`` without the host round trip: the same per-scene dicts as device tensors (views of the batch arrays where
-        the layout allows), the epilogue of agent_decoder.py:2303-2389 evaluated for all scenes at once on the device"""
+        the layout allows), the epilogue of agent_decoder.py:2303-2389 evaluated for all scenes at once on the device.
+        VIEWS: the per-scene tensors are slices of batch-wide results of this call (an in-place edit of one scene's tensor edits
+        that slice only); ``pos_a`` / ``head_a`` / ``logits`` / ``x_pt`` additionally alias this engine's own buffers, which the next
+        rollout overwrites - ``detach=True`` copies those four batch arrays once (what ``InfGenDecoder`` does, whose engines are
+        reused across calls)."""
         cfg, hc, H, dev = self.cfg, self.hc, self.cfg.num_historical_steps, self.device
         S, A_cap, T, R = self.S, self.A_cap, self.T, self.R
         if getattr(self, '_epi', None) is None:
@@ -1013,6 +1091,7 @@ class RolloutEngine:
                 shp[s, :A0] = np.asarray(sc['shape'])[f][:, hc - 1]
                 val[s, :A0] = h['valid']
             t = lambda a: torch.from_numpy(a).to(dev)
+            self._gt_len = [int(np.asarray(sc['agent']['position']).shape[1]) - H for sc in self.scenes]
             self._epi = dict(htok=t(htok), hst=t(hst), p0=t(p0), h0=t(h0), ids=t(ids), shp=t(shp), gt=t(gt), val=t(val), n0=t(n0),
                              n0_host=n0, eval_shape=t(np.asarray([[4.3, 1.8, 1.0], [0.5, 0.5, 1.0], [1.9, 0.5, 1.0]], np.float32)))
         E = self._epi
@@ -1021,6 +1100,11 @@ class RolloutEngine:
         init = row < E['n0'][:, None]                                                 # rows of the initial agents
         pos_a = self.pos.permute(0, 2, 1, 3)                                          # [S, A_cap, T, 2]
         head_a = self.head.permute(0, 2, 1)
+        lg_all, x_pt_all = self.logits, self.x_pt
+        if detach:
+            pos_a, head_a = pos_a.contiguous(), head_a.contiguous()
+            lg_all = lg_all.clone() if lg_all is not None else None
+            x_pt_all = x_pt_all.clone() if x_pt_all is not None else None
         nstate = self.state.permute(0, 2, 1).long().clone()
         ntok = self.token.permute(0, 2, 1).long().clone()
         # history columns of next_token_idx / next_state_idx are the input tokens (:1733-1735); inserted rows: no token up to and
@@ -1061,7 +1145,8 @@ class RolloutEngine:
             o = dict(ego_index=h['av'], agent_id=E['ids'][s, :A], valid_mask=E['val'][s, :A0], pos_a=pos_a[s, :A], head_a=head_a[s, :A],
                      pred_traj=pt[s, :A], pred_head=ph[s, :A], pred_state=ps[s, :A], pred_valid=pvalid[s, :A], pred_type=atype[s, :A],
                      pred_shape=pshape[s, :A], eval_shape=eval_shape[s, :A], pred_z=torch.zeros_like(ph[s, :A]),
-                     next_token_idx=ntok[s, :A], next_state_idx=nstate[s, :A], gt_traj=E['gt'][s, :A0], num_inserted=A - A0)
+                     next_token_idx=ntok[s, :A], next_state_idx=nstate[s, :A], gt_traj=E['gt'][s, :A0, :self._gt_len[s]],
+                     num_inserted=A - A0)
             if self.ins is not None:
                 labels = [[None] * T for _ in range(A)]
                 per_step = {}
@@ -1075,10 +1160,10 @@ class RolloutEngine:
                 so = self.seed_out
                 o.update(next_state_prob_seed=so['state'][s], next_pos_rel_prob_seed=so['pos'][s], grid_agent_occ_seed=so['occ_a'][s],
                          grid_pt_occ_seed=so['occ_p'][s], grid_agent_occ_gt_seed=so['occ_gt'][s])
-            if self.logits is not None:
-                o['logits'] = self.logits[:, s * A_cap:s * A_cap + A]
-            if self.x_pt is not None:
-                o['x_pt'] = self.x_pt[s * self.M_cap:s * self.M_cap + M]
+            if lg_all is not None:
+                o['logits'] = lg_all[:, s * A_cap:s * A_cap + A]
+            if x_pt_all is not None:
+                o['x_pt'] = x_pt_all[s * self.M_cap:s * self.M_cap + M]
             outs.append(o)
         return outs
 
@@ -1105,20 +1190,22 @@ def rollout_many(engines: Sequence[RolloutEngine], streams: Optional[Sequence[to
         return
     cur = torch.cuda.current_stream(dev)
     live = []
-    for e, st in zip(engines, streams):
-        st.wait_stream(cur)
-        with torch.cuda.stream(st):
-            e.prologue()
-            live.append((e.run_gen(), st))
-    while live:
-        nxt = []
-        for g, st in live:
+    try:
+        for e, st in zip(engines, streams):
+            st.wait_stream(cur)
             with torch.cuda.stream(st):
-                try:
-                    next(g)
-                    nxt.append((g, st))
-                except StopIteration:
-                    pass
-        live = nxt
-    for st in streams:
-        cur.wait_stream(st)
+                e.prologue()
+                live.append((e.run_gen(), st))
+        while live:
+            nxt = []
+            for g, st in live:
+                with torch.cuda.stream(st):
+                    try:
+                        next(g)
+                        nxt.append((g, st))
+                    except StopIteration:
+                        pass
+            live = nxt
+    finally:
+        for st in streams:          # also when a generator raised (InsertionHeadroomError): the caller's stream waits for all
+            cur.wait_stream(st)

@@ -76,12 +76,10 @@ class LongMetric:
         self.sums = {k: 0.0 for k in self.field_names}
         self.longs: Dict[str, List[Tensor]] = {k: [] for k in self.field_names}
         self.scenario_counter = self.placement_valid_scenario_counter = self.removement_valid_scenario_counter = 0
-        self._synced = False
 
     def update(self, features: Optional[MetricFeatures] = None, metrics=None) -> None:
         """one scenario: its MetricFeatures (scored here) or the (scalars, per-window) pair of compute_scenario_metrics"""
         scal, long = metrics if metrics is not None else compute_scenario_metrics(self.metrics_config, self.log_distributions, features)
-        self._synced = False
         self.scenario_counter += 1
         self.placement_valid_scenario_counter += scal['distance_placement_likelihood'] > 0
         self.removement_valid_scenario_counter += scal['distance_removement_likelihood'] > 0
@@ -96,18 +94,24 @@ class LongMetric:
                     counters=(self.scenario_counter, self.placement_valid_scenario_counter,
                               self.removement_valid_scenario_counter))
 
-    def sync(self) -> None:
+    def synced_state(self) -> Dict:
         """the reference's torchmetrics reduction at compute() (dist_reduce_fx 'sum' for the scalars, 'cat' for the per-window
-        lists, compute_metrics.py:1199-1204): every rank ends with the state of all ranks.  No-op without a process group."""
+        lists, compute_metrics.py:1199-1204): the state of ALL ranks, returned as a new dict - this object keeps its local state
+        (torchmetrics restores it after compute() too), so update() / compute() may be repeated without double counting.
+        A COLLECTIVE when a process group is up: every rank must call it (hence compute())."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or self._synced:
-            return
+        st = self.state()
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return st
         states = [None] * dist.get_world_size()
-        dist.all_gather_object(states, self.state())
-        for r, st in enumerate(states):
-            if r != dist.get_rank():
-                self.merge(st)
-        self._synced = True
+        dist.all_gather_object(states, st)
+        tot = dict(sums={k: 0.0 for k in self.field_names}, longs={k: [] for k in self.field_names}, counters=(0, 0, 0))
+        for o in states:                      # rank order: the 'cat' lists are rank-major like torchmetrics' gather
+            for k in self.field_names:
+                tot['sums'][k] += o['sums'][k]
+                tot['longs'][k] += o['longs'][k]
+            tot['counters'] = tuple(a + b for a, b in zip(tot['counters'], o['counters']))
+        return tot
 
     def merge(self, other_state: Dict) -> None:
         """add another rank's state (sum / cat)"""
@@ -120,21 +124,23 @@ class LongMetric:
         self.removement_valid_scenario_counter += c[2]
 
     def compute(self) -> Dict:
-        """reference :1401-1447 (the state is reduced across ranks first, like torchmetrics does)"""
-        self.sync()
+        """reference :1401-1447, on the state of all ranks (``synced_state``: a collective under a process group; the local
+        state is left as it is)"""
+        st = self.synced_state()
+        sums, longs, (n_all, n_place, n_remove) = st['sums'], st['longs'], st['counters']
         mean, mean_long = {}, {}
         for k in self.field_names:
-            den = self.scenario_counter
+            den = n_all
             if k == 'distance_placement_likelihood':
-                den = self.placement_valid_scenario_counter
+                den = n_place
             if k == 'distance_removement_likelihood':
-                den = self.removement_valid_scenario_counter
-            mean[k] = self.sums[k] / max(den, 1)
-            if self.longs[k]:
-                mean_long[k] = _reduce_mean(torch.cat(self.longs[k]), dim=0)
+                den = n_remove
+            mean[k] = sums[k] / max(den, 1)
+            if longs[k]:
+                mean_long[k] = _reduce_mean(torch.cat(longs[k]), dim=0)
         w = {f: _hist(self.metrics_config, f)[3] for f in FIELDS}
         out = {f'{self.prefix}/wosac/realism_meta_metric': mean['metametric'], f'{self.prefix}/wosac/min_ade':
-               mean['min_average_displacement_error'], f'{self.prefix}/wosac/scenario_counter': int(self.scenario_counter)}
+               mean['min_average_displacement_error'], f'{self.prefix}/wosac/scenario_counter': int(n_all)}
         n_win = next(iter(mean_long.values())).shape[0] if mean_long else 0
         long_b = {'realism_meta_metric': mean_long.get('metametric')}
         for b, fields in BUCKETS.items():

@@ -158,6 +158,7 @@ class InfGenDecoder(nn.Module):
                             state_token=dict(state_token))
         self._packed = None
         self._packed_ver = None
+        self._engines = {}          # RolloutEngine per batch layout, reused across calls (RolloutEngine.reload)
 
     # ------------------------------------------------------------------ weights
     def _weights(self) -> PackedWeights:
@@ -177,6 +178,7 @@ class InfGenDecoder(nn.Module):
             sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items()}
             self._packed = PackedWeights(sd, cfg, dev)
             self._packed_ver = ver
+            self._engines = {}
         return self._packed
 
     # ------------------------------------------------------------------ driver
@@ -199,9 +201,12 @@ class InfGenDecoder(nn.Module):
         w.cfg.disable_insertion = bool(ae.disable_insertion)
         k = int(getattr(ae, 'motion_beam_size', 1))
         if k > 1 and sample_uniforms is None and not map_only:
-            # stochastic decode like the reference's default (top-k multinomial), driven by torch's RNG
+            # stochastic decode like the reference's default (top-k multinomial), driven by torch's RNG: one uniform per decode
+            # step and agent row - with insertion on for every row a scene can ever hold (a row without its own uniform would
+            # be decoded greedily)
             amax = max(int(np.asarray(s_['agent']['state_idx']).shape[0]) for s_ in scenes)
-            sample_uniforms = torch.rand(w.cfg.num_decode_steps, len(scenes), amax + 128).numpy()
+            ucols = amax if w.cfg.disable_insertion else int(_lib.load().infgen_layout_query(_lib.Q_MAX_AGENTS))
+            sample_uniforms = torch.rand(w.cfg.num_decode_steps, len(scenes), ucols).numpy()
         ik = int(getattr(ae, 'insert_beam_size', 1))
         insert_uniforms = None
         if ik > 1 and not w.cfg.disable_insertion and not map_only:
@@ -214,7 +219,19 @@ class InfGenDecoder(nn.Module):
                                  insert_k=ik if insert_uniforms is not None else 1, insert_uniforms=insert_uniforms,
                                  # the seed node's per-insertion outputs (plot inputs of the reference): single-scene entry only
                                  seed_outputs=batch is None and not w.cfg.disable_insertion and not map_only)
-        eng = make_engine()
+        # one engine per batch layout is kept across calls: a second call of the same shape re-uploads the scene arrays into
+        # the first call's device buffers instead of building (and allocating) an engine again
+        ekey = (len(scenes), PackedWeights.tables_key(*(vocab[k_] for k_ in ('veh', 'ped', 'cyc')), grid, map_vocab),
+                bool(w.cfg.disable_insertion), w.cfg.num_recurrent_steps_val, k if not map_only else 1,
+                ik if insert_uniforms is not None else 1, bool(int(os.getenv('DEBUG', 0))), batch is None, map_only, xo is None)
+        eng = self._engines.get(ekey)
+        if eng is not None and eng.fits(scenes):
+            eng.reload(scenes, sample_uniforms=sample_uniforms, insert_uniforms=insert_uniforms, x_pt_override=xo)
+        else:
+            eng = make_engine()
+            if len(self._engines) >= 2:
+                self._engines.pop(next(iter(self._engines)))
+            self._engines[ekey] = eng
         if map_only:
             eng.prologue(map_only=True)
             return eng.x_pt[:eng.hosts[0]['M']].clone()
@@ -229,8 +246,9 @@ class InfGenDecoder(nn.Module):
                 limit = eng.lib.infgen_layout_query(_lib.Q_MAX_AGENTS)
                 if eng.A_cap >= limit:
                     raise
-                eng = make_engine(headroom=min(2 * eng.A_cap, limit) - amax)
-        outs = eng.outputs_device()            # per-scene dicts of device tensors (no host round trip of the results)
+                eng = self._engines[ekey] = make_engine(headroom=min(2 * eng.A_cap, limit) - amax)
+        # per-scene dicts of device tensors (no host round trip of the results), detached from the engine's buffers
+        outs = eng.outputs_device(detach=True)
         dev = w.device
         res = []
         steps = w.cfg.num_decode_steps

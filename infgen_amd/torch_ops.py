@@ -12,8 +12,11 @@ take the PACKED parameter blocks the library reads (``infgen_amd.packing``; the 
     torch.ops.infgen_hip.mlp_layer(x (N, K), pack, n_out)                                   -> (N, n_out)
     torch.ops.infgen_hip.mlp_embedding(x (N, K), pack)                                      -> (N, 128)
 
-(the fused ``decode_step`` / ``rollout`` level works on the persistent state struct and stays a C-ABI call: ``InfgenRollout`` in
-include/infgen_hip.h, driven by infgen_amd/engine.py).  ``register_fake`` gives every op a shape function, so they trace under
+    torch.ops.infgen_hip.integrate_tokenise(token, state, type, pos, head, n_agents, ego, vocab, grid) -> pos', head', pred_traj, pred_head, grid, state'
+    torch.ops.infgen_hip.decode_step(ctx_bytes, t, pos, head, state, token, grid, x, next_token, next_state) -> next_token, next_state
+
+(``decode_step`` works on the persistent state block ``InfgenRollout`` of include/infgen_hip.h, which ``RolloutEngine.ctx_tensor()``
+hands out as bytes; whole rollouts stay a C-ABI call, ``infgen_rollout_run``, driven by infgen_amd/engine.py).  ``register_fake`` gives every op a shape function, so they trace under
 ``torch.compile`` / ``make_fx`` as opaque calls.  Inference only: no autograd formula is registered.
 """
 from __future__ import annotations
@@ -174,3 +177,81 @@ def mlp_embedding(x: torch.Tensor, pack: torch.Tensor) -> torch.Tensor:
 @mlp_embedding.register_fake
 def _(x, pack):
     return x.new_empty(x.shape[0], D, dtype=torch.float32)
+
+
+@torch.library.custom_op('infgen_hip::integrate_tokenise', mutates_args=())
+def integrate_tokenise(token: torch.Tensor, state: torch.Tensor, agent_type: torch.Tensor, pos: torch.Tensor, head: torch.Tensor,
+                       n_agents: torch.Tensor, ego: torch.Tensor, vocab: torch.Tensor, grid_xy: torch.Tensor
+                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """token -> trajectory -> next pose -> grid cell for dense batches (reference agent_decoder.py:2175-2239,
+    attr_tokenizer.py:77-89): ``token`` / ``state`` / ``agent_type`` (S, A) int, ``pos`` (S, A, 2), ``head`` (S, A) the current
+    pose, ``n_agents`` / ``ego`` (S,), ``vocab`` (3, token_size, 6, 4, 2), ``grid_xy`` (G, 2).  ``state`` is the state head's
+    class index (2 -> exit; the ego is forced valid).  Returns the next pose ``pos'`` (S, A, 2), ``head'`` (S, A) (zeros for
+    invalid rows), the five intermediate poses ``pred_traj`` (S, A, 5, 2) / ``pred_head`` (S, A, 5), the cell of the new position in
+    the ego's new frame ``grid`` (S, A) (-1 invalid) and the stored ``state'`` (S, A).  One launch of ``infgen_integrate``."""
+    dev = pos.device
+    ops = _ops(dev)
+    S, A = token.shape
+    A_cap = max(32, (A + 31) // 32 * 32)
+    if A_cap > ops.lib.infgen_layout_query(_lib.Q_MAX_AGENTS):
+        raise _lib.InfgenHipError('integrate_tokenise: more rows per scene than the layout holds')
+    i32 = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.int32)
+    T = 3
+    P = torch.zeros(S, T, A_cap, 2, device=dev); H = torch.zeros(S, T, A_cap, device=dev)
+    ST, TK, GR = i32(S, T, A_cap), i32(S, T, A_cap), i32(S, T, A_cap)
+    IM = torch.ones(S, T, A_cap, device=dev, dtype=torch.uint8); CF = torch.ones_like(IM); TM = torch.ones_like(IM)
+    P[:, 1, :A] = pos.float(); H[:, 1, :A] = head.float()
+    ty, nt, ns = i32(S, A_cap), i32(S, A_cap), i32(S, A_cap)
+    ty[:, :A] = agent_type.int(); nt[:, :A] = token.int(); ns[:, :A] = state.int()
+    bos = i32(S, A_cap)
+    na, av = n_agents.to(dev).int().contiguous(), ego.to(dev).int().contiguous()
+    traj, phead, pstate = torch.zeros(S, A_cap, 5, 2, device=dev), torch.zeros(S, A_cap, 5, device=dev), torch.zeros(S, A_cap, 5, device=dev)
+    voc, gxy = _f32(vocab), _f32(grid_xy)
+    c = _lib.Rollout()
+    Pp = _lib.ptr
+    c.S, c.A_cap, c.T, c.M_cap, c.W, c.ring, c.R = S, A_cap, T, 32, 1, 2, 5
+    c.token_size, c.grid_size, c.num_layers = int(voc.shape[1]), int(gxy.shape[0]), 1
+    c.n_agents, c.n_map, c.av_index = Pp(na), Pp(i32(S)), Pp(av)
+    c.pos, c.head, c.state, c.token, c.grid = Pp(P), Pp(H), Pp(ST), Pp(TK), Pp(GR)
+    c.tmask, c.imask, c.catflag, c.type, c.bos = Pp(TM), Pp(IM), Pp(CF), Pp(ty), Pp(bos)
+    c.next_token, c.next_state = Pp(nt.view(-1)), Pp(ns.view(-1))
+    c.vocab, c.grid_xy = Pp(voc), Pp(gxy)
+    c.pred_traj, c.pred_head, c.pred_state = Pp(traj), Pp(phead), Pp(pstate)
+    if S and A:
+        _lib.check(ops.lib.infgen_integrate(C.byref(c), 0, ops.stream), 'infgen_integrate')
+    return (P[:, 2, :A].contiguous(), H[:, 2, :A].contiguous(), traj[:, :A].contiguous(), phead[:, :A].contiguous(),
+            GR[:, 2, :A].contiguous(), ST[:, 2, :A].contiguous())
+
+
+@integrate_tokenise.register_fake
+def _(token, state, agent_type, pos, head, n_agents, ego, vocab, grid_xy):
+    S, A = token.shape
+    f = lambda *shape: pos.new_empty(*shape, dtype=torch.float32)
+    i = lambda *shape: pos.new_empty(*shape, dtype=torch.int32)
+    return f(S, A, 2), f(S, A), f(S, A, 5, 2), f(S, A, 5), i(S, A), i(S, A)
+
+
+@torch.library.custom_op('infgen_hip::decode_step',
+                         mutates_args=('pos', 'head', 'state', 'token', 'grid', 'x', 'next_token', 'next_state'))
+def decode_step(ctx: torch.Tensor, t: int, pos: torch.Tensor, head: torch.Tensor, state: torch.Tensor, token: torch.Tensor,
+                grid: torch.Tensor, x: torch.Tensor, next_token: torch.Tensor, next_state: torch.Tensor
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """one decode step over a persistent state block (reference agent_decoder.py:1740-2301 without the
+    insertion sub-loop): edge sets of column 1 + t, the 18 sublayers, heads, token -> pose -> grid cell, raw feature of the new
+    column - ``infgen_decode_step``.  ``ctx``: the bytes of the ``InfgenRollout`` block (include/infgen_hip.h) as a uint8 CPU
+    tensor (``RolloutEngine.ctx_tensor()``); the arrays the block points to that a step writes are passed (and declared
+    mutated) so that a tracer sees the data flow: ``pos`` / ``head`` / ``state`` / ``token`` / ``grid`` [S][T][A_cap], the residual
+    stream ``x`` [rows][128] and the heads' outputs ``next_token`` / ``next_state`` [rows], copies of which are returned."""
+    ops = _ops(pos.device)
+    blk = _lib.Rollout.from_buffer_copy(ctx.numpy().tobytes())
+    for name, ten in (('pos', pos), ('head', head), ('state', state), ('token', token), ('grid', grid), ('X', x),
+                      ('next_token', next_token), ('next_state', next_state)):
+        if int(getattr(blk, name) or 0) != ten.data_ptr():
+            raise _lib.InfgenHipError(f'decode_step: `{name}` is not the array the state block points to')
+    _lib.check(ops.lib.infgen_decode_step(C.byref(blk), int(t), ops.stream), 'infgen_decode_step')
+    return next_token.clone(), next_state.clone()
+
+
+@decode_step.register_fake
+def _(ctx, t, pos, head, state, token, grid, x, next_token, next_state):
+    return torch.empty_like(next_token), torch.empty_like(next_state)

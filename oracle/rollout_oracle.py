@@ -196,10 +196,14 @@ class RolloutOracle:
     (``motion_beam_size = 1``; ``disable_insertion`` as in BASELINE configs C1-C3)."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], cfg, grid: np.ndarray, prefix: str = 'agent_encoder',
-                 live_state: bool = False):
+                 live_state: bool = False, all_columns: bool = False):
         self.sd, self.cfg, self.p = sd, cfg, prefix
         self.grid = _t(grid).float()
         self.live_state = live_state
+        # "reference-shaped" control flow (SURVEY 8d, CPU baseline only): every decode step pushes ALL A*T nodes through the
+        # 18 layers like agent_decoder.py:2133-2158 does (edges only into column c; the other columns' outputs are discarded
+        # there too, :2153-2154) instead of column c alone.  Same results for column c, T times the node-side work.
+        self.all_columns = all_columns
         self.W = cfg.window
         self.H, self.dh = cfg.num_heads, cfg.head_dim
 
@@ -333,6 +337,9 @@ class RolloutOracle:
             st['edge_count'].append((int(trow.numel()), int(adst.numel()), int(mdst.numel())))
         for i in range(cfg.num_agent_layers):
             st['X'][i][:, c] = x
+            if self.all_columns and not edgeless:
+                x = self._triple_all_columns(st, c, i, (tj, trow, r_t), (msrc, mdst, r_m), (asrc, adst, r_a))
+                continue
             if edgeless:
                 x = attention_layer(sd, f'{p}.t_attn_layers.{i}', x, None, z, z)
                 x = attention_layer(sd, f'{p}.pt2a_attn_layers.{i}', x, None, z, z, x_src_raw=st['x_pt'])
@@ -349,6 +356,21 @@ class RolloutOracle:
             x = attention_layer(sd, f'{p}.pt2a_attn_layers.{i}', x, r_m, msrc, mdst, x_src_raw=st['x_pt'])
             x = attention_layer(sd, f'{p}.a2a_attn_layers.{i}', x, r_a, asrc, adst)
         return x
+
+    def _triple_all_columns(self, st, c, i, te, me, ae):
+        """layer triple i over all A*T nodes (agent_decoder.py:2133-2147): node n = row * T + column; the temporal layer's
+        sources are the cached layer inputs of the past columns (a-Q4), x_pt is repeated T times for the bipartite layer"""
+        sd, p = self.sd, self.p
+        Xi = st['X'][i]
+        A, T, Dh = Xi.shape
+        M = st['x_pt'].shape[0]
+        (tj, trow, r_t), (msrc, mdst, r_m), (asrc, adst, r_a) = te, me, ae
+        feat = Xi.reshape(A * T, Dh)
+        feat = attention_layer(sd, f'{p}.t_attn_layers.{i}', feat, r_t if trow.numel() else None, trow * T + tj, trow * T + c)
+        x_pt_rep = st['x_pt'].repeat(T, 1)                                   # (T*M, 128), step-major like :2142-2144
+        feat = attention_layer(sd, f'{p}.pt2a_attn_layers.{i}', feat, r_m, c * M + msrc, mdst * T + c, x_src_raw=x_pt_rep)
+        feat = attention_layer(sd, f'{p}.a2a_attn_layers.{i}', feat, r_a, asrc * T + c, adst * T + c)
+        return feat.view(A, T, Dh)[:, c].clone()
 
     # ---- full rollout
     @torch.no_grad()
@@ -521,11 +543,11 @@ class RolloutOracle:
 
 
 def run_scene(sd, scene, cfg, vocab, map_vocab, grid, live_state=False, teacher=None, sample_k=1,
-              sample_uniforms=None):
+              sample_uniforms=None, all_columns=False):
     """map prologue + rollout; returns the rollout dict plus ``x_pt``."""
     with torch.no_grad():
         x_pt = map_encoder(sd, scene, cfg, map_vocab)
-        orc = RolloutOracle(sd, cfg, grid, live_state=live_state)
+        orc = RolloutOracle(sd, cfg, grid, live_state=live_state, all_columns=all_columns)
         tt = ts = None
         if teacher is not None:
             tt, ts = teacher

@@ -39,12 +39,12 @@ def load_case(name):
     map_vocab = synth.make_map_vocab()
     grid = synth.build_grid(cfg.grid_range, cfg.grid_interval, cfg.pl2seed_radius)
     scene = synth.make_scene(meta['seed'], meta['A'], meta['M'], cfg, ego_last=meta['ego_last'],
-                             edge_cases=meta['edge_cases'], vocab=vocab, grid=grid)
+                             edge_cases=meta['edge_cases'], vocab=vocab, grid=grid, slip=float(meta.get('slip', 0.0)))
     sd = make_weights(seed=meta['weight_seed'], head_gain=meta['head_gain'])
     return dict(z=z, meta=meta, cfg=cfg, vocab=vocab, map_vocab=map_vocab, grid=grid, scene=scene, sd=sd)
 
 
-GOLDEN_CASES = ['c1_a8_m128', 'a24_m256_edge', 'a16_m128_egofirst_state', 'c2_a32_m512']
+GOLDEN_CASES = ['c1_a8_m128', 'a24_m256_edge', 'a16_m128_egofirst_state', 'c2_a32_m512', 'c3_a64_m1024']
 
 
 @pytest.fixture(scope='session')

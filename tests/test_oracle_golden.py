@@ -19,12 +19,32 @@ def test_oracle_matches_reference_fixture(case):
     assert np.abs(out['x_pt'].numpy() - z['x_pt']).max() <= 1e-5
     assert np.array_equal(out['next_token_idx'].numpy(), z['next_token_idx'])
     assert np.array_equal(out['next_state_idx'].numpy(), z['next_state_idx'])
-    assert np.abs(out['logits'].numpy() - z['logits']).max() <= 1e-5 * max(1.0, m['head_gain']) * 4
+    nl = z['logits'].shape[0]                   # (the C3-sized fixture keeps the full logits of its first steps only ...)
+    assert np.abs(out['logits'].numpy()[:nl] - z['logits']).max() <= 1e-5 * max(1.0, m['head_gain']) * 4
+    if 'logit_max' in z.files:                  # (... and every row's maximum / arg-max for all steps)
+        assert np.abs(out['logits'].numpy().max(-1) - z['logit_max']).max() <= 1e-5 * max(1.0, m['head_gain']) * 4
+        assert np.array_equal(out['logits'].numpy().argmax(-1), z['logit_argmax'])
     for k in ('pos_a', 'head_a', 'pred_traj', 'pred_head', 'pred_state'):
         assert np.abs(out[k].numpy() - z[k]).max() <= 1e-5, k
     assert np.array_equal(out['pred_valid'].numpy(), z['pred_valid'])
     assert np.array_equal(out['agent_id'].numpy(), z['agent_id'])
     assert out['ego_index'] == int(z['ego_index'])
+    assert np.array_equal(out['edge_count'], z['edge_count'])
+
+
+@pytest.mark.parametrize('case', ['c1_a8_m128', 'a24_m256_edge'])
+def test_reference_shaped_oracle_matches_reference_fixture(case):
+    """the all-columns control flow of agent_decoder.py:2133-2158 (bench.py's "reference-shaped" CPU baseline) gives the
+    reference's tokens / logits too - it only re-does the node-side work of every column"""
+    c = load_case(case)
+    z, m = c['z'], c['meta']
+    sd = {k: torch.from_numpy(v) for k, v in c['sd'].items()}
+    torch.set_num_threads(8)
+    out = ro.run_scene(sd, c['scene'], c['cfg'], c['vocab'], c['map_vocab'], c['grid'], live_state=m['live_state'],
+                       all_columns=True)
+    assert np.array_equal(out['next_token_idx'].numpy(), z['next_token_idx'])
+    assert np.array_equal(out['next_state_idx'].numpy(), z['next_state_idx'])
+    assert np.abs(out['logits'].numpy() - z['logits']).max() <= 1e-5 * max(1.0, m['head_gain']) * 4
     assert np.array_equal(out['edge_count'], z['edge_count'])
 
 

@@ -102,3 +102,81 @@ def test_ops_refuse_cpu_tensors(env):
     from infgen_amd import _lib
     with pytest.raises(_lib.InfgenHipError):
         torch.ops.infgen_hip.mlp_embedding(torch.zeros(4, 8), torch.zeros(10))
+
+
+def test_integrate_tokenise_op(env):
+    """token -> contour -> next pose -> grid cell (agent_decoder.py:2175-2239, attr_tokenizer.py:77-89) against the oracle's
+    restatement of the same lines; ragged scenes, an invalid and an exit state, ego first / last"""
+    from infgen_amd import synth
+    from oracle import rollout_oracle as ro
+    rng = np.random.default_rng(5)
+    cfg = synth.standard_config()
+    vocab = synth.make_agent_vocab(cfg.token_size)
+    grid = synth.build_grid(cfg.grid_range, cfg.grid_interval, cfg.pl2seed_radius)
+    tabs = np.stack([vocab[k] for k in ('veh', 'ped', 'cyc')]).astype(np.float32)
+    S, A = 3, 40
+    n = np.array([40, 7, 33], np.int32)
+    ego = np.array([39, 0, 5], np.int32)
+    tok = rng.integers(0, cfg.token_size, (S, A)).astype(np.int32)
+    st = np.ones((S, A), np.int32)
+    st[0, 3], st[2, 9] = 0, 2                    # one invalid row, one 'exit' (class 2 -> state 3)
+    ty = rng.integers(0, 3, (S, A)).astype(np.int32)
+    pos = rng.uniform(-60, 60, (S, A, 2)).astype(np.float32)
+    head = rng.uniform(-np.pi, np.pi, (S, A)).astype(np.float32)
+    dev = env['dev']
+    d = lambda a: torch.from_numpy(a).to(dev)
+    npos, nhead, traj, phead, cell, nst = torch.ops.infgen_hip.integrate_tokenise(
+        d(tok), d(st), d(ty), d(pos), d(head), d(n), d(ego), d(tabs), d(grid.astype(np.float32)))
+    for s in range(S):
+        a = int(n[s])
+        c = torch.from_numpy(tabs)[torch.from_numpy(ty[s, :a]).long(), torch.from_numpy(tok[s, :a]).long()]     # (a, 6, 4, 2)
+        c = ro.rot_right(c.view(a, 24, 2), torch.from_numpy(head[s, :a])).view(a, 6, 4, 2) + torch.from_numpy(pos[s, :a])[:, None, None]
+        want_traj = c[:, 1:].mean(dim=2)
+        dxy = c[:, 1:, 0] - c[:, 1:, 3]
+        want_head = torch.atan2(dxy[..., 1], dxy[..., 0])
+        assert float((traj[s, :a].cpu() - want_traj).abs().max()) <= 1e-4
+        assert float((phead[s, :a].cpu() - want_head).abs().max()) <= 1e-5
+        want_state = st[s, :a].copy()
+        want_state[want_state == 2] = 3
+        want_state[ego[s]] = 1
+        assert np.array_equal(nst[s, :a].cpu().numpy(), want_state)
+        ok = torch.from_numpy(want_state != 0)
+        p_n, h_n = want_traj[:, -1], want_head[:, -1]
+        assert float((npos[s, :a].cpu() - p_n)[ok].abs().max()) <= 1e-4
+        e = int(ego[s])
+        want_cell = ro.encode_pos(torch.from_numpy(grid).float(), p_n, p_n[e][None].expand(a, 2), h_n[e]).numpy()
+        got = cell[s, :a].cpu().numpy()
+        okn = ok.numpy()
+        # a cell border within float noise of the position can go either way: require the same distance there
+        diff = (got != want_cell) & okn
+        if diff.any():
+            g = torch.from_numpy(grid).float()
+            cx = ro.rot_right((p_n - p_n[e])[:, None], (-(h_n[e] - np.pi / 2)).expand(a))[:, 0]
+            d_got = (cx - g[torch.from_numpy(got).long().clamp(min=0)]).norm(dim=-1)
+            d_want = (cx - g[torch.from_numpy(want_cell).long()]).norm(dim=-1)
+            assert float((d_got - d_want)[torch.from_numpy(diff)].abs().max()) <= 1e-4
+            assert diff.sum() <= 1
+        assert (got[~okn] == -1).all() and float(npos[s, :a].cpu()[~ok].abs().sum()) == 0.0
+
+
+def test_decode_step_op_equals_the_engine(env):
+    """torch.ops.infgen_hip.decode_step over the engine's state block reproduces RolloutEngine.step bit for bit"""
+    from conftest import load_case
+    from infgen_amd import engine
+    c = load_case('a24_m256_edge')
+    dev = env['dev']
+    w = engine.PackedWeights(c['sd'], c['cfg'], dev)
+    mk = lambda: engine.RolloutEngine(w, [c['scene']], c['vocab'], c['map_vocab'], c['grid'], use_graph=False)
+    a, b = mk(), mk()
+    a.prologue(); b.prologue()
+    ctx = b.ctx_tensor()
+    for t in range(3):
+        a.step(t)
+        tok, st = torch.ops.infgen_hip.decode_step(ctx, t, b.pos, b.head, b.state, b.token, b.gridtok, b.X, b.next_token, b.next_state)
+        assert torch.equal(tok, a.next_token) and torch.equal(st, a.next_state)
+    for k in ('pos', 'head', 'state', 'token', 'gridtok', 'X'):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    z = c['z']
+    assert np.array_equal(b.outputs()[0]['next_token_idx'][:, :5], z['next_token_idx'][:, :5])
+    with pytest.raises(Exception):
+        torch.ops.infgen_hip.decode_step(ctx, 3, b.pos.clone(), b.head, b.state, b.token, b.gridtok, b.X, b.next_token, b.next_state)
