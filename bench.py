@@ -30,6 +30,7 @@ dominant kernel and for the whole step; DESIGN.md "Measurement" has the arithmet
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import socket
@@ -433,6 +434,7 @@ def main():
     # roofline leg 2: events only around the dominant kernel's launches, inside the timed region
     _lib.prof_enable(1 << _lib.KERNEL_IDS.index(dominant))
     dt_local = timed(ranks, eng.rollout, args.steps)
+    log(f'timed region done: {1e3 * dt_local / args.steps:.2f} ms per step')
     dt = dt_local
     timed_k = _lib.prof_collect()
     dom = timed_k[dominant]
@@ -514,7 +516,7 @@ def main():
     inserted = int((eng.n_agents.sum().item() - sum(h['A'] for h in eng.hosts))) if args.insertion else 0
     n_scenes_local = len(scenes)
     rows_per_scene = engines[0].A_cap
-    graph_used = bool(engines[0].use_graph)
+    graph_used = False      # (the timed region carries HIP events around the dominant kernel: launches are issued eagerly)
     per_rank = igdist.gather_metrics([1e3 * dt_local / args.steps, float(n_scenes_local)], dev)
     dt, agent_steps = igdist.reduce_run(dt, agent_steps, dev)
 
@@ -528,12 +530,16 @@ def main():
         torch.cuda.empty_cache()
 
         def leg(total, ids, steps):
+            log(f'c3_literal leg: {len(ids)} of {total} scenes')
             sc, _, _, _ = build_scenes(cfg, ids, args.agents, args.map_tokens)
             e = engine.RolloutEngine(w, sc, vocab, map_vocab, grid, store_logits=False, use_graph=use_graph)
-            for _ in range(3):                  # (a graph engine: eager, capture, first replay)
-                e.rollout()
-            torch.cuda.synchronize(dev)
-            t = timed(ranks, e.rollout, steps)
+            side = torch.cuda.Stream(device=dev) if os.environ.get('BENCH_SIDE_STREAM') else None
+            ctx = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+            with ctx:
+                for _ in range(3):                  # (a graph engine: eager, capture, first replay)
+                    e.rollout()
+                torch.cuda.synchronize(dev)
+                t = timed(ranks, e.rollout, steps)
             t, n = igdist.reduce_run(t, float(e.agent_steps() * steps), dev)
             return {'total_scenes': total, 'scenes_per_gpu': len(ids), 'value': n / t, 'ms_per_step': 1e3 * t / steps,
                     'steps': steps, 'hip_graph': bool(e.use_graph)}

@@ -257,6 +257,11 @@ extern "C" int infgen_set_fourier_mode(int mode) {
   return 0;
 }
 
+static int qs_dbg() {
+  static const int v = getenv("INFGEN_QS_DBG") ? atoi(getenv("INFGEN_QS_DBG")) : 0;
+  return v;
+}
+
 // out_r24: rows in the packed 24-bit format of kernels.h (k_fourier_h only; the rollout's private rhat buffers)
 static int fourier_embed_impl(const float* raw, int n, const int* count_dev, int e_cap, const float* pack,
                               const float* cat, int ldcat, float* out, int ldo, int normalize, int out_r24, void* stream,
@@ -267,7 +272,7 @@ static int fourier_embed_impl(const float* raw, int n, const int* count_dev, int
   if (dt_mode && (O().fourier_mode == 0 || n < 2 || (dt_mode == 1 && !dt_tab)))
     return fail("infgen_fourier_embed", "the last-dim table needs the split kernel, n_dims >= 2 and a table");
   FourierArgs a{raw, n, count_dev, e_cap, pack, cat, ldcat, out, ldo, normalize,
-                (g_prof.mask >> INFGEN_KID_FOURIER) & 1u && dt_mode != 2 ? g_prof.rows_dev : nullptr, out_r24, dt_tab, dt_mode};
+                (g_prof.mask >> INFGEN_KID_FOURIER) & 1u && dt_mode != 2 ? g_prof.rows_dev : nullptr, out_r24, dt_tab, dt_mode, qs_dbg()};
   if (O().fourier_mode == 0) {
     int grid = ceil_div(e_cap, TR);
     if (grid > 2048) grid = 2048;
@@ -349,6 +354,7 @@ extern "C" int infgen_active_row_groups(const int* n_agents, int S, int A_cap, i
 
 static void launch_attn_h(const AttnHArgs& a_in, void* stream) {
   AttnHArgs a = a_in;
+  a.dbg = qs_dbg();
   if (O().row_groups && a.rows == group_rows()) { a.groups = O().row_groups; a.n_groups = O().n_row_groups; }
   if (attn_kind(a.rows) == 2) {            // one 16-row group per workgroup
     const int grid = ceil_div(a.rows, 16);

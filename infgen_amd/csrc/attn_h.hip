@@ -76,6 +76,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnH
   }
   __syncthreads();
   QuarterStream<NTH, XRING> qs;
+  qs.dbg = a.dbg;
   qs.init(seg_ptr, seg_n, 5, (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x, Wb, tid);
   auto take = [&]() { return qs.take(); };
   auto gemm_unit = [&](f32x4 (&acc)[8], const u32x4 (&Bh)[4], const u32x4 (&Bl)[4]) {

@@ -32,6 +32,34 @@ struct AttnState {
 //     the K / V / rhat rows of PF edges are requested together.
 typedef float pk2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pk2 pk_fma(pk2 a, pk2 b, pk2 c) { return __builtin_elementwise_fma(a, b, c); }
+// Broadcast operands of the packed fp32 instructions.  hipcc folds pk2{s, s} into an operand-select modifier on a 32-bit register
+// (`v_pk_fma_f32 v[..], s[36:37], .. op_sel_hi:[0,1,1]`: the pair's high register is never written).  tools/hazard_repro2.hip shows that
+// such instructions give wrong results now and then while other waves of the CU execute MFMAs; the IG_EDGE_*
+// switches build the variants of that bisect: SPAIR - wave-uniform values as fully written SGPR pairs; VPAIR - per-lane values
+// as fully written VGPR pairs.
+__device__ __forceinline__ pk2 bc_s(float s) {          // s is wave-uniform (a v_readlane result)
+#if defined(IG_EDGE_SPAIR)
+  const unsigned u = __builtin_amdgcn_readfirstlane(__float_as_uint(s));
+  unsigned long long p = ((unsigned long long)u << 32) | u;
+  asm volatile("" : "+s"(p));
+  return __builtin_bit_cast(pk2, p);
+#elif defined(IG_EDGE_SVPAIR)
+  pk2 p = {s, s};
+  asm volatile("" : "+v"(p));
+  return p;
+#else
+  return pk2{s, s};
+#endif
+}
+__device__ __forceinline__ pk2 bc_v(float v) {
+#if defined(IG_EDGE_VPAIR)
+  pk2 p = {v, v};
+  asm volatile("" : "+v"(p));
+  return p;
+#else
+  return pk2{v, v};
+#endif
+}
 constexpr float EA_LOG2E = 1.44269504088896340736f;
 constexpr float EA_TAU = 8.0f;
 
@@ -67,7 +95,7 @@ struct EdgeAcc {
     if constexpr (HASR) {
       pk2 pp[H / 2];
 #pragma unroll
-      for (int j = 0; j < H / 2; ++j) pp[j] = pk_fma(uy[j], pk2{r2[1], r2[1]}, ux[j] * pk2{r2[0], r2[0]});
+      for (int j = 0; j < H / 2; ++j) pp[j] = pk_fma(uy[j], bc_v(r2[1]), ux[j] * bc_v(r2[0]));
       // halving exchange over lane bits 5 and 4 (gfx950 half / row swaps): after swapping the upper half of X with the
       // lower half of Y, X + Y holds the X sum in the lower lanes and the Y sum in the upper ones
       float k4[4];
@@ -96,25 +124,25 @@ struct EdgeAcc {
       const float mn = grow ? val : m;
       const float sc = __builtin_amdgcn_exp2f(m - mn);      // 0 on the first edge, 1 for heads that keep their reference
       lsum *= sc;
-      ag *= pk2{sc, sc};
+      ag *= bc_v(sc);
       if constexpr (HASR) {
 #pragma unroll
         for (int h = 0; h < H; ++h) {
           const float sh = readlane_f(sc, 8 * h);
-          zz[h] *= pk2{sh, sh};
+          zz[h] *= bc_s(sh);
         }
       }
       m = mn;
     }
     const float pe = __builtin_amdgcn_exp2f(val - m);
     lsum += pe;
-    ag = pk_fma(pk2{pe, pe}, v2, ag);
+    ag = pk_fma(bc_v(pe), v2, ag);
     if constexpr (HASR) {
       float ph[H];
 #pragma unroll
       for (int h = 0; h < H; ++h) ph[h] = readlane_f(pe, 8 * h);
 #pragma unroll
-      for (int h = 0; h < H; ++h) zz[h] = pk_fma(pk2{ph[h], ph[h]}, r2, zz[h]);
+      for (int h = 0; h < H; ++h) zz[h] = pk_fma(bc_s(ph[h]), r2, zz[h]);
     }
   }
 };

@@ -33,6 +33,7 @@ struct FourierArgs {
   //            (8 of the 4 (2 n + 1) weight quarters per tile are never staged);
   // dt_mode 2: writes that table - row e = the last dim's branch mlps[n - 1](-e) without its bias (the bias sum stays in the pack)
   const float* dt_tab; int dt_mode;
+  int dbg;                 // diagnostics (INFGEN_QS_DBG; wrong results): 1 free-running waves over a static weight ring
 };
 constexpr int DT_TAB_ROWS = 32;
 struct FourierMultiArgs { FourierArgs set[3]; };
@@ -113,6 +114,7 @@ struct AttnHArgs {
   int next_src_ln;                   // 1: LayerNorm with the *_src parameters (K/V of a bipartite source)
   float* nQ; float* nU; float* nK; float* nV;
   const int* groups; const int* n_groups;   // optional: the 16-row groups to process (device list + count), see k_active_groups
+  int dbg;                           // diagnostics (INFGEN_QS_DBG; wrong results): 1 free-running waves over a static weight ring
 };
 
 struct ActiveGroupsArgs { const int* n_agents; int S, A_cap, margin; int* groups; int* n_groups; };

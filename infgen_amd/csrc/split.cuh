@@ -142,6 +142,7 @@ struct QuarterStream {
   const int* seg_n;
   unsigned short (*Wb)[QUARTER];
   int nseg, total, consumed, slot, slot_stage, sseg, soff, tid;
+  int dbg = 0;
   __device__ __forceinline__ void stage_next() {
     while (soff >= seg_n[sseg]) { soff = 0; sseg = (sseg + 1 == nseg) ? 0 : sseg + 1; }
     stage_quarter<NTH>(seg_ptr[sseg] + (size_t)soff * QUARTER, Wb[slot_stage], tid);
@@ -158,6 +159,13 @@ struct QuarterStream {
     for (int d = 0; d < ND && d < total; ++d) stage_next();
   }
   __device__ __forceinline__ const unsigned short* take() {
+    if (dbg & 1) {                       // timing experiment: no barrier, no restaging - what free-running waves would cost
+      if (consumed == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+      const unsigned short* cur = Wb[slot];
+      slot = (slot + 1 == NR) ? 0 : slot + 1;
+      ++consumed;
+      return cur;
+    }
     if (consumed + ND <= total) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((ND - 1) * GLDS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

@@ -64,6 +64,9 @@ class ForwardEngine:
         self.vocab = t(np.stack([vocab[k] for k in ('veh', 'ped', 'cyc')]), np.float32)
         self._map_vocab = t(np.asarray(map_vocab, np.float32).reshape(map_vocab.shape[0], -1))
         self.grid_xy = t(grid, np.float32)
+        self._tables_key = PackedWeights.tables_key(np.stack([vocab[k] for k in ('veh', 'ped', 'cyc')]).astype(np.float32),
+                                                    np.asarray(grid, dtype=np.float32),
+                                                    np.asarray(map_vocab, dtype=np.float32).reshape(map_vocab.shape[0], -1))
         self.G = int(grid.shape[0])
         sd, ap = weights.sd, weights.ap
         if not hasattr(weights, 'fwd_heads'):
@@ -208,7 +211,7 @@ class ForwardEngine:
         A, T, B, S, N, G = self.A, self.T, self.B, self.S, self.N, self.G
         nn = T * N
         lt = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a).astype(np.int64))).to(dev)
-        tabs = w.tables(ops, self.vocab, self.grid_xy, self._map_vocab)
+        tabs = w.tables(ops, self.vocab, self.grid_xy, self._map_vocab, self._tables_key)
         x_pt = self.map_encoder(tabs)
         out = {'x_pt': x_pt, 'ego_pos': torch.from_numpy(h['pos'][h['av']]).to(dev)}
 
