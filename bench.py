@@ -30,7 +30,6 @@ dominant kernel and for the whole step; DESIGN.md "Measurement" has the arithmet
 from __future__ import annotations
 
 import argparse
-import contextlib
 import json
 import os
 import socket
@@ -330,7 +329,7 @@ def main():
     ap.add_argument('--edge-loop', type=int, default=-1, choices=(-1, 4, 6, 8))
     ap.add_argument('--graph', type=int, default=-1, choices=(-1, 0, 1),
                     help='replay the decode steps of a rollout from a captured HIP graph: 1 always, 0 never, -1 (default) the '
-                         'engine\'s rule (batches of up to 64 scenes)')
+                         'engine\'s rule (off unless INFGEN_GRAPH=1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-literal', action='store_true', help='skip the config.c3_literal legs')
@@ -533,13 +532,10 @@ def main():
             log(f'c3_literal leg: {len(ids)} of {total} scenes')
             sc, _, _, _ = build_scenes(cfg, ids, args.agents, args.map_tokens)
             e = engine.RolloutEngine(w, sc, vocab, map_vocab, grid, store_logits=False, use_graph=use_graph)
-            side = torch.cuda.Stream(device=dev) if os.environ.get('BENCH_SIDE_STREAM') else None
-            ctx = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
-            with ctx:
-                for _ in range(3):                  # (a graph engine: eager, capture, first replay)
-                    e.rollout()
-                torch.cuda.synchronize(dev)
-                t = timed(ranks, e.rollout, steps)
+            for _ in range(3):                  # (a graph engine: eager, capture, first replay)
+                e.rollout()
+            torch.cuda.synchronize(dev)
+            t = timed(ranks, e.rollout, steps)
             t, n = igdist.reduce_run(t, float(e.agent_steps() * steps), dev)
             return {'total_scenes': total, 'scenes_per_gpu': len(ids), 'value': n / t, 'ms_per_step': 1e3 * t / steps,
                     'steps': steps, 'hip_graph': bool(e.use_graph)}

@@ -279,11 +279,11 @@ static int fourier_embed_impl(const float* raw, int n, const int* count_dev, int
     ProfScope _ps(INFGEN_KID_FOURIER, stream);
     hipLaunchKernelGGL(k_fourier, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a);
   } else {
-    int grid = ceil_div(e_cap, 128);     // 128-row tiles (8 waves x 16 rows), persistent
-    if (grid > 256) grid = 256;          // one workgroup per CU (fourier_h.hip explains why)
+    int grid = ceil_div(e_cap, FH_TILE);     // 128-row tiles (8 waves x 16 rows), persistent
+    if (grid > 256 * FH_WG_PER_CU) grid = 256 * FH_WG_PER_CU;          // one workgroup per CU (fourier_h.hip explains why)
     ProfScope _ps(INFGEN_KID_FOURIER, stream);
-    if (O().gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h<1>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_fourier_h<3>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    if (O().gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h<1>, dim3(grid), dim3(FH_NT), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_fourier_h<3>, dim3(grid), dim3(FH_NT), 0, (hipStream_t)stream, a);
   }
   return check_launch("infgen_fourier_embed");
 }
@@ -362,7 +362,7 @@ static void launch_attn_h(const AttnHArgs& a_in, void* stream) {
     else hipLaunchKernelGGL(k_attn_hs<3>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     return;
   }
-  static const int waves = getenv("INFGEN_ATTN_WAVES") ? atoi(getenv("INFGEN_ATTN_WAVES")) : 4;
+  static const int waves = getenv("INFGEN_ATTN_WAVES") ? atoi(getenv("INFGEN_ATTN_WAVES")) : (IG_QSF ? 8 : 4);
   if (waves != 8) {
     int grid = ceil_div(a.rows, 64);
     if (grid > 512) grid = 512;          // two workgroups per CU, persistent over the 64-row tiles beyond that
@@ -423,7 +423,7 @@ extern "C" int infgen_set_edge_loop(int v) {
 // resident workgroups per CU the runtime reports for k_edge_fused<6> (diagnostics; tools/edge_probe.sh)
 extern "C" int infgen_edge_fused_occupancy(void) {
   int n = -1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_edge_fused<6, false, 2>, 1024, 0) != hipSuccess) return -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_edge_fused<6, true, 1, 8>, 512, 0) != hipSuccess) return -1;
   return n;
 }
 
@@ -436,10 +436,13 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
   static const int no_xcd = getenv("INFGEN_EDGE_NOXCD") ? atoi(getenv("INFGEN_EDGE_NOXCD")) : 0;
   static const int persist = getenv("INFGEN_EDGE_P") ? atoi(getenv("INFGEN_EDGE_P")) : 0;
   static const int small_max = getenv("INFGEN_EDGE_SMALL") ? atoi(getenv("INFGEN_EDGE_SMALL")) : 4096;
+  static const int wg2 = getenv("INFGEN_EDGE_WG2") ? atoi(getenv("INFGEN_EDGE_WG2")) : 0;
   const int G = O().edge_loop;
   // small launches: one 16-row group per workgroup (edge_fused.hip), twice the workgroups for the same rows
   const bool small = rows <= small_max && G == 6 && !persist;
-  const int tr = small ? 16 : 32;          // rows per tile
+  // INFGEN_EDGE_WG2=1: large launches as 8-wave workgroups of one 16-row group, two per CU
+  const bool two = !small && wg2 && G == 6 && !persist;
+  const int tr = (small || two) ? 16 : 32;          // rows per tile
   EdgeFusedArgs a{rows, Q, pack, Ksrc, Vsrc, EdgeSet{off, cnt, src, rhat}, AGG, nullptr, nullptr, dbg, 0, kv_once};
   int grid = ceil_div(rows, tr);           // with a group list at most that many
   if (O().row_groups && rows == group_rows()) { a.groups = O().row_groups; a.n_groups = O().n_row_groups; }
@@ -488,10 +491,11 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
     return check_launch("infgen_edge_attn_fused");
   }
   { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
-    auto kern = small ? (r24 ? k_edge_fused<6, true, 1> : k_edge_fused<6, false, 1>)
-              : r24 ? (G == 4 ? k_edge_fused<4, true, 2> : G == 8 ? k_edge_fused<8, true, 2> : k_edge_fused<6, true, 2>)
-                    : (G == 4 ? k_edge_fused<4, false, 2> : G == 8 ? k_edge_fused<8, false, 2> : k_edge_fused<6, false, 2>);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 0, (hipStream_t)stream, a); }
+    auto kern = small ? (r24 ? k_edge_fused<6, true, 1, 16> : k_edge_fused<6, false, 1, 16>)
+              : two ? (r24 ? k_edge_fused<6, true, 1, 8> : k_edge_fused<6, false, 1, 8>)
+              : r24 ? (G == 4 ? k_edge_fused<4, true, 2, 16> : G == 8 ? k_edge_fused<8, true, 2, 16> : k_edge_fused<6, true, 2, 16>)
+                    : (G == 4 ? k_edge_fused<4, false, 2, 16> : G == 8 ? k_edge_fused<8, false, 2, 16> : k_edge_fused<6, false, 2, 16>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(two ? 512 : 1024), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_edge_attn_fused");
 }
 
@@ -952,11 +956,11 @@ extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless,
     m.set[2] = FourierArgs{r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, pr, r24, nullptr, 0};
     int cap = r->et.cap > r->em.cap ? r->et.cap : r->em.cap;
     if (r->ea.cap > cap) cap = r->ea.cap;
-    int grid = ceil_div(cap, 128);
-    if (grid > 256) grid = 256;
+    int grid = ceil_div(cap, FH_TILE);
+    if (grid > 256 * FH_WG_PER_CU) grid = 256 * FH_WG_PER_CU;
     { ProfScope _ps(INFGEN_KID_FOURIER, stream);
-      if (O().gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h_multi<1>, dim3(grid, 3), dim3(512), 0, (hipStream_t)stream, m);
-      else hipLaunchKernelGGL(k_fourier_h_multi<3>, dim3(grid, 3), dim3(512), 0, (hipStream_t)stream, m); }
+      if (O().gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h_multi<1>, dim3(grid, 3), dim3(FH_NT), 0, (hipStream_t)stream, m);
+      else hipLaunchKernelGGL(k_fourier_h_multi<3>, dim3(grid, 3), dim3(FH_NT), 0, (hipStream_t)stream, m); }
     RET_IF(check_launch("infgen_decode_layers(fourier)"));
   } else if (!edgeless) {
     RET_IF(fourier_embed_impl(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, r24, stream, dt, dt != nullptr));

@@ -32,11 +32,15 @@ struct AttnState {
 //     the K / V / rhat rows of PF edges are requested together.
 typedef float pk2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pk2 pk_fma(pk2 a, pk2 b, pk2 c) { return __builtin_elementwise_fma(a, b, c); }
-// Broadcast operands of the packed fp32 instructions.  hipcc folds pk2{s, s} into an operand-select modifier on a 32-bit register
-// (`v_pk_fma_f32 v[..], s[36:37], .. op_sel_hi:[0,1,1]`: the pair's high register is never written).  tools/hazard_repro2.hip shows that
-// such instructions give wrong results now and then while other waves of the CU execute MFMAs; the IG_EDGE_*
-// switches build the variants of that bisect: SPAIR - wave-uniform values as fully written SGPR pairs; VPAIR - per-lane values
-// as fully written VGPR pairs.
+// Broadcast operands of the packed fp32 instructions.  hipcc folds pk2{v, v} of a per-lane value into an operand-select modifier on
+// a 32-bit VGPR (`v_pk_fma_f32 v[90:91], v[86:87], v[84:85], v[56:57] op_sel_hi:[0,1,1]`: the pair's other register is whatever
+// lives there).  On this gfx950 / ROCm 7.2 stack such instructions now and then compute with the OTHER register of the pair while
+// other waves of the CU execute MFMAs: tools/hazard_repro2.hip (this loop next to k_edge_fused's matrix phases, no data shared)
+// shows it in ~40 % of its launches, never without the MFMAs, never without packed fp32 instructions, never once the per-lane
+// broadcasts are real register pairs - while wave-uniform broadcasts from SGPRs (`s[36:37] op_sel_hi:[0,..]`) are innocent
+// (profiles/r03_hazard_bisect*.log).  So a per-lane broadcast is materialised as a register pair (one v_mov;
+// three per edge).  IG_EDGE_OPSEL_BROADCAST restores hipcc's own form (the reproducer's failing arm), IG_EDGE_SPAIR / IG_EDGE_SVPAIR
+// are the SGPR arms of the bisect.
 __device__ __forceinline__ pk2 bc_s(float s) {          // s is wave-uniform (a v_readlane result)
 #if defined(IG_EDGE_SPAIR)
   const unsigned u = __builtin_amdgcn_readfirstlane(__float_as_uint(s));
@@ -52,12 +56,12 @@ __device__ __forceinline__ pk2 bc_s(float s) {          // s is wave-uniform (a 
 #endif
 }
 __device__ __forceinline__ pk2 bc_v(float v) {
-#if defined(IG_EDGE_VPAIR)
-  pk2 p = {v, v};
-  asm volatile("" : "+v"(p));
-  return p;
-#else
+#if defined(IG_EDGE_OPSEL_BROADCAST)
   return pk2{v, v};
+#else
+  pk2 p = {v, v};
+  asm("" : "+v"(p));        // (not volatile: the scheduler may move it; it only hides the value's origin from the op_sel fold)
+  return p;
 #endif
 }
 constexpr float EA_LOG2E = 1.44269504088896340736f;
@@ -136,7 +140,11 @@ struct EdgeAcc {
     }
     const float pe = __builtin_amdgcn_exp2f(val - m);
     lsum += pe;
+#if defined(IG_EDGE_OPSEL_BROADCAST)
     ag = pk_fma(bc_v(pe), v2, ag);
+#else
+    ag = pk2{fmaf(pe, v2[0], ag[0]), fmaf(pe, v2[1], ag[1])};      // two scalar FMAs: a register pair for pe would cost the same
+#endif
     if constexpr (HASR) {
       float ph[H];
 #pragma unroll

@@ -35,8 +35,12 @@ constexpr int EF_LDA = D + 4;
 // format (kernels.h); HALVES = 16-row groups per workgroup: 2 when the launch fills the chip, 1 for small launches (up to 256
 // groups = 4 k rows: twice the workgroups, and the 16 waves take ONE row each in the edge loop instead of two - the loop of a
 // small launch is the latency of its longest rows; the 8 waves without a (head, half) idle in the matrix phases)
-template <int G, bool R24, int HALVES>
-__global__ __launch_bounds__(EF_NT, 4) void k_edge_fused(EdgeFusedArgs a) {
+// WAVES = 16: one 1024-thread workgroup per CU; WAVES = 8 (HALVES = 1 only, 75 KB of LDS): two co-resident workgroups per CU, whose
+// matrix phases run under each other's edge loops - the configuration that gave wrong rows in round 2 and is exact since the
+// loop's per-lane broadcasts are real register pairs (edge_attn.cuh: bc_v)
+template <int G, bool R24, int HALVES, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 4) void k_edge_fused(EdgeFusedArgs a) {
+  static_assert(WAVES == 16 || (WAVES == 8 && HALVES == 1), "8-wave workgroups take one 16-row group");
   constexpr int ROWS = 16 * HALVES;
   __shared__ __attribute__((aligned(16))) float UZ[ROWS * EF_LDU];
   __shared__ __attribute__((aligned(16))) float AG[ROWS * EF_LDA];     // q tile (phase 1 -> 2), then agg (phase 2 -> 3)
@@ -471,14 +475,16 @@ __global__ __launch_bounds__(EF_NT, 4) void k_edge_fused_p(EdgeFusedArgs a) {
   }   // tile slots of this workgroup
 }
 
-template __global__ void k_edge_fused<4, false, 2>(EdgeFusedArgs);
-template __global__ void k_edge_fused<6, false, 2>(EdgeFusedArgs);
-template __global__ void k_edge_fused<8, false, 2>(EdgeFusedArgs);
-template __global__ void k_edge_fused<4, true, 2>(EdgeFusedArgs);
-template __global__ void k_edge_fused<6, true, 2>(EdgeFusedArgs);
-template __global__ void k_edge_fused<8, true, 2>(EdgeFusedArgs);
-template __global__ void k_edge_fused<6, false, 1>(EdgeFusedArgs);
-template __global__ void k_edge_fused<6, true, 1>(EdgeFusedArgs);
+template __global__ void k_edge_fused<4, false, 2, 16>(EdgeFusedArgs);
+template __global__ void k_edge_fused<6, false, 2, 16>(EdgeFusedArgs);
+template __global__ void k_edge_fused<8, false, 2, 16>(EdgeFusedArgs);
+template __global__ void k_edge_fused<4, true, 2, 16>(EdgeFusedArgs);
+template __global__ void k_edge_fused<6, true, 2, 16>(EdgeFusedArgs);
+template __global__ void k_edge_fused<8, true, 2, 16>(EdgeFusedArgs);
+template __global__ void k_edge_fused<6, false, 1, 16>(EdgeFusedArgs);
+template __global__ void k_edge_fused<6, true, 1, 16>(EdgeFusedArgs);
+template __global__ void k_edge_fused<6, false, 1, 8>(EdgeFusedArgs);
+template __global__ void k_edge_fused<6, true, 1, 8>(EdgeFusedArgs);
 template __global__ void k_edge_fused_p<6>(EdgeFusedArgs);
 template __global__ void k_edge_fused_p<4>(EdgeFusedArgs);
 

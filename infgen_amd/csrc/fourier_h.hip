@@ -35,9 +35,6 @@
 
 namespace ig {
 
-constexpr int FH_WAVES = 8;
-constexpr int FH_NT = 64 * FH_WAVES;     // threads per workgroup
-constexpr int FH_TILE = 16 * FH_WAVES;   // edges per workgroup tile (16 per wave)
 
 // sin/cos: three-constant Cody-Waite reduction by pi/2 with fused multiply-adds (the products n * c are
 // exact inside the fma), then the classic minimax polynomials on [-pi/4, pi/4] (Cephes sinf/cosf
@@ -75,14 +72,14 @@ __device__ __forceinline__ void sincos_fast(float z, float& s, float& c) {
 }
 
 template <int TERMS>
-__global__ __launch_bounds__(FH_NT, 1) void k_fourier_h(FourierArgs a) {
+__global__ __launch_bounds__(FH_NT, 2) void k_fourier_h(FourierArgs a) {
 #include "fourier_h_body.inc"
 }
 
 // up to three independent edge sets in one launch (gridDim.y = sets): the three Fourier embeddings of a decode step side by
 // side when the sets are too small to fill the chip one after the other (a single tile costs 28 - 36 quarters = 35 - 45 us)
 template <int TERMS>
-__global__ __launch_bounds__(FH_NT, 1) void k_fourier_h_multi(FourierMultiArgs m) {
+__global__ __launch_bounds__(FH_NT, 2) void k_fourier_h_multi(FourierMultiArgs m) {
   const FourierArgs& a = m.set[blockIdx.y];
 #include "fourier_h_body.inc"
 }

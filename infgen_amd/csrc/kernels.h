@@ -36,6 +36,25 @@ struct FourierArgs {
   int dbg;                 // diagnostics (INFGEN_QS_DBG; wrong results): 1 free-running waves over a static weight ring
 };
 constexpr int DT_TAB_ROWS = 32;
+// k_fourier_h geometry (experiments: -DIG_FH_WAVES=4 -DIG_FH_RING=4 builds the two-workgroups-per-CU variant)
+#ifndef IG_FH_WAVES
+#define IG_FH_WAVES 8
+#endif
+// IG_QSF = 1: k_fourier_h and the 8-wave k_attn_h take their weights from the barrier-free stream (split.cuh: QuarterStreamF)
+#ifndef IG_QSF
+#define IG_QSF 0
+#endif
+#ifndef IG_FH_RING
+#define IG_FH_RING (IG_QSF ? 8 : 5)
+#endif
+constexpr int FH_WAVES = IG_FH_WAVES;
+constexpr int FH_NT = 64 * FH_WAVES;     // threads per workgroup
+constexpr int FH_TILE = 16 * FH_WAVES;   // edges per workgroup tile (16 per wave)
+constexpr int FH_RING = IG_FH_RING;      // quarter buffers of its weight ring
+constexpr int FH_WG_PER_CU = FH_WAVES == 8 ? 1 : 2;
+#ifndef IG_AH_RING4
+#define IG_AH_RING4 3
+#endif
 struct FourierMultiArgs { FourierArgs set[3]; };
 
 // Packed 24-bit rows of the normalised relative-position embedding (the rollout's private edge buffers; k_fourier_h writes,
@@ -415,7 +434,7 @@ template <int WAVES, int TERMS> __global__ void k_attn_h(AttnHArgs a);
 template <int TERMS> __global__ void k_attn_hs(AttnHArgs a);             // attn_hs.hip: the same for few rows (one 16-row group per workgroup)   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);
-template <int G, bool R24, int HALVES> __global__ void k_edge_fused(EdgeFusedArgs a);        // edge_fused.hip (R24: rhat rows in the packed format)
+template <int G, bool R24, int HALVES, int WAVES> __global__ void k_edge_fused(EdgeFusedArgs a);        // edge_fused.hip (R24: rhat rows in the packed format)
 template <int G> __global__ void k_edge_fused_p(EdgeFusedArgs a);      // persistent workgroups, decoupled halves
 __global__ void k_edge_attn_wide(EdgeAttnArgs a);
 __global__ void k_attn_post(AttnPostArgs a);

@@ -355,10 +355,9 @@ class RolloutEngine:
         assert mmax <= M_cap
         self.rows = rows = S * A_cap
         if self._use_graph_arg is None:
-            # batches of up to 64 scenes of 64 rows are launch-to-launch latency bound: +6-7 % from the replay
-            # (INFGEN_GRAPH=0 / 1 overrides)
-            env = os.environ.get('INFGEN_GRAPH')
-            self.use_graph = (rows <= 4096 and not self.insertion) if env is None else env == '1'
+            # replaying the decode steps from a captured HIP graph: opt-in (use_graph=True or INFGEN_GRAPH=1).  Measured in round 3:
+            # 64 scenes 25.9 ms with and without it (the step is its kernels' dependency chains, not launch overhead)
+            self.use_graph = os.environ.get('INFGEN_GRAPH') == '1' and not self.insertion
 
         arr = self._scene_arrays(hosts)
         t = lambda a: torch.from_numpy(a).to(dev)
@@ -925,22 +924,7 @@ class RolloutEngine:
             # a replay runs what was captured: fall back to the eager sequence while per-kernel profiling is on (events are not
             # part of the graph) and re-capture when the context's kernel switches changed since the capture
             if self.use_graph and (t0, t1) == (0, self.cfg.num_decode_steps) and not _lib.prof_active():
-                snap = bytes(self._ctx.opts)[:_lib.OPTIONS_VALUE_BYTES] + bytes([self._ctx.four_t_dt is not None])
-                if self._graph is not None and snap != self._graph_opts:
-                    self._graph = None
-                if self._graph is None and not getattr(self, '_graph_warm', False):
-                    # the first rollout runs eagerly: kernels are loaded lazily at their first launch, which must not happen
-                    # inside a capture
-                    self._graph_warm = True
-                    _lib.check(self.lib.infgen_rollout_run(C.byref(self._ctx), t0, t1, self.ops.stream), 'infgen_rollout_run')
-                    return
-                if self._graph is None:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        _lib.check(self.lib.infgen_rollout_run(C.byref(self._ctx), t0, t1, self.ops.stream), 'infgen_rollout_run')
-                    self._graph = g
-                    self._graph_opts = snap
-                self._graph.replay()
+                self._run_graph(t0, t1)
                 return
             _lib.check(self.lib.infgen_rollout_run(C.byref(self._ctx), t0, t1, self.ops.stream), 'infgen_rollout_run')
             return
@@ -955,6 +939,35 @@ class RolloutEngine:
                 yield from self._insert_step(t)
             self._decoded_rows.add_(self.n_agents.sum())       # A_t: rows decoded at this step, incl. the inserted ones
             self.step(t)
+
+    def _run_graph(self, t0, t1):
+        """the decode steps as a HIP-graph replay.  Replays launched into the LEGACY DEFAULT stream fault now and then on this
+        ROCm 7.2 stack (memory access fault inside the second or a later replay, 2 of 4 runs; never with AMD_SERIALIZE_KERNEL=3, never
+        on a created stream: profiles/r03_graph_replay_fault.log), so capture and replay always run on a stream of the engine's
+        own, fenced against the caller's stream on both sides."""
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, '_gstream', None) is None:
+            self._gstream = torch.cuda.Stream(device=self.device)
+        gs = self._gstream
+        gs.wait_stream(cur)
+        with torch.cuda.stream(gs):
+            snap = bytes(self._ctx.opts)[:_lib.OPTIONS_VALUE_BYTES] + bytes([self._ctx.four_t_dt is not None])
+            if self._graph is not None and snap != self._graph_opts:
+                self._graph = None
+            if self._graph is None and not getattr(self, '_graph_warm', False):
+                # the first rollout runs eagerly: kernels are loaded lazily at their first launch, which must not happen
+                # inside a capture
+                self._graph_warm = True
+                _lib.check(self.lib.infgen_rollout_run(C.byref(self._ctx), t0, t1, self.ops.stream), 'infgen_rollout_run')
+            else:
+                if self._graph is None:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=gs):
+                        _lib.check(self.lib.infgen_rollout_run(C.byref(self._ctx), t0, t1, self.ops.stream), 'infgen_rollout_run')
+                    self._graph = g
+                    self._graph_opts = snap
+                self._graph.replay()
+        cur.wait_stream(gs)
 
     def edge_totals(self):
         """(temporal, map, agent) edge counts of the last decode step's edge sets (one host sync)"""

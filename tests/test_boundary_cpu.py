@@ -220,3 +220,19 @@ def test_torch_library_ops_are_registered_with_shape_functions():
     tok, st, lg = torch.ops.infgen_hip.token_state_head(m(6, 128), m(10), m(10), 2048, True)
     assert tok.shape == (6,) and lg.shape == (6, 2048)
     assert torch.ops.infgen_hip.mlp_layer(m(6, 128), m(10), 120).shape == (6, 120)
+
+
+def test_library_has_no_packed_fp32_op_sel_broadcast_of_a_vgpr():
+    """packed fp32 instructions that broadcast one half of a VGPR pair through op_sel / op_sel_hi compute with
+    the wrong register now and then while other waves of the CU execute MFMAs (stand-alone reproducer tools/hazard_repro2.hip).
+    The library is built without a single such instruction - checked here on the disassembly of the built code objects."""
+    import importlib.util
+    from infgen_amd import _lib
+    spec = importlib.util.spec_from_file_location('pk_opsel_scan', os.path.join(REPO, 'tools', 'pk_opsel_scan.py'))
+    scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scan)
+    if not os.path.exists(scan.OBJDUMP):
+        pytest.skip('llvm-objdump not found')
+    tot, risky, per_func, n = scan.scan_library(_lib.LIB_PATH)
+    assert n >= 10 and tot > 3000, 'the scan must see the kernels (packed fp32 arithmetic is used on purpose)'
+    assert risky == 0, f'op_sel broadcasts of a VGPR half in: {sorted(per_func.items(), key=lambda kv: -kv[1])[:5]}'

@@ -6,7 +6,11 @@
 //   waves 0-7  ("matrix half"): what k_edge_fused's phases 1 and 3 execute - fragment loads from L2, split_pair (packed fp32 subtract,
 //                               cvt_pkrtz), v_mfma_f32_16x16x16_f16 / 16x16x32_f16 chains, ds_write_b128 / ds_read_b128 of its own LDS tile
 // mode 0: matrix half idle, mode 1: busy.  Every launch's loop results are compared bitwise with the first mode-0 launch.
-//   hipcc -O3 --offload-arch=gfx950 -I infgen_amd/csrc tools/hazard_repro2.hip -o /tmp/hazard_repro2 && /tmp/hazard_repro2 [launches] [edges]
+// Arms (profiles/r03_hazard_bisect*.log): -DIG_EDGE_OPSEL_BROADCAST = the loop as hipcc compiles pk2{v, v} (per-lane broadcasts as op_sel
+// modifiers on a 32-bit VGPR): ~40 % of the launches differ; without it (the shipped form: per-lane broadcasts as real register
+// pairs): none.  With the failing arm: -DMAT_NO_MFMA none; -DMAT_NO_SPLIT / -DMAT_NO_LDS still differ; -Xclang -target-feature -Xclang
+// -packed-fp32-ops (no packed fp32 instruction in the kernel) none; -DIG_EDGE_SPAIR / -DIG_EDGE_SVPAIR (SGPR broadcasts changed) still differ.
+//   hipcc -O3 --offload-arch=gfx950 -I infgen_amd/csrc -DIG_EDGE_OPSEL_BROADCAST tools/hazard_repro2.hip -o /tmp/hazard_repro2 && /tmp/hazard_repro2 [launches] [edges]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
