@@ -153,6 +153,12 @@ typedef struct InfgenRollout {
    * opts.gemm_terms) the context runs with: the temporal edges' time-gap input takes the values -1 .. -16 only, so its branch
    * of r_t_emb (layers.py:150-153, mlps[3]) is looked up instead of evaluated per edge.  NULL: evaluated per edge. */
   const float* four_t_dt;
+  /* optional [S][T][A_cap][2] / [S][T][A_cap]: pose of the teacher-forced state per (column, row).  When given, the pose a decode step
+   * stores for its new column is the teacher's (rows the teacher marks invalid excepted); the step's OWN result still goes to
+   * pred_traj / pred_head.  Every step then starts from the same geometry as the reference run, so a long comparison has no
+   * accumulated pose drift and no radius / first-K decision can flip: logits are comparable row by row with a maximum, and the
+   * one-step pose update is checked separately (tests/test_baseline_shapes_gpu.py) */
+  const float* teacher_pos; const float* teacher_head;
 } InfgenRollout;
 
 int infgen_linear(const float* X, int ldx, const int* gather, int rows, int K,
@@ -210,6 +216,14 @@ int infgen_edge_attn_fused_r24(int rows, const float* Q, const float* pack, cons
 int infgen_set_edge_fuse(int mode);
 /* the process-wide defaults (what the infgen_set_* functions edited so far), e.g. to seed a context's own InfgenOptions */
 int infgen_get_options(InfgenOptions* out);
+/* Re-entrancy of the OPERATOR-level entries (infgen_fourier_embed, infgen_attn_*, infgen_edge_attn*, infgen_heads, infgen_linear ...):
+ * they take their switches from the calling THREAD's option block when one is installed, else from the process-wide defaults.
+ * infgen_thread_options(o) installs a copy of *o for the calling thread (o == NULL removes it); a rollout-level entry called
+ * with a context whose opts.use != 0 still takes the context's block.  Two engines driven from two host threads therefore never
+ * see each other's settings, whatever the infgen_set_* defaults are (infgen_amd/engine.py installs the engine's block around its
+ * prologue).  infgen_get_effective_options returns what an operator-level call from this thread would use right now. */
+int infgen_thread_options(const InfgenOptions* o);
+int infgen_get_effective_options(InfgenOptions* out);
 /* diagnostics: resident workgroups per CU the runtime reports for k_edge_fused; a plain streaming read of n_bytes with 8 or
  * 16 bytes per lane for calibrating rocprofv3 FETCH_SIZE (tools/calibrate_fetch.sh; out: 2048 floats) */
 int infgen_edge_fused_occupancy(void);

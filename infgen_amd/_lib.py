@@ -6,6 +6,7 @@ an exception is raised.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import os
 from typing import Optional
 
@@ -95,6 +96,7 @@ class Rollout(C.Structure):
         ('opts', Options),
         ('teacher_grid', _p),
         ('four_t_dt', _p),
+        ('teacher_pos', _p), ('teacher_head', _p),
     ]
 
 
@@ -115,6 +117,8 @@ SYMBOLS = {
     'infgen_set_edge_fuse': (_i, [_i]),
     'infgen_set_edge_loop': (_i, [_i]),
     'infgen_get_options': (_i, [C.POINTER(Options)]),
+    'infgen_thread_options': (_i, [C.POINTER(Options)]),
+    'infgen_get_effective_options': (_i, [C.POINTER(Options)]),
     'infgen_edge_fused_occupancy': (_i, []),
     'infgen_debug_stream_read': (_i, [_p, C.c_ulonglong, _i, _p, _p]),
     'infgen_set_overlap': (_i, [_i]),
@@ -211,6 +215,32 @@ def ptr(t) -> Optional[int]:
         return None
     assert t.is_contiguous(), 'tensor must be contiguous'
     return t.data_ptr()
+
+
+_tl = threading.local()
+
+
+class thread_options:
+    """context manager: the calling thread's option block for operator-level entries (infgen_thread_options, include/infgen_hip.h);
+    nests (the outer block is restored on exit)"""
+
+    def __init__(self, opts: 'Options'):
+        self.opts, self.prev = opts, None
+
+    def __enter__(self):
+        lib = load()
+        depth = getattr(_tl, 'depth', 0)
+        if depth > 0:
+            self.prev = Options()
+            check(lib.infgen_get_effective_options(C.byref(self.prev)), 'infgen_get_effective_options')
+        check(lib.infgen_thread_options(C.byref(self.opts)), 'infgen_thread_options')
+        _tl.depth = depth + 1
+        return self
+
+    def __exit__(self, *exc):
+        _tl.depth -= 1
+        check(load().infgen_thread_options(C.byref(self.prev) if self.prev is not None else None), 'infgen_thread_options')
+        return False
 
 
 _prof_mask = 0

@@ -38,7 +38,9 @@ const int* g_def_limit_n_agents = nullptr; // process-wide row limits (infgen_se
 int g_def_limit_A_cap = 0;
 struct Active { const InfgenOptions* o; int group_rows; const int* n_agents; int A_cap; };
 thread_local Active tl_active = {nullptr, 0, nullptr, 0};
-inline const InfgenOptions& O() { return tl_active.o ? *tl_active.o : g_def; }
+thread_local InfgenOptions tl_thread_opts;         // infgen_thread_options: the calling thread's block for operator-level entries
+thread_local bool tl_thread_set = false;
+inline const InfgenOptions& O() { return tl_active.o ? *tl_active.o : tl_thread_set ? tl_thread_opts : g_def; }
 inline int group_rows() { return tl_active.o ? tl_active.group_rows : g_def_group_rows; }
 inline const int* limit_n_agents() { return tl_active.o ? tl_active.n_agents : g_def_limit_n_agents; }
 inline int limit_A_cap() { return tl_active.o ? tl_active.A_cap : g_def_limit_A_cap; }
@@ -54,6 +56,18 @@ struct OptScope {
 extern "C" int infgen_get_options(InfgenOptions* out) {
   if (!out) return fail("infgen_get_options", "null pointer");
   *out = g_def;
+  return 0;
+}
+
+extern "C" int infgen_thread_options(const InfgenOptions* o) {
+  if (o) { tl_thread_opts = *o; tl_thread_opts.row_groups = nullptr; tl_thread_opts.n_row_groups = nullptr; }
+  tl_thread_set = o != nullptr;
+  return 0;
+}
+
+extern "C" int infgen_get_effective_options(InfgenOptions* out) {
+  if (!out) return fail("infgen_get_effective_options", "null pointer");
+  *out = O();
   return 0;
 }
 
@@ -362,7 +376,7 @@ static void launch_attn_h(const AttnHArgs& a_in, void* stream) {
     else hipLaunchKernelGGL(k_attn_hs<3>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     return;
   }
-  static const int waves = getenv("INFGEN_ATTN_WAVES") ? atoi(getenv("INFGEN_ATTN_WAVES")) : (IG_QSF ? 8 : 4);
+  static const int waves = getenv("INFGEN_ATTN_WAVES") ? atoi(getenv("INFGEN_ATTN_WAVES")) : 4;
   if (waves != 8) {
     int grid = ceil_div(a.rows, 64);
     if (grid > 512) grid = 512;          // two workgroups per CU, persistent over the 64-row tiles beyond that
@@ -436,11 +450,12 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
   static const int no_xcd = getenv("INFGEN_EDGE_NOXCD") ? atoi(getenv("INFGEN_EDGE_NOXCD")) : 0;
   static const int persist = getenv("INFGEN_EDGE_P") ? atoi(getenv("INFGEN_EDGE_P")) : 0;
   static const int small_max = getenv("INFGEN_EDGE_SMALL") ? atoi(getenv("INFGEN_EDGE_SMALL")) : 4096;
-  static const int wg2 = getenv("INFGEN_EDGE_WG2") ? atoi(getenv("INFGEN_EDGE_WG2")) : 0;
+  static const int wg2 = getenv("INFGEN_EDGE_WG2") ? atoi(getenv("INFGEN_EDGE_WG2")) : 1;
   const int G = O().edge_loop;
   // small launches: one 16-row group per workgroup (edge_fused.hip), twice the workgroups for the same rows
   const bool small = rows <= small_max && G == 6 && !persist;
-  // INFGEN_EDGE_WG2=1: large launches as 8-wave workgroups of one 16-row group, two per CU
+  // large launches: 8-wave workgroups of one 16-row group, two per CU - one's matrix phases run under the other's edge loop
+  // (128 vs 140 us per launch at 512 scenes; INFGEN_EDGE_WG2=0: one 16-wave workgroup of two groups per CU)
   const bool two = !small && wg2 && G == 6 && !persist;
   const int tr = (small || two) ? 16 : 32;          // rows per tile
   EdgeFusedArgs a{rows, Q, pack, Ksrc, Vsrc, EdgeSet{off, cnt, src, rhat}, AGG, nullptr, nullptr, dbg, 0, kv_once};
@@ -807,6 +822,7 @@ extern "C" int infgen_integrate(const InfgenRollout* r, int t, void* stream) {
   a.st = scene_of(r); a.c = 1 + t; a.t = t; a.R = r->R; a.force_valid = r->force_valid;
   a.next_token = r->next_token; a.next_state = r->next_state;
   a.teacher_token = r->teacher_token; a.teacher_state = r->teacher_state; a.teacher_grid = r->teacher_grid;
+  a.teacher_pos = r->teacher_pos; a.teacher_head = r->teacher_head;
   a.vocab = r->vocab; a.token_size = r->token_size; a.grid_xy = r->grid_xy; a.grid_size = r->grid_size;
   a.pred_traj = r->pred_traj; a.pred_head = r->pred_head; a.pred_state = r->pred_state;
   { ProfScope _ps(INFGEN_KID_INTEGRATE, stream);

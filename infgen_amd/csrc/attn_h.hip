@@ -15,7 +15,6 @@
 // and - unlike k_fourier_h, see fourier_h.hip - bitwise reproducible with several workgroups per CU: 40 re-runs each of
 // 16 k / 32 k / 64 k / 100 k rows; tests/test_ops_gpu.py::test_attn_split_is_deterministic keeps watching it).
 // WAVES = 8 (128-row tiles, one workgroup per CU) is kept for comparison.
-#include <type_traits>
 #include "kernels.h"
 #include "layout.h"
 #include "tile.cuh"
@@ -29,7 +28,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnH
   constexpr int NTH = 64 * WAVES, TILE = 16 * WAVES;
   // 4 waves: three quarter buffers (59 KB with the vectors) and <= 256 registers -> two workgroups per CU;
   // 8 waves: the five-buffer ring of split.cuh, one workgroup per CU
-  constexpr int XRING = WAVES == 4 ? IG_AH_RING4 : (IG_QSF ? 8 : RING);
+  constexpr int XRING = WAVES == 4 ? IG_AH_RING4 : IG_AH_RING8;
   __shared__ __attribute__((aligned(16))) unsigned short Wb[XRING][QUARTER];
   __shared__ __attribute__((aligned(16))) float Vt[VT_SIZE];
   __shared__ const unsigned short* seg_ptr[5];
@@ -75,22 +74,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnH
     }
     if (tid < 16) Vt[VT_N_HDR + tid] = NP[AH_HDR + tid];
   }
-#if IG_QSF
-  typedef QuarterStreamF<WAVES, XRING> QSF;
-  __shared__ typename QSF::Shared qsh;
-  if (tid < (int)(sizeof(qsh) / sizeof(int))) reinterpret_cast<int*>(&qsh)[tid] = 0;
-#endif
   __syncthreads();
-#if IG_QSF
-  typename std::conditional<WAVES == 8, QSF, QuarterStream<NTH, XRING>>::type qs;
-  qs.dbg = a.dbg;
-  if constexpr (WAVES == 8) qs.init(seg_ptr, seg_n, 5, (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x, Wb, &qsh, tid);
-  else qs.init(seg_ptr, seg_n, 5, (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x, Wb, tid);
-#else
   QuarterStream<NTH, XRING> qs;
   qs.dbg = a.dbg;
   qs.init(seg_ptr, seg_n, 5, (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x, Wb, tid);
-#endif
   auto take = [&]() { return qs.take(); };
   auto gemm_unit = [&](f32x4 (&acc)[8], const u32x4 (&Bh)[4], const u32x4 (&Bl)[4]) {
 #pragma unroll

@@ -489,6 +489,10 @@ __global__ __launch_bounds__(BT) void k_integrate(IntegrateArgs a) {
       a.pred_state[o] = (float)ns;
       if (k == 5) { lx = mx; ly = my; lth = hh; }
     }
+    if (a.teacher_pos) {        // the stored pose is the teacher's (pred_traj / pred_head above keep this step's own result)
+      const size_t in_ = sidx(st, s, n, t);
+      lx = a.teacher_pos[2 * in_]; ly = a.teacher_pos[2 * in_ + 1]; lth = a.teacher_head[in_];
+    }
     npx[t] = lx; npy[t] = ly; nth[t] = lth; nst[t] = ns;
   }
   __syncthreads();

@@ -40,12 +40,8 @@ constexpr int DT_TAB_ROWS = 32;
 #ifndef IG_FH_WAVES
 #define IG_FH_WAVES 8
 #endif
-// IG_QSF = 1: k_fourier_h and the 8-wave k_attn_h take their weights from the barrier-free stream (split.cuh: QuarterStreamF)
-#ifndef IG_QSF
-#define IG_QSF 0
-#endif
 #ifndef IG_FH_RING
-#define IG_FH_RING (IG_QSF ? 8 : 5)
+#define IG_FH_RING 5
 #endif
 constexpr int FH_WAVES = IG_FH_WAVES;
 constexpr int FH_NT = 64 * FH_WAVES;     // threads per workgroup
@@ -54,6 +50,9 @@ constexpr int FH_RING = IG_FH_RING;      // quarter buffers of its weight ring
 constexpr int FH_WG_PER_CU = FH_WAVES == 8 ? 1 : 2;
 #ifndef IG_AH_RING4
 #define IG_AH_RING4 3
+#endif
+#ifndef IG_AH_RING8
+#define IG_AH_RING8 5
 #endif
 struct FourierMultiArgs { FourierArgs set[3]; };
 
@@ -316,6 +315,7 @@ struct IntegrateArgs {
   const int* next_token; const int* next_state;   // [rows] from the heads
   const int* teacher_token; const int* teacher_state;   // optional [S][T][A_cap]
   const int* teacher_grid;                               // optional [S][T][A_cap], < -1: none
+  const float* teacher_pos; const float* teacher_head;   // optional [S][T][A_cap](x2): the stored pose of column c + 1
   const float* vocab;               // [3][token_size][6][4][2]
   int token_size;
   const float* grid_xy; int grid_size;    // [G][2]

@@ -187,90 +187,6 @@ struct QuarterStream {
   }
 };
 
-// QuarterStreamF: the same weight stream WITHOUT workgroup barriers - the waves of a workgroup run free.
-// QuarterStream's take() is an s_barrier per quarter: every wave waits for the slowest one 28 - 60 times per tile, and since all
-// waves run the same program they sit in their matrix phases together and in their vector phases (sine / cosine, LayerNorm,
-// hi / lo splitting) together - the two waves of a SIMD never overlap one's MFMAs with the other's VALU work.  Measured on the
-// shipped kernels (INFGEN_QS_DBG): without the LDS-DMA waits -12 %, without the barriers as well -21 ... -24 %.
-// Here a quarter is staged by WHICHEVER wave finds the stream less than ND quarters ahead of itself: it claims the next index
-// (LDS atomic), waits until every wave has released the slot's previous occupant (done[slot], one LDS atomic per wave and
-// quarter), issues the sixteen 1 KB LDS-DMA pieces, waits for them (vmcnt) and publishes ready[slot] = generation.  A consumer
-// polls ready[slot] of its next quarter.  LDS operations of a wave execute in order and the data landed before the publishing
-// store was issued, so a wave that has seen the flag reads the new bytes; a stager that has seen done[slot] overwrites only
-// what every wave has finished reading (a wave releases a quarter at its NEXT take(): its fragment reads have returned by
-// then, they fed MFMAs that were issued).  Waves may drift by up to NR - 1 quarters.
-template <int NW, int NR>
-struct QuarterStreamF {
-  static constexpr int ND = NR - 2;              // how far ahead of itself a wave keeps the stream staged
-  struct Shared { int ready[NR]; int done[NR]; int claim; int pad; };
-  const unsigned short* const* seg_ptr;
-  const int* seg_n;
-  unsigned short (*Wb)[QUARTER];
-  Shared* sh;
-  int nseg, nq, total, consumed, lane;
-  int dbg = 0;
-  static __device__ __forceinline__ int ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-  // every spin is bounded: ~1 s of polling, then the wave traps (the launch fails loudly instead of hanging the GPU)
-  static __device__ __forceinline__ void spin_until(const int* p, int want) {
-    for (unsigned n = 0; ld(p) < want; ++n) {
-      __builtin_amdgcn_s_sleep(1);
-      if (n > (1u << 24)) __builtin_trap();
-    }
-  }
-  // sn / sp: the tables in LDS (filled before the caller's one barrier); sh_: zeroed before that barrier too
-  __device__ __forceinline__ void init(const unsigned short* const* sp, const int* sn, int nseg_, int my_tiles,
-                                       unsigned short (*wb)[QUARTER], Shared* sh_, int tid_) {
-    seg_ptr = sp; seg_n = sn; nseg = nseg_; Wb = wb; sh = sh_; lane = tid_ & 63;
-    nq = 0;
-    for (int i = 0; i < nseg; ++i) nq += sn[i];
-    total = my_tiles * nq;
-    consumed = 0;
-  }
-  __device__ __forceinline__ const unsigned short* src_of(int s) const {
-    int r = s % nq, i = 0;
-    while (r >= seg_n[i]) { r -= seg_n[i]; ++i; }
-    return seg_ptr[i] + (size_t)r * QUARTER;
-  }
-  __device__ __noinline__ void stage_ahead(int q) {
-    const int lim = min(q + ND, total);
-    for (;;) {
-      // claim quarter s = the stream's frontier, but only while it is inside MY window (compare-and-swap, not fetch-add: with a
-      // bare add a slow wave could be handed an index far ahead of itself whose slot still holds a quarter the wave has not
-      // consumed yet - it would wait for its own release)
-      const int f = ld(&sh->claim);
-      if (f >= lim) break;
-      int got = 0;
-      if (lane == 0) {
-        int expect = f;
-        got = __hip_atomic_compare_exchange_strong(&sh->claim, &expect, f + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      if (!__builtin_amdgcn_readfirstlane(got)) continue;
-      const int s = f;
-      const int slot = s % NR;
-      if (s >= NR) spin_until(&sh->done[slot], NW * (s / NR));
-      const unsigned short* g = src_of(s);
-      unsigned short* l = Wb[slot];
-#pragma unroll
-      for (int c = 0; c < 16; ++c)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (c * 64 + lane) * 8),
-                                         (__attribute__((address_space(3))) void*)(l + c * 64 * 8), 16, 0, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(&sh->ready[slot], s / NR + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-  }
-  __device__ __forceinline__ const unsigned short* take() {
-    const int q = consumed;
-    if (q > 0 && lane == 0)
-      __hip_atomic_fetch_add(&sh->done[(q - 1) % NR], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (ld(&sh->claim) < min(q + ND, total)) stage_ahead(q);
-    const int slot = q % NR, want = q / NR + 1;
-    spin_until(&sh->ready[slot], want);
-    asm volatile("" ::: "memory");
-    ++consumed;
-    return Wb[slot];
-  }
-};
-
 // Row-scaled fragments: the 128-vector of this lane's row is multiplied by the power of two that brings its
 // largest magnitude into [2^14, 2^15) (exact), split into fp16 hi/lo B fragments, and the inverse factor is
 // returned - scaling a column of B scales the same column of C, so the caller multiplies its GEMM result by it.

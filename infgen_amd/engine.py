@@ -102,17 +102,14 @@ class PackedWeights:
         under the arithmetic ``terms`` (infgen_fourier_last_dim_table), cached per pack"""
         tab = self._time_gap_tables.get(terms)
         if tab is None:
+            # (the arithmetic is chosen through the calling thread's option block, not by editing the process-wide default)
             o = _lib.Options()
-            _lib.check(lib.infgen_get_options(C.byref(o)), 'infgen_get_options')
+            _lib.check(lib.infgen_get_effective_options(C.byref(o)), 'infgen_get_effective_options')
             tab = torch.zeros(32, D, device=self.four_t.device)
-            if o.gemm_terms != terms:
-                _lib.check(lib.infgen_set_gemm_terms(terms), 'infgen_set_gemm_terms')
-            try:
+            o.gemm_terms, o.use = terms, 0
+            with _lib.thread_options(o):
                 _lib.check(lib.infgen_fourier_last_dim_table(_lib.ptr(self.four_t), 4, _lib.ptr(tab), stream),
                            'infgen_fourier_last_dim_table')
-            finally:
-                if o.gemm_terms != terms:
-                    _lib.check(lib.infgen_set_gemm_terms(int(o.gemm_terms)), 'infgen_set_gemm_terms')
             torch.cuda.synchronize(tab.device)
             self._time_gap_tables[terms] = tab
         return tab
@@ -371,19 +368,26 @@ class RolloutEngine:
         self.vocab, self._map_vocab, self.grid_xy = t(vocab_np), t(map_vocab_np), t(grid_np)
         self.G = int(grid.shape[0])
         self.teacher_token = self.teacher_state = None
-        self.teacher_grid = None
+        self.teacher_grid = self.teacher_pos = self.teacher_head = None
         if teacher is not None:
             tt = np.full((S, T, A_cap), -1, np.int32); ts = np.zeros((S, T, A_cap), np.int32)
             tg = np.full((S, T, A_cap), -2, np.int32)
+            tp, th = None, None
             for s, tch in enumerate(teacher):
                 tok_s, st_s = tch[0], tch[1]
                 A = min(np.asarray(tok_s).shape[0], A_cap)        # rows beyond the initial agents: inserted ones (insertion on)
                 tt[s, :, :A] = np.asarray(tok_s)[:A].T; ts[s, :, :A] = np.asarray(st_s)[:A].T
                 if len(tch) > 2 and tch[2] is not None:           # optional third entry: grid cells (A, T) of the teacher state
                     tg[s, :, :A] = np.asarray(tch[2])[:A].T
+                if len(tch) > 4 and tch[3] is not None:           # optional fourth / fifth: poses (A, T, 2) / (A, T) of the teacher state
+                    if tp is None:
+                        tp, th = np.zeros((S, T, A_cap, 2), np.float32), np.zeros((S, T, A_cap), np.float32)
+                    tp[s, :, :A] = np.asarray(tch[3], np.float32)[:A].transpose(1, 0, 2); th[s, :, :A] = np.asarray(tch[4], np.float32)[:A].T
             self.teacher_token, self.teacher_state = t(tt), t(ts)
             if (tg > -2).any():
                 self.teacher_grid = t(tg)
+            if tp is not None:
+                self.teacher_pos, self.teacher_head = t(tp), t(th)
 
         # ------------------------------------------------ scratch / caches
         f = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.float32)
@@ -564,7 +568,7 @@ class RolloutEngine:
         """is the Fourier embedding of the operator-level entries the split kernel (infgen_set_fourier_mode != 0)?  (they read
         the process-wide switches, like every call of the map encoder)"""
         o = _lib.Options()
-        _lib.check(self.lib.infgen_get_options(C.byref(o)), 'infgen_get_options')
+        _lib.check(self.lib.infgen_get_effective_options(C.byref(o)), 'infgen_get_effective_options')
         return o.fourier_mode != 0
 
     # ------------------------------------------------------------------ prologue (once per rollout)
@@ -584,6 +588,20 @@ class RolloutEngine:
         """per-scene constants and the first columns: agent categorical embeddings, map encoder
         (map_decoder.py:70-130), map K/V of the six map->agent layers, the edgeless column-0 chain
         (SURVEY a-Q3) and column 1's raw feature."""
+        # the operator-level calls below (map encoder, tables) run under THIS engine's switches: installed as the calling thread's
+        # option block for the duration of the prologue (re-entrant across host threads; include/infgen_hip.h)
+        with _lib.thread_options(self._effective_options()):
+            return self._prologue(map_only)
+
+    def _effective_options(self):
+        o = _lib.Options()
+        _lib.check(self.lib.infgen_get_options(C.byref(o)), 'infgen_get_options')
+        for k, v in (self.options or {}).items():
+            setattr(o, k, int(v))
+        o.use, o.row_groups, o.n_row_groups = 0, None, None
+        return o
+
+    def _prologue(self, map_only: bool = False):
         ops, w, cfg, dev = self.ops, self.w, self.cfg, self.device
         S, A_cap, M_cap, rows = self.S, self.A_cap, self.M_cap, self.rows
         tabs = w.tables(ops, self.vocab, self.grid_xy, self._map_vocab, self._tables_key)
@@ -629,7 +647,7 @@ class RolloutEngine:
             if tot > g['cap']:
                 self._map_nbr_cap = (tot + mrows - 1) // mrows + 4
                 self._mg = None
-                return self.prologue(map_only=map_only)
+                return self._prologue(map_only=map_only)
             self._mg_checked = True
         fused = os.environ.get('INFGEN_MAP_FUSE', '1') != '0'
         # rhat rows of the pt <-> pt edges in the packed 24-bit form when both ends know it (split Fourier kernel -> k_edge_fused)
@@ -880,6 +898,7 @@ class RolloutEngine:
         c.next_token, c.next_state, c.logits = P(self.next_token), P(self.next_state), P(self.logits)
         c.teacher_token, c.teacher_state = P(self.teacher_token), P(self.teacher_state)
         c.teacher_grid = P(self.teacher_grid)
+        c.teacher_pos, c.teacher_head = P(self.teacher_pos), P(self.teacher_head)
         c.pred_traj, c.pred_head, c.pred_state = P(self.pred_traj), P(self.pred_head), P(self.pred_state)
         if self.insertion:
             c.first_new, c.hv_ovr = P(self.ins['first_new']), P(self.ins['hv_ovr'])

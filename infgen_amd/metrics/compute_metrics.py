@@ -178,3 +178,12 @@ def compute_metric_features(simulate_trajectories: ObjectTrajectories, evaluate_
                           collision_per_step=dist < COLLISION_DISTANCE_THRESHOLD, time_to_collision=ttc,
                           distance_to_road_edge=road, offroad_per_step=offroad, num_placement=num_in[None],
                           num_removement=num_out[None], distance_placement=d_in, distance_removement=d_out)
+
+
+def __getattr__(name):
+    # the reference keeps LongMetric in this module (infgen/metrics/compute_metrics.py:1105); here it lives in long_metric.py,
+    # which imports from this file - resolved on first use
+    if name in ('LongMetric', 'compute_log_distributions', 'get_log_distributions'):
+        from . import long_metric
+        return getattr(long_metric, name)
+    raise AttributeError(name)

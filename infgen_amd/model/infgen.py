@@ -228,10 +228,14 @@ class InfGen(nn.Module):
                 return loss
         if not (self.val_close_loop and (self.predict_motion or self.predict_state)):
             return
-        rollout = None
-        for _ in range(self.n_rollout_close_val):
+        if self.n_rollout_close_val > 1:
+            # the reference's loop (:704-706) as one batch of n copies of the scene with their own sampling uniforms
+            self.last_rollouts = self.encoder.inference_rollouts(data, self.n_rollout_close_val)
+            rollout = self.last_rollouts[-1]
+        else:
             rollout = self.encoder.inference(data.clone() if hasattr(data, 'clone') else data)
-        rollouts = [rollout]                                   # the reference appends outside its loop (:704-706)
+            self.last_rollouts = [rollout]
+        rollouts = [rollout]                                   # the reference appends outside its loop (:704-706): the last one
         if not (self._online_metric or self._save_validate_reuslts):
             return rollout
         formatted = compute_metrics.format_rollouts(data, rollouts)

@@ -325,6 +325,15 @@ class InfGenDecoder(nn.Module):
         return {**map_enc, **r}
 
     @torch.no_grad()
+    def inference_rollouts(self, data, n: int) -> List[Dict[str, torch.Tensor]]:
+        """``n`` independent rollouts of ONE scene (the reference's ``n_rollout_close_val`` loop, infgen/model/infgen.py:704-706,
+        which calls ``inference(data.clone())`` n times) as one batch of n copies decoded in lockstep: with
+        ``motion_beam_size`` / ``insert_beam_size`` > 1 every copy draws its own uniforms from torch's RNG, so the results are n
+        samples; greedy copies are identical.  ``data`` itself is not mutated (the copies are)."""
+        copies = [data.clone() if hasattr(data, 'clone') else dict(data) for _ in range(int(n))]
+        return self.inference_batch(copies)
+
+    @torch.no_grad()
     def inference_batch(self, datas: Sequence) -> List[Dict[str, torch.Tensor]]:
         """throughput entry: many independent scenes decoded in lockstep on this GPU"""
         rs = self._run(None, batch=datas)

@@ -29,6 +29,32 @@ def _assert_rows_within(row_err, tol, frac=0.999, cap_factor=50):
     assert row_err.max() <= cap_factor * tol
 
 
+def _assert_strict(o, ref_logits, ref_pos, ref_head, ref_state, tol=1e-3):
+    """teacher-forced POSES (InfgenRollout.teacher_pos / teacher_head): every decode step starts from the oracle's geometry, so no
+    radius / first-K / cell decision can flip and nothing accumulates - EVERY (step, row) must be inside the bar (a maximum, no
+    quantile), and the step's own pose update (pred_traj / pred_head keep it) must match the oracle's next pose from the same
+    start to round-off"""
+    worst = 0.0
+    for t, lg in enumerate(ref_logits):
+        lg = lg.numpy() if hasattr(lg, 'numpy') else lg
+        n = lg.shape[0]
+        worst = max(worst, float(np.abs(o['logits'][t, :n] - lg).max()))
+    print(f'teacher-forced poses: max logits error over all (step, row) pairs {worst:.2e}')
+    assert worst <= tol, worst
+    H = o['pred_traj'].shape[1] - 5 * len(ref_logits)
+    worst_p = worst_h = 0.0
+    for t in range(len(ref_logits)):
+        n = ref_logits[t].shape[0]
+        col = 2 + t                                              # the column this step writes
+        ok = np.asarray(ref_state)[:n, col] != 0                 # (invalid rows store zeros)
+        own = o['pred_traj'][:n, H + 5 * t + 4][ok]
+        worst_p = max(worst_p, float(np.abs(own - np.asarray(ref_pos)[:n, col][ok]).max()))
+        dh = np.abs(o['pred_head'][:n, H + 5 * t + 4][ok] - np.asarray(ref_head)[:n, col][ok])
+        worst_h = max(worst_h, float(np.minimum(dh, 2 * np.pi - dh).max()))
+    print(f'one-step pose update from the oracle\'s pose: max |dpos| {worst_p:.2e} m, max |dhead| {worst_h:.2e} rad')
+    assert worst_p <= 2e-4 and worst_h <= 2e-5
+
+
 def test_c4_shape_insertion_r800_matches_oracle():
     from infgen_amd import engine, synth
     from oracle import insertion_oracle as io
@@ -70,6 +96,16 @@ def test_c4_shape_insertion_r800_matches_oracle():
         assert n == n_ref[t]
         errs.append(np.abs(o['logits'][t, :n] - lg.numpy()).max(-1))
     _assert_rows_within(np.concatenate(errs), 1e-3)
+    # the strict form: poses teacher-forced as well - all 149 insertion decisions again, every row of every step inside 1e-3
+    teacher = [(ref['next_token_idx'].numpy(), ref['next_state_idx'].numpy(), ref['grid_a'].numpy(), ref['pos_a'].numpy(),
+                ref['head_a'].numpy())]
+    eng = engine.RolloutEngine(w, [scene], c['vocab'], c['map_vocab'], c['grid'], store_logits=True, teacher=teacher,
+                               insert_headroom=int(n_ref[-1]) - 64 + 16)
+    eng.rollout()
+    o = eng.outputs()[0]
+    assert o['pos_a'].shape[0] == A and np.array_equal(o['pred_type'], ref['pred_type'].numpy())
+    assert np.array_equal(o['next_state_idx'], ref['next_state_idx'].numpy())
+    _assert_strict(o, ref['logits'], ref['pos_a'].numpy(), ref['head_a'].numpy(), ref['next_state_idx'].numpy())
 
 
 @pytest.fixture(scope='module')
@@ -86,12 +122,14 @@ def c5():
     return dict(c=c, cfg=cfg, sd=sd, scene=scene, ref=ref)
 
 
-def _run_c5(c5, options=None):
+def _run_c5(c5, options=None, poses=False):
     from infgen_amd import engine
     c, ref = c5['c'], c5['ref']
     dev = torch.device('cuda:0')
     w = engine.PackedWeights(c5['sd'], c5['cfg'], dev)
     teacher = [(ref['next_token_idx'].numpy(), ref['next_state_idx'].numpy(), ref['gridtok'].numpy())]   # (grid cells: see the C4 test)
+    if poses:
+        teacher = [teacher[0] + (ref['pos_a'].numpy(), ref['head_a'].numpy())]
     eng = engine.RolloutEngine(w, [c5['scene']], c['vocab'], c['map_vocab'], c['grid'], store_logits=True, teacher=teacher,
                                options=options)
     eng.rollout()
@@ -109,6 +147,12 @@ def test_c5_shape_r800_fp32_matches_oracle(c5):
     sure = (part[..., -1] - part[..., -2]) > 2e-3
     assert (o['logits'].argmax(-1)[sure] == lg.argmax(-1)[sure]).mean() >= 0.9999
     assert ref['edge_count'][:, 1].max() > 256 * 20
+
+
+def test_c5_shape_r800_fp32_strict_with_teacher_poses(c5):
+    """the same run with the poses teacher-forced: all 40,960 (step, row) pairs inside 1e-3, one-step pose updates to round-off"""
+    o, ref = _run_c5(c5, poses=True), c5['ref']
+    _assert_strict(o, list(ref['logits']), ref['pos_a'].numpy(), ref['head_a'].numpy(), ref['next_state_idx'].numpy())
 
 
 def test_c5_shape_reduced_precision_bar(c5):

@@ -236,3 +236,50 @@ def test_library_has_no_packed_fp32_op_sel_broadcast_of_a_vgpr():
     tot, risky, per_func, n = scan.scan_library(_lib.LIB_PATH)
     assert n >= 10 and tot > 3000, 'the scan must see the kernels (packed fp32 arithmetic is used on purpose)'
     assert risky == 0, f'op_sel broadcasts of a VGPR half in: {sorted(per_func.items(), key=lambda kv: -kv[1])[:5]}'
+
+
+def test_infgen_import_surface_is_the_mi355x_package():
+    """`import infgen.model.infgen` with this repository on the path (instead of the reference) resolves to infgen_amd - the
+    module objects are the same, so run.py / val.py of the reference need no import edits (reference run.py:103-105)"""
+    import subprocess
+    import sys
+    code = ('import sys; sys.path.insert(0, %r); import infgen.model.infgen as a, infgen_amd.model.infgen as b; '
+            'from infgen.modules.infgen_decoder import InfGenDecoder as D1; from infgen_amd.modules import InfGenDecoder as D2; '
+            'from infgen.utils.func import wrap_angle; from infgen.metrics.compute_metrics import LongMetric; '
+            'print(a is b, D1 is D2, a.InfGen.__module__)' % REPO)
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert out.stdout.split() == ['True', 'True', 'infgen_amd.model.infgen']
+
+
+def test_operator_level_options_are_per_thread():
+    """the operator-level entries read a per-thread option block when one is installed
+    (infgen_thread_options), so engines driven from different host threads never see each other's switches"""
+    import ctypes as C
+    import threading
+    from infgen_amd import _lib
+    lib = _lib.load()
+    base = _lib.Options()
+    _lib.check(lib.infgen_get_options(C.byref(base)))
+    mine = _lib.Options.from_buffer_copy(bytes(base))
+    mine.attn_mode, mine.gemm_terms, mine.edge_fuse = 1, 1, 2
+    seen = {}
+
+    def eff():
+        e = _lib.Options()
+        _lib.check(lib.infgen_get_effective_options(C.byref(e)))
+        return (e.attn_mode, e.gemm_terms, e.edge_fuse)
+
+    with _lib.thread_options(mine):
+        seen['inside'] = eff()
+        inner = _lib.Options.from_buffer_copy(bytes(mine))
+        inner.gemm_terms = 3
+        with _lib.thread_options(inner):
+            seen['nested'] = eff()
+        seen['restored'] = eff()
+        t = threading.Thread(target=lambda: seen.__setitem__('other', eff()))
+        t.start(); t.join()
+    seen['after'] = eff()
+    default = (base.attn_mode, base.gemm_terms, base.edge_fuse)
+    assert seen['inside'] == (1, 1, 2) and seen['nested'] == (1, 3, 2) and seen['restored'] == (1, 1, 2)
+    assert seen['other'] == default and seen['after'] == default
