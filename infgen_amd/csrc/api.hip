@@ -708,8 +708,12 @@ extern "C" int infgen_match_map_tokens(const float* traj_pos, const float* theta
 }
 
 // scratch: optional rows x 8 bytes - with it, launches of few row tiles deal the logit chunks to several workgroups per tile
+// keys_stay (infgen_rollout_run's folded tail): the split path neither clears the keys before (k_integrate of the previous step
+// did) nor decodes them after (k_integrate of this step will); *split_used tells the caller whether that path ran
 static int heads_impl(const float* X, int rows, const float* tok_pack, const float* st_pack, int token_size,
-                      float* logits, int* next_token, int* next_state, unsigned long long* scratch, void* stream) {
+                      float* logits, int* next_token, int* next_state, unsigned long long* scratch, void* stream,
+                      bool keys_stay = false, bool* split_used = nullptr) {
+  if (split_used) *split_used = false;
   if (rows <= 0) return 0;
   if (token_size % 128) return fail("infgen_heads", "token_size must be a multiple of 128");
   HeadsArgs a{X, rows, tok_pack, st_pack, token_size, logits, next_token, next_state, nullptr, 1};
@@ -719,12 +723,14 @@ static int heads_impl(const float* X, int rows, const float* tok_pack, const flo
     int ns = 1;
     while (!no_split && 2 * ns <= nchunk && nchunk % (2 * ns) == 0 && tiles * 2 * ns <= 512) ns *= 2;
     if (ns > 1) {
-      if (hipMemsetAsync(scratch, 0, (size_t)rows * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess)
+      if (!keys_stay && hipMemsetAsync(scratch, 0, (size_t)rows * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess)
         return fail("infgen_heads", "memset failed");
       a.part = scratch; a.nsplit = ns;
       { ProfScope _ps(INFGEN_KID_HEADS, stream, (double)rows * (2 * 16384.0 + 128.0 * token_size + 384.0));
         hipLaunchKernelGGL(k_heads, dim3(tiles, ns), dim3(NT), 0, (hipStream_t)stream, a);
-        hipLaunchKernelGGL(k_heads_finish, dim3(ceil_div(rows, NT)), dim3(NT), 0, (hipStream_t)stream, scratch, rows, next_token); }
+        if (!keys_stay)
+          hipLaunchKernelGGL(k_heads_finish, dim3(ceil_div(rows, NT)), dim3(NT), 0, (hipStream_t)stream, scratch, rows, next_token); }
+      if (split_used) *split_used = true;
       return check_launch("infgen_heads");
     }
   }
@@ -791,11 +797,16 @@ static int validate(const InfgenRollout* r, const char* where) {
   return 0;
 }
 
+static int build_edges_impl(const InfgenRollout* r, int c, int edgeless, void* stream, bool zero_totals);
 extern "C" int infgen_build_edges(const InfgenRollout* r, int c, int edgeless, void* stream) {
+  return build_edges_impl(r, c, edgeless, stream, true);
+}
+// zero_totals = false: the three totals were cleared by the previous step's k_integrate (IntegrateArgs.edge_totals)
+static int build_edges_impl(const InfgenRollout* r, int c, int edgeless, void* stream, bool zero_totals) {
   RET_IF(validate(r, "infgen_build_edges"));
   OptScope _opts(r);
   hipStream_t s = (hipStream_t)stream;
-  if (!edgeless) {
+  if (!edgeless && zero_totals) {
     if (r->em.total == r->et.total + 1 && r->ea.total == r->et.total + 2) {      // laid out back to back: one fill
       if (hipMemsetAsync(r->et.total, 0, 3 * sizeof(int), s) != hipSuccess) return fail("infgen_build_edges", "memset failed");
     } else if (hipMemsetAsync(r->et.total, 0, sizeof(int), s) != hipSuccess ||
@@ -815,10 +826,19 @@ extern "C" int infgen_build_edges(const InfgenRollout* r, int c, int edgeless, v
   return check_launch("infgen_build_edges");
 }
 
+static RawFeatArgs rawfeat_args(const InfgenRollout* r, int col);
+static int integrate_impl(const InfgenRollout* r, int t, void* stream, unsigned long long* heads_part, bool zero_totals, bool prep);
 extern "C" int infgen_integrate(const InfgenRollout* r, int t, void* stream) {
+  return integrate_impl(r, t, stream, nullptr, false, false);
+}
+static int integrate_impl(const InfgenRollout* r, int t, void* stream, unsigned long long* heads_part, bool zero_totals, bool prep) {
   RET_IF(validate(r, "infgen_integrate"));
   OptScope _opts(r);
   IntegrateArgs a;
+  a.heads_part = heads_part; a.next_token_w = r->next_token;
+  a.edge_totals = zero_totals ? r->et.total : nullptr;
+  a.do_prep = prep ? 1 : 0;
+  if (prep) a.prep = rawfeat_args(r, 2 + t);
   a.st = scene_of(r); a.c = 1 + t; a.t = t; a.R = r->R; a.force_valid = r->force_valid;
   a.next_token = r->next_token; a.next_state = r->next_state;
   a.teacher_token = r->teacher_token; a.teacher_state = r->teacher_state; a.teacher_grid = r->teacher_grid;
@@ -836,19 +856,31 @@ extern "C" int infgen_integrate(const InfgenRollout* r, int t, void* stream) {
 static inline int mlpemb_off2(int K0p) { return K0p * 128 + 3 * 128; }
 static inline int mlpemb_off3(int K0p) { return mlpemb_off2(K0p) + 16384 + 3 * 128; }
 
-extern "C" int infgen_raw_feature(const InfgenRollout* r, int col, void* stream) {
-  RET_IF(validate(r, "infgen_raw_feature"));
-  OptScope _opts(r);
-  const int rows = r->S * r->A_cap;
+static RawFeatArgs rawfeat_args(const InfgenRollout* r, int col) {
   RawFeatArgs a;
   a.st = scene_of(r); a.col = col; a.tok_tab = r->tok_tab; a.token_size = r->token_size;
   a.grid_tab = r->grid_tab; a.grid_size = r->grid_size; a.state_emb = r->state_emb;
   a.cat_agent = r->cat_agent; a.cat_seed = r->cat_seed; a.raw2 = r->raw2; a.cat = r->cat; a.fus_in = r->fus_in;
   a.row_list = nullptr; a.row_mask = nullptr; a.n_list = 0;
+  return a;
+}
+
+static int raw_feature_fusion(const InfgenRollout* r, void* stream);
+extern "C" int infgen_raw_feature(const InfgenRollout* r, int col, void* stream) {
+  RET_IF(validate(r, "infgen_raw_feature"));
+  OptScope _opts(r);
+  const int rows = r->S * r->A_cap;
+  RawFeatArgs a = rawfeat_args(r, col);
   { ProfScope _ps(INFGEN_KID_RAWFEAT, stream);
     hipLaunchKernelGGL(k_rawfeat_prep, dim3(ceil_div(rows * 32, NT)), dim3(NT), 0, (hipStream_t)stream, a); }
   RET_IF(check_launch("infgen_raw_feature/prep"));
   RET_IF(infgen_fourier_embed(r->raw2, 2, nullptr, rows, r->four_xa, r->cat, 128, r->fus_in + 128, 512, 0, stream));
+  return raw_feature_fusion(r, stream);
+}
+
+// fusion_emb of the gathered rows (fus_in [rows][512]) -> X
+static int raw_feature_fusion(const InfgenRollout* r, void* stream) {
+  const int rows = r->S * r->A_cap;
   const float* P = r->fusion_pack;
   if (O().attn_mode != 0) {    // the three Linear stages of fusion_emb in one launch on the fp16 split (any row count: one
                                // 25 us chain instead of three dependent fp32 launches of 30-40 us each)
@@ -941,19 +973,33 @@ static int fourier_nomulti() {
   return v;
 }
 
-extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless, void* stream) {
-  RET_IF(validate(r, "infgen_decode_layers"));
-  OptScope _opts(r);
-  const int rows = r->S * r->A_cap;
-  RET_IF(infgen_build_edges(r, c, edgeless, stream));
-  const bool overlap = O().overlap && g_side && !edgeless;
-  const bool fuse = O().edge_fuse == 2 || (O().edge_fuse == 1 && rows > 256);      // U / Z / SIG stay on chip inside k_edge_fused
+// ---- a decode step in two halves: the edge sets of a column with their embeddings, and the 18 sublayers that consume them
+struct StepMode { bool overlap, fuse; int r24; const float* dt; };
+static StepMode step_mode(const InfgenRollout* r, int rows, int edgeless) {
+  StepMode m;
+  m.overlap = O().overlap && g_side && !edgeless;
+  m.fuse = O().edge_fuse == 2 || (O().edge_fuse == 1 && rows > 256);      // U / Z / SIG stay on chip inside k_edge_fused
   // the step's rhat rows never leave the library: packed 24-bit rows (kernels.h) when both ends are the kernels that know them
   // (INFGEN_NO_R24=1, read per call: fp32 rows instead - tests/test_rollout_gpu.py compares the two)
   const char* no_r24 = getenv("INFGEN_NO_R24");
-  const int r24 = fuse && O().fourier_mode != 0 && !(no_r24 && atoi(no_r24));
+  m.r24 = m.fuse && O().fourier_mode != 0 && !(no_r24 && atoi(no_r24));
   // the temporal set's fourth input (the time gap, one of -1 .. -16) as a lookup of its branch (kernels.h: dt_mode)
-  const float* dt = O().fourier_mode != 0 ? r->four_t_dt : nullptr;
+  m.dt = O().fourier_mode != 0 ? r->four_t_dt : nullptr;
+  return m;
+}
+// few rows: the step's Fourier embeddings side by side in one launch (k_fourier_h_multi)
+static bool fourier_multi_ok(int rows, int edgeless) {
+  return !edgeless && O().fourier_mode != 0 && rows <= 10240 && !fourier_nomulti() && !(O().overlap && g_side);
+}
+
+// edge sets of column c + their Fourier embeddings.  zero_totals = false: the totals were cleared by k_integrate; with_xa: the
+// x_a_emb embedding of the rows' raw features (raw2 / cat -> fus_in, infgen_raw_feature's middle launch) rides along as a
+// fourth set of the multi launch
+static int prepare_edges(const InfgenRollout* r, int c, int edgeless, void* stream, bool zero_totals, bool with_xa) {
+  const int rows = r->S * r->A_cap;
+  RET_IF(build_edges_impl(r, c, edgeless, stream, zero_totals));
+  const StepMode sm = step_mode(r, rows, edgeless);
+  const bool overlap = sm.overlap; const int r24 = sm.r24; const float* dt = sm.dt;
   if (overlap) {
     hipStream_t ms = (hipStream_t)stream;
     if (hipEventRecord(g_ev_fork, ms) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork, 0) != hipSuccess)
@@ -963,26 +1009,35 @@ extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless,
     RET_IF(fourier_embed_impl(r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, r24, g_side));
     if (hipEventRecord(g_ev_a, g_side) != hipSuccess) return fail("infgen_decode_layers", "event failed");
     RET_IF(fourier_embed_impl(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, r24, stream, dt, dt != nullptr));
-  } else if (!edgeless && O().fourier_mode != 0 && rows <= 10240 && !fourier_nomulti()) {
+  } else if (fourier_multi_ok(rows, edgeless)) {
     // few rows: the three sets side by side in one launch (each is a handful of 128-edge tiles of 35 - 45 us)
     unsigned long long* pr = (g_prof.mask >> INFGEN_KID_FOURIER) & 1u ? g_prof.rows_dev : nullptr;
     FourierMultiArgs m;
     m.set[0] = FourierArgs{r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, pr, r24, dt, dt != nullptr};
     m.set[1] = FourierArgs{r->em.raw, 3, r->em.total, r->em.cap, r->four_m, nullptr, 0, r->em.rhat, 128, 1, pr, r24, nullptr, 0};
     m.set[2] = FourierArgs{r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, pr, r24, nullptr, 0};
+    if (with_xa)
+      m.set[3] = FourierArgs{r->raw2, 2, nullptr, rows, r->four_xa, r->cat, 128, r->fus_in + 128, 512, 0, pr, 0, nullptr, 0};
     int cap = r->et.cap > r->em.cap ? r->et.cap : r->em.cap;
     if (r->ea.cap > cap) cap = r->ea.cap;
     int grid = ceil_div(cap, FH_TILE);
     if (grid > 256 * FH_WG_PER_CU) grid = 256 * FH_WG_PER_CU;
     { ProfScope _ps(INFGEN_KID_FOURIER, stream);
-      if (O().gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h_multi<1>, dim3(grid, 3), dim3(FH_NT), 0, (hipStream_t)stream, m);
-      else hipLaunchKernelGGL(k_fourier_h_multi<3>, dim3(grid, 3), dim3(FH_NT), 0, (hipStream_t)stream, m); }
+      if (O().gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h_multi<1>, dim3(grid, with_xa ? 4 : 3), dim3(FH_NT), 0, (hipStream_t)stream, m);
+      else hipLaunchKernelGGL(k_fourier_h_multi<3>, dim3(grid, with_xa ? 4 : 3), dim3(FH_NT), 0, (hipStream_t)stream, m); }
     RET_IF(check_launch("infgen_decode_layers(fourier)"));
   } else if (!edgeless) {
     RET_IF(fourier_embed_impl(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, r24, stream, dt, dt != nullptr));
     RET_IF(fourier_embed_impl(r->em.raw, 3, r->em.total, r->em.cap, r->four_m, nullptr, 0, r->em.rhat, 128, 1, r24, stream));
     RET_IF(fourier_embed_impl(r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, r24, stream));
   }
+  return 0;
+}
+
+static int layers_core(const InfgenRollout* r, int c, int edgeless, void* stream) {
+  const int rows = r->S * r->A_cap;
+  const StepMode sm = step_mode(r, rows, edgeless);
+  const bool overlap = sm.overlap, fuse = sm.fuse; const int r24 = sm.r24;
   const size_t slot = (size_t)(c % r->ring) * rows * D;
   const int L = r->num_layers;
   // prologue of the first (temporal) layer; every later layer's prologue is fused into the previous
@@ -1021,6 +1076,13 @@ extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless,
   return 0;
 }
 
+extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless, void* stream) {
+  RET_IF(validate(r, "infgen_decode_layers"));
+  OptScope _opts(r);
+  RET_IF(prepare_edges(r, c, edgeless, stream, true, false));
+  return layers_core(r, c, edgeless, stream);
+}
+
 extern "C" int infgen_decode_step(const InfgenRollout* r, int t, void* stream) {
   RET_IF(validate(r, "infgen_decode_step"));
   OptScope _opts(r);
@@ -1041,9 +1103,46 @@ extern "C" int infgen_decode_step(const InfgenRollout* r, int t, void* stream) {
   return 0;
 }
 
+// The decode steps t0 .. t1 - 1.  With few rows (the Fourier embeddings of a step fit one multi-set launch) the step's tail is
+// folded: the edge sets of column c + 1 are built right after the poses of column c + 1 exist, their embeddings and the rows'
+// x_a_emb embedding share one launch, and k_integrate also decodes / clears the split arg-max keys, clears the edge totals and
+// gathers the raw features - 8 dependent launches between the last sublayer of a step and the first of the next instead of 13
+// (memset, k_heads, k_heads_finish, k_integrate, k_rawfeat_prep, k_fourier_h, k_mlpemb_h, memset, k_build_edges,
+// k_fourier_h_multi, k_attn_hs ...).  Same arithmetic on the same data as infgen_decode_step (tests compare the two).
 extern "C" int infgen_rollout_run(const InfgenRollout* r, int t0, int t1, void* stream) {
+  RET_IF(validate(r, "infgen_rollout_run"));
   OptScope _opts(r);
-  for (int t = t0; t < t1; ++t) RET_IF(infgen_decode_step(r, t, stream));
+  const int rows = r->S * r->A_cap;
+  static const int no_fold = getenv("INFGEN_NO_TAIL_FOLD") ? atoi(getenv("INFGEN_NO_TAIL_FOLD")) : 0;
+  const bool sample = r->sample_k > 1 && r->sample_u;
+  const bool fold = !no_fold && t1 > t0 && fourier_multi_ok(rows, 0) && O().attn_mode != 0 && !sample && !r->first_new &&
+                    r->et.total && r->em.total == r->et.total + 1 && r->ea.total == r->et.total + 2;
+  if (!fold) {
+    for (int t = t0; t < t1; ++t) RET_IF(infgen_decode_step(r, t, stream));
+    return 0;
+  }
+  if (t0 < 0 || 1 + t1 > r->T - 1) return fail("infgen_rollout_run", "step beyond the column range");
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(r->tmp2);     // (free scratch under attn_mode != 0)
+  if (hipMemsetAsync(keys, 0, (size_t)rows * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess)
+    return fail("infgen_rollout_run", "memset failed");
+  RET_IF(prepare_edges(r, 1 + t0, 0, stream, true, false));
+  for (int t = t0; t < t1; ++t) {
+    const int c = 1 + t;
+    RET_IF(layers_core(r, c, 0, stream));
+    float* lg = (r->store_logits && r->logits) ? r->logits + (size_t)t * rows * r->token_size : nullptr;
+    bool split = false;
+    RET_IF(heads_impl(r->X, rows, r->tok_head_pack, r->st_head_pack, r->token_size, lg, r->next_token, r->next_state, keys, stream,
+                      true, &split));
+    RET_IF(integrate_impl(r, t, stream, split ? keys : nullptr, true, true));
+    if (t + 1 < t1) {
+      RET_IF(prepare_edges(r, c + 1, 0, stream, false, true));
+    } else {          // after the last step only the raw feature of the new column is left (kept: the context's X stays what
+                      // infgen_decode_step leaves)
+      RET_IF(infgen_fourier_embed(r->raw2, 2, nullptr, rows, r->four_xa, r->cat, 128, r->fus_in + 128, 512, 0, stream));
+      if (hipMemsetAsync(r->et.total, 0, 3 * sizeof(int), (hipStream_t)stream) != hipSuccess) return fail("infgen_rollout_run", "memset failed");
+    }
+    RET_IF(raw_feature_fusion(r, stream));
+  }
   return 0;
 }
 

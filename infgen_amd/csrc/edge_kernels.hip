@@ -441,6 +441,7 @@ __global__ __launch_bounds__(NT) void k_map_graph(MapGraphArgs a) {
 // tokenisation of the new position (attr_tokenizer.py:77-89), invalid handling.
 // One workgroup per scene.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rawfeat_prep_item(const RawFeatArgs& a, int row, int slot, int c4);     // (defined below)
 constexpr int GRID_LDS = 2048;   // grid cells staged in LDS (1961 for the 150 m / 3 m / 75 m grid)
 template <int BT>
 __global__ __launch_bounds__(BT) void k_integrate(IntegrateArgs a) {
@@ -455,9 +456,19 @@ __global__ __launch_bounds__(BT) void k_integrate(IntegrateArgs a) {
   const int A = st.n_agents[s];
   const int av = st.av_index[s];
   const int c = a.c, n = a.c + 1;
+  // the split arg-max keys of k_heads (ordered 64-bit (max, first index) keys): decoded here instead of by k_heads_finish, and
+  // cleared for the next decode step - for EVERY row of the scene (an appended row must not inherit an older maximum)
+  int tok_dec = 0;
+  if (a.heads_part && t < st.A_cap) {
+    const int row = s * st.A_cap + t;
+    tok_dec = (int)(0xffffffffu - (unsigned)(a.heads_part[row] & 0xffffffffull));
+    a.heads_part[row] = 0ull;
+    a.next_token_w[row] = tok_dec;
+  }
+  if (a.edge_totals && s == 0 && t < 3) a.edge_totals[t] = 0;       // the next column's k_build_edges starts from zero
   if (t < A) {
     const int row = s * st.A_cap + t;
-    int tok = a.next_token[row];
+    int tok = a.heads_part ? tok_dec : a.next_token[row];
     int ns = a.next_state[row];
     if (ns == 2) ns = EXIT;                     // valid_state_type index 2 == 'exit'
     if (t == av) ns = VALID;                    // ego forced valid
@@ -532,11 +543,19 @@ __global__ __launch_bounds__(BT) void k_integrate(IntegrateArgs a) {
         int cell = bi;
         if (a.teacher_grid && a.teacher_grid[in_] >= -1) cell = a.teacher_grid[in_];
         st.grid[in_] = inv ? -1 : cell;
-        int tok = a.next_token[s * st.A_cap + ag];
+        int tok = a.heads_part ? a.next_token_w[s * st.A_cap + ag] : a.next_token[s * st.A_cap + ag];
         if (a.teacher_token) { tok = a.teacher_token[in_]; }
         st.token[in_] = inv ? -1 : tok;
         if (inv) { st.imask[in_] = 0; st.catflag[in_] = 0; }
       }
+    }
+  }
+  if (a.do_prep) {
+    // the raw-feature gather of the column just written (k_rawfeat_prep), all rows of this scene: one launch less per step
+    __syncthreads();
+    for (int item = t; item < st.A_cap * 32; item += BT) {
+      const int row = s * st.A_cap + (item >> 5);
+      rawfeat_prep_item(a.prep, row, row, item & 31);
     }
   }
 }
@@ -548,14 +567,10 @@ template __global__ void k_integrate<1024>(IntegrateArgs);
 // embedding row, and the gathered token / state / grid embedding rows of the fusion input.
 // One thread per float4 of a row (32 threads per row).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_rawfeat_prep(RawFeatArgs a) {
+// one (row, 16-byte column group) item of the raw-feature gather: `row` = the state row read, `slot` = the row of the
+// raw2 / cat / fus_in arrays written (differ only for row subsets)
+__device__ __forceinline__ void rawfeat_prep_item(const RawFeatArgs& a, int row, int slot, int c4) {
   const SceneState& st = a.st;
-  const int gid = blockIdx.x * NT + threadIdx.x;
-  const int slot = gid >> 5, c4 = gid & 31;
-  const int rows = st.S * st.A_cap;
-  if (slot >= (a.row_list ? a.n_list : rows)) return;
-  // row subset (insertion: the rows appended in this iteration): read row_list[slot], write the compact slot
-  const int row = a.row_list ? (a.row_mask[slot] ? a.row_list[slot] : 0) : slot;
   const int s = row / st.A_cap, ag = row % st.A_cap;
   const int j = a.col;
   const size_t i = sidx(st, s, j, ag);
@@ -593,6 +608,17 @@ __global__ __launch_bounds__(NT) void k_rawfeat_prep(RawFeatArgs a) {
   *reinterpret_cast<float4*>(f + 4 * c4) = *reinterpret_cast<const float4*>(tsrc + 4 * c4);
   *reinterpret_cast<float4*>(f + 256 + 4 * c4) = *reinterpret_cast<const float4*>(ssrc + 4 * c4);
   *reinterpret_cast<float4*>(f + 384 + 4 * c4) = *reinterpret_cast<const float4*>(gsrc + 4 * c4);
+}
+
+__global__ __launch_bounds__(NT) void k_rawfeat_prep(RawFeatArgs a) {
+  const SceneState& st = a.st;
+  const int gid = blockIdx.x * NT + threadIdx.x;
+  const int slot = gid >> 5, c4 = gid & 31;
+  const int rows = st.S * st.A_cap;
+  if (slot >= (a.row_list ? a.n_list : rows)) return;
+  // row subset (insertion: the rows appended in this iteration): read row_list[slot], write the compact slot
+  const int row = a.row_list ? (a.row_mask[slot] ? a.row_list[slot] : 0) : slot;
+  rawfeat_prep_item(a, row, slot, c4);
 }
 
 // dst[row_list[k]][:] = src[k][:] for the rows with row_mask[k] != 0 (128 floats per row, 32 threads per row)

@@ -54,7 +54,7 @@ constexpr int FH_WG_PER_CU = FH_WAVES == 8 ? 1 : 2;
 #ifndef IG_AH_RING8
 #define IG_AH_RING8 5
 #endif
-struct FourierMultiArgs { FourierArgs set[3]; };
+struct FourierMultiArgs { FourierArgs set[4]; };      // (the fourth: the rows' x_a_emb embedding, infgen_rollout_run)
 
 // Packed 24-bit rows of the normalised relative-position embedding (the rollout's private edge buffers; k_fourier_h writes,
 // k_edge_fused reads): the upper 24 bits of every fp32 value (sign, exponent, 15 mantissa bits, round to nearest even) as two
@@ -306,24 +306,6 @@ struct BuildEdgesArgs {
   int map_lds;                      // float2 slots of dynamic LDS for the scene's map-token positions (0 .. 4096)
 };
 
-struct IntegrateArgs {
-  SceneState st;
-  int c;                            // current column; writes column c + 1
-  int t;                            // decode step
-  int R;                            // num_recurrent_steps_val
-  int force_valid;                  // disable_insertion: every state := valid
-  const int* next_token; const int* next_state;   // [rows] from the heads
-  const int* teacher_token; const int* teacher_state;   // optional [S][T][A_cap]
-  const int* teacher_grid;                               // optional [S][T][A_cap], < -1: none
-  const float* teacher_pos; const float* teacher_head;   // optional [S][T][A_cap](x2): the stored pose of column c + 1
-  const float* vocab;               // [3][token_size][6][4][2]
-  int token_size;
-  const float* grid_xy; int grid_size;    // [G][2]
-  float* pred_traj;                 // [S][A_cap][R][2]
-  float* pred_head;                 // [S][A_cap][R]
-  float* pred_state;                // [S][A_cap][R]
-};
-
 struct RawFeatArgs {
   SceneState st;
   int col;
@@ -339,6 +321,30 @@ struct RawFeatArgs {
   float* fus_in;                    // [rows][512]
   const int* row_list; const int* row_mask; int n_list;   // optional: only these rows (row_mask[k] != 0), outputs compact at k
 };
+
+struct IntegrateArgs {
+  SceneState st;
+  int c;                            // current column; writes column c + 1
+  int t;                            // decode step
+  int R;                            // num_recurrent_steps_val
+  int force_valid;                  // disable_insertion: every state := valid
+  const int* next_token; const int* next_state;   // [rows] from the heads
+  const int* teacher_token; const int* teacher_state;   // optional [S][T][A_cap]
+  const int* teacher_grid;                               // optional [S][T][A_cap], < -1: none
+  const float* teacher_pos; const float* teacher_head;   // optional [S][T][A_cap](x2): the stored pose of column c + 1
+  // the tail of a decode step folded into this launch (infgen_rollout_run with few rows; all optional):
+  unsigned long long* heads_part;   // k_heads' split arg-max keys [rows]: decoded here (k_heads_finish) and reset for the next step
+  int* next_token_w;                // where the decoded tokens go (the context's next_token array)
+  int* edge_totals;                 // the three edge totals of the context, zeroed for the next column's k_build_edges
+  RawFeatArgs prep; int do_prep;    // the raw-feature gather (k_rawfeat_prep) of the new column, all rows of the scene
+  const float* vocab;               // [3][token_size][6][4][2]
+  int token_size;
+  const float* grid_xy; int grid_size;    // [G][2]
+  float* pred_traj;                 // [S][A_cap][R][2]
+  float* pred_head;                 // [S][A_cap][R]
+  float* pred_state;                // [S][A_cap][R]
+};
+
 
 // edges into ONE query point per scene (insertion: the seed node at the ego pose, or a freshly
 // inserted row during its heading stage): first-K agents / map tokens within a radius of the

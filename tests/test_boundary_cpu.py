@@ -283,3 +283,40 @@ def test_operator_level_options_are_per_thread():
     default = (base.attn_mode, base.gemm_terms, base.edge_fuse)
     assert seen['inside'] == (1, 1, 2) and seen['nested'] == (1, 3, 2) and seen['restored'] == (1, 1, 2)
     assert seen['other'] == default and seen['after'] == default
+
+
+def test_stacked_host_setup_equals_the_per_scene_path():
+    """RolloutEngine._setup_scenes: a one-shape batch is set up with stacked numpy statements (the drop-in entry's host time);
+    every array must equal the per-scene loop's - history edge cases included - and ragged / filtered batches must fall back"""
+    from infgen_amd import engine, synth
+    cfg = synth.standard_config()
+    vocab = synth.make_agent_vocab(cfg.token_size)
+    grid = synth.build_grid(cfg.grid_range, cfg.grid_interval, cfg.pl2seed_radius)
+    e = engine.RolloutEngine.__new__(engine.RolloutEngine)
+    e.cfg, e.T, e.hc = cfg, cfg.num_columns, cfg.hist_columns
+
+    def check(scenes, expect_stacked):
+        e.S, e.A_cap = len(scenes), 64
+        e.M_cap = max(int(np.asarray(sc['pt_token']['position']).shape[0]) for sc in scenes)
+        e.M_cap = (e.M_cap + 31) // 32 * 32
+        e._stacked = None
+        fast = e._setup_scenes(scenes)
+        assert (e._stacked is not None) == expect_stacked
+        arr_fast = e._scene_arrays(fast)
+        e._stacked = None
+        slow = [e._setup_scene(sc) for sc in scenes]
+        arr_slow = e._scene_arrays(slow)
+        for f, s_ in zip(fast, slow):
+            assert f.keys() == s_.keys()
+            for k in f:
+                assert np.array_equal(np.asarray(f[k]), np.asarray(s_[k])), k
+        for k in arr_slow:
+            assert arr_fast[k].dtype == arr_slow[k].dtype and np.array_equal(arr_fast[k], arr_slow[k]), k
+
+    uniform = [synth.make_scene(900 + i, 40, 200, cfg, ego_last=(i % 2 == 0), edge_cases=(i % 3 == 0), vocab=vocab, grid=grid)
+               for i in range(12)]
+    uniform = [sc for sc in uniform if (np.asarray(sc['agent']['state_idx'])[:, 1] != 0).all()]
+    assert len(uniform) >= 8
+    check(uniform, True)
+    ragged = uniform[:7] + [synth.make_scene(77, 24, 100, cfg, vocab=vocab, grid=grid)] + uniform[7:]
+    check(ragged, False)

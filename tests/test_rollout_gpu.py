@@ -734,3 +734,29 @@ def test_reference_internal_invariants_hold():
         assert not imask[s, :, A:].any()
         inv = o['next_state_idx'] == INVALID
         assert (o['pos_a'][inv] == 0).all() and (o['head_a'][inv] == 0).all()
+
+
+def test_folded_step_tail_equals_stepwise_decode():
+    """infgen_rollout_run folds a step's tail for few rows (next column's edge sets early, x_a_emb in the multi-set Fourier launch,
+    k_integrate decoding / clearing the arg-max keys, clearing the edge totals and gathering the raw features): bit-identical to
+    the step-by-step sequence of infgen_decode_step, free-running, on a ragged three-scene batch and on the C3-sized fixture"""
+    from infgen_amd import engine, synth
+    dev = torch.device('cuda:0')
+    for name in ('a24_m256_edge', 'c3_a64_m1024'):
+        c = load_case(name)
+        cfg = c['cfg']
+        scenes = [c['scene']] + [synth.make_scene(8100 + i, a, m, cfg, ego_last=(i % 2 == 0), vocab=c['vocab'], grid=c['grid'])
+                                 for i, (a, m) in enumerate([(9, 100), (40, 300)])]
+        w = engine.PackedWeights(c['sd'], cfg, dev)
+        mk = lambda: engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=True, use_graph=False)
+        a, b = mk(), mk()
+        a.prologue(); b.prologue()
+        a.run()                                             # one infgen_rollout_run: the folded sequence
+        for t in range(cfg.num_decode_steps):
+            b.step(t)                                       # infgen_decode_step per step
+        for k in ('pos', 'head', 'state', 'token', 'gridtok', 'X', 'logits', 'pred_traj', 'pred_head', 'next_token'):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (name, k)
+        z = c['z']
+        assert np.array_equal(a.outputs()[0]['next_token_idx'], z['next_token_idx'])
+        a.rollout()                                         # a second rollout on the same engine starts from cleared keys again
+        assert np.array_equal(a.outputs()[0]['next_token_idx'], z['next_token_idx'])
