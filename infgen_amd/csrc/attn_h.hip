@@ -15,6 +15,7 @@
 // and - unlike k_fourier_h, see fourier_h.hip - bitwise reproducible with several workgroups per CU: 40 re-runs each of
 // 16 k / 32 k / 64 k / 100 k rows; tests/test_ops_gpu.py::test_attn_split_is_deterministic keeps watching it).
 // WAVES = 8 (128-row tiles, one workgroup per CU) is kept for comparison.
+#include <type_traits>
 #include "kernels.h"
 #include "layout.h"
 #include "tile.cuh"
@@ -75,7 +76,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnH
     if (tid < 16) Vt[VT_N_HDR + tid] = NP[AH_HDR + tid];
   }
   __syncthreads();
+#if IG_QSU
+  typename std::conditional<WAVES == 8, QuarterStreamU<NTH>, QuarterStream<NTH, XRING>>::type qs;
+#else
   QuarterStream<NTH, XRING> qs;
+#endif
   qs.dbg = a.dbg;
   qs.init(seg_ptr, seg_n, 5, (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x, Wb, tid);
   auto take = [&]() { return qs.take(); };

@@ -67,6 +67,7 @@ __device__ __forceinline__ void exchange(float* buf, f32x4 own, f32x4 (&v)[8], i
 template <int TERMS>
 __global__ __launch_bounds__(512, 1) void k_attn_hs(AttnHArgs a) {
   __shared__ __attribute__((aligned(16))) float Xb[2][8 * 64 * 4];
+  __shared__ __attribute__((aligned(16))) float Hb[4][8 * 64 * 4];      // the FFN's hidden layer, four 128-wide chunks
   __shared__ __attribute__((aligned(16))) float Vt[VT_SIZE];
   const int ngroups = a.groups ? *a.n_groups : (a.rows + 15) / 16;
   if ((int)blockIdx.x >= ngroups) return;
@@ -203,15 +204,30 @@ __global__ __launch_bounds__(512, 1) void k_attn_hs(AttnHArgs a) {
       u32x4 Fh[4], Fl[4];
       const float inv_f = frags_scaled(t8, Fh, Fl);
       f32x4 f = {0.f, 0.f, 0.f, 0.f};
+      // FFN: the four 128-wide chunks of the hidden layer first (W1 chunk cc from the same B fragments; A fragments alternate
+      // between fa and fc, requested a chunk ahead), parked in LDS behind ONE barrier, then the four W2 chunks - three barriers
+      // fewer than chunk-by-chunk; per chunk the arithmetic (scale, products, order of the partial sums) is unchanged
+      fc.load(post + (size_t)28 * QUARTER, w, lane);                                      // W1, chunk 1
+#pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
-        f32x4 hd = mm_own<TERMS>(fa, Fh, Fl);
-        fb.load(post + (size_t)(24 + 8 * cc) * QUARTER, w, lane);                        // W2, chunk cc
-        if (cc < 3) fa.load(post + (size_t)(28 + 8 * cc) * QUARTER, w, lane);            // W1, chunk cc + 1
+        f32x4 hd = (cc & 1) ? mm_own<TERMS>(fc, Fh, Fl) : mm_own<TERMS>(fa, Fh, Fl);
+        if (cc == 0) fa.load(post + (size_t)36 * QUARTER, w, lane);                       // W1, chunk 2
+        if (cc == 1) fc.load(post + (size_t)44 * QUARTER, w, lane);                       // W1, chunk 3
+        if (cc == 2) fb.load(post + (size_t)24 * QUARTER, w, lane);                       // W2, chunk 0
+        if (cc == 3) fa.load(post + (size_t)32 * QUARTER, w, lane);                       // W2, chunk 1
         hd = fma4(hd, splat4(inv_f * hdr[8]), lds4(Vt + VT_B1 + 128 * cc + own));
         hd = __builtin_elementwise_max(hd, splat4(0.f));
-        exchange(Xb[pp], hd, t8, w, lane); pp ^= 1;
+        *reinterpret_cast<float4*>(Hb[cc] + (w * 64 + lane) * 4) = make_float4(hd[0], hd[1], hd[2], hd[3]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) t8[t] = lds4(Hb[cc] + (t * 64 + lane) * 4);
         const float inv_h = frags_scaled(t8, Bh, Bl);
-        const f32x4 part = mm_own<TERMS>(fb, Bh, Bl);
+        const f32x4 part = (cc & 1) ? mm_own<TERMS>(fa, Bh, Bl) : mm_own<TERMS>(fb, Bh, Bl);
+        if (cc == 0) fb.load(post + (size_t)40 * QUARTER, w, lane);                       // W2, chunk 2
+        if (cc == 1) fa.load(post + (size_t)48 * QUARTER, w, lane);                       // W2, chunk 3
         f = fma4(part, splat4(inv_h * hdr[9]), f);
       }
       f = fma4(f, splat4(1.0f), lds4(Vt + VT_B2 + own));

@@ -185,19 +185,25 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_edge_fused(EdgeFusedArgs a) {
       if ((lane & 7) == 0) SG[rl * H + (lane >> 3)] = acc.lsum * inv;
     }
   }
+  // (phase 3's weight fragments are requested BEFORE the barrier: a wave that has finished its rows waits there anyway, and the
+  // fragments' L2 latency runs under that wait)
+  v8h p3h[4], p3l[4];
+  if (mat) {
+    const unsigned short* Wv = reinterpret_cast<const unsigned short*>(a.pack + AH_POST) + (size_t)hp * QUARTER +
+                               (size_t)(hh * 4) * 2 * 512 + lane * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      p3h[s] = *reinterpret_cast<const v8h*>(Wv + (s * 2) * 512);
+      p3l[s] = *reinterpret_cast<const v8h*>(Wv + (s * 2 + 1) * 512);
+    }
+  }
   __syncthreads();
 
   // ---- phase 3: agg' = agg + W'_vr,h z_h + b'_h sigma_h  (k_attn_h's z-GEMM: |z| <= sqrt(127), static prescale 1024)
   if (mat) {
     const float* zrow = UZ + jl * EF_LDU + h * D + 8 * g;
-    const unsigned short* Wv = reinterpret_cast<const unsigned short*>(a.pack + AH_POST) + (size_t)hp * QUARTER +
-                               (size_t)(hh * 4) * 2 * 512 + lane * 8;
-    v8h ah[4], al[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      ah[s] = *reinterpret_cast<const v8h*>(Wv + (s * 2) * 512);
-      al[s] = *reinterpret_cast<const v8h*>(Wv + (s * 2 + 1) * 512);
-    }
+    v8h (&ah)[4] = p3h;
+    v8h (&al)[4] = p3l;
     const float zs = 1024.0f, zinv = hdr[4] * (1.0f / 1024.0f);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -40,8 +40,13 @@ constexpr int DT_TAB_ROWS = 32;
 #ifndef IG_FH_WAVES
 #define IG_FH_WAVES 8
 #endif
+// IG_QSU = 1: k_fourier_h and the 8-wave k_attn_h take their weights from the unit-granular stream (split.cuh: QuarterStreamU,
+// one workgroup barrier per GEMM instead of one per quarter-matrix; 8 quarter buffers)
+#ifndef IG_QSU
+#define IG_QSU 0
+#endif
 #ifndef IG_FH_RING
-#define IG_FH_RING 5
+#define IG_FH_RING (IG_QSU ? 8 : 5)
 #endif
 constexpr int FH_WAVES = IG_FH_WAVES;
 constexpr int FH_NT = 64 * FH_WAVES;     // threads per workgroup
@@ -52,7 +57,7 @@ constexpr int FH_WG_PER_CU = FH_WAVES == 8 ? 1 : 2;
 #define IG_AH_RING4 3
 #endif
 #ifndef IG_AH_RING8
-#define IG_AH_RING8 5
+#define IG_AH_RING8 (IG_QSU ? 8 : 5)
 #endif
 struct FourierMultiArgs { FourierArgs set[4]; };      // (the fourth: the rows' x_a_emb embedding, infgen_rollout_run)
 

@@ -187,6 +187,48 @@ struct QuarterStream {
   }
 };
 
+// QuarterStreamU: the same stream with ONE barrier per GEMM unit (four quarters) instead of one per quarter.  Two units live
+// in LDS (8 x 16 KB): at a unit boundary every wave waits for its LDS-DMA pieces of the unit it is about to read (staged a whole
+// unit earlier), the workgroup meets once, and the slots of the unit just finished are refilled with the unit after next.
+// Inside a unit the waves run free, so they drift apart by up to a unit: the two waves of a SIMD are no longer in their matrix
+// and vector phases at the same instants.  Every GEMM of the kernels that use it consumes exactly four quarters.
+template <int NTH>
+struct QuarterStreamU {
+  static constexpr int GLDS = 1024 / NTH, NR = 8;
+  const unsigned short* const* seg_ptr;
+  const int* seg_n;
+  unsigned short (*Wb)[QUARTER];
+  int nseg, total, consumed, staged, sseg, soff, tid;
+  int dbg = 0;
+  __device__ __forceinline__ void stage_next() {
+    while (soff >= seg_n[sseg]) { soff = 0; sseg = (sseg + 1 == nseg) ? 0 : sseg + 1; }
+    stage_quarter<NTH>(seg_ptr[sseg] + (size_t)soff * QUARTER, Wb[staged & (NR - 1)], tid);
+    ++soff;
+    ++staged;
+  }
+  __device__ __forceinline__ void init(const unsigned short* const* sp, const int* sn, int nseg_, int my_tiles,
+                                       unsigned short (*wb)[QUARTER], int tid_) {
+    seg_ptr = sp; seg_n = sn; nseg = nseg_; Wb = wb; tid = tid_;
+    int nq = 0;
+    for (int i = 0; i < nseg; ++i) nq += sn[i];
+    total = my_tiles * nq;
+    consumed = staged = sseg = soff = 0;
+    for (int d = 0; d < NR && d < total; ++d) stage_next();          // units 0 and 1
+  }
+  __device__ __forceinline__ const unsigned short* take() {
+    if ((consumed & 3) == 0) {
+      // unit boundary: my pieces of this unit have landed once nothing older than the NEXT unit's pieces is outstanding
+      if (consumed == 0 && total > 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * GLDS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (consumed >= 4) for (int d = 0; d < 4 && staged < total; ++d) stage_next();    // the unit after next, into the slots just freed
+    }
+    const unsigned short* cur = Wb[consumed & (NR - 1)];
+    ++consumed;
+    return cur;
+  }
+};
+
 // Row-scaled fragments: the 128-vector of this lane's row is multiplied by the power of two that brings its
 // largest magnitude into [2^14, 2^15) (exact), split into fp16 hi/lo B fragments, and the inverse factor is
 // returned - scaling a column of B scales the same column of C, so the caller multiplies its GEMM result by it.
