@@ -40,21 +40,14 @@ namespace ig {
 // exact inside the fma), then the classic minimax polynomials on [-pi/4, pi/4] (Cephes sinf/cosf
 // coefficients); about 1 ulp, like the sleef kernels torch uses on the CPU.  Arguments of 1e5 rad and more
 // (never produced by in-radius geometry) are reduced in fp64 with a three-term pi/2, good to 2^40 rad.
+// (the fast path is branch-free so that the evaluations of a feature group interleave; arguments beyond the fast reduction are
+// redone by sincos_big behind ONE wave-uniform branch per group - sincos_group)
 __device__ __forceinline__ void sincos_fast(float z, float& s, float& c) {
   const float n = rintf(z * 0.636619772f);
   float r = __builtin_fmaf(n, -1.57079601e+00f, z);
   r = __builtin_fmaf(n, -3.13916473e-07f, r);
   r = __builtin_fmaf(n, -5.39030253e-15f, r);
-  int qi = (int)n;
-  if (__builtin_expect(!(fabsf(z) < 1.0e5f), 0)) {
-    const double zd = (double)z;
-    const double nd = rint(zd * 0.63661977236758134308);
-    double rd = __builtin_fma(-nd, 1.57079632679489655800e+00, zd);
-    rd = __builtin_fma(-nd, 6.12323399573676603587e-17, rd);
-    rd = __builtin_fma(-nd, -1.49738490485916983e-33, rd);
-    r = (float)rd;
-    qi = (int)(nd - 4.0 * floor(nd * 0.25));
-  }
+  const int qi = (int)n;
   const float r2 = r * r;
   float ps = __builtin_fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f);
   ps = __builtin_fmaf(ps, r2, -1.6666654611e-1f);
@@ -70,10 +63,99 @@ __device__ __forceinline__ void sincos_fast(float z, float& s, float& c) {
   s = __uint_as_float(sv ^ (((unsigned)qi & 2u) << 30));
   c = __uint_as_float(cv ^ ((((unsigned)qi + 1u) & 2u) << 30));
 }
+// (results by value: reference arguments of a non-inlined function would go through scratch memory)
+__device__ __noinline__ f32x2 sincos_big(float z) {
+  const double zd = (double)z;
+  const double nd = rint(zd * 0.63661977236758134308);
+  double rd = __builtin_fma(-nd, 1.57079632679489655800e+00, zd);
+  rd = __builtin_fma(-nd, 6.12323399573676603587e-17, rd);
+  rd = __builtin_fma(-nd, -1.49738490485916983e-33, rd);
+  const float r = (float)rd;
+  const int qi = (int)(nd - 4.0 * floor(nd * 0.25));
+  const float r2 = r * r;
+  float ps = __builtin_fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f);
+  ps = __builtin_fmaf(ps, r2, -1.6666654611e-1f);
+  ps = __builtin_fmaf(ps * r2, r, r);
+  float pc = __builtin_fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(pc, r2, 4.166664568298827e-2f);
+  pc = __builtin_fmaf(pc * r2, r2, __builtin_fmaf(-0.5f, r2, 1.0f));
+  const unsigned m = 0u - ((unsigned)qi & 1u);
+  const unsigned ups = __float_as_uint(ps), upc = __float_as_uint(pc);
+  const unsigned sv = (upc & m) | (ups & ~m);
+  const unsigned cv = (ups & m) | (upc & ~m);
+  return f32x2{__uint_as_float(sv ^ (((unsigned)qi & 2u) << 30)), __uint_as_float(cv ^ ((((unsigned)qi + 1u) & 2u) << 30))};
+}
+// eight features of one input: z[p] = x * f[p] * 2 pi as the reference forms it (left to right, fp32), sine and cosine of each
+__device__ __forceinline__ void sincos_group(float x, const float (&fr)[8], float (&sn)[8], float (&cs)[8]) {
+  float z[8], zmax = 0.f;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    z[p] = x * fr[p] * 2.0f * PI_F;
+    zmax = fmaxf(zmax, fabsf(z[p]));          // (a NaN argument gives NaN on the fast path as well)
+    sincos_fast(z[p], sn[p], cs[p]);
+  }
+  if (__builtin_expect(__any(!(zmax < 1.0e5f)), 0)) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p)          // (unrolled: a runtime index would move z / sn / cs to scratch memory)
+      if (!(fabsf(z[p]) < 1.0e5f)) { const f32x2 r = sincos_big(z[p]); sn[p] = r[0]; cs[p] = r[1]; }
+  }
+}
+
+// Packed 24-bit rows (kernels.h: R24_ROW_BYTES) of a wave's 16 edges, written as whole 128-byte lines.  A lane holds four
+// columns of every feature tile of ONE row, so stored from the registers a row leaves as 16 pieces of 8 and 4 bytes per lane -
+// sixteen store instructions of scattered fragments per wave, ~4,400 cycles of store issue at every tile end (s_memtime).  Here the
+// two planes pass through a wave-private LDS image (padded rows: conflict-free both ways) and leave as six 1 KB instructions whose
+// 16- / 8-lane runs are the contiguous 256 / 128 bytes of a row's plane.  No barrier: LDS operations of one wave retire in order.
+constexpr int R24_IMG_BYTES = 16 * 272;
+__device__ __forceinline__ void store_rows_r24(const f32x4 (&v)[8], char* img, char* out, int row0, int E, int lane) {
+  const int j = lane & 15, rg = lane >> 4;
+  unsigned lo[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    unsigned u[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned b = __float_as_uint(v[t][k]);
+      u[k] = b + 0x7fu + ((b >> 8) & 1u);                        // round to nearest even at bit 8
+    }
+    *reinterpret_cast<uint2*>(img + j * 272 + 32 * t + 8 * rg) = make_uint2((u[0] >> 16) | (u[1] & 0xffff0000u), (u[2] >> 16) | (u[3] & 0xffff0000u));
+    lo[t] = ((u[0] >> 8) & 0xffu) | (u[1] & 0xff00u) | ((u[2] << 8) & 0xff0000u) | ((u[3] << 16) & 0xff000000u);
+  }
+  uint4 h[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) h[k] = *reinterpret_cast<const uint4*>(img + (4 * k + (lane >> 4)) * 272 + (lane & 15) * 16);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = row0 + 4 * k + (lane >> 4);
+    if (r < E) *reinterpret_cast<uint4*>(out + (size_t)r * R24_ROW_BYTES + (lane & 15) * 16) = h[k];
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) *reinterpret_cast<unsigned*>(img + j * 144 + 16 * t + 4 * rg) = lo[t];
+  uint4 l[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) l[k] = *reinterpret_cast<const uint4*>(img + (8 * k + (lane >> 3)) * 144 + (lane & 7) * 16);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int r = row0 + 8 * k + (lane >> 3);
+    if (r < E) *reinterpret_cast<uint4*>(out + (size_t)r * R24_ROW_BYTES + R24_LO_PLANE + (lane & 7) * 16) = l[k];
+  }
+}
+
+#ifndef IG_FH_TRACE
+#define IG_FH_TRACE 0
+#endif
+#if IG_FH_TRACE
+// timing experiment (variant builds only): s_memtime of waves 0 and 4 of workgroup 0 at both sides of every slot barrier
+__device__ unsigned long long g_fh_trace[512];
+#endif
 
 template <int TERMS>
 __global__ __launch_bounds__(FH_NT, 2) void k_fourier_h(FourierArgs a) {
+#if IG_FH_AP
+#include "fourier_ap_body.inc"
+#else
 #include "fourier_h_body.inc"
+#endif
 }
 
 // up to three independent edge sets in one launch (gridDim.y = sets): the three Fourier embeddings of a decode step side by
@@ -81,7 +163,11 @@ __global__ __launch_bounds__(FH_NT, 2) void k_fourier_h(FourierArgs a) {
 template <int TERMS>
 __global__ __launch_bounds__(FH_NT, 2) void k_fourier_h_multi(FourierMultiArgs m) {
   const FourierArgs& a = m.set[blockIdx.y];
+#if IG_FH_AP
+#include "fourier_ap_body.inc"
+#else
 #include "fourier_h_body.inc"
+#endif
 }
 
 template __global__ void k_fourier_h_multi<3>(FourierMultiArgs);
@@ -90,3 +176,9 @@ template __global__ void k_fourier_h<3>(FourierArgs);
 template __global__ void k_fourier_h<1>(FourierArgs);
 
 }  // namespace ig
+
+#if IG_FH_TRACE
+extern "C" int infgen_debug_fh_trace(unsigned long long* host512) {
+  return (int)hipMemcpyFromSymbol(host512, HIP_SYMBOL(ig::g_fh_trace), 512 * sizeof(unsigned long long));
+}
+#endif

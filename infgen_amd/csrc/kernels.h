@@ -45,8 +45,13 @@ constexpr int DT_TAB_ROWS = 32;
 #ifndef IG_QSU
 #define IG_QSU 0
 #endif
+// IG_FH_AP = 1 (default): k_fourier_h as two groups of four waves one phase apart (fourier_ap_body.inc: the matrix phases of
+// one wave of a SIMD run under the vector phases of the other); 0: all eight waves in step, one barrier per quarter
+#ifndef IG_FH_AP
+#define IG_FH_AP 1
+#endif
 #ifndef IG_FH_RING
-#define IG_FH_RING (IG_QSU ? 8 : 5)
+#define IG_FH_RING ((IG_QSU || IG_FH_AP) ? 8 : 5)
 #endif
 constexpr int FH_WAVES = IG_FH_WAVES;
 constexpr int FH_NT = 64 * FH_WAVES;     // threads per workgroup

@@ -30,15 +30,58 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
   lo = pk_rtz(r[0], r[1]);
 }
 
+// sum over lanes ^ 16, ^ 32 (the four lanes that hold one row): the gfx950 row / half swaps with both operands equal leave
+// (own, partner) in the two results - one VALU instruction per step instead of a ds_bpermute round trip through the LDS queue
+// (which the partner wave's fragment reads keep busy); the sums are the same two-operand additions, bitwise
+typedef unsigned u32x2_sw __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float xor_lanes(float v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  u32x2_sw a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ float xor_lanes_max(float v) {
+  u32x2_sw a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
 }
 
+// LDS-DMA by hand.  Through the builtin (__builtin_amdgcn_global_load_lds) hipcc treats every such load as a store to LDS that
+// any later LDS access may alias: it puts s_waitcnt vmcnt(0) in front of the next ds_read and in front of every __syncthreads()
+// (whose release fence waits for "LDS stores"), i.e. each quarter's pieces were waited for right after their issue and the ring
+// of quarters in flight never was one - the 1.2 - 1.3 us per-quarter cadence of rounds 1 - 2.  As inline assembly the loads are
+// invisible to that bookkeeping; the streams order them themselves (counted s_waitcnt vmcnt + wg_barrier below, as they always
+// did), and loads hipcc issues on its own only make its own counted waits longer, never shorter (vmcnt retires in order).
+// M0 = LDS byte address of lane 0's 16 bytes (wave-uniform); one wait state between the M0 write and the LDS-DMA instruction.
+#ifndef IG_DMA_BUILTIN
+#define IG_DMA_BUILTIN 0
+#endif
+#ifndef IG_GQ_INTERLEAVE
+#define IG_GQ_INTERLEAVE 0
+#endif
+__device__ __forceinline__ void lds_dma16(const void* gptr, unsigned lds_byte_addr_uniform) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :: "s"(lds_byte_addr_uniform), "v"(gptr) : "memory");     // (M0 is reserved - not a legal clobber; nothing else in these kernels uses it: tests/test_boundary_cpu.py scans for that)
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+// workgroup barrier without __syncthreads()' fence (which would wait for every outstanding LDS-DMA piece): LDS operations of
+// this wave retired (lgkmcnt), then s_barrier; callers wait for the LDS-DMA pieces they need with a counted vmcnt before it
+__device__ __forceinline__ void wg_barrier() {
+#if IG_DMA_BUILTIN
+  __syncthreads();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#endif
+}
 template <int NTH>
 __device__ __forceinline__ void stage_quarter(const unsigned short* __restrict__ gsrc, unsigned short* ldst, int tid) {
   // 16 KB = 1024 sixteen-byte units; a wave instruction lands 1 KB at (uniform base + lane * 16)
+#if IG_DMA_BUILTIN
 #pragma unroll
   for (int c = 0; c < 1024 / NTH; ++c) {
     const int unit = c * NTH + tid;
@@ -46,6 +89,11 @@ __device__ __forceinline__ void stage_quarter(const unsigned short* __restrict__
                                      (__attribute__((address_space(3))) void*)(ldst + (c * NTH + (tid & ~63)) * 8),
                                      16, 0, 0);
   }
+#else
+  const unsigned lbase = __builtin_amdgcn_readfirstlane(lds_addr(ldst) + (unsigned)(tid & ~63) * 16u);
+#pragma unroll
+  for (int c = 0; c < 1024 / NTH; ++c) lds_dma16(gsrc + (c * NTH + tid) * 8, lbase + (unsigned)(c * NTH) * 16u);
+#endif
 }
 
 // acc[t] += W[16 t .., this k-step] * B   (three MFMAs per feature tile; the two A fragments of tile t + 1 are
@@ -61,6 +109,46 @@ __device__ __forceinline__ void gemm_quarter(f32x4 (&acc)[8], const unsigned sho
   // by term ACROSS the tiles, so that consecutive MFMAs never share an accumulator (a dependent MFMA waits ~40 cycles, and
   // any instruction between two MFMAs on one accumulator costs another ~43).  The scheduling barriers keep hipcc from
   // sinking each tile's ds_reads back in front of its own MFMAs, which serialises LDS latency and MFMA latency per tile.
+  // Round 3: the second group's fragments are requested in the shadow of the first group's products (one read after every
+  // product) instead of in a block between the groups, where their issue left the matrix pipe idle (gemm_unit below).
+#if IG_GQ_INTERLEAVE
+  v8h ah[2][4], al[2][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    ah[0][t] = *reinterpret_cast<const v8h*>(p + t * 1024);
+    if constexpr (TERMS == 3) al[0][t] = *reinterpret_cast<const v8h*>(p + t * 1024 + 512);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    ah[1][t] = *reinterpret_cast<const v8h*>(p + (4 + t) * 1024);
+    if constexpr (TERMS == 3) al[1][t] = *reinterpret_cast<const v8h*>(p + (4 + t) * 1024 + 512);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0][t], bh, acc[t], 0, 0, 0);
+  if constexpr (TERMS == 3) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0][t], bl, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[0][t], bh, acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < (TERMS == 3 ? 8 : 4); ++r) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+  }
+  if constexpr (TERMS == 3) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1][t], bh, acc[4 + t], 0, 0, 0);
+  if constexpr (TERMS == 3) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1][t], bl, acc[4 + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[1][t], bh, acc[4 + t], 0, 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
   for (int g = 0; g < 8; g += 4) {
     v8h ah[4], al[4];
@@ -80,6 +168,61 @@ __device__ __forceinline__ void gemm_quarter(f32x4 (&acc)[8], const unsigned sho
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+#endif
+}
+
+// One whole 128 x 128 GEMM (four quarters resident in LDS, no barrier inside): acc[t] += W[16 t .., :] * B.  Eight groups of four
+// feature tiles; the A fragments of the next group are requested while the products of the current one are issued (two fragment
+// sets in registers).  Issue order inside a group: one fragment read of the NEXT group in the shadow of every product - an MFMA
+// occupies the matrix pipe for 16 cycles and blocks only its own issue slot; eight reads in a row ahead of the products left the
+// pipe idle while they were issued (2,250 instead of ~1,600 cycles per GEMM, s_memtime).  Products term by term across the four
+// tiles as in gemm_quarter: the same products in the same order per accumulator as four gemm_quarter calls, bitwise equal.
+template <int TERMS>
+struct GemmUnit {
+  v8h ah[2][4], al[2][4];
+  const unsigned short* p;
+  __device__ __forceinline__ void request(int grp, int buf) {       // group grp = quarter grp >> 1, feature tiles 4 (grp & 1) ..
+    const unsigned short* q = p + (grp >> 1) * QUARTER + (grp & 1) * 4096;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      ah[buf][t] = *reinterpret_cast<const v8h*>(q + t * 1024);
+      if constexpr (TERMS == 3) al[buf][t] = *reinterpret_cast<const v8h*>(q + t * 1024 + 512);
+    }
+  }
+  template <bool LAST>
+  __device__ __forceinline__ void group(f32x4 (&acc)[8], int grp, u32x4 Bh, u32x4 Bl) {
+    const int buf = grp & 1, o = 4 * (grp & 1);
+    if (!LAST) request(grp + 1, buf ^ 1);
+    const v8h bh = __builtin_bit_cast(v8h, Bh);
+    const v8h bl = __builtin_bit_cast(v8h, Bl);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[o + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[buf][t], bh, acc[o + t], 0, 0, 0);
+    if constexpr (TERMS == 3) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[o + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[buf][t], bl, acc[o + t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[o + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[buf][t], bh, acc[o + t], 0, 0, 0);
+    }
+    if constexpr (!LAST) {
+#pragma unroll
+      for (int r = 0; r < (TERMS == 3 ? 8 : 4); ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      if constexpr (TERMS == 3) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+};
+template <int TERMS = 3>
+__device__ __forceinline__ void gemm_unit(f32x4 (&acc)[8], const unsigned short* Wu, const u32x4 (&Bh)[4], const u32x4 (&Bl)[4], int lane) {
+  GemmUnit<TERMS> u;
+  u.p = Wu + lane * 8;
+  u.request(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int grp = 0; grp < 7; ++grp) u.template group<false>(acc, grp, Bh[grp >> 1], Bl[grp >> 1]);
+  u.template group<true>(acc, 7, Bh[3], Bl[3]);
 }
 
 // LayerNorm over the 128 features of this lane's edge (32 here, the rest in lanes ^ 16, ^ 32, ^ 48), biased
@@ -101,8 +244,9 @@ __device__ __forceinline__ f32x4 lds4(const float* p) {
   return f32x4{v.x, v.y, v.z, v.w};
 }
 
-template <bool AFFINE, bool RELU>
-__device__ __forceinline__ void ln_regs(f32x4 (&v)[8], const float* gtab, const float* btab, int rg) {
+// (two halves so that a kernel can put a slot barrier between them: ln_stats centres v and returns 1 / sqrt(var + eps), ln_apply
+// scales and applies the affine part / ReLU; ln_regs = both, the same operations in the same order)
+__device__ __forceinline__ float ln_stats(f32x4 (&v)[8]) {
   f32x4 s4 = (v[0] + v[1]) + (v[2] + v[3]);
   s4 += (v[4] + v[5]) + (v[6] + v[7]);
   const float mean = xor_lanes((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 128.0f);
@@ -115,7 +259,10 @@ __device__ __forceinline__ void ln_regs(f32x4 (&v)[8], const float* gtab, const 
     q5 = fma4(v[t + 1], v[t + 1], q5);
   }
   q4 += q5;
-  const float rstd = 1.0f / sqrtf(xor_lanes((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 128.0f) + LN_EPS);
+  return 1.0f / sqrtf(xor_lanes((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 128.0f) + LN_EPS);
+}
+template <bool AFFINE, bool RELU>
+__device__ __forceinline__ void ln_apply(f32x4 (&v)[8], float rstd, const float* gtab, const float* btab, int rg) {
   const f32x4 r4 = splat4(rstd);
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -124,6 +271,11 @@ __device__ __forceinline__ void ln_regs(f32x4 (&v)[8], const float* gtab, const 
     if (RELU) y = __builtin_elementwise_max(y, splat4(0.f));
     v[t] = y;
   }
+}
+template <bool AFFINE, bool RELU>
+__device__ __forceinline__ void ln_regs(f32x4 (&v)[8], const float* gtab, const float* btab, int rg) {
+  const float rstd = ln_stats(v);
+  ln_apply<AFFINE, RELU>(v, rstd, gtab, btab, rg);
 }
 
 // C registers -> B fragments of the next GEMM: k-step s takes tiles 2 s (slots 0..3) and 2 s + 1 (slots 4..7)
@@ -169,8 +321,8 @@ struct QuarterStream {
   __device__ __forceinline__ const unsigned short* take() {
     if (dbg & 3) {                       // timing experiments (wrong results): the ring is never restaged; 1: no barrier either -
                                          // what free-running waves would cost; 2: the barrier stays - what the LDS-DMA waits cost
-      if (consumed == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
-      else if (dbg & 2) __syncthreads();
+      if (consumed == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); wg_barrier(); }
+      else if (dbg & 2) wg_barrier();
       const unsigned short* cur = Wb[slot];
       slot = (slot + 1 == NR) ? 0 : slot + 1;
       ++consumed;
@@ -178,7 +330,7 @@ struct QuarterStream {
     }
     if (consumed + ND <= total) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((ND - 1) * GLDS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    wg_barrier();
     if (consumed + ND < total) stage_next();
     const unsigned short* cur = Wb[slot];
     slot = (slot + 1 == NR) ? 0 : slot + 1;
@@ -220,7 +372,7 @@ struct QuarterStreamU {
       // unit boundary: my pieces of this unit have landed once nothing older than the NEXT unit's pieces is outstanding
       if (consumed == 0 && total > 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * GLDS) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      wg_barrier();
       if (consumed >= 4) for (int d = 0; d < 4 && staged < total; ++d) stage_next();    // the unit after next, into the slots just freed
     }
     const unsigned short* cur = Wb[consumed & (NR - 1)];
@@ -237,8 +389,7 @@ __device__ __forceinline__ float frags_scaled(const f32x4 (&v)[8], u32x4 (&Bh)[4
 #pragma unroll
   for (int t = 0; t < 8; ++t)
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v[t][0]), fabsf(v[t][1]))), fmaxf(fabsf(v[t][2]), fabsf(v[t][3])));
-  m = fmaxf(m, __shfl_xor(m, 16, 64));
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  m = xor_lanes_max(m);
   unsigned eb = __float_as_uint(m) >> 23;
   eb = min(max(eb, 15u), 253u);
   const float sc = __uint_as_float((268u - eb) << 23), inv = __uint_as_float((eb - 14u) << 23);

@@ -238,6 +238,22 @@ def test_library_has_no_packed_fp32_op_sel_broadcast_of_a_vgpr():
     assert risky == 0, f'op_sel broadcasts of a VGPR half in: {sorted(per_func.items(), key=lambda kv: -kv[1])[:5]}'
 
 
+def test_library_writes_m0_only_for_its_own_lds_dma():
+    """split.cuh: lds_dma16 issues the LDS-DMA loads as inline assembly (through the builtin hipcc waits for every piece before the
+    next LDS access, which defeats the weight ring) and sets M0 itself.  M0 is not a legal clobber, so the built code is checked
+    instead: every M0 write sits in front of a global_load_lds, every LDS-DMA load has one, nothing else touches M0."""
+    import importlib.util
+    from infgen_amd import _lib
+    spec = importlib.util.spec_from_file_location('pk_opsel_scan', os.path.join(REPO, 'tools', 'pk_opsel_scan.py'))
+    scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scan)
+    if not os.path.exists(scan.OBJDUMP):
+        pytest.skip('llvm-objdump not found')
+    writes, dma, bad = scan.scan_library_m0(_lib.LIB_PATH)
+    assert dma > 50 and writes == dma, (writes, dma)
+    assert not bad, bad[:5]
+
+
 def test_infgen_import_surface_is_the_mi355x_package():
     """`import infgen.model.infgen` with this repository on the path (instead of the reference) resolves to infgen_amd - the
     module objects are the same, so run.py / val.py of the reference need no import edits (reference run.py:103-105)"""

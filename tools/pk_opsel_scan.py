@@ -62,6 +62,49 @@ def scan_library(path):
     return tot, risky, per_func, len(objs)
 
 
+def scan_m0(lines):
+    """the hand-written LDS-DMA of split.cuh (lds_dma16) sets M0 itself, which is not a legal inline-asm clobber: every write of
+    M0 has to be the one in front of a global_load_lds within the next three instructions, and nothing else may read M0
+    -> (M0 writes, LDS-DMA loads, offending lines)"""
+    ins = []
+    for line in lines:
+        m = re.match(r'^\s*(?:[0-9a-f]+:\s+)?([sv]_\w+|ds_\w+|global_\w+|buffer_\w+|scratch_\w+|flat_\w+)\s*(.*?)(?:\s*//.*)?$', line)
+        if m:
+            ins.append((m.group(1), m.group(2)))
+    writes = dma = 0
+    bad = []
+    for i, (op, rest) in enumerate(ins):
+        if op.startswith('global_load_lds'):
+            dma += 1
+        if not re.search(r'\bm0\b', rest):
+            continue
+        if op == 's_mov_b32' and rest.split(',')[0].strip() == 'm0':
+            writes += 1
+            if not any(o.startswith('global_load_lds') for o, _ in ins[i + 1:i + 4]):
+                bad.append(f'{op} {rest}')
+        else:
+            bad.append(f'{op} {rest}')
+    return writes, dma, bad
+
+
+def scan_library_m0(path):
+    writes = dma = 0
+    bad = []
+    with tempfile.TemporaryDirectory() as d:
+        lib = os.path.join(d, os.path.basename(path))
+        with open(path, 'rb') as f, open(lib, 'wb') as g:
+            g.write(f.read())
+        subprocess.run([OBJDUMP, '--offloading', lib], cwd=d, check=True, capture_output=True)
+        for n in os.listdir(d):
+            if n.endswith('gfx950'):
+                dis = subprocess.run([OBJDUMP, '-d', os.path.join(d, n)], check=True, capture_output=True, text=True).stdout
+                w, m, b = scan_m0(dis.splitlines())
+                writes += w
+                dma += m
+                bad += b
+    return writes, dma, bad
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 2 and sys.argv[1] == '--lib':
         t, r, pf, n = scan_library(sys.argv[2])
