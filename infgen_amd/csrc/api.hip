@@ -366,16 +366,42 @@ extern "C" int infgen_active_row_groups(const int* n_agents, int S, int A_cap, i
   return check_launch("infgen_active_row_groups");
 }
 
+// The next small launch's warm workgroups (tile.cuh: WarmArgs): set by the sublayer loop right before the launch that carries them,
+// taken (and cleared) by launch_attn_h / edge_fused_launch.  INFGEN_WARM=0 switches them off; launches of more than
+// INFGEN_WARM_MAX_GROUPS 16-row groups (default 128) never carry any - they leave no CU idle.
+static thread_local WarmArgs t_warm = {};
+static int warm_max_groups() {
+  static const int on = getenv("INFGEN_WARM") ? atoi(getenv("INFGEN_WARM")) : 1;
+  static const int mx = getenv("INFGEN_WARM_MAX_GROUPS") ? atoi(getenv("INFGEN_WARM_MAX_GROUPS")) : 128;
+  return on ? mx : 0;
+}
+static void warm_request(const void* p0, int len0, const void* p1, int len1) {
+  t_warm.p[0] = (const char*)p0; t_warm.len[0] = p0 ? len0 : 0; t_warm.p[1] = (const char*)p1; t_warm.len[1] = p1 ? len1 : 0;
+}
+// -> grid with the warm workgroups appended (or the grid as it was)
+static int warm_take(WarmArgs& w, int grid) {
+  WarmArgs req = t_warm;
+  t_warm = WarmArgs{};
+  w = WarmArgs{};
+  if (!(req.len[0] > 0 || req.len[1] > 0) || grid > warm_max_groups()) return grid;
+  const int wg0 = (grid + 7) & ~7;
+  const int per = (256 - wg0) / 8 < 24 ? (256 - wg0) / 8 : 24;
+  if (per <= 0) return grid;
+  w = req; w.wg0 = wg0; w.per_xcd = per;
+  return wg0 + 8 * per;
+}
+
 static void launch_attn_h(const AttnHArgs& a_in, void* stream) {
   AttnHArgs a = a_in;
   a.dbg = qs_dbg();
   if (O().row_groups && a.rows == group_rows()) { a.groups = O().row_groups; a.n_groups = O().n_row_groups; }
   if (attn_kind(a.rows) == 2) {            // one 16-row group per workgroup
-    const int grid = ceil_div(a.rows, 16);
+    const int grid = warm_take(a.warm, ceil_div(a.rows, 16));
     if (O().gemm_terms == 1) hipLaunchKernelGGL(k_attn_hs<1>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_attn_hs<3>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     return;
   }
+  t_warm = WarmArgs{};
   static const int waves = getenv("INFGEN_ATTN_WAVES") ? atoi(getenv("INFGEN_ATTN_WAVES")) : (IG_QSU ? 8 : 4);
   if (waves != 8) {
     int grid = ceil_div(a.rows, 64);
@@ -468,6 +494,7 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
   }
   if (no_xcd & 2) a.kv_once = 0;
   a.n_virtual = grid;
+  if (small && !persist) grid = warm_take(a.warm, grid); else t_warm = WarmArgs{};
   if (persist && !r24) {
     const int pg = grid < 256 ? grid : 256;
     // INFGEN_EDGE_DBG bit 3 (diagnostic, synchronous): checksums of what each phase hands to the next, compared between the
@@ -1046,27 +1073,36 @@ static int layers_core(const InfgenRollout* r, int c, int edgeless, void* stream
   const float* Z = fuse ? nullptr : r->Z;
   const float* SIG = fuse ? nullptr : r->SIG;
   const int has_pos = fuse ? 0 : 1;                 // the fused edge kernel already added W'vr z + b' sigma to AGG
-  auto edge = [&](const float* pack, const float* Ks, const float* Vs, const InfgenEdgeBuf& e, int kv_once = 0) {
+  // warm requests (tile.cuh: WarmArgs): an edge launch pulls what the node launch after it reads (the layer's post part without
+  // W'vr, the next layer's pre part), a node launch the whole post part of the layer after it (W'vr first: the next edge launch)
+  const int QB = 16384;                              // bytes of a quarter-matrix (split.cuh: QUARTER fp16 elements)
+  auto edge = [&](const float* pack, const float* Ks, const float* Vs, const InfgenEdgeBuf& e, int kv_once = 0, const float* next_pack = nullptr) {
+    if (fuse && O().attn_mode != 0)
+      warm_request(pack + AH_POST + 4 * (QB / 4), 48 * QB, next_pack ? next_pack + AH_PRE : nullptr, 16 * QB);
     return fuse ? edge_fused_launch(rows, r->Q, pack, Ks, Vs, e.off, e.cnt, e.src, e.rhat, r->AGG, r->A_cap, kv_once, stream, r24)
                 : infgen_edge_attn(rows, r->Q, r->U, Ks, Vs, e.off, e.cnt, e.src, e.rhat, r->AGG, r->Z, r->SIG, stream);
   };
   RET_IF(infgen_attn_pre(r->X, rows, r->attn_t[0], 0, r->Q, U, r->ringK[0] + slot, r->ringV[0] + slot, stream));
+  auto warm_post = [&](const float* pack) { if (fuse && O().attn_mode != 0) warm_request(pack + AH_POST, 52 * QB, nullptr, 0); };
   for (int i = 0; i < L; ++i) {
     // temporal: K/V of this column sit in the ring (they are the cached layer inputs' projections)
-    RET_IF(edge(r->attn_t[i], r->ringK[i], r->ringV[i], r->et, 1));
+    RET_IF(edge(r->attn_t[i], r->ringK[i], r->ringV[i], r->et, 1, r->attn_m[i]));
+    warm_post(r->attn_m[i]);
     RET_IF(infgen_attn_post_pre(r->X, rows, r->attn_t[i], r->AGG, Z, SIG, has_pos, r->attn_m[i], r->Q, U,
                                 nullptr, nullptr, stream));
     // map -> agent (bipartite: K/V of the map tokens are per-scene constants)
     if (overlap && i == 0 && hipStreamWaitEvent((hipStream_t)stream, g_ev_m, 0) != hipSuccess)
       return fail("infgen_decode_layers", "join failed");
-    RET_IF(edge(r->attn_m[i], r->mapK[i], r->mapV[i], r->em));
+    RET_IF(edge(r->attn_m[i], r->mapK[i], r->mapV[i], r->em, 0, r->attn_a[i]));
+    warm_post(r->attn_a[i]);
     RET_IF(infgen_attn_post_pre(r->X, rows, r->attn_m[i], r->AGG, Z, SIG, has_pos, r->attn_a[i], r->Q, U,
                                 r->Ka, r->Va, stream));
     // agent <-> agent
     if (overlap && i == 0 && hipStreamWaitEvent((hipStream_t)stream, g_ev_a, 0) != hipSuccess)
       return fail("infgen_decode_layers", "join failed");
-    RET_IF(edge(r->attn_a[i], r->Ka, r->Va, r->ea));
+    RET_IF(edge(r->attn_a[i], r->Ka, r->Va, r->ea, 0, i + 1 < L ? r->attn_t[i + 1] : nullptr));
     if (i + 1 < L) {
+      warm_post(r->attn_t[i + 1]);
       RET_IF(infgen_attn_post_pre(r->X, rows, r->attn_a[i], r->AGG, Z, SIG, has_pos, r->attn_t[i + 1], r->Q, U,
                                   r->ringK[i + 1] + slot, r->ringV[i + 1] + slot, stream));
     } else {

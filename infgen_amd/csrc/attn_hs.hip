@@ -68,10 +68,11 @@ template <int TERMS>
 __global__ __launch_bounds__(512, 1) void k_attn_hs(AttnHArgs a) {
   __shared__ __attribute__((aligned(16))) float Xb[2][8 * 64 * 4];
   __shared__ __attribute__((aligned(16))) float Hb[4][8 * 64 * 4];      // the FFN's hidden layer, four 128-wide chunks
-  __shared__ __attribute__((aligned(16))) float Vt[VT_SIZE];
+  __shared__ __attribute__((aligned(16))) float Vt[VT_SIZE + 4];        // (+ 4: the spare slot)
+  const int tid = threadIdx.x;
+  if (warm_l2(a.warm, blockIdx.x, tid, 512)) return;            // kernels.h: WarmArgs
   const int ngroups = a.groups ? *a.n_groups : (a.rows + 15) / 16;
   if ((int)blockIdx.x >= ngroups) return;
-  const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   const int j = lane & 15, rg = lane >> 4;
   const float* P = a.pack;
@@ -84,59 +85,56 @@ __global__ __launch_bounds__(512, 1) void k_attn_hs(AttnHArgs a) {
   const int row = grp * 16 + j;
   const bool valid = row < a.rows;
   float* xrow = valid ? a.X + (size_t)row * D : nullptr;
+  // Request order = arrival order (one in-order counter): the small vector tables first (their LDS copy and the barrier then
+  // wait for 30 KB instead of for 220 KB), the rows next (the first LayerNorm runs while the weights are still arriving), then the
+  // A fragments of the first three GEMMs.  The fragment sets are three register sets used round-robin by the layer's fifteen
+  // 128 x 128 matrices in consumption order (gate a / gate x / self / out / W1 chunks 0..3 / W2 chunks 0..3 / q / k / v): set i % 3
+  // is requested again as soon as GEMM i has issued its products, i.e. two to three GEMMs ahead of its use instead of one.
+  // Loads only moved: arithmetic and results are unchanged (bitwise).
+  // (tables: two 16-byte slots per thread, loaded unconditionally - a thread without a slot re-reads the first one and stores to
+  // the spare slot behind the table; rows beyond the end load the last row and are never stored.  A conditional load gets a basic
+  // block of its own in which hipcc waits for it before the next one is issued: every `valid ? load : 0` and every per-table copy
+  // loop of the first version was a memory round trip of ~3,000 cycles on its own.)
+  const int d0 = 4 * tid, d1 = 4 * (tid + 512);
+  const float* anyp = P ? P : NP;
+  const float* ts0 = attn_table_src(d0, P, NP, a.next_src_ln);
+  const float* ts1 = d1 < VT_SIZE ? attn_table_src(d1, P, NP, a.next_src_ln) : nullptr;
+  const float4 tv0 = *reinterpret_cast<const float4*>(ts0 ? ts0 : anyp);
+  const float4 tv1 = *reinterpret_cast<const float4*>(ts1 ? ts1 : anyp);
+  const int rowc = valid ? row : a.rows - 1;
   f32x4 x[8];
-  load_row(x, xrow, rg);
-
-  // the first GEMMs' A fragments are requested before the vector tables are staged
+  load_row_nc(x, a.X + (size_t)rowc * D, rg);
+  const int own = 16 * w + 4 * rg;               // first of this lane's four features of the wave's tile
+  // this wave's tile of agg, and (has_pos = 0) the whole rows for the gate GEMM; the first three fragment sets - all of it
+  // unconditional (a launch without a post part reads its x rows / its q, k, v matrices here, which it needs anyway or ignores)
+  const float* aggp = (P ? a.AGG : a.X) + (size_t)rowc * D;
+  f32x4 ago;
+  { const float4 t = *reinterpret_cast<const float4*>(aggp + own); ago = f32x4{t.x, t.y, t.z, t.w}; }
+  f32x4 ag[8];
+  load_row_nc(ag, aggp, rg);
   AFrag<TERMS> fa, fb, fc;
-  if (P) { fa.load(post + 4 * QUARTER, w, lane); fb.load(post + 8 * QUARTER, w, lane); fc.load(post + 12 * QUARTER, w, lane); }
-
-  if (P) {
-    for (int i = tid; i < 128; i += 512) {
-      Vt[VT_LND_G + i] = P[AL_LN_DST_G + i]; Vt[VT_LND_B + i] = P[AL_LN_DST_B + i];
-      Vt[VT_BVR + i] = P[AL_BVR + i]; Vt[VT_BG + i] = P[AL_BG + i]; Vt[VT_BS + i] = P[AL_BS + i]; Vt[VT_BO + i] = P[AL_BO + i];
-      Vt[VT_LNP_G + i] = P[AL_LN_POST_G + i]; Vt[VT_LNP_B + i] = P[AL_LN_POST_B + i];
-      Vt[VT_LNF_G + i] = P[AL_LN_FFPRE_G + i]; Vt[VT_LNF_B + i] = P[AL_LN_FFPRE_B + i];
-      Vt[VT_B2 + i] = P[AL_B2 + i];
-      Vt[VT_LNO_G + i] = P[AL_LN_FFPOST_G + i]; Vt[VT_LNO_B + i] = P[AL_LN_FFPOST_B + i];
-    }
-    for (int i = tid; i < 512; i += 512) Vt[VT_B1 + i] = P[AL_B1 + i];
-    if (tid < 16) Vt[VT_HDR + tid] = P[AH_HDR + tid];
-  }
-  if (NP) {
-    for (int i = tid; i < 128; i += 512) {
-      Vt[VT_N_LN_G + i] = NP[(a.next_src_ln ? AL_LN_SRC_G : AL_LN_DST_G) + i];
-      Vt[VT_N_LN_B + i] = NP[(a.next_src_ln ? AL_LN_SRC_B : AL_LN_DST_B) + i];
-      Vt[VT_N_BQ + i] = NP[AL_BQ + i]; Vt[VT_N_BV + i] = NP[AL_BV + i];
-    }
-    if (tid < 16) Vt[VT_N_HDR + tid] = NP[AH_HDR + tid];
-  }
+  fa.load(P ? post + 4 * QUARTER : pre, w, lane);
+  fb.load(P ? post + 8 * QUARTER : pre + 8 * QUARTER, w, lane);
+  fc.load(P ? post + 12 * QUARTER : pre + 12 * QUARTER, w, lane);
+  *reinterpret_cast<float4*>(Vt + (ts0 ? d0 : VT_SIZE)) = tv0;
+  *reinterpret_cast<float4*>(Vt + (ts1 ? d1 : VT_SIZE)) = tv1;
   __syncthreads();
 
   int pp = 0;                                    // ping-pong index of the exchange buffer
   u32x4 Bh[4], Bl[4];
-  const int own = 16 * w + 4 * rg;               // first of this lane's four features of the wave's tile
 
   if (P) {
     const float* hdr = Vt + VT_HDR;
-    // this wave's tile of agg, and (below) the whole rows as the B operand of the gate GEMM
-    f32x4 ago = {0.f, 0.f, 0.f, 0.f};
-    if (valid) { const float4 t = *reinterpret_cast<const float4*>(a.AGG + (size_t)row * D + own); ago = f32x4{t.x, t.y, t.z, t.w}; }
-    f32x4 ag[8];
-    if (!a.has_pos) load_row(ag, valid ? a.AGG + (size_t)row * D : nullptr, rg);
     if (a.has_pos) {
       // z-GEMM of head w (k_attn_h's, k_edge_fused's phase 3): B fragments straight from Z[row][w][:], |z| <= sqrt(127)
-      const float* zrow = valid ? a.Z + (size_t)row * (H * D) + w * D : nullptr;
+      const float* zrow = a.Z + (size_t)rowc * (H * D) + w * D;
       const unsigned short* Wl = post + (size_t)(w >> 1) * QUARTER + (size_t)((w & 1) * 4) * 2 * 512 + lane * 8;
       const float zs = 1024.0f, zinv = hdr[4] * (1.0f / 1024.0f);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f), z1 = z0;
-        if (zrow) {
-          z0 = *reinterpret_cast<const float4*>(zrow + 32 * s + 8 * rg);
-          z1 = *reinterpret_cast<const float4*>(zrow + 32 * s + 8 * rg + 4);
-        }
+        const float4 z0 = *reinterpret_cast<const float4*>(zrow + 32 * s + 8 * rg);
+        const float4 z1 = *reinterpret_cast<const float4*>(zrow + 32 * s + 8 * rg + 4);
         u32x4 bh, bl;
         unsigned hi, lo;
         split_pair(z0.x * zs, z0.y * zs, hi, lo); bh[0] = hi; bl[0] = lo;
@@ -152,7 +150,7 @@ __global__ __launch_bounds__(512, 1) void k_attn_hs(AttnHArgs a) {
           acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, vbh, acc, 0, 0, 0);
         }
       }
-      const float sg = valid ? a.SIG[(size_t)row * H + w] : 0.f;
+      const float sg = a.SIG[(size_t)rowc * H + w];
       const f32x4 bvr = lds4(Vt + VT_BVR + own);
 #pragma unroll
       for (int r = 0; r < 4; ++r) ago[r] += acc[r] * zinv + bvr[r] * sg;
@@ -176,6 +174,8 @@ __global__ __launch_bounds__(512, 1) void k_attn_hs(AttnHArgs a) {
         sf = mm_step<TERMS>(fc, s, Xh[s], Xl[s], sf);
       }
       fa.load(post + 16 * QUARTER, w, lane);    // Wo
+      fb.load(post + 20 * QUARTER, w, lane);    // W1, chunk 0
+      fc.load(post + (size_t)28 * QUARTER, w, lane);                                      // W1, chunk 1
       const float ca = inv_a * hdr[5], cx = inv_x * hdr[5], cs = inv_x * hdr[6];
       const f32x4 bg = lds4(Vt + VT_BG + own), bs = lds4(Vt + VT_BS + own);
 #pragma unroll
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512, 1) void k_attn_hs(AttnHArgs a) {
       exchange(Xb[pp], upd_own, t8, w, lane); pp ^= 1;
       const float inv_u = frags_scaled(t8, Bh, Bl);
       f32x4 o = mm_own<TERMS>(fa, Bh, Bl);
-      fa.load(post + 20 * QUARTER, w, lane);    // W1, chunk 0
+      fa.load(post + (size_t)36 * QUARTER, w, lane);                                      // W1, chunk 2
       o = fma4(o, splat4(inv_u * hdr[7]), lds4(Vt + VT_BO + own));
       exchange(Xb[pp], o, t8, w, lane); pp ^= 1;
       ln_regs<true, false>(t8, Vt + VT_LNP_G, Vt + VT_LNP_B, rg);
@@ -207,14 +207,14 @@ __global__ __launch_bounds__(512, 1) void k_attn_hs(AttnHArgs a) {
       // FFN: the four 128-wide chunks of the hidden layer first (W1 chunk cc from the same B fragments; A fragments alternate
       // between fa and fc, requested a chunk ahead), parked in LDS behind ONE barrier, then the four W2 chunks - three barriers
       // fewer than chunk-by-chunk; per chunk the arithmetic (scale, products, order of the partial sums) is unchanged
-      fc.load(post + (size_t)28 * QUARTER, w, lane);                                      // W1, chunk 1
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
-        f32x4 hd = (cc & 1) ? mm_own<TERMS>(fc, Fh, Fl) : mm_own<TERMS>(fa, Fh, Fl);
-        if (cc == 0) fa.load(post + (size_t)36 * QUARTER, w, lane);                       // W1, chunk 2
-        if (cc == 1) fc.load(post + (size_t)44 * QUARTER, w, lane);                       // W1, chunk 3
-        if (cc == 2) fb.load(post + (size_t)24 * QUARTER, w, lane);                       // W2, chunk 0
-        if (cc == 3) fa.load(post + (size_t)32 * QUARTER, w, lane);                       // W2, chunk 1
+        // W1 chunks 0, 1, 2, 3 sit in sets fb, fc, fa, fb; the freed set takes W1 chunk 3 / W2 chunks 0, 1, 2
+        f32x4 hd = cc == 1 ? mm_own<TERMS>(fc, Fh, Fl) : cc == 2 ? mm_own<TERMS>(fa, Fh, Fl) : mm_own<TERMS>(fb, Fh, Fl);
+        if (cc == 0) fb.load(post + (size_t)44 * QUARTER, w, lane);                       // W1, chunk 3
+        if (cc == 1) fc.load(post + (size_t)24 * QUARTER, w, lane);                       // W2, chunk 0
+        if (cc == 2) fa.load(post + (size_t)32 * QUARTER, w, lane);                       // W2, chunk 1
+        if (cc == 3) fb.load(post + (size_t)40 * QUARTER, w, lane);                       // W2, chunk 2
         hd = fma4(hd, splat4(inv_f * hdr[8]), lds4(Vt + VT_B1 + 128 * cc + own));
         hd = __builtin_elementwise_max(hd, splat4(0.f));
         *reinterpret_cast<float4*>(Hb[cc] + (w * 64 + lane) * 4) = make_float4(hd[0], hd[1], hd[2], hd[3]);
@@ -225,9 +225,12 @@ __global__ __launch_bounds__(512, 1) void k_attn_hs(AttnHArgs a) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) t8[t] = lds4(Hb[cc] + (t * 64 + lane) * 4);
         const float inv_h = frags_scaled(t8, Bh, Bl);
-        const f32x4 part = (cc & 1) ? mm_own<TERMS>(fa, Bh, Bl) : mm_own<TERMS>(fb, Bh, Bl);
-        if (cc == 0) fb.load(post + (size_t)40 * QUARTER, w, lane);                       // W2, chunk 2
-        if (cc == 1) fa.load(post + (size_t)48 * QUARTER, w, lane);                       // W2, chunk 3
+        // W2 chunks 0, 1, 2, 3 sit in sets fc, fa, fb, fc; the freed set takes W2 chunk 3 / the next layer's q, k, v
+        const f32x4 part = cc == 1 ? mm_own<TERMS>(fa, Bh, Bl) : cc == 2 ? mm_own<TERMS>(fb, Bh, Bl) : mm_own<TERMS>(fc, Bh, Bl);
+        if (cc == 0) fc.load(post + (size_t)48 * QUARTER, w, lane);                       // W2, chunk 3
+        if (cc == 1 && need_q) fa.load(pre, w, lane);
+        if (cc == 2 && need_kv) fb.load(pre + 8 * QUARTER, w, lane);
+        if (cc == 3 && need_kv) fc.load(pre + 12 * QUARTER, w, lane);
         f = fma4(part, splat4(inv_h * hdr[9]), f);
       }
       f = fma4(f, splat4(1.0f), lds4(Vt + VT_B2 + own));
@@ -241,9 +244,7 @@ __global__ __launch_bounds__(512, 1) void k_attn_hs(AttnHArgs a) {
 
   if (NP) {
     const float* hdr = Vt + VT_N_HDR;
-    if (need_q) fa.load(pre, w, lane);
-    if (need_kv) { fb.load(pre + 8 * QUARTER, w, lane); fc.load(pre + 12 * QUARTER, w, lane); }
-    ln_regs<true, false>(x, Vt + VT_N_LN_G, Vt + VT_N_LN_B, rg);
+    ln_regs<true, false>(x, Vt + VT_N_LN_G, Vt + VT_N_LN_B, rg);        // (q / k / v fragments: requested under the FFN, or at the top)
     const float inv_n = frags_scaled(x, Bh, Bl);
     if (need_q) {
       f32x4 q = mm_own<TERMS>(fa, Bh, Bl);

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_edge_fused(EdgeFusedArgs a) {
   // XCD-aware tile order: consecutive workgroups go to consecutive XCDs (b % 8), each with its own L2.  With tps tiles per
   // scene, workgroups b, b + 8, ..., b + 8 (tps - 1) - one XCD - take the tiles of ONE scene, so that the scene's K / V rows
   // (agent set: read by every row of the scene) are fetched into one L2 instead of tps of them.
+  if (HALVES == 1 && WAVES == 16 && warm_l2(a.warm, blockIdx.x, threadIdx.x, 64 * WAVES)) return;       // kernels.h: WarmArgs
   int tile = blockIdx.x;
   if (a.tiles_per_scene > 1) {
     const int tps = a.tiles_per_scene, grp = 8 * tps;

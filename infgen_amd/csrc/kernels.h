@@ -118,6 +118,7 @@ struct EdgeFusedArgs {
   int kv_once;                       // 1: every K / V source row is read once (temporal ring): non-temporal loads
   int n_virtual;                     // tile slots to visit (tiles rounded up to whole XCD groups)
   unsigned* dbgbuf;                  // k_edge_fused_p only (INFGEN_EDGE_DBG bit 3): [rows][12] checksums of the hand-offs between the phases
+  WarmArgs warm;                     // one-group variant only
 };
 
 struct AttnPostArgs {
@@ -143,6 +144,7 @@ struct AttnHArgs {
   float* nQ; float* nU; float* nK; float* nV;
   const int* groups; const int* n_groups;   // optional: the 16-row groups to process (device list + count), see k_active_groups
   int dbg;                           // diagnostics (INFGEN_QS_DBG; wrong results): 1 free-running waves over a static weight ring
+  WarmArgs warm;                     // k_attn_hs only
 };
 
 struct ActiveGroupsArgs { const int* n_agents; int S, A_cap, margin; int* groups; int* n_groups; };

@@ -326,4 +326,35 @@ __device__ __forceinline__ void ln_tile(const float* src, int lds_, float* dst, 
   seg_store(dst + row * ldd, y);
 }
 
+
+// Warm workgroups of a small launch (k_attn_hs, k_edge_fused's one-group variant).  A decode step streams 24 MB of
+// layer weights through eight 4 MB L2s, so every kernel of the chain finds its weights in the Infinity Cache, and a 16-row group's
+// chain waits ~3 us for a 64 KB matrix it has to fetch itself.  A launch of a few dozen groups leaves most CUs idle: workgroups
+// wg0 .. wg0 + 8 per_xcd - 1 (consecutive workgroup ids go round the XCDs) read the two regions once - the per_xcd workgroups of
+// an XCD one slice each - and exit.  The regions are what the NEXT kernels of the chain will read (the library's sublayer loop
+// sets them: api.hip), so the lines have a whole kernel of head start.  Placement is only assumed for speed.
+struct WarmArgs { const char* p[2]; int len[2]; int wg0, per_xcd; };
+
+// workgroup b of a launch (b >= w.wg0) reads its slice of the regions once and returns true
+__device__ __forceinline__ bool warm_l2(const WarmArgs& w, int b, int tid, int nth) {
+  if (w.per_xcd <= 0 || b < w.wg0) return false;
+  const int k = (b - w.wg0) >> 3, K = w.per_xcd, step = 16 * nth;
+  unsigned sink = 0;
+  if (k < K) {
+    for (int r = 0; r < 2; ++r) {
+      const char* base = r ? w.p[1] : w.p[0];
+      const int len = r ? w.len[1] : w.len[0];
+      if (!base || len <= 0) continue;
+      const int per = ((len + K - 1) / K + step - 1) / step * step;       // slice per workgroup, whole passes of the workgroup
+      const int hi = min(len, (k + 1) * per);
+      for (int off = k * per + tid * 16; off < hi; off += step) {
+        const uint4 v = *reinterpret_cast<const uint4*>(base + off);
+        sink ^= v.x ^ v.y ^ v.z ^ v.w;
+      }
+    }
+  }
+  asm volatile("" :: "v"(sink));                  // (the loads must not be dropped; nothing is stored)
+  return true;
+}
+
 }  // namespace ig

@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+EXP_LIB=build_exp/libinfgen_hip_hstrace.so python tools/hs_trace.py 512 0 0 2>&1 | tail -2
+for wm in 128 0; do echo "-- warm=$wm"; INFGEN_ATTN_WARM=$wm HAS_POS=0 timeout 60 python tools/bench_attn.py 512 2>&1 | grep "mode=3\|rror\|16-row split - split| X"; INFGEN_ATTN_WARM=$wm HAS_POS=0 timeout 60 python tools/bench_attn.py 2048 2>&1 | grep "mode=3\|rror"; done
+HAS_POS=0 timeout 60 python tools/bench_attn.py 32768 2>&1 | grep "mode=1\|rror"
+python tools/ab_bench.py --scenes 8 --reps 1 shipped build_exp/libinfgen_hip_hsold.so
