@@ -57,6 +57,9 @@ __device__ __forceinline__ float xor_lanes_max(float v) {
 #ifndef IG_DMA_BUILTIN
 #define IG_DMA_BUILTIN 0
 #endif
+#ifndef IG_LN_RSQ
+#define IG_LN_RSQ 0
+#endif
 #ifndef IG_GQ_INTERLEAVE
 #define IG_GQ_INTERLEAVE 0
 #endif
@@ -225,6 +228,53 @@ __device__ __forceinline__ void gemm_unit(f32x4 (&acc)[8], const unsigned short*
   u.template group<true>(acc, 7, Bh[3], Bl[3]);
 }
 
+// The same GEMM with ONE set of fragment registers (32 instead of 64; three waves per SIMD have 168 registers each): a tile's hi
+// fragment is dead after its second product and its lo fragment after the third, so the next group's fragments are requested into
+// the registers the running group has just finished with - hi(t) behind the hi x lo product of tile t, lo(t) behind lo x hi -
+// seven to eight products (~120 cycles) ahead of their first use.  Same products in the same order per accumulator.
+template <int TERMS = 3>
+__device__ __forceinline__ void gemm_unit_sb(f32x4 (&acc)[8], const unsigned short* Wu, const u32x4 (&Bh)[4], const u32x4 (&Bl)[4], int lane) {
+  static_assert(TERMS == 3, "the single-buffered schedule is written for the three-term split");
+  const unsigned short* p = Wu + lane * 8;
+  v8h ah[4], al[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    ah[t] = *reinterpret_cast<const v8h*>(p + t * 1024);
+    al[t] = *reinterpret_cast<const v8h*>(p + t * 1024 + 512);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int grp = 0; grp < 8; ++grp) {
+    const int o = 4 * (grp & 1);
+    const unsigned short* q = p + ((grp + 1) >> 1) * QUARTER + ((grp + 1) & 1) * 4096;      // the next group's fragments
+    const v8h bh = __builtin_bit_cast(v8h, Bh[grp >> 1]);
+    const v8h bl = __builtin_bit_cast(v8h, Bl[grp >> 1]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[o + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc[o + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc[o + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acc[o + t], 0, 0, 0);
+      if (grp < 7) ah[t] = *reinterpret_cast<const v8h*>(q + t * 1024);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc[o + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc[o + t], 0, 0, 0);
+      if (grp < 7) al[t] = *reinterpret_cast<const v8h*>(q + t * 1024 + 512);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    if (grp < 7) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // LayerNorm over the 128 features of this lane's edge (32 here, the rest in lanes ^ 16, ^ 32, ^ 48), biased
 // variance, eps 1e-5; register r of tile t is feature 16 t + 4 rg + r.
 // Packed-math helpers: whole-f32x4 expressions lower to v_pk_* (two floats per instruction); fused multiply-adds
@@ -259,7 +309,16 @@ __device__ __forceinline__ float ln_stats(f32x4 (&v)[8]) {
     q5 = fma4(v[t + 1], v[t + 1], q5);
   }
   q4 += q5;
-  return 1.0f / sqrtf(xor_lanes((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 128.0f) + LN_EPS);
+  const float var_eps = xor_lanes((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 128.0f) + LN_EPS;
+#if IG_LN_RSQ
+  // v_rsq_f32 (1 ulp) + one Newton step instead of the correctly rounded square root and division (~25 dependent instructions of a
+  // chain that a lone wave pays in full: s_memtime traces of k_fourier_h); var + eps >= 1e-5, far from the denormal range
+  const float y = __builtin_amdgcn_rsqf(var_eps);
+  const float e = __builtin_fmaf(-(var_eps * y), y, 1.0f);
+  return __builtin_fmaf(0.5f * y, e, y);
+#else
+  return 1.0f / sqrtf(var_eps);
+#endif
 }
 template <bool AFFINE, bool RELU>
 __device__ __forceinline__ void ln_apply(f32x4 (&v)[8], float rstd, const float* gtab, const float* btab, int rg) {
