@@ -53,6 +53,9 @@ __device__ __forceinline__ void load_row(f32x4 (&v)[8], const float* row, int rg
   }
 }
 __device__ __forceinline__ void store_row(float* row, const f32x4 (&v)[8], int rg) {
+#ifdef IG_AH_NOSTORE          // timing experiment (wrong results): what the row stores cost
+  if (rg >= 0) return;
+#endif
   if (!row) return;
 #pragma unroll
   for (int t = 0; t < 8; ++t)

@@ -95,17 +95,20 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnH
     const int row = grp * 16 + j;
     const bool valid = grp >= 0 && row < a.rows;
     float* xrow = valid ? a.X + (size_t)row * D : nullptr;
+    // (rows beyond the end load the last row and are never stored: a conditional load gets a basic block of its own in which
+    // hipcc waits for it before it issues the next one - section 5.4 of DESIGN.md)
+    const int rowc = valid ? row : a.rows - 1;
     f32x4 x[8];
-    load_row(x, xrow, rg);
+    load_row_nc(x, a.X + (size_t)rowc * D, rg);
     u32x4 Bh[4], Bl[4];
 
     if (P) {
       const float* hdr = Vt + VT_HDR;
       f32x4 ag[8];
-      load_row(ag, valid ? a.AGG + (size_t)row * D : nullptr, rg);
+      load_row_nc(ag, a.AGG + (size_t)rowc * D, rg);
       if (a.has_pos) {
         // z-GEMM: head h is feature tile h; B fragments straight from Z[row][h][:] (k = 32 s + 8 rg + p), |z| <= sqrt(127)
-        const float* zrow = valid ? a.Z + (size_t)row * (H * D) : nullptr;
+        const float* zrow = a.Z + (size_t)rowc * (H * D);
         const float zs = 1024.0f, zinv = hdr[4] * (1.0f / 1024.0f);
         for (int hp = 0; hp < 4; ++hp) {
           const unsigned short* Wl = take();
@@ -115,11 +118,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnH
             float4 z[4][2];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-              z[s][0] = z[s][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (zrow) {
-                z[s][0] = *reinterpret_cast<const float4*>(zrow + h * D + 32 * s + 8 * rg);
-                z[s][1] = *reinterpret_cast<const float4*>(zrow + h * D + 32 * s + 8 * rg + 4);
-              }
+              z[s][0] = *reinterpret_cast<const float4*>(zrow + h * D + 32 * s + 8 * rg);
+              z[s][1] = *reinterpret_cast<const float4*>(zrow + h * D + 32 * s + 8 * rg + 4);
             }
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
