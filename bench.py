@@ -327,7 +327,7 @@ def main():
     ap.add_argument('--edge-fuse', type=int, default=-1, choices=(-1, 0, 1, 2),
                     help='infgen_set_edge_fuse: 1 (library default) k_edge_fused from 257 rows, 0 the unfused sequence with U / Z in HBM')
     ap.add_argument('--edge-loop', type=int, default=-1, choices=(-1, 4, 6, 8))
-    ap.add_argument('--graph', type=int, default=-1, choices=(-1, 0, 1),
+    ap.add_argument('--graph', type=int, default=-1, choices=(-1, 0, 1, 2),
                     help='replay the decode steps of a rollout from a captured HIP graph: 1 always, 0 never, -1 (default) the '
                          'engine\'s rule (off unless INFGEN_GRAPH=1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -379,7 +379,7 @@ def main():
     w = engine.PackedWeights(sd, cfg, dev)
     ns = max(1, args.streams)
     per = (len(scenes) + ns - 1) // ns
-    use_graph = None if args.graph < 0 else bool(args.graph)
+    use_graph = None if args.graph < 0 else ('all' if args.graph == 2 else bool(args.graph))       # 2: the whole rollout as one graph
 
     def make_engines(headroom):
         return [engine.RolloutEngine(w, scenes[i * per:(i + 1) * per], vocab, map_vocab, grid, store_logits=False,

@@ -325,6 +325,14 @@ class RolloutEngine:
         self.seed_out = None
         # capture the decode steps of a rollout (no insertion: ~47 launches per step, all shapes static) in a HIP graph at the
         # first run and replay it afterwards
+        # use_graph = 'all': the WHOLE rollout (reset, map encoder, column-0 chain, every decode step) as one graph, replayed on a
+        # stream of the engine's own - what lets one host thread keep several engines on several streams busy (rollout_many): a
+        # rollout is ~1,000 launches, and issuing four engines' launches one after the other takes longer than the GPU needs
+        self._graph_all = use_graph == 'all' or (use_graph is None and os.environ.get('INFGEN_GRAPH') == '2')
+        if self._graph_all:
+            use_graph = False
+        self._wgraph = None
+        self._wgraph_opts = None
         self._use_graph_arg = use_graph              # None: by size (set below, once the row count is known)
         self.use_graph = bool(use_graph)
         self._graph = None
@@ -505,6 +513,7 @@ class RolloutEngine:
             self._insert_u.copy_(torch.from_numpy(np.ascontiguousarray(insert_uniforms, dtype=np.float32)))
         self._x_pt_override = x_pt_override
         self._init = None                  # reset() snapshots the new initial state
+        self._wgraph = None                # (the whole-rollout graph restores the state from the old snapshot's buffers)
         self._epi = None
         self._mg_checked = False           # the new map may hold more pt <-> pt edges than the buffers
         self._prologue_done = False
@@ -813,8 +822,36 @@ class RolloutEngine:
 
     def rollout(self):
         """one full pass of the hot path over the batch: prologue + every decode step"""
+        if (self._graph_all and not self.insertion and self._x_pt_override is None and self._mg_checked and self._init is not None
+                and self._ctx is not None and not _lib.prof_active()):
+            self._rollout_graph()                # (the first rollout of a batch runs eagerly: buffers, tables, edge capacities)
+            return
         self.prologue()
         self.run()
+
+    def _rollout_graph(self):
+        """prologue + decode steps as ONE HIP-graph replay on the engine's own stream, fenced against the caller's stream on both
+        sides (see _run_graph for why not on the caller's stream).  Nothing in a rollout without insertion depends on the host
+        after the first one: the scene state is restored from device copies, every launch has static shapes."""
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, '_gstream', None) is None:
+            self._gstream = torch.cuda.Stream(device=self.device)
+        gs = self._gstream
+        gs.wait_stream(cur)
+        with torch.cuda.stream(gs):
+            self._refresh_opts(groups=True)
+            snap = bytes(self._ctx.opts)[:_lib.OPTIONS_VALUE_BYTES] + bytes([self._ctx.four_t_dt is not None])
+            if self._wgraph is not None and snap != self._wgraph_opts:
+                self._wgraph = None
+            if self._wgraph is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=gs):
+                    self.prologue()
+                    self.run()
+                self._wgraph, self._wgraph_opts = g, snap
+            self._wgraph.replay()
+            self._prologue_done = True
+        cur.wait_stream(gs)
 
     # ------------------------------------------------------------------ scenario insertion (host-sequenced)
     def _alloc_insertion(self):
@@ -1312,6 +1349,17 @@ def rollout_many(engines: Sequence[RolloutEngine], streams: Optional[Sequence[to
             e.rollout()
         return
     cur = torch.cuda.current_stream(dev)
+    if all(e._graph_all and not e.insertion for e in engines):
+        # whole-rollout graphs: one replay per engine, nothing for the host to sequence
+        try:
+            for e, st in zip(engines, streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    e.rollout()
+        finally:
+            for st in streams:
+                cur.wait_stream(st)
+        return
     live = []
     try:
         for e, st in zip(engines, streams):
