@@ -343,6 +343,73 @@ def test_graph_replay_equals_eager_rollout():
     assert np.array_equal(r[0]['next_token_idx'], c['z']['next_token_idx'])
 
 
+def test_whole_rollout_graph_equals_eager_rollout():
+    """RolloutEngine(use_graph='all'): reset, map encoder, column-0 chain and every decode step as ONE HIP graph (captured at the
+    second rollout, replayed from then on; dropped by reload()) give the eager rollout bit for bit - also as several engines on
+    several streams (rollout_many replays one graph per engine)"""
+    from infgen_amd import engine, synth
+    c = load_case('a24_m256_edge')
+    cfg = c['cfg']
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], cfg, dev)
+    scenes = [c['scene']] + [synth.make_scene(8300 + i, 20 + i, 200, cfg, ego_last=True, vocab=c['vocab'], grid=c['grid']) for i in range(3)]
+    ref = engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=True)
+    ref.rollout()
+    r = ref.outputs()
+    eng = engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=True, use_graph='all')
+    for i in range(3):
+        eng.rollout()
+        torch.cuda.synchronize()
+        assert (eng._wgraph is not None) == (i >= 1)
+        for a, b in zip(eng.outputs(), r):
+            assert np.array_equal(a['next_token_idx'], b['next_token_idx'])
+            assert np.array_equal(a['logits'], b['logits'])
+            assert np.array_equal(a['pos_a'], b['pos_a'])
+    assert np.array_equal(r[0]['next_token_idx'], c['z']['next_token_idx'])
+    eng.reload(scenes[::-1])
+    assert eng._wgraph is None
+    eng.rollout(); eng.rollout()
+    torch.cuda.synchronize()
+    for a, b in zip(eng.outputs(), r[::-1]):
+        assert np.array_equal(a['next_token_idx'], b['next_token_idx'])
+    halves = [engine.RolloutEngine(w, scenes[i:i + 2], c['vocab'], c['map_vocab'], c['grid'], store_logits=True, use_graph='all')
+              for i in (0, 2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in halves]
+    for _ in range(3):
+        engine.rollout_many(halves, streams)
+    torch.cuda.synchronize()
+    outs = halves[0].outputs() + halves[1].outputs()
+    for a, b in zip(outs, r):
+        assert np.array_equal(a['next_token_idx'], b['next_token_idx'])
+        assert np.array_equal(a['logits'], b['logits'])
+
+
+def test_warm_workgroups_are_bitwise_neutral(monkeypatch):
+    """small launches carry workgroups that only read the next kernels' weights (tile.cuh: WarmArgs): same results with and
+    without them (INFGEN_WARM_MAX_GROUPS is read once per process, so the comparison is against the reference fixture and a
+    batch that is too large to carry any)"""
+    from infgen_amd import engine, synth, _lib
+    lib = _lib.load()
+    c = load_case('a24_m256_edge')
+    cfg = c['cfg']
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], cfg, dev)
+    _lib.check(lib.infgen_set_edge_fuse(2))                     # the fused edge kernel's one-group variant carries them
+    try:
+        few = [c['scene']] + [synth.make_scene(8400 + i, 24, 256, cfg, ego_last=True, vocab=c['vocab'], grid=c['grid']) for i in range(7)]
+        many = few + [synth.make_scene(8500 + i, 24, 256, cfg, ego_last=True, vocab=c['vocab'], grid=c['grid']) for i in range(120)]
+        a = engine.RolloutEngine(w, few, c['vocab'], c['map_vocab'], c['grid'], store_logits=True)      # 8 x 32 rows: 16 groups
+        b = engine.RolloutEngine(w, many, c['vocab'], c['map_vocab'], c['grid'], store_logits=True)     # 256 groups: none
+        a.rollout(); b.rollout()
+        torch.cuda.synchronize()
+        for x, y in zip(a.outputs(), b.outputs()[:8]):
+            assert np.array_equal(x['next_token_idx'], y['next_token_idx'])
+            assert np.array_equal(x['logits'], y['logits'])
+        assert np.array_equal(a.outputs()[0]['next_token_idx'], c['z']['next_token_idx'])
+    finally:
+        _lib.check(lib.infgen_set_edge_fuse(1))
+
+
 def test_rollout_many_streams_equals_single_engine():
     """engine.rollout_many: engines on their own streams, sequenced cooperatively by one host thread (each yields where it
     needs the device's insertion decisions) - the same scenes give the same rollouts as one engine after the other"""
