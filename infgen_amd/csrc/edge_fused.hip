@@ -77,6 +77,25 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_edge_fused(EdgeFusedArgs a) {
   const bool valid = mat && r0 >= 0 && row < a.rows;
   const float* hdr = a.pack + AH_HDR;
   if (threadIdx.x == 0) next_row = 0;
+  // Longest rows first: the tile's rows are dealt to the waves in descending order of their edge counts (the agent set's lists
+  // run from a few to 60+ edges; dealt in index order a long row that comes last is the tile's tail while the other waves
+  // wait at the barrier).  Only the ORDER in which rows are picked changes - every row is still summed edge by edge by one wave,
+  // results are bitwise the same.  The last wave ranks the rows (a load of ROWS counts, ROWS compares) while phase 1 runs.
+  constexpr bool SORT_ROWS = !(HALVES == 1 && WAVES == 16);            // (one row per wave: nothing to order)
+  __shared__ unsigned char row_order[ROWS];
+  if (SORT_ROWS && w == WAVES - 1) {
+    const int rl = lane & (ROWS - 1);
+    const int rb = (HALVES > 1 && (rl >> 4)) ? r0h[HALVES - 1] : r0h[0];
+    const int dr = rb + (rl & 15);
+    const int cnt = (rb >= 0 && dr < a.rows) ? a.es.cnt[dr] : 0;
+    int rank = 0;
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+      const int ck = __shfl(cnt, k, 64);
+      rank += (ck > cnt || (ck == cnt && k < rl)) ? 1 : 0;
+    }
+    if (lane < ROWS) row_order[rank] = (unsigned char)rl;
+  }
 
   // ---- phase 1: u_h = q_h W'_kr,h (K = 16: v_mfma_f32_16x16x16_f16; B fragment = the head's 16 query values of row j)
   if (mat) {
@@ -138,7 +157,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_edge_fused(EdgeFusedArgs a) {
     // rows are dealt to the waves through an LDS counter (the agent set's lists vary in length)
     auto take_row = [&]() {
       int r = 0;
-      if (lane == 0) r = atomicAdd(&next_row, 1);
+      if (lane == 0) { r = atomicAdd(&next_row, 1); if (SORT_ROWS && r < ROWS) r = row_order[r]; }
       return __builtin_amdgcn_readfirstlane(r);
     };
     for (int rl = take_row(); rl < ROWS; rl = take_row()) {
