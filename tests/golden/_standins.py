@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import copy
 import inspect
+import os
 import sys
 import types
 from unittest import mock
@@ -142,8 +143,46 @@ def _softmax_safe(src, index, ptr=None, num_nodes=None, dim=0):
     return _softmax(src, index, ptr, num_nodes, dim)
 
 
+REFERENCE = '/root/reference'
+
+
+def bind_reference():
+    """Make the name ``infgen`` mean the REFERENCE, whatever else is importable: the reference's ``infgen/`` has no
+    ``__init__.py`` (a namespace package), so any regular package called ``infgen`` on ``sys.path`` - e.g. this repository's
+    ``compat/infgen`` alias over ``infgen_amd`` - would win over it regardless of the path order.  A module object whose
+    ``__path__`` is the reference's directory alone is registered before anything imports ``infgen``; a previously imported
+    ``infgen`` from anywhere else is an error (the fixtures would be produced by the code under test)."""
+    import importlib.machinery
+    import types
+    ref_pkg = os.path.join(REFERENCE, 'infgen')
+    if not os.path.isdir(ref_pkg):
+        raise RuntimeError(f'{ref_pkg} not found: the golden generators run in the build container only')
+    have = sys.modules.get('infgen')
+    if have is not None:
+        if list(getattr(have, '__path__', [])) != [ref_pkg]:
+            raise RuntimeError(f'`infgen` is already imported from {getattr(have, "__path__", None)}, not from the reference')
+        return
+    if REFERENCE not in sys.path:
+        sys.path.insert(0, REFERENCE)
+    m = types.ModuleType('infgen')
+    m.__path__ = [ref_pkg]
+    m.__spec__ = importlib.machinery.ModuleSpec('infgen', None, is_package=True)
+    m.__spec__.submodule_search_locations = [ref_pkg]
+    sys.modules['infgen'] = m
+
+
+def assert_reference(obj):
+    """``obj`` (class / function / module) was defined by a file under /root/reference"""
+    import inspect
+    f = inspect.getsourcefile(obj) or ''
+    if not os.path.realpath(f).startswith(REFERENCE + os.sep):
+        raise RuntimeError(f'{obj!r} comes from {f}, not from the reference')
+    return obj
+
+
 def install():
-    """Register the stand-in modules in sys.modules (idempotent)."""
+    """Register the stand-in modules in sys.modules (idempotent) and bind ``infgen`` to the reference."""
+    bind_reference()
     if 'torch_cluster' in sys.modules and getattr(sys.modules['torch_cluster'], '_is_standin', False):
         return
 

@@ -114,6 +114,7 @@ def build_reference(cfg: synth.RolloutConfig, map_vocab: np.ndarray):
         sys.path.insert(0, REFERENCE)
     from infgen.modules.attr_tokenizer import Attr_Tokenizer
     from infgen.modules.infgen_decoder import InfGenDecoder
+    _standins.assert_reference(InfGenDecoder), _standins.assert_reference(Attr_Tokenizer)
 
     tok = Attr_Tokenizer(grid_range=cfg.grid_range, grid_interval=cfg.grid_interval,
                          radius=cfg.pl2seed_radius, angle_interval=cfg.angle_interval)

@@ -21,6 +21,8 @@ sys.path.insert(0, '/root/reference')
 from infgen.model.infgen import InfGen  # noqa: E402
 from infgen.modules.attr_tokenizer import Attr_Tokenizer  # noqa: E402
 
+_standins.assert_reference(InfGen), _standins.assert_reference(Attr_Tokenizer)
+
 
 class _Data(dict):
     num_graphs = 2

@@ -18,6 +18,9 @@ from make_golden_road import make_roads  # noqa: E402  (installs the stand-ins, 
 from make_golden_metrics import make_platoon  # noqa: E402
 
 import infgen.metrics.compute_metrics as cm  # noqa: E402
+import _standins  # noqa: E402
+
+_standins.assert_reference(cm)
 
 # waymo_open_dataset.utils.sim_agents.submission_specs is absent here (a mock): its published constants
 cm.submission_specs = SimpleNamespace(CURRENT_TIME_INDEX=10, STEP_DURATION_SECONDS=0.1)

@@ -53,8 +53,11 @@ def fetch_enterings(batch, cfg):
     """the reference's own InfGen._fetch_enterings (infgen/model/infgen.py:1008-1128) on this batch: the agent outputs equal the
     committed enterings fixture (same agents), pt_grid_token_idx is new (these map tokens)"""
     import types
+    import _standins
+    _standins.install()
     from infgen.model.infgen import InfGen
     from infgen.modules.attr_tokenizer import Attr_Tokenizer
+    _standins.assert_reference(InfGen), _standins.assert_reference(Attr_Tokenizer)
     tok = Attr_Tokenizer(grid_range=cfg.grid_range, grid_interval=cfg.grid_interval, radius=cfg.pl2seed_radius,
                          angle_interval=cfg.angle_interval)
     fake = types.SimpleNamespace(predict_occ=True, enter_state=2, invalid_state=0, pl2seed_radius=cfg.pl2seed_radius,

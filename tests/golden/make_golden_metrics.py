@@ -21,6 +21,9 @@ from infgen.metrics.interact_features import (compute_distance_to_nearest_object
 from infgen.metrics.trajectory_features import compute_kinematic_features  # noqa: E402
 from infgen.metrics.placement_features import compute_num_placement, compute_distance_placement  # noqa: E402
 
+for _f in (compute_distance_to_nearest_object, compute_kinematic_features, compute_num_placement):
+    _standins.assert_reference(_f)
+
 
 def make_boxes(seed, N, T, extent):
     rng = np.random.default_rng(seed)

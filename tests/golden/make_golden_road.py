@@ -18,6 +18,8 @@ from make_golden_metrics import make_boxes  # noqa: E402  (imports the reference
 
 from infgen.metrics.map_features import compute_distance_to_road_edge  # noqa: E402
 
+_standins.assert_reference(compute_distance_to_road_edge)
+
 
 def make_roads(seed, extent, n_open):
     """a counter-clockwise closed outer boundary (cyclic), a clockwise island, open wiggly edges of different lengths,

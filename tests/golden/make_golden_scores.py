@@ -19,6 +19,9 @@ sys.path.insert(0, HERE)
 from make_golden_metrics import make_platoon  # noqa: E402  (installs the stand-ins, imports the reference)
 
 import infgen.metrics.compute_metrics as cm  # noqa: E402
+import _standins  # noqa: E402
+
+_standins.assert_reference(cm)
 from google.protobuf import text_format  # noqa: E402
 
 cm.submission_specs = SimpleNamespace(CURRENT_TIME_INDEX=10, STEP_DURATION_SECONDS=0.1, N_SIMULATION_STEPS=80)

@@ -18,6 +18,8 @@ _standins.install()
 sys.path.insert(0, '/root/reference')
 from infgen.modules.attr_tokenizer import Attr_Tokenizer  # noqa: E402
 
+_standins.assert_reference(Attr_Tokenizer)
+
 
 def main():
     tok = Attr_Tokenizer(grid_range=150., grid_interval=3., radius=75., angle_interval=3.)

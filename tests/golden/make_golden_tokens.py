@@ -20,6 +20,8 @@ _standins.install()
 sys.path.insert(0, '/root/reference')
 from infgen.datasets.preprocess import TokenProcessor  # noqa: E402
 
+_standins.assert_reference(TokenProcessor)
+
 from infgen_amd import synth  # noqa: E402
 
 

@@ -255,17 +255,30 @@ def test_library_writes_m0_only_for_its_own_lds_dma():
 
 
 def test_infgen_import_surface_is_the_mi355x_package():
-    """`import infgen.model.infgen` with this repository on the path (instead of the reference) resolves to infgen_amd - the
-    module objects are the same, so run.py / val.py of the reference need no import edits (reference run.py:103-105)"""
+    """`import infgen.model.infgen` with <repo>/compat and <repo> on the path (instead of the reference) resolves to infgen_amd -
+    the module objects are the same (reference run.py:103-105); the real modules keep their own __spec__ / __package__ (no
+    ImportWarning from their relative imports, reload works)"""
     import subprocess
     import sys
-    code = ('import sys; sys.path.insert(0, %r); import infgen.model.infgen as a, infgen_amd.model.infgen as b; '
+    code = ('import sys, importlib; sys.path.insert(0, %r); sys.path.insert(0, %r); '
+            'import infgen.model.infgen as a, infgen_amd.model.infgen as b; '
             'from infgen.modules.infgen_decoder import InfGenDecoder as D1; from infgen_amd.modules import InfGenDecoder as D2; '
             'from infgen.utils.func import wrap_angle; from infgen.metrics.compute_metrics import LongMetric; '
-            'print(a is b, D1 is D2, a.InfGen.__module__)' % REPO)
-    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+            'import infgen_amd.metrics.compute_metrics as cm; importlib.reload(cm); '
+            'print(a is b, D1 is D2, a.InfGen.__module__, cm.__spec__.name, cm.__package__)'
+            % (REPO, os.path.join(REPO, 'compat')))
+    out = subprocess.run([sys.executable, '-W', 'error::ImportWarning', '-W', 'error::DeprecationWarning', '-c', code],
+                         capture_output=True, text=True, timeout=120, cwd='/tmp')
     assert out.returncode == 0, out.stderr[-1500:]
-    assert out.stdout.split() == ['True', 'True', 'infgen_amd.model.infgen']
+    assert out.stdout.split() == ['True', 'True', 'infgen_amd.model.infgen', 'infgen_amd.metrics.compute_metrics',
+                                  'infgen_amd.metrics']
+
+
+def test_repository_root_has_no_package_called_infgen():
+    """the reference's `infgen/` is a namespace package: a regular package of that name in the import root would shadow it for
+    tests/golden/make_golden*.py - the alias lives under compat/"""
+    assert not os.path.exists(os.path.join(REPO, 'infgen'))
+    assert os.path.isfile(os.path.join(REPO, 'compat', 'infgen', '__init__.py'))
 
 
 def test_operator_level_options_are_per_thread():
