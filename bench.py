@@ -289,6 +289,19 @@ def dry_run(args, ranks):
     mine = (igdist.scenes_for_rank_strided(ranks.rank, ranks.world, args.total_scenes) if args.scaling == 'strong'
             else igdist.scenes_for_rank_weak(ranks.rank, args.scenes))
     literal = igdist.scenes_for_rank_strided(ranks.rank, ranks.world, 64)
+    balance = None
+    if args.insertion and ranks.world > 1 and not args.no_balance:
+        # the pilot's cost exchange and the cost-sorted re-deal of a real insertion run, on synthetic per-scene costs
+        total = args.total_scenes if args.scaling == 'strong' else ranks.world * args.scenes
+        local = [(i, igdist.scene_cost(args.agents + (37 * (i + 1)) % 53, args.map_tokens)) for i in mine]
+        costs = igdist.gather_costs(local, total, ranks.dev)
+        dealt = [igdist.scenes_for_rank_strided(r, ranks.world, total) if args.scaling == 'strong'
+                 else igdist.scenes_for_rank_weak(r, args.scenes) for r in range(ranks.world)]
+        parts = [igdist.scenes_for_rank_balanced(costs, r, ranks.world) for r in range(ranks.world)]
+        balance = {'max_over_mean_before': igdist.partition_spread(costs, dealt),
+                   'max_over_mean_after': igdist.partition_spread(costs, parts), 'scenes_per_rank': [len(p_) for p_ in parts],
+                   'all_scenes_dealt_once': sorted(i for p_ in parts for i in p_) == list(range(total))}
+        mine = parts[ranks.rank]
     dt = timed(ranks, lambda: time.sleep(0.002 * (ranks.rank + 1)), args.steps)
     steps_local = float(len(mine) * args.agents * args.rollout_steps * args.steps)
     per_rank = igdist.gather_metrics([1e3 * dt / args.steps, float(len(mine)), float(len(literal))], ranks.dev)
@@ -299,7 +312,7 @@ def dry_run(args, ranks):
                           'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'scaling': args.scaling,
                           'agent_steps_counted': agent_steps, 'per_rank_ms': [r[0] for r in per_rank],
                           'scenes_per_rank': [int(r[1]) for r in per_rank],
-                          'c3_literal_scenes_per_rank': [int(r[2]) for r in per_rank]}))
+                          'c3_literal_scenes_per_rank': [int(r[2]) for r in per_rank], 'insertion_balance': balance}))
 
 
 def main():
@@ -333,6 +346,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-literal', action='store_true', help='skip the config.c3_literal legs')
+    ap.add_argument('--no-strict', action='store_true', help='skip the config.strict_fp32 leg')
+    ap.add_argument('--no-balance', action='store_true',
+                    help='insertion on several ranks: keep the initial deal instead of the cost-sorted one (dist.scenes_for_rank_balanced)')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     ap.add_argument('--dry-run', action='store_true',
                     help='the rank path only (launcher, sharding, barriers, reductions) on CPU with the gloo backend; no kernels')
@@ -409,20 +425,45 @@ def main():
 
     # warm-up; with insertion the row head-room is doubled until the (deterministic) rollout fits - an engine never drops
     # an insertion silently
-    done = 0
-    while done < max(args.warmup, 1 if args.insertion else 0):
-        try:
-            eng.rollout()
-            torch.cuda.synchronize(dev)
-            done += 1
-        except engine.InsertionHeadroomError:
-            limit = lib.infgen_layout_query(_lib.Q_MAX_AGENTS)
-            if engines[0].A_cap >= limit:
-                raise
-            engines[:] = make_engines(min(2 * engines[0].A_cap, limit) - args.agents)
-            log(f'insertion head-room exhausted: rows per scene -> {engines[0].A_cap}')
-            done = 0
-        log('warmup rollout done')
+    def warm_up():
+        done = 0
+        while done < max(args.warmup, 1 if args.insertion else 0):
+            try:
+                eng.rollout()
+                torch.cuda.synchronize(dev)
+                done += 1
+            except engine.InsertionHeadroomError:
+                limit = lib.infgen_layout_query(_lib.Q_MAX_AGENTS)
+                if engines[0].A_cap >= limit:
+                    raise
+                engines[:] = make_engines(min(2 * engines[0].A_cap, limit) - args.agents)
+                log(f'insertion head-room exhausted: rows per scene -> {engines[0].A_cap}')
+                done = 0
+            log('warmup rollout done')
+    warm_up()
+    # insertion on several ranks: per-scene cost is data dependent.  The warm-up rollout is the pilot: every rank
+    # contributes the agents its scenes ended with, the cost vector is all-reduced, and the scenes are dealt again longest
+    # first (dist.scenes_for_rank_balanced) - a control-plane exchange before the timed region, none inside it
+    balance = None
+    if args.insertion and world > 1 and not args.no_balance:
+        total = args.total_scenes if args.scaling == 'strong' else world * args.scenes
+        fin = eng.n_agents.tolist()
+        local = [(i, igdist.scene_cost(n, args.map_tokens)) for i, n in zip(mine, fin)]
+        costs = igdist.gather_costs(local, total, dev)
+        dealt = [igdist.scenes_for_rank_strided(r, world, total) if args.scaling == 'strong' else igdist.scenes_for_rank_weak(r, args.scenes)
+                 for r in range(world)]
+        parts = [igdist.scenes_for_rank_balanced(costs, r, world) for r in range(world)]
+        balance = {'cost': 'agents at the end of the pilot rollout x (1 + map tokens / 8192)',
+                   'max_over_mean_before': igdist.partition_spread(costs, dealt),
+                   'max_over_mean_after': igdist.partition_spread(costs, parts), 'scenes_per_rank': [len(p_) for p_ in parts]}
+        log(f'balanced dealing: {balance}')
+        mine = parts[rank]
+        del engines[:]
+        torch.cuda.empty_cache()
+        scenes, vocab, map_vocab, grid = build_scenes(cfg, mine, args.agents, args.map_tokens)
+        per = (len(scenes) + ns - 1) // ns
+        engines[:] = make_engines(args.insert_headroom)
+        warm_up()
     # roofline leg 1 (untimed): one rollout with HIP events around EVERY kernel -> which kernel dominates
     # (an engine that replays a HIP graph runs this rollout eagerly: events are not part of the captured graph)
     _lib.prof_enable((1 << len(_lib.KERNEL_IDS)) - 1)
@@ -466,38 +507,48 @@ def main():
               'share_of_gpu_time': per_kernel[dominant]['ms'] / max(1e-9, sum(v['ms'] for v in per_kernel.values())),
               'per_kernel_ms_one_rollout': {k: round(v['ms'], 3) for k, v in per_kernel.items()}, 'step': step_roof}
     if dom['calls'] > 0 and dominant == 'k_edge_attn':
-        # the edge kernel (k_edge_fused): one launch per sublayer.  8d's bytes of a launch: 1 KB of K / V per temporal or map
-        # edge (every edge has its own source row), 1 KB per decoded row for the agent set (a scene's K / V rows are shared by
-        # its rows).  8d's FLOPs: the reference's per-edge projections, 33,024 MAC per edge and layer.  SURVEY 8d: the bound is
-        # whichever of the two fractions is larger.
-        ed = timed_k['k_edge_attn']['edges_built']                        # all timed rollouts
-        rows_t = rows_dec * args.steps
+        # the edge kernel (k_edge_fused), one launch per sublayer: HBM-bound.  SURVEY 8d's bytes of a decode-step
+        # launch: 1 KB of K / V per temporal or map edge (every edge has its own source row), 1 KB per decoded row for the agent
+        # set (a scene's K / V rows are shared by its rows).  Only the launches issued INSIDE decode steps are priced - the
+        # profiler tags them (infgen_prof_collect_steps); the map encoder's pt <-> pt launches and the edgeless column-0 chain of
+        # the prologue are reported next to them, their edges are not in the numerator.
+        ed = timed_k['k_edge_attn']['edges_built']                        # all timed rollouts (decode steps only: the edgeless
+        rows_t = rows_dec * args.steps                                    # column-0 chain builds none)
         nedge = ed['temporal'] + ed['map'] + ed['agent']
         nbytes = L * KV_ROW_BYTES * (ed['temporal'] + ed['map'] + rows_t)
-        nflop = 2.0 * L * EDGE_MAC_PER_LAYER * nedge
-        # the multiply-adds this design executes for the same launches (section 3.2 of DESIGN.md: absorbed form): 2,304 per edge and
-        # layer + two 128 x 128 products per row and layer
-        nflop_exec = 2.0 * L * (2304.0 * nedge + 3 * 2 * 16384.0 * rows_t)
-        # what this design has to move for the same launches: + the rhat row per edge, + q in / agg out per row
+        calls, secs = max(1, dom['step_calls']), max(1e-9, dom['step_ms'] * 1e-3)
+        hbm_frac = nbytes / secs / (HBM_PEAK_GBS * 1e9)
+        # what this design has to move for the same launches: + the 24-bit rhat row per edge, + q in / agg out per row
         rhat_b = 384.0
         model = nbytes + L * rhat_b * nedge + 3 * L * 1024.0 * rows_t
-        secs = dom['ms'] * 1e-3
-        hbm_frac = nbytes / secs / (HBM_PEAK_GBS * 1e9)
-        mfma_frac = nflop / secs / (mm_peak * 1e12)
-        bound = 'hbm' if hbm_frac >= mfma_frac else 'mfma'
-        roof = {'bound': bound, 'kernel': 'k_edge_fused',
-                'achieved': nbytes / secs / 1e9 if bound == 'hbm' else nflop / secs / 1e12,
-                'peak': HBM_PEAK_GBS if bound == 'hbm' else mm_peak, 'unit': 'GB/s' if bound == 'hbm' else 'TFLOP/s',
-                'frac': max(hbm_frac, mfma_frac), 'traffic': None, 'hbm_fraction': hbm_frac, 'mfma_fraction': mfma_frac,
-                'mfma_fraction_executed_flop': nflop_exec / secs / (mm_peak * 1e12),
-                'algorithmic_bytes_per_launch': nbytes / dom['calls'], 'algorithmic_flop_per_launch': nflop / dom['calls'],
-                'traffic_model_bytes_per_launch': model / dom['calls'],
+        # the REFERENCE's per-edge projections (33,024 MAC per edge and layer) that these launches stand for, and what the absorbed
+        # form executes instead: 2,304 per edge and layer + two 128 x 128 products per row and sublayer
+        nflop_ref = 2.0 * L * EDGE_MAC_PER_LAYER * nedge
+        nflop_exec = 2.0 * L * (2304.0 * nedge + 3 * 2 * 16384.0 * rows_t)
+        alg_per_launch = nbytes / calls
+        traffic = pmc_traffic('k_edge_attn_step', args)
+        roof = {'bound': 'hbm', 'kernel': 'k_edge_fused (the launches inside decode steps)',
+                'achieved': nbytes / secs / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_frac, 'traffic': traffic,
+                'traffic_ratio': (traffic / alg_per_launch) if traffic else None,
+                'hbm_fraction': hbm_frac,
+                'algorithmic_bytes_per_launch': alg_per_launch,
+                'traffic_model_bytes_per_launch': model / calls,
                 'traffic_model_frac': model / secs / (HBM_PEAK_GBS * 1e9),
-                'edges_per_launch': nedge * L / dom['calls'],
-                'note': 'SURVEY 8d: bound = argmax(hbm_fraction, mfma_fraction); hbm_fraction = 1 KB of K / V per temporal / map edge '
-                        'and per decoded row of the agent set; mfma_fraction = the REFERENCE\'s per-edge multiply-adds (33,024 per edge '
-                        'and layer) over the fp16-split peak (2500 / 3 TFLOP/s) - the absorbed form executes 14x fewer '
-                        '(mfma_fraction_executed_flop)', **common}
+                'edges_per_launch': nedge * L / calls,
+                'launches': dom['step_calls'], 'avg_launch_us': 1e6 * secs / calls,
+                'other_launches': {'what': 'map encoder pt <-> pt sublayers + edgeless column-0 chain (prologue)',
+                                   'launches': dom['calls'] - dom['step_calls'],
+                                   'avg_launch_us': 1e3 * (dom['ms'] - dom['step_ms']) / max(1, dom['calls'] - dom['step_calls'])},
+                'reference_flop_equivalent': {
+                    'tflops': nflop_ref / secs / 1e12, 'of_fp16_split_peak': nflop_ref / secs / (mm_peak * 1e12),
+                    'of_fp32_matrix_peak': nflop_ref / secs / (FP32_MATRIX_PEAK_TFLOPS * 1e12),
+                    'executed_tflops': nflop_exec / secs / 1e12,
+                    'note': 'the reference computes W_kr / W_vr per edge (33,024 MAC per edge and layer); the absorbed form does '
+                            'not execute that work (14x fewer multiply-adds), so this is NOT a roofline fraction of the kernel'},
+                'note': 'SURVEY 8d bytes (1 KB of K / V per temporal / map edge and per decoded row of the agent set) of the '
+                        'decode-step launches / their summed HIP-event duration / 8 TB/s; traffic = HBM-side bytes per such launch from '
+                        'the rocprofv3 PMC passes (profiles/traffic.json), traffic_ratio = traffic / algorithmic bytes',
+                **{k: v for k, v in common.items() if k not in ('launches', 'avg_launch_us')}}
     elif dom['calls'] > 0 and dom['macs'] > 0:
         secs = dom['ms'] * 1e-3
         flops = 2.0 * dom['macs']
@@ -508,7 +559,7 @@ def main():
                 'unit': 'TFLOP/s', 'frac': frac, 'traffic': None, 'mfma_fraction': frac, 'hbm_fraction': None,
                 'arithmetic': 'fp16 MFMA, three-term hi/lo split (peak = 2500 / 3)' if split else 'fp32-input MFMA',
                 'algorithmic_flop_per_launch': flops / dom['calls'], **common}
-    if roof is not None:
+    if roof is not None and roof.get('traffic') is None and dominant != 'k_edge_attn':
         roof['traffic'] = pmc_traffic(dominant, args)
 
     agent_steps = float(eng.agent_steps() * args.steps)       # (with insertion: the rows decoded at every step of the last rollout)
@@ -518,6 +569,36 @@ def main():
     graph_used = False      # (the timed region carries HIP events around the dominant kernel: launches are issued eagerly)
     per_rank = igdist.gather_metrics([1e3 * dt_local / args.steps, float(n_scenes_local)], dev)
     dt, agent_steps = igdist.reduce_run(dt, agent_steps, dev)
+
+    # ---- config.strict_fp32: the same batch through the fp32-MFMA kernels with fp32 rhat rows (no fp16 split, no 24-bit rows)
+    strict = None
+    if not args.no_strict and args.gemm_terms == 3 and not args.insertion and ns == 1:
+        log('strict fp32 leg')
+        o0 = _lib.Options()
+        _lib.check(lib.infgen_get_options(_lib.C.byref(o0)))
+        old_env = os.environ.get('INFGEN_NO_R24')
+        try:
+            _lib.check(lib.infgen_set_fourier_mode(0))
+            _lib.check(lib.infgen_set_attn_mode(0))
+            os.environ['INFGEN_NO_R24'] = '1'
+            e = engine.RolloutEngine(w, scenes, vocab, map_vocab, grid, store_logits=False, use_graph=False)
+            e.rollout()
+            torch.cuda.synchronize(dev)
+            ssteps = max(1, min(2, args.steps))
+            t = timed(ranks, e.rollout, ssteps)
+            t, n = igdist.reduce_run(t, float(e.agent_steps() * ssteps), dev)
+            strict = {'value': n / t, 'ms_per_step': 1e3 * t / ssteps, 'steps': ssteps,
+                      'arithmetic': 'v_mfma_f32_32x32x2_f32 (fp32 operands) in every GEMM kernel, fp32 rhat rows; '
+                                    'infgen_set_fourier_mode(0), infgen_set_attn_mode(0), INFGEN_NO_R24=1'}
+            del e
+        finally:
+            _lib.check(lib.infgen_set_fourier_mode(o0.fourier_mode))
+            _lib.check(lib.infgen_set_attn_mode(o0.attn_mode))
+            if old_env is None:
+                os.environ.pop('INFGEN_NO_R24', None)
+            else:
+                os.environ['INFGEN_NO_R24'] = old_env
+        torch.cuda.empty_cache()
 
     # ---- config.c3_literal: BASELINE C3 as written - 64 scenes in total, dealt to the ranks like the reference's
     # DistributedSampler (scene i -> rank i mod N); at N = 1 also the 8 scenes one GPU of an 8-way shard owns
@@ -566,6 +647,7 @@ def main():
             'rccl_ranks': world if ranks.dist is not None else 0,
             'backend': ranks.backend,
             'per_rank_ms': [r[0] for r in per_rank],
+            'per_rank_ms_spread': max(r[0] for r in per_rank) / (sum(r[0] for r in per_rank) / len(per_rank)),
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps,
@@ -588,6 +670,8 @@ def main():
                 'agent_token_steps_per_s': agent_steps / dt / cfg.shift,
                 'parallelism': f'scenes sharded over {world} rank(s), no data-path collective',
                 'c3_literal': literal,
+                'strict_fp32': strict,
+                'insertion_balance': balance,
             },
             'roofline': roof,
             'cpu_baseline': cpu,

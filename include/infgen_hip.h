@@ -475,6 +475,10 @@ enum {
 };
 int infgen_prof_enable(unsigned mask, int max_launches);
 int infgen_prof_collect(double* total_ms, int* calls, double* total_macs, unsigned long long* counters);
+/* the same, plus the share of every kernel that was launched INSIDE a decode step (infgen_decode_step / infgen_rollout_run):
+ * step_ms / step_calls [INFGEN_KID_COUNT]; the remainder is the prologue (map encoder, column-0 chain) and operator-level calls */
+int infgen_prof_collect_steps(double* total_ms, int* calls, double* total_macs, unsigned long long* counters,
+                              double* step_ms, int* step_calls);
 
 #ifdef __cplusplus
 }

@@ -167,6 +167,8 @@ SYMBOLS = {
     'infgen_insert_finalize': (_i, [C.POINTER(Rollout), _i, _f, _p, _p, _p, _i, _p, _p, _p]),
     'infgen_prof_enable': (_i, [C.c_uint, _i]),
     'infgen_prof_collect': (_i, [C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]),
+    'infgen_prof_collect_steps': (_i, [C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_ulonglong),
+                                       C.POINTER(C.c_double), C.POINTER(_i)]),
 }
 
 Q_ATTN_PACK_SIZE, Q_FOURIER_N2, Q_FOURIER_N3, Q_FOURIER_N4, Q_TILE_ROWS, Q_EDGE_ATTN_CAP, Q_MAX_AGENTS, \
@@ -258,14 +260,17 @@ def prof_active() -> bool:
 
 
 def prof_collect():
-    """-> {kernel: dict(ms, calls, macs)} of the launches recorded since prof_enable; synchronises"""
+    """-> {kernel: dict(ms, calls, macs, step_ms, step_calls)} of the launches recorded since prof_enable; synchronises"""
     n = len(KERNEL_IDS)
     ms = (C.c_double * n)()
     calls = (_i * n)()
     macs = (C.c_double * n)()
     rows = (C.c_ulonglong * 16)()
-    check(load().infgen_prof_collect(ms, calls, macs, rows), 'infgen_prof_collect')
-    out = {k: dict(ms=ms[i], calls=calls[i], macs=macs[i]) for i, k in enumerate(KERNEL_IDS)}
+    sms = (C.c_double * n)()
+    scalls = (_i * n)()
+    check(load().infgen_prof_collect_steps(ms, calls, macs, rows, sms, scalls), 'infgen_prof_collect_steps')
+    # step_ms / step_calls: the launches issued inside decode steps (the rest: prologue and operator-level calls)
+    out = {k: dict(ms=ms[i], calls=calls[i], macs=macs[i], step_ms=sms[i], step_calls=scalls[i]) for i, k in enumerate(KERNEL_IDS)}
     # edges built per set; every decode step's sets are consumed by one edge-attention launch per layer
     out['k_edge_attn']['edges_built'] = dict(temporal=int(rows[8]), map=int(rows[9]), agent=int(rows[10]))
     # FourierEmbedding: n x (129x128 + 128x128) + 128x128 MACs per row (reference layers.py:126-141)

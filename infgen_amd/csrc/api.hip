@@ -79,7 +79,9 @@ struct Prof {
   unsigned mask = 0;
   std::vector<hipEvent_t> e0, e1;
   std::vector<int> kid;
+  std::vector<int> phase_of;                // 0: prologue / operator-level call, 1: inside a decode step (infgen_decode_step, infgen_rollout_run)
   std::vector<double> macs;                 // algorithmic multiply-accumulates of the launch (0: not a GEMM kernel)
+  int phase = 0;
   size_t used = 0;
   unsigned long long* rows_dev = nullptr;   // [16] device counters: [n] rows processed by k_fourier with n input dims (n < 8);
                                             // [8 + kind] edges built by k_build_edges (kind 0 temporal, 1 map, 2 agent)
@@ -93,6 +95,7 @@ struct ProfScope {
       if (g_prof.used < g_prof.e0.size()) {
         slot = (int)g_prof.used++;
         g_prof.kid[slot] = kid;
+        g_prof.phase_of[slot] = g_prof.phase;
         g_prof.macs[slot] = macs;
         (void)hipEventRecord(g_prof.e0[slot], s);
       }
@@ -100,12 +103,19 @@ struct ProfScope {
   }
   ~ProfScope() { if (slot >= 0) (void)hipEventRecord(g_prof.e1[slot], s); }
 };
+// launches issued inside a decode step are tagged (bench.py separates the step's edge launches from the prologue's)
+struct ProfPhase {
+  int old;
+  explicit ProfPhase(int p) : old(g_prof.phase) { g_prof.phase = p; }
+  ~ProfPhase() { g_prof.phase = old; }
+};
 }  // namespace
 
 extern "C" int infgen_prof_enable(unsigned mask, int max_launches) {
   if (mask && (int)g_prof.e0.size() < max_launches) {
     const size_t old = g_prof.e0.size();
     g_prof.e0.resize(max_launches); g_prof.e1.resize(max_launches); g_prof.kid.resize(max_launches);
+    g_prof.phase_of.resize(max_launches);
     g_prof.macs.resize(max_launches);
     for (size_t i = old; i < (size_t)max_launches; ++i) {
       if (hipEventCreate(&g_prof.e0[i]) != hipSuccess || hipEventCreate(&g_prof.e1[i]) != hipSuccess)
@@ -123,8 +133,13 @@ extern "C" int infgen_prof_enable(unsigned mask, int max_launches) {
 }
 
 // total_ms / calls: [INFGEN_KID_COUNT]; counters: [16] device-side row / edge counts (see Prof::rows_dev).  Synchronises.
-extern "C" int infgen_prof_collect(double* total_ms, int* calls, double* total_macs, unsigned long long* fourier_rows) {
-  for (int k = 0; k < INFGEN_KID_COUNT; ++k) { total_ms[k] = 0.0; calls[k] = 0; total_macs[k] = 0.0; }
+static int prof_collect_impl(double* total_ms, int* calls, double* total_macs, unsigned long long* fourier_rows,
+                             double* step_ms, int* step_calls) {
+  for (int k = 0; k < INFGEN_KID_COUNT; ++k) {
+    total_ms[k] = 0.0; calls[k] = 0; total_macs[k] = 0.0;
+    if (step_ms) step_ms[k] = 0.0;
+    if (step_calls) step_calls[k] = 0;
+  }
   if (hipDeviceSynchronize() != hipSuccess) return fail("infgen_prof_collect", "sync failed");
   for (size_t i = 0; i < g_prof.used; ++i) {
     float ms = 0.f;
@@ -133,14 +148,24 @@ extern "C" int infgen_prof_collect(double* total_ms, int* calls, double* total_m
     total_ms[g_prof.kid[i]] += ms;
     calls[g_prof.kid[i]] += 1;
     total_macs[g_prof.kid[i]] += g_prof.macs[i];
+    if (g_prof.phase_of[i] == 1) {
+      if (step_ms) step_ms[g_prof.kid[i]] += ms;
+      if (step_calls) step_calls[g_prof.kid[i]] += 1;
+    }
   }
   if (fourier_rows) {
     for (int i = 0; i < 16; ++i) fourier_rows[i] = 0;
     if (g_prof.rows_dev) (void)hipMemcpy(fourier_rows, g_prof.rows_dev, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   }
-  const int dropped = 0;
   g_prof.used = 0;
-  return dropped;
+  return 0;
+}
+extern "C" int infgen_prof_collect(double* total_ms, int* calls, double* total_macs, unsigned long long* fourier_rows) {
+  return prof_collect_impl(total_ms, calls, total_macs, fourier_rows, nullptr, nullptr);
+}
+extern "C" int infgen_prof_collect_steps(double* total_ms, int* calls, double* total_macs, unsigned long long* fourier_rows,
+                                         double* step_ms, int* step_calls) {
+  return prof_collect_impl(total_ms, calls, total_macs, fourier_rows, step_ms, step_calls);
 }
 
 extern "C" int infgen_layout_query(int what) {
@@ -1115,6 +1140,7 @@ static int layers_core(const InfgenRollout* r, int c, int edgeless, void* stream
 extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless, void* stream) {
   RET_IF(validate(r, "infgen_decode_layers"));
   OptScope _opts(r);
+  ProfPhase _pp(edgeless ? g_prof.phase : 1);        // (the edgeless column-0 chain belongs to the prologue)
   RET_IF(prepare_edges(r, c, edgeless, stream, true, false));
   return layers_core(r, c, edgeless, stream);
 }
@@ -1122,6 +1148,7 @@ extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless,
 extern "C" int infgen_decode_step(const InfgenRollout* r, int t, void* stream) {
   RET_IF(validate(r, "infgen_decode_step"));
   OptScope _opts(r);
+  ProfPhase _pp(1);
   const int rows = r->S * r->A_cap;
   const int c = 1 + t;
   if (t < 0 || c + 1 > r->T - 1) return fail("infgen_decode_step", "step beyond the column range");
@@ -1148,6 +1175,7 @@ extern "C" int infgen_decode_step(const InfgenRollout* r, int t, void* stream) {
 extern "C" int infgen_rollout_run(const InfgenRollout* r, int t0, int t1, void* stream) {
   RET_IF(validate(r, "infgen_rollout_run"));
   OptScope _opts(r);
+  ProfPhase _pp(1);
   const int rows = r->S * r->A_cap;
   static const int no_fold = getenv("INFGEN_NO_TAIL_FOLD") ? atoi(getenv("INFGEN_NO_TAIL_FOLD")) : 0;
   const bool sample = r->sample_k > 1 && r->sample_u;
@@ -1169,13 +1197,13 @@ extern "C" int infgen_rollout_run(const InfgenRollout* r, int t0, int t1, void* 
     bool split = false;
     RET_IF(heads_impl(r->X, rows, r->tok_head_pack, r->st_head_pack, r->token_size, lg, r->next_token, r->next_state, keys, stream,
                       true, &split));
-    RET_IF(integrate_impl(r, t, stream, split ? keys : nullptr, true, true));
+    // (the last step keeps its edge totals, like infgen_decode_step: RolloutEngine.edge_totals() / overflow checks read them)
+    RET_IF(integrate_impl(r, t, stream, split ? keys : nullptr, t + 1 < t1, true));
     if (t + 1 < t1) {
       RET_IF(prepare_edges(r, c + 1, 0, stream, false, true));
     } else {          // after the last step only the raw feature of the new column is left (kept: the context's X stays what
                       // infgen_decode_step leaves)
       RET_IF(infgen_fourier_embed(r->raw2, 2, nullptr, rows, r->four_xa, r->cat, 128, r->fus_in + 128, 512, 0, stream));
-      if (hipMemsetAsync(r->et.total, 0, 3 * sizeof(int), (hipStream_t)stream) != hipSuccess) return fail("infgen_rollout_run", "memset failed");
     }
     RET_IF(raw_feature_fusion(r, stream));
   }

@@ -96,6 +96,7 @@ class PackedWeights:
                        'seed_offset_xy_predict_head', 'seed_agent_occ_embed')}
         self._tables = None
         self._tables_key = None
+        self._tables_by_key = {}
 
     def time_gap_table(self, lib, terms: int, stream):
         """[32][128] table of r_t_emb's fourth branch (the time gap of a temporal edge is one of -1 .. -16, agent_decoder.py:586-600)
@@ -121,8 +122,12 @@ class PackedWeights:
         categorical embedding and the map-token embedding table.  ``key``: a content hash of the vocabularies / grid the
         caller computed on the host before the upload (``tables_key``) - device addresses say nothing about contents, the
         caching allocator hands a freed engine's addresses to the next one."""
-        if self._tables is not None and self._tables_key == key:
-            return self._tables
+        # one entry PER key, never evicted: engines of different vocabularies share a pack and keep raw pointers to their
+        # tables in their contexts / captured graphs (ADVICE r3: a single-entry cache freed tables a live engine still addressed)
+        hit = self._tables_by_key.get(key)
+        if hit is not None:
+            self._tables, self._tables_key = hit, key
+            return hit
         dev, ts, G = self.device, self.cfg.token_size, grid_dev.shape[0]
         tok_tab = torch.empty(3, ts + 2, D, device=dev)
         for k in range(3):
@@ -145,6 +150,7 @@ class PackedWeights:
         f_seed = ops.mlp_embedding(fus, self.fusion, 4 * D)
         self._tables = dict(tok_tab=tok_tab, grid_tab=grid_tab, cat_seed=cat_seed, map_tab=map_tab, f_seed=f_seed)
         self._tables_key = key
+        self._tables_by_key[key] = self._tables
         return self._tables
 
     @staticmethod
@@ -706,6 +712,7 @@ class RolloutEngine:
         S, A_cap, M_cap, rows = self.S, self.A_cap, self.M_cap, self.rows
         tabs = w.tables(ops, self.vocab, self.grid_xy, self._map_vocab, self._tables_key)
         self.tok_tab, self.grid_tab, self.cat_seed = tabs['tok_tab'], tabs['grid_tab'], tabs['cat_seed']
+        self.f_seed = tabs['f_seed']                 # (this engine's entry, not whatever the pack built last)
         self.reset()
         # categorical embedding rows (agent_decoder.py:376-380,492)
         if self.cat_agent is None:
@@ -923,7 +930,7 @@ class RolloutEngine:
         b.head_state, b.head_type, b.head_shape = P(H['seed_state_predict_head']), P(H['seed_type_predict_head']), P(H['seed_shape_predict_head'])
         b.head_pos, b.head_heading = P(H['seed_pos_rel_token_predict_head']), P(H['seed_heading_rel_token_predict_head'])
         b.head_offset, b.occ_embed = P(H['seed_offset_xy_predict_head']), P(H['seed_agent_occ_embed'])
-        b.shape_emb, b.type_a_emb, b.f_seed = P(w.shape_emb), P(w.type_a_emb), P(w._tables['f_seed'])
+        b.shape_emb, b.type_a_emb, b.f_seed = P(w.shape_emb), P(w.type_a_emb), P(self.f_seed)
         b.occ, b.occ_emb, b.Xc = P(I['occ']), P(I['occ_emb']), P(I['Xc'])
         b.zero_agg, b.zero_z, b.zero_sig = P(I['AGG0']), P(I['Z0']), P(I['SIG0'])
         for k in ('XS', 'QS', 'US', 'AGGS', 'ZS', 'SIGS', 'KN', 'VN'):
@@ -1317,9 +1324,10 @@ class RolloutEngine:
                         labels[a_][hc + t_] = f'A{k_}'
                 o['agent_labels'] = labels
             if self.seed_out is not None:
-                so = self.seed_out
-                o.update(next_state_prob_seed=so['state'][s], next_pos_rel_prob_seed=so['pos'][s], grid_agent_occ_seed=so['occ_a'][s],
-                         grid_pt_occ_seed=so['occ_p'][s], grid_agent_occ_gt_seed=so['occ_gt'][s])
+                # (detach: the seed arrays are engine-owned and zeroed / rewritten by the next rollout of a reused engine)
+                so = {k: (v[s].clone() if detach else v[s]) for k, v in self.seed_out.items()}
+                o.update(next_state_prob_seed=so['state'], next_pos_rel_prob_seed=so['pos'], grid_agent_occ_seed=so['occ_a'],
+                         grid_pt_occ_seed=so['occ_p'], grid_agent_occ_gt_seed=so['occ_gt'])
             if lg_all is not None:
                 o['logits'] = lg_all[:, s * A_cap:s * A_cap + A]
             if x_pt_all is not None:

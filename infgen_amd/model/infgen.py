@@ -7,7 +7,9 @@ close-loop validation branch - ``__init__(model_config, save_path, logger)``, ``
 
 Every stage runs in the HIP library; this class only sequences them.  It is a plain ``nn.Module`` (pytorch_lightning is
 not a dependency): ``self.log`` / trainer hooks are not provided, ``global_rank`` comes from torch.distributed.
-The open-loop branch (``forward`` = the teacher-forced pass) is not built.
+The open-loop branch (``val_open_loop`` / ``OPEN_LOOP=1``, reference :627-686) runs ``InfGenDecoder.forward`` - the teacher-forced pass
+of SURVEY section 8f rank 3 (infgen_amd/forward_engine.py) - and leaves the token + state cross-entropy in ``self.val_loss``;
+training (autograd) is not built.
 
 The reference reads its token tables from ``infgen/tokens/*.pkl`` (data of that repository).  Here they are arguments:
 ``map_token_traj`` (n_token, 11, 2) or ``map_token_traj_path`` (pickle with ['traj_src']), and ``agent_tokens`` /

@@ -182,7 +182,8 @@ class InfGenDecoder(nn.Module):
         return self._packed
 
     # ------------------------------------------------------------------ driver
-    def _run(self, data, x_pt=None, map_only=False, batch: Optional[Sequence] = None, sample_uniforms=None):
+    def _run(self, data, x_pt=None, map_only=False, batch: Optional[Sequence] = None, sample_uniforms=None,
+             batch_seed_outputs: bool = False):
         ae = self.agent_encoder
         datas = list(batch) if batch is not None else [data]
         scenes = scenes_from_datas(datas)
@@ -217,13 +218,16 @@ class InfGenDecoder(nn.Module):
                                  force_enter=bool(int(os.getenv('DEBUG', 0))),    # DEBUG=1 forces 'enter' (agent_decoder.py:1888)
                                  sample_k=k if not map_only else 1, sample_uniforms=sample_uniforms,
                                  insert_k=ik if insert_uniforms is not None else 1, insert_uniforms=insert_uniforms,
-                                 # the seed node's per-insertion outputs (plot inputs of the reference): single-scene entry only
-                                 seed_outputs=batch is None and not w.cfg.disable_insertion and not map_only)
+                                 # the seed node's per-insertion outputs (plot inputs of the reference, 5.5 MB per scene): the
+                                 # single-scene entry and the n-copies batch of inference_rollouts; the throughput entry
+                                 # (inference_batch) returns the zero arrays the reference initialises them to
+                                 seed_outputs=(batch is None or batch_seed_outputs) and not w.cfg.disable_insertion and not map_only)
         # one engine per batch layout is kept across calls: a second call of the same shape re-uploads the scene arrays into
         # the first call's device buffers instead of building (and allocating) an engine again
         ekey = (len(scenes), PackedWeights.tables_key(*(vocab[k_] for k_ in ('veh', 'ped', 'cyc')), grid, map_vocab),
                 bool(w.cfg.disable_insertion), w.cfg.num_recurrent_steps_val, k if not map_only else 1,
-                ik if insert_uniforms is not None else 1, bool(int(os.getenv('DEBUG', 0))), batch is None, map_only, xo is None)
+                ik if insert_uniforms is not None else 1, bool(int(os.getenv('DEBUG', 0))), batch is None, map_only, xo is None,
+                bool(batch_seed_outputs))
         eng = self._engines.get(ekey)
         if eng is not None and eng.fits(scenes):
             eng.reload(scenes, sample_uniforms=sample_uniforms, insert_uniforms=insert_uniforms, x_pt_override=xo)
@@ -331,14 +335,22 @@ class InfGenDecoder(nn.Module):
         ``motion_beam_size`` / ``insert_beam_size`` > 1 every copy draws its own uniforms from torch's RNG, so the results are n
         samples; greedy copies are identical.  ``data`` itself is not mutated (the copies are)."""
         copies = [data.clone() if hasattr(data, 'clone') else dict(data) for _ in range(int(n))]
-        return self.inference_batch(copies)
+        # every rollout carries what ``inference`` returns for it: the seed node's outputs and the map_next_token_* keys too
+        return self.inference_batch(copies, seed_outputs=True)
 
     @torch.no_grad()
-    def inference_batch(self, datas: Sequence) -> List[Dict[str, torch.Tensor]]:
-        """throughput entry: many independent scenes decoded in lockstep on this GPU"""
-        rs = self._run(None, batch=datas)
+    def inference_batch(self, datas: Sequence, seed_outputs: bool = False) -> List[Dict[str, torch.Tensor]]:
+        """throughput entry: many independent scenes decoded in lockstep on this GPU.  Every dict has the key set of
+        ``inference``; the seed node's per-insertion arrays (``*_seed``) are recorded only with ``seed_outputs=True`` (5.5 MB per
+        scene), otherwise they are the zero arrays the reference initialises them to (agent_decoder.py:1746-1750)."""
+        rs = self._run(None, batch=datas, batch_seed_outputs=seed_outputs)
         out = []
+        dev, ts = self._weights().device, self.map_encoder.token_size
+        map_keys = {'map_next_token_idx': torch.zeros(0, 10, dtype=torch.long, device=dev),
+                    'map_next_token_prob': torch.zeros(0, ts, device=dev),
+                    'map_next_token_idx_gt': torch.zeros(0, dtype=torch.long, device=dev),
+                    'map_next_token_eval_mask': torch.zeros(0, dtype=torch.bool, device=dev)}
         for d, r in zip(datas, rs):
             x_pt = r.pop('_x_pt')
-            out.append({'x_pt': x_pt, **r, **{k: d[k] for k in self.data_keys if k in d}})
+            out.append({'x_pt': x_pt, **map_keys, **r, **{k: d[k] for k in self.data_keys if k in d}})
         return out

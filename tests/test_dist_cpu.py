@@ -27,7 +27,12 @@ def _worker(rank, world, port, q):
     dist.barrier()
     secs, steps = igd.reduce_run(1.0 + rank, 100.0 * (rank + 1), torch.device('cpu'))
     gathered = igd.gather_metrics([float(rank), float(len(strided))], torch.device('cpu'))
-    q.put((rank, mine, strided, secs, steps, gathered))
+    # insertion runs: a pilot on the strided deal measures every scene's cost, the cost vector is all-reduced, and every rank
+    # computes the same balanced partition from it
+    local = [(i, 10.0 + 7.0 * (i % 5) + (40.0 if i == 2 else 0.0)) for i in strided]
+    costs = igd.gather_costs(local, 7, torch.device('cpu'))
+    balanced = igd.scenes_for_rank_balanced(costs, rank, world)
+    q.put((rank, mine, strided, secs, steps, gathered, costs, balanced))
     dist.destroy_process_group()
 
 
@@ -43,12 +48,34 @@ def test_two_rank_sharding_and_reduction():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, m0, s0, t0, c0, g0), (r1, m1, s1, t1, c1, g1) = res
+    (r0, m0, s0, t0, c0, g0, k0, b0), (r1, m1, s1, t1, c1, g1, k1, b1) = res
+    from infgen_amd import dist as igd
+    assert k0 == k1 and len(k0) == 7 and min(k0) > 0                   # the same full cost vector on both ranks
+    assert sorted(b0 + b1) == list(range(7)) and not set(b0) & set(b1)   # balanced: a partition too
+    assert igd.partition_spread(k0, [b0, b1]) <= igd.partition_spread(k0, [s0, s1])
+    assert igd.partition_spread(k0, [b0, b1]) < 1.05
     assert m0 == [0, 1, 2] and m1 == [3, 4, 5]                       # weak scaling: disjoint scene ids
     assert sorted(s0 + s1) == list(range(7)) and not set(s0) & set(s1)   # strided: a partition
     assert t0 == t1 == 2.0                                            # MAX over ranks
     assert c0 == c1 == 300.0                                          # SUM over ranks
     assert g0 == g1 == [[0.0, 4.0], [1.0, 3.0]]
+
+
+def test_balanced_dealing_is_deterministic_and_tighter_than_strided():
+    """LPT dealing on a skewed cost vector (a few scenes insert many agents): every scene dealt exactly once, ranks agree
+    without communication, max / mean load below the strided deal's (reference layout: scalable_dataset.py:266-269)"""
+    import numpy as np
+    from infgen_amd import dist as igd
+    rng = np.random.default_rng(5)
+    costs = (64 + rng.gamma(1.2, 30.0, size=64)).tolist()            # 64 agents + a long-tailed number of inserted ones
+    for world in (2, 4, 8):
+        parts = [igd.scenes_for_rank_balanced(costs, r, world) for r in range(world)]
+        assert sorted(i for p in parts for i in p) == list(range(64))
+        strided = [igd.scenes_for_rank_strided(r, world, 64) for r in range(world)]
+        assert igd.partition_spread(costs, parts) <= igd.partition_spread(costs, strided) + 1e-12
+        assert igd.partition_spread(costs, parts) < (1.03 if world <= 4 else 1.08)       # (8 scenes per rank at world 8)
+    assert igd.scenes_for_rank_balanced([1.0] * 6, 1, 3) == [1, 4]    # equal costs: ties by index / rank, like a strided deal
+    assert igd.scene_cost(64, 1024, 22) > igd.scene_cost(64, 1024)
 
 
 def test_single_process_is_a_noop():
@@ -90,6 +117,17 @@ def test_bench_gpus_flag_spawns_the_ranks():
 def test_bench_strong_scaling_deals_the_fixed_batch():
     line = _run_bench('--gpus', '2', '--dry-run', '--scaling', 'strong', '--total-scenes', '7', '--steps', '1')
     assert line['scenes_per_rank'] == [4, 3]
+
+
+def test_bench_insertion_run_deals_scenes_by_cost():
+    """`bench.py --gpus 2 --insertion`: per-scene costs measured by the pilot are exchanged (one all-reduce of a dense vector) and
+    the scenes dealt again longest first - every scene exactly once, tighter than the initial deal"""
+    line = _run_bench('--gpus', '2', '--dry-run', '--insertion', '--steps', '1', '--scenes', '9')
+    b = line['insertion_balance']
+    assert b['all_scenes_dealt_once'] and sum(b['scenes_per_rank']) == 18
+    assert b['max_over_mean_after'] <= b['max_over_mean_before'] and b['max_over_mean_after'] < 1.02
+    assert line['scenes_per_rank'] == b['scenes_per_rank']
+    assert _run_bench('--gpus', '2', '--dry-run', '--steps', '1', '--scenes', '3')['insertion_balance'] is None
 
 
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():

@@ -74,6 +74,28 @@ def test_inference_batch_equals_single():
     single = dec.inference(_to_data(scenes[1], dev))
     assert np.array_equal(outs[0]['next_token_idx'].cpu().numpy(), c['z']['next_token_idx'])
     assert torch.equal(outs[1]['next_token_idx'], single['next_token_idx'])
+    assert set(outs[1]) == set(single), set(outs[1]) ^ set(single)       # the batch entry returns inference's key set
+
+
+def test_inference_rollouts_carry_the_seed_outputs(monkeypatch):
+    """the n-copies batch of inference_rollouts (reference loop infgen/model/infgen.py:704-706) returns for every
+    rollout what inference() returns for it - key set, and (greedy) the same seed-node arrays instead of zero placeholders"""
+    c = load_case('ins_forced_a16_m256')
+    monkeypatch.setenv('DEBUG', '1')
+    dev = torch.device('cuda:0')
+    dec = _decoder(c['cfg'])
+    dec.agent_encoder.disable_insertion = False
+    _load(dec, c['sd'])
+    dec = dec.to(dev).eval()
+    single = dec.inference(_to_data(c['scene'], dev))
+    outs = dec.inference_rollouts(_to_data(c['scene'], dev), 2)
+    assert len(outs) == 2
+    for o in outs:
+        assert set(o) == set(single), set(o) ^ set(single)
+        assert torch.equal(o['next_token_idx'], single['next_token_idx'])
+        for k in ('next_state_prob_seed', 'next_pos_rel_prob_seed', 'grid_agent_occ_seed', 'grid_pt_occ_seed',
+                  'grid_agent_occ_gt_seed'):
+            assert float(single[k].abs().sum()) > 0 and torch.allclose(o[k], single[k], atol=1e-5), k
 
 
 def test_infgen_decoder_inference_with_insertion(monkeypatch):
@@ -92,6 +114,18 @@ def test_infgen_decoder_inference_with_insertion(monkeypatch):
     assert np.array_equal(out['next_token_idx'].cpu().numpy(), z['next_token_idx'])
     assert np.array_equal(out['agent_id'].cpu().numpy(), z['agent_id'])
     assert 'inserted' in out['log_message']
+    # the decoder reuses its engine for a second call of the same layout - nothing a call returned may
+    # alias engine-owned buffers.  A second call on a DIFFERENT scene of the same shape must leave the first call's tensors alone
+    keys = ('pos_a', 'head_a', 'next_token_idx', 'next_state_prob_seed', 'next_pos_rel_prob_seed', 'grid_agent_occ_seed',
+            'grid_pt_occ_seed', 'grid_agent_occ_gt_seed')
+    snap = {k: out[k].clone() for k in keys}
+    assert float(snap['next_pos_rel_prob_seed'].abs().sum()) > 0
+    from infgen_amd import synth
+    other = synth.make_scene(99321, 16, 256, cfg, ego_last=True, vocab=c['vocab'], grid=c['grid'])
+    out2 = dec.inference(_to_data(other, dev))
+    for k in keys:
+        assert torch.equal(out[k], snap[k]), k
+    assert not torch.equal(out2['next_pos_rel_prob_seed'], snap['next_pos_rel_prob_seed'])
 
 
 def test_operator_modules_match_oracle():

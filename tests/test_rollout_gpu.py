@@ -823,6 +823,8 @@ def test_folded_step_tail_equals_stepwise_decode():
             b.step(t)                                       # infgen_decode_step per step
         for k in ('pos', 'head', 'state', 'token', 'gridtok', 'X', 'logits', 'pred_traj', 'pred_head', 'next_token'):
             assert torch.equal(getattr(a, k), getattr(b, k)), (name, k)
+        # both sequences leave the LAST step's edge counts in the context (the folded one used to leave zeros)
+        assert a.edge_totals() == b.edge_totals() and sum(a.edge_totals()) > 0, (a.edge_totals(), b.edge_totals())
         z = c['z']
         assert np.array_equal(a.outputs()[0]['next_token_idx'], z['next_token_idx'])
         a.rollout()                                         # a second rollout on the same engine starts from cleared keys again

@@ -1,6 +1,7 @@
 """profiles/traffic.json from the two PMC summaries of tools/prof_round.sh (FETCH_SIZE / WRITE_SIZE per kernel, KB summed over
 the dispatches of the pass): bytes per launch, FETCH corrected by the factors tools/calibrate_fetch.sh measured.
-usage: make_traffic_json.py <pmc_FETCH_SIZE.summary.csv> <pmc_WRITE_SIZE.summary.csv> <fetch_factor_8B> <fetch_factor_16B> <tag>"""
+usage: make_traffic_json.py <pmc_FETCH_SIZE.summary.csv> <pmc_WRITE_SIZE.summary.csv> <fetch_factor_8B> <fetch_factor_16B> <tag>
+       [<pmc_FETCH_SIZE.bygrid.csv> <pmc_WRITE_SIZE.bygrid.csv>]   -> also `k_edge_attn_step`: the decode-step launches alone"""
 import csv, json, sys
 fetch, write, f8, f16, tag = sys.argv[1], sys.argv[2], float(sys.argv[3]), float(sys.argv[4]), sys.argv[5]
 names = {'k_edge_fused': ('k_edge_attn', f8), 'k_attn_h': ('k_attn_post', f16), 'k_fourier_h': ('k_fourier', f16)}
@@ -17,8 +18,25 @@ def load(path, col):
     return out
 
 
+def load_step(path):
+    """the decode-step launches of k_edge_fused from a --by-grid summary: the (kernel, grid) group with the most dispatches
+    (18 launches per decode step, all of one grid size; the map encoder's three pt <-> pt launches have another)"""
+    best = None
+    for line in list(open(path))[1:]:
+        kernel, disp, val = line.rstrip('\n').rsplit(',', 2)
+        if 'k_edge_fused' in kernel and '@grid=' in kernel and (best is None or int(disp) > best[1]):
+            best = (float(val) * 1024.0, int(disp), kernel)
+    return best
+
+
 fe, wr = load(fetch, 'FETCH_SIZE'), load(write, 'WRITE_SIZE')
 kern = {}
+if len(sys.argv) > 7:            # <pmc_FETCH_SIZE.bygrid.csv> <pmc_WRITE_SIZE.bygrid.csv>
+    sf, sw = load_step(sys.argv[6]), load_step(sys.argv[7])
+    if sf and sw:
+        kern['k_edge_attn_step'] = dict(fetch_bytes_per_launch=sf[0] / sf[1] / f8, fetch_counter_bytes_per_launch=sf[0] / sf[1],
+                                        fetch_counter_factor=f8, write_bytes_per_launch=sw[0] / sw[1], dispatches=sf[1],
+                                        group=sf[2])
 for kid in fe:
     fb, n, fac = fe[kid]
     wb, nw, _ = wr[kid]
