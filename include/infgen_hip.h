@@ -233,6 +233,12 @@ int infgen_set_edge_loop(int variant);
 /* 1: infgen_decode_layers runs the Fourier embeddings of the map and agent edge sets on an internal side stream, overlapped
  * with the first temporal / map sublayers on the caller's stream (joined with events before their first use) */
 int infgen_set_overlap(int mode);
+/* 1 (default; INFGEN_LAYERS_P=0 in the environment: off): launches of up to 256 16-row groups run ALL 18 sublayers of a decode step
+ * in one launch of k_layers_p (one resident workgroup per group, wave = feature tile; the scene's groups meet at a counter before
+ * each agent sublayer) instead of 36 launches of k_edge_fused + k_attn_hs - same operators (infgen/modules/layers.py:61-113),
+ * rounding-level differences only.  Needs fused edge attention (infgen_set_edge_fuse != 0), the split GEMM kernels and no
+ * row-group list; otherwise the per-sublayer launches run. */
+int infgen_set_layers_p(int mode);
 /* same with the kernel variant forced: wide = 1 -> one 8-wave workgroup per destination (long edge lists, few rows),
  * wide = 0 -> one wave per destination; infgen_edge_attn picks wide when rows <= 256 */
 int infgen_edge_attn_mode(int rows, const float* Q, const float* U, const float* Ksrc, const float* Vsrc,

@@ -1025,12 +1025,39 @@ static int fourier_nomulti() {
   return v;
 }
 
+// ---- k_layers_p (layers_p.hip): every sublayer of a step in one launch, one resident workgroup per 16-row group
+static int g_layers_p = -1;                 // -1: INFGEN_LAYERS_P (default on)
+extern "C" int infgen_set_layers_p(int mode) {
+  if (mode != 0 && mode != 1) return fail("infgen_set_layers_p", "mode must be 0 or 1");
+  g_layers_p = mode;
+  return 0;
+}
+// the launch shape qualifies (the kernel keeps U / Z on chip like k_edge_fused: step_mode treats it as a fused launch)
+static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless) {
+  if (g_layers_p < 0) g_layers_p = getenv("INFGEN_LAYERS_P") ? (atoi(getenv("INFGEN_LAYERS_P")) != 0) : 1;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) n_cu = 1;
+    else n_cu = prop.multiProcessorCount;
+  }
+  // all workgroups must be resident at once (they meet at per-scene counters): at most one 16-row group per CU.  Beyond ~128
+  // groups the XCDs' L2s saturate (every workgroup streams each sublayer's 1.1 MB of weight fragments: 35 MB per XCD and sublayer
+  // at 256 groups) and the per-sublayer launches are faster again: 8 / 16 / 32 / 48 / 64 scenes of 64 agents 12.98 / 14.31 /
+  // 17.27 / 20.50 / 23.90 ms per rollout against 15.41 / 16.44 / 18.01 / 20.08 / 22.15 (INFGEN_LP_MAX_GROUPS moves the limit)
+  static const int max_groups = getenv("INFGEN_LP_MAX_GROUPS") ? atoi(getenv("INFGEN_LP_MAX_GROUPS")) : 128;
+  return g_layers_p && !edgeless && O().edge_fuse != 0 && O().attn_mode != 0 && O().gemm_terms == 3 && O().fourier_mode != 0 &&
+         !(O().overlap && g_side) && !O().row_groups && r->A_cap % 16 == 0 && rows / 16 <= n_cu && rows / 16 <= max_groups &&
+         rows / 16 <= 256 && r->num_layers <= LP_MAX_LAYERS && r->U && r->SIG;
+}
+
 // ---- a decode step in two halves: the edge sets of a column with their embeddings, and the 18 sublayers that consume them
-struct StepMode { bool overlap, fuse; int r24; const float* dt; };
+struct StepMode { bool overlap, fuse, lp; int r24; const float* dt; };
 static StepMode step_mode(const InfgenRollout* r, int rows, int edgeless) {
   StepMode m;
   m.overlap = O().overlap && g_side && !edgeless;
-  m.fuse = O().edge_fuse == 2 || (O().edge_fuse == 1 && rows > 256);      // U / Z / SIG stay on chip inside k_edge_fused
+  m.lp = layers_p_shape(r, rows, edgeless);
+  m.fuse = O().edge_fuse == 2 || (O().edge_fuse == 1 && (rows > 256 || m.lp));      // U / Z / SIG stay on chip inside k_edge_fused / k_layers_p
   // the step's rhat rows never leave the library: packed 24-bit rows (kernels.h) when both ends are the kernels that know them
   // (INFGEN_NO_R24=1, read per call: fp32 rows instead - tests/test_rollout_gpu.py compares the two)
   const char* no_r24 = getenv("INFGEN_NO_R24");
@@ -1086,9 +1113,55 @@ static int prepare_edges(const InfgenRollout* r, int c, int edgeless, void* stre
   return 0;
 }
 
+static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, void* stream) {
+  const int rows = r->S * r->A_cap;
+  LayersPArgs a;
+  a.rows = rows; a.A_cap = r->A_cap; a.num_layers = r->num_layers;
+  const int gps = r->A_cap / 16;
+  a.xcd_order = (rows / 16) % (8 * gps) == 0 ? 1 : 0;
+  a.X = r->X;
+  for (int i = 0; i < r->num_layers; ++i) {
+    a.attn_t[i] = r->attn_t[i]; a.attn_m[i] = r->attn_m[i]; a.attn_a[i] = r->attn_a[i];
+    a.ringK[i] = r->ringK[i]; a.ringV[i] = r->ringV[i]; a.mapK[i] = r->mapK[i]; a.mapV[i] = r->mapV[i];
+  }
+  a.slot_off = (size_t)(c % r->ring) * rows * D;
+  // the agent set's K / V rows double buffered by layer parity: the context's Ka / Va, and the first rows of its U array (4 KB per
+  // row, unused while U stays on chip); the scenes' counters in its SIG array (unused for the same reason)
+  a.Ka[0] = r->Ka; a.Va[0] = r->Va; a.Ka[1] = r->U; a.Va[1] = r->U + (size_t)rows * D;
+  a.et = EdgeSet{r->et.off, r->et.cnt, r->et.src, r->et.rhat};
+  a.em = EdgeSet{r->em.off, r->em.cnt, r->em.src, r->em.rhat};
+  a.ea = EdgeSet{r->ea.off, r->ea.cnt, r->ea.src, r->ea.rhat};
+  a.sync = reinterpret_cast<int*>(r->SIG);
+  a.trace = nullptr;
+  static const int lp_trace = getenv("INFGEN_LP_TRACE") ? atoi(getenv("INFGEN_LP_TRACE")) : 0;
+  static unsigned long long* trace_dev = nullptr;
+  if (lp_trace) {
+    if (!trace_dev && hipMalloc(&trace_dev, 2048 * sizeof(unsigned long long)) != hipSuccess) return fail("infgen_decode_layers", "trace buffer");
+    (void)hipMemsetAsync(trace_dev, 0, 2048 * sizeof(unsigned long long), (hipStream_t)stream);
+    a.trace = trace_dev;
+  }
+  if (hipMemsetAsync(a.sync, 0, (size_t)r->S * sizeof(int), (hipStream_t)stream) != hipSuccess)
+    return fail("infgen_decode_layers", "memset failed");
+  { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
+    if (sm.r24) hipLaunchKernelGGL(k_layers_p<true>, dim3(rows / 16), dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_layers_p<false>, dim3(rows / 16), dim3(512), 0, (hipStream_t)stream, a); }
+  if (lp_trace) {          // synchronous dump of the last launch's stamps (diagnostic runs only)
+    static int dumps = 0;
+    if (dumps++ == lp_trace) {
+      std::vector<unsigned long long> h(2048);
+      (void)hipStreamSynchronize((hipStream_t)stream);
+      (void)hipMemcpy(h.data(), trace_dev, 2048 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      for (int i = 0; i < 1024 && (i == 0 || h[2 * i + 1]); ++i)
+        fprintf(stderr, "[lp trace] %d %llu %llu\n", i, h[2 * i], i ? h[2 * i + 1] - h[2 * i - 1] : 0ull);
+    }
+  }
+  return check_launch("infgen_decode_layers(k_layers_p)");
+}
+
 static int layers_core(const InfgenRollout* r, int c, int edgeless, void* stream) {
   const int rows = r->S * r->A_cap;
   const StepMode sm = step_mode(r, rows, edgeless);
+  if (sm.lp && sm.fuse) return layers_p_launch(r, c, sm, stream);
   const bool overlap = sm.overlap, fuse = sm.fuse; const int r24 = sm.r24;
   const size_t slot = (size_t)(c % r->ring) * rows * D;
   const int L = r->num_layers;

@@ -121,6 +121,22 @@ struct EdgeFusedArgs {
   WarmArgs warm;                     // one-group variant only
 };
 
+// k_layers_p (layers_p.hip): every sublayer of a decode step in one launch for up to 256 16-row groups; one workgroup owns a group
+constexpr int LP_MAX_LAYERS = 8;
+struct LayersPArgs {
+  int rows, A_cap, num_layers;
+  int xcd_order;                     // 1: a scene's workgroups share an XCD (groups a multiple of 8 * A_cap / 16)
+  float* X;                          // [rows][128] in / out: the layer stack's input rows (raw features) -> its output
+  const float* attn_t[LP_MAX_LAYERS]; const float* attn_m[LP_MAX_LAYERS]; const float* attn_a[LP_MAX_LAYERS];
+  float* ringK[LP_MAX_LAYERS]; float* ringV[LP_MAX_LAYERS];      // [ring][rows][128]
+  size_t slot_off;                   // floats: the current column's slot of the ring
+  const float* mapK[LP_MAX_LAYERS]; const float* mapV[LP_MAX_LAYERS];
+  float* Ka[2]; float* Va[2];        // agent-set K / V rows, double buffered by layer parity
+  EdgeSet et, em, ea;
+  int* sync;                         // [scenes] zeroed before the launch: arrivals of a scene's workgroups per layer
+  unsigned long long* trace;         // diagnostics (INFGEN_LP_TRACE=1): [1024][2] (stamp id, s_memtime) of workgroup 0
+};
+
 struct AttnPostArgs {
   float* X; int rows;                // in/out residual stream
   const float* pack;
@@ -453,6 +469,7 @@ template <int TERMS> __global__ void k_attn_hs(AttnHArgs a);             // attn
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);
 template <int G, bool R24, int HALVES, int WAVES> __global__ void k_edge_fused(EdgeFusedArgs a);        // edge_fused.hip (R24: rhat rows in the packed format)
+template <bool R24> __global__ void k_layers_p(LayersPArgs a);          // layers_p.hip
 template <int G> __global__ void k_edge_fused_p(EdgeFusedArgs a);      // persistent workgroups, decoupled halves
 __global__ void k_edge_attn_wide(EdgeAttnArgs a);
 __global__ void k_attn_post(AttnPostArgs a);

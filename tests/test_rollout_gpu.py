@@ -395,6 +395,7 @@ def test_warm_workgroups_are_bitwise_neutral(monkeypatch):
     dev = torch.device('cuda:0')
     w = engine.PackedWeights(c['sd'], cfg, dev)
     _lib.check(lib.infgen_set_edge_fuse(2))                     # the fused edge kernel's one-group variant carries them
+    _lib.check(lib.infgen_set_layers_p(0))                      # (the per-sublayer launches: k_layers_p has no warm workgroups)
     try:
         few = [c['scene']] + [synth.make_scene(8400 + i, 24, 256, cfg, ego_last=True, vocab=c['vocab'], grid=c['grid']) for i in range(7)]
         many = few + [synth.make_scene(8500 + i, 24, 256, cfg, ego_last=True, vocab=c['vocab'], grid=c['grid']) for i in range(120)]
@@ -408,6 +409,7 @@ def test_warm_workgroups_are_bitwise_neutral(monkeypatch):
         assert np.array_equal(a.outputs()[0]['next_token_idx'], c['z']['next_token_idx'])
     finally:
         _lib.check(lib.infgen_set_edge_fuse(1))
+        _lib.check(lib.infgen_set_layers_p(1))
 
 
 def test_rollout_many_streams_equals_single_engine():
@@ -576,6 +578,7 @@ def test_side_stream_overlap_is_bitwise_neutral():
     scenes = [synth.make_scene(700 + i, 20 + i, 256, c['cfg'], vocab=c['vocab'], grid=c['grid'], slip=0.2) for i in range(8)]
     lib = _lib.load()
     outs = []
+    _lib.check(lib.infgen_set_layers_p(0))       # (the per-sublayer launches: k_layers_p does not run with the side stream)
     try:
         for mode in (0, 1):
             _lib.check(lib.infgen_set_overlap(mode))
@@ -584,6 +587,7 @@ def test_side_stream_overlap_is_bitwise_neutral():
             outs.append(eng.outputs())
     finally:
         _lib.check(lib.infgen_set_overlap(0))
+        _lib.check(lib.infgen_set_layers_p(1))
     for a, b in zip(*outs):
         assert np.array_equal(a['logits'], b['logits']) and np.array_equal(a['pos_a'], b['pos_a'])
 
@@ -829,3 +833,65 @@ def test_folded_step_tail_equals_stepwise_decode():
         assert np.array_equal(a.outputs()[0]['next_token_idx'], z['next_token_idx'])
         a.rollout()                                         # a second rollout on the same engine starts from cleared keys again
         assert np.array_equal(a.outputs()[0]['next_token_idx'], z['next_token_idx'])
+
+
+def test_layers_p_matches_per_sublayer_launches_and_reruns_bitwise():
+    """k_layers_p (csrc/layers_p.hip: all 18 sublayers of a decode step in ONE launch, a resident workgroup per 16-row group, the
+    scene's workgroups meeting at a counter before every agent sublayer) against the per-sublayer launches of k_edge_fused +
+    k_attn_hs on a ragged 8-scene batch: same tokens / states / poses free-running over 16 steps, logits within the fp32 noise of
+    two roundings of the same operators (reference layers.py:61-113); two runs of the new path bitwise equal (fixed-order
+    reductions only, no atomics in the arithmetic); single-scene fixtures (2 / 4 workgroups) still reproduce the reference"""
+    from infgen_amd import engine, synth, _lib
+    lib = _lib.load()
+    c = load_case('c3_a64_m1024')
+    cfg = c['cfg']
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], cfg, dev)
+    scenes = [c['scene']] + [synth.make_scene(8600 + i, a, m, cfg, ego_last=(i % 2 == 0), vocab=c['vocab'], grid=c['grid'], slip=0.3)
+                             for i, (a, m) in enumerate([(64, 1024), (9, 100), (40, 300), (64, 700), (33, 512), (17, 64), (50, 900)])]
+    runs = {}
+    try:
+        for mode in (0, 1, 1):
+            _lib.check(lib.infgen_set_layers_p(mode))
+            e = engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=True, use_graph=False)
+            e.rollout()
+            torch.cuda.synchronize()
+            runs.setdefault(mode, []).append({k: getattr(e, k).clone() for k in ('pos', 'head', 'state', 'token', 'X', 'logits')})
+            if mode == 1 and len(runs[1]) == 1:
+                assert np.array_equal(e.outputs()[0]['next_token_idx'], c['z']['next_token_idx'])
+    finally:
+        _lib.check(lib.infgen_set_layers_p(1))
+    old, new, again = runs[0][0], runs[1][0], runs[1][1]
+    for k in new:
+        assert torch.equal(new[k], again[k]), k                  # bitwise reproducible
+    assert torch.equal(old['token'], new['token']) and torch.equal(old['state'], new['state'])
+    assert torch.allclose(old['pos'], new['pos'], atol=1e-4) and torch.allclose(old['head'], new['head'], atol=1e-5)
+    gain = 64.0                                                   # the fixture's sharpened token head (make_golden.py: head_gain)
+    err = (old['logits'] - new['logits']).abs().max().item()
+    assert err <= 1e-3 * gain / 16, err
+    assert not torch.equal(old['logits'], new['logits'])          # (it IS another kernel: the switch took effect)
+
+
+def test_layers_p_one_launch_per_decode_step():
+    """with the default switches a small batch spends ONE edge / node launch per decode step (profiling ids of the per-sublayer
+    kernels: k_edge_attn 1 instead of 18, k_attn_post / k_attn_pre 0 instead of 19 inside the steps)"""
+    from infgen_amd import engine, synth, _lib
+    lib = _lib.load()
+    c = load_case('a24_m256_edge')
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], c['cfg'], dev)
+    e = engine.RolloutEngine(w, [c['scene']], c['vocab'], c['map_vocab'], c['grid'], store_logits=False, use_graph=False)
+    e.rollout()
+    counts = {}
+    try:
+        for mode in (1, 0):
+            _lib.check(lib.infgen_set_layers_p(mode))
+            _lib.prof_enable((1 << len(_lib.KERNEL_IDS)) - 1)
+            e.rollout()
+            counts[mode] = _lib.prof_collect()
+    finally:
+        _lib.prof_enable(0)
+        _lib.check(lib.infgen_set_layers_p(1))
+    steps = c['cfg'].num_decode_steps
+    assert counts[1]['k_edge_attn']['step_calls'] == steps and counts[1]['k_attn_post']['step_calls'] == 0
+    assert counts[0]['k_edge_attn']['step_calls'] == 18 * steps and counts[0]['k_attn_post']['step_calls'] == 18 * steps
