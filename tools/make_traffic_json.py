@@ -34,9 +34,13 @@ kern = {}
 if len(sys.argv) > 7:            # <pmc_FETCH_SIZE.bygrid.csv> <pmc_WRITE_SIZE.bygrid.csv>
     sf, sw = load_step(sys.argv[6]), load_step(sys.argv[7])
     if sf and sw:
-        kern['k_edge_attn_step'] = dict(fetch_bytes_per_launch=sf[0] / sf[1] / f8, fetch_counter_bytes_per_launch=sf[0] / sf[1],
-                                        fetch_counter_factor=f8, write_bytes_per_launch=sw[0] / sw[1], dispatches=sf[1],
-                                        group=sf[2])
+        # the group holds, per rollout, the 16 x 18 decode-step launches AND the 18 edgeless launches of the column-0 chain (same
+        # grid; they read q and write agg only, ~2 x 512 B per row).  All of the group's bytes are charged to the decode-step
+        # launches: a slight over-estimate of their traffic, never an under-estimate
+        n_step = sf[1] * 288 // 306
+        kern['k_edge_attn_step'] = dict(fetch_bytes_per_launch=sf[0] / n_step / f8, fetch_counter_bytes_per_launch=sf[0] / n_step,
+                                        fetch_counter_factor=f8, write_bytes_per_launch=sw[0] / n_step, dispatches=n_step,
+                                        group=sf[2], group_dispatches=sf[1])
 for kid in fe:
     fb, n, fac = fe[kid]
     wb, nw, _ = wr[kid]
