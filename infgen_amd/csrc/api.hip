@@ -1032,6 +1032,10 @@ extern "C" int infgen_set_layers_p(int mode) {
   g_layers_p = mode;
   return 0;
 }
+static int lp_max_groups() {
+  static const int v = getenv("INFGEN_LP_MAX_GROUPS") ? atoi(getenv("INFGEN_LP_MAX_GROUPS")) : 128;
+  return v;
+}
 // the launch shape qualifies (the kernel keeps U / Z on chip like k_edge_fused: step_mode treats it as a fused launch)
 static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless) {
   if (g_layers_p < 0) g_layers_p = getenv("INFGEN_LAYERS_P") ? (atoi(getenv("INFGEN_LAYERS_P")) != 0) : 1;
@@ -1045,7 +1049,7 @@ static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless) {
   // groups the XCDs' L2s saturate (every workgroup streams each sublayer's 1.1 MB of weight fragments: 35 MB per XCD and sublayer
   // at 256 groups) and the per-sublayer launches are faster again: 8 / 16 / 32 / 48 / 64 scenes of 64 agents 12.98 / 14.31 /
   // 17.27 / 20.50 / 23.90 ms per rollout against 15.41 / 16.44 / 18.01 / 20.08 / 22.15 (INFGEN_LP_MAX_GROUPS moves the limit)
-  static const int max_groups = getenv("INFGEN_LP_MAX_GROUPS") ? atoi(getenv("INFGEN_LP_MAX_GROUPS")) : 128;
+  const int max_groups = lp_max_groups();
   return g_layers_p && !edgeless && O().edge_fuse != 0 && O().attn_mode != 0 && O().gemm_terms == 3 && O().fourier_mode != 0 &&
          !(O().overlap && g_side) && !O().row_groups && r->A_cap % 16 == 0 && rows / 16 <= n_cu && rows / 16 <= max_groups &&
          rows / 16 <= 256 && r->num_layers <= LP_MAX_LAYERS && r->U && r->SIG;
@@ -1117,8 +1121,12 @@ static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, vo
   const int rows = r->S * r->A_cap;
   LayersPArgs a;
   a.rows = rows; a.A_cap = r->A_cap; a.num_layers = r->num_layers;
-  const int gps = r->A_cap / 16;
-  a.xcd_order = (rows / 16) % (8 * gps) == 0 ? 1 : 0;
+  // 8 rows per workgroup while that keeps the launch within the group limit (twice the workgroups, half the edge loop each)
+  static const int lp_rows8 = getenv("INFGEN_LP_ROWS8") ? atoi(getenv("INFGEN_LP_ROWS8")) : 1;
+  a.rows_per_wg = (lp_rows8 && r->A_cap % 8 == 0 && rows / 8 <= lp_max_groups()) ? 8 : 16;
+  const int gps = r->A_cap / a.rows_per_wg;
+  const int n_wg = rows / a.rows_per_wg;
+  a.xcd_order = n_wg % (8 * gps) == 0 ? 1 : 0;
   a.X = r->X;
   for (int i = 0; i < r->num_layers; ++i) {
     a.attn_t[i] = r->attn_t[i]; a.attn_m[i] = r->attn_m[i]; a.attn_a[i] = r->attn_a[i];
@@ -1143,8 +1151,8 @@ static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, vo
   if (hipMemsetAsync(a.sync, 0, (size_t)r->S * sizeof(int), (hipStream_t)stream) != hipSuccess)
     return fail("infgen_decode_layers", "memset failed");
   { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
-    if (sm.r24) hipLaunchKernelGGL(k_layers_p<true>, dim3(rows / 16), dim3(512), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_layers_p<false>, dim3(rows / 16), dim3(512), 0, (hipStream_t)stream, a); }
+    if (sm.r24) hipLaunchKernelGGL(k_layers_p<true>, dim3(n_wg), dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_layers_p<false>, dim3(n_wg), dim3(512), 0, (hipStream_t)stream, a); }
   if (lp_trace) {          // synchronous dump of the last launch's stamps (diagnostic runs only)
     static int dumps = 0;
     if (dumps++ == lp_trace) {

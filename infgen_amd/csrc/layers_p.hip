@@ -161,7 +161,10 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int j = lane & 15, rg = lane >> 4;
-  const int gps = a.A_cap / 16;                                         // workgroups (16-row groups) per scene
+  // R rows per workgroup: 16, or 8 for the smallest batches (twice the workgroups: ONE row per wave in the edge loop, the phase the
+  // agent sublayers spend most of their time in; lanes j >= 8 then shadow rows j - 8 - same loads, no stores, never read)
+  const int R = a.rows_per_wg;
+  const int gps = a.A_cap / R;                                          // workgroups per scene
   const int L = a.num_layers;
   // a scene's workgroups on ONE XCD (consecutive workgroups go to consecutive XCDs): its K / V rows and its counter share an L2
   int grp = blockIdx.x;
@@ -169,7 +172,8 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
     const int per = 8 * gps, bq = grp / per, br = grp % per;
     grp = bq * per + (br % 8) * gps + br / 8;
   }
-  const int r0 = 16 * grp, row = r0 + j;
+  const int r0 = R * grp, row = r0 + (j & (R - 1));
+  const bool own_row = j < R;                                           // (this lane's row is not a shadow: it may store)
   const int scene = r0 / a.A_cap;
   const int own = 16 * w + 4 * rg;                                      // this lane's four features
   int* ctr = a.sync + scene;
@@ -216,12 +220,13 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
   // (two halves: the loads' return is in order, so whoever consumes a load waits for every load issued before it - the counts /
   // offsets are requested BEFORE a batch of weight fragments and consumed after the GEMMs that wait for those fragments anyway)
   auto edge_lists_request = [&](const EdgeSet& es) __attribute__((always_inline)) {
-    el_cnt = es.cnt[r0 + (lane & 15)];
-    el_off = es.off[r0 + (lane & 15)];
+    el_cnt = es.cnt[r0 + (lane & (R - 1))];
+    el_off = es.off[r0 + (lane & (R - 1))];
   };
   auto edge_lists_resolve = [&](const EdgeSet& es) __attribute__((always_inline)) {
     const int rl = lane & 15;
-    const int cnt = el_cnt, off = el_off;
+    const int off = el_off;
+    const int cnt = rl < R ? el_cnt : -1;                        // (shadow rows rank last: ranks 0 .. R - 1 are the real rows)
     int rank = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int want = i == 0 ? w : 15 - w;
+      const int want = i == 0 ? w : 15 - w;                       // (R = 8: the second row does not exist, the edge loop skips it)
       const unsigned long long m = __ballot(rank == want && lane < 16);
       const int r = __builtin_ctzll(m);
       eR[i] = r;
@@ -262,8 +267,10 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
       f32x4 vv = gemm_tiles(fc, FRx, SCx, lane);
       kk = kk * splat4(hdr[2]);
       vv = fma4(vv, splat4(hdr[3]), lds4(Vt + VT_N_BV + own));
-      *reinterpret_cast<float4*>(nK + (size_t)row * D + own) = make_float4(kk[0], kk[1], kk[2], kk[3]);
-      *reinterpret_cast<float4*>(nV + (size_t)row * D + own) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      if (own_row) {
+        *reinterpret_cast<float4*>(nK + (size_t)row * D + own) = make_float4(kk[0], kk[1], kk[2], kk[3]);
+        *reinterpret_cast<float4*>(nV + (size_t)row * D + own) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      }
     }
     STAMP(19);
     // u_w = q_w W'_kr,w (attn_hs.hip / edge_fused.hip phase 1): K = 16, the head's query is this wave's own tile
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
         const unsigned lo = __builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(rowp + R24_LO_PLANE + 2 * lane));
         return pk2{__uint_as_float((hi << 16) | ((lo & 0xffu) << 8)), __uint_as_float((hi & 0xffff0000u) | (lo & 0xff00u))};
       };
-      for (int ri = 0; ri < 2; ++ri) {
+      for (int ri = 0; ri < (R == 16 ? 2 : 1); ++ri) {
         const int rl = ri == 0 ? eR[0] : eR[1];
         const int E = ri == 0 ? eE[0] : eE[1];
         const int e_base = ri == 0 ? eB[0] : eB[1];
@@ -551,7 +558,7 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
     STAMP(0);
     sublayer(es, es_next, Ksrc, Vsrc, kind == 0, P, NP, nK, nV);
   }
-  *reinterpret_cast<float4*>(a.X + (size_t)row * D + own) = make_float4(x[0], x[1], x[2], x[3]);
+  if (own_row) *reinterpret_cast<float4*>(a.X + (size_t)row * D + own) = make_float4(x[0], x[1], x[2], x[3]);
 }
 
 template __global__ void k_layers_p<true>(LayersPArgs);
