@@ -15,7 +15,7 @@ import os, sys
 sys.path.insert(0, %r)
 from infgen_amd import _lib
 if os.environ.get("EXP_LIB_BENCH"): _lib.LIB_PATH = os.path.join(%r, os.environ["EXP_LIB_BENCH"])
-sys.argv = ["bench.py", "--no-cpu-baseline", "--no-parity", "--no-literal", "--scenes", %r, "--steps", "5"] + %r
+sys.argv = ["bench.py", "--no-cpu-baseline", "--no-parity", "--no-literal", "--no-strict", "--scenes", %r, "--steps", "5"] + %r
 import runpy; runpy.run_path(os.path.join(%r, "bench.py"), run_name="__main__")
 ''' % (root, root, scenes, extra, root)
 for rep in range(reps):
