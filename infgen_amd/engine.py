@@ -1356,6 +1356,24 @@ def rollout_many(engines: Sequence[RolloutEngine], streams: Optional[Sequence[to
         for e in engines:
             e.rollout()
         return
+    # k_layers_p's workgroups of one launch meet at per-scene counters and must all be resident; launches of SEVERAL streams share
+    # the CUs, so together they must not exceed them either (two launches each half resident would wait for each other for ever)
+    def _lp_wgs(e):
+        for r in (8, 16):
+            if e.rows % r == 0 and e.rows // r <= 128:
+                return e.rows // r
+        return 0
+    guard = sum(_lp_wgs(e) for e in engines) > 256
+    if guard:
+        _lib.check(engines[0].lib.infgen_set_layers_p(0), 'infgen_set_layers_p')
+    try:
+        return _rollout_many_streams(engines, streams, dev)
+    finally:
+        if guard and os.environ.get('INFGEN_LAYERS_P', '1') != '0':
+            _lib.check(engines[0].lib.infgen_set_layers_p(1), 'infgen_set_layers_p')
+
+
+def _rollout_many_streams(engines, streams, dev):
     cur = torch.cuda.current_stream(dev)
     if all(e._graph_all and not e.insertion for e in engines):
         # whole-rollout graphs: one replay per engine, nothing for the host to sequence
