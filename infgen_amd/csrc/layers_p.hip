@@ -34,6 +34,24 @@
 #ifndef IG_LP_NOLOAD
 #define IG_LP_NOLOAD 0
 #endif
+#ifndef IG_LP_NOLOAD
+#define IG_LP_NOLOAD 0           // timing experiments (wrong results): 1 no weight-fragment loads, IG_LP_NOMFMA no products in the
+#endif                          // GEMM stages, IG_LP_NOEDGE empty edge lists - what each costs in wall time
+#ifndef IG_LP_NOMFMA
+#define IG_LP_NOMFMA 0
+#endif
+#ifndef IG_LP_NOAUX
+#define IG_LP_NOAUX 0            // (timing) no W'kr / W'vr loads, IG_LP_NOSYNC no scene counter, IG_LP_NOKV no K / V stores
+#endif
+#ifndef IG_LP_NOSYNC
+#define IG_LP_NOSYNC 0
+#endif
+#ifndef IG_LP_NOKV
+#define IG_LP_NOKV 0
+#endif
+#ifndef IG_LP_NOEDGE
+#define IG_LP_NOEDGE 0
+#endif
 #ifndef IG_LP_TRACE
 #define IG_LP_TRACE 0          // 1: s_memtime stamps at the phase boundaries (tools/lp_trace.py; build with -DIG_LP_TRACE=1)
 #endif
@@ -49,6 +67,10 @@ constexpr int LP_G = 6;                    // edges per trip of the edge loop
 struct AFragP {                // the four k-steps of ONE feature tile of a 128 x 128 matrix (attn_hs.hip: AFrag)
   v8h h[4], l[4];
   __device__ __forceinline__ void load(const unsigned short* W, int w, int lane) {
+#if IG_LP_NOLOAD
+    asm volatile("" : "+v"(h[0]), "+v"(l[0]));
+    return;
+#endif
 #if IG_LP_NOLOAD          // timing experiment (wrong results): the node part without its weight stream
     asm volatile("" : "+v"(h[0]), "+v"(l[0]));
     return;
@@ -109,6 +131,9 @@ __device__ __forceinline__ f32x4 gemm_tiles(const AFragP& f, const uint4* FR, co
   __builtin_amdgcn_sched_barrier(0);           // (independent GEMMs side by side would multiply the live fragments / accumulators)
   const int j = lane & 15;
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#if IG_LP_NOMFMA
+  { const uint4 b0 = FR[lane]; o[0] = __uint_as_float(b0.x) + SC[j * 8] + (float)f.h[0][0]; return o; }
+#endif
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const float4 sv = *reinterpret_cast<const float4*>(SC + j * 8 + 4 * g);
@@ -267,7 +292,7 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
       f32x4 vv = gemm_tiles(fc, FRx, SCx, lane);
       kk = kk * splat4(hdr[2]);
       vv = fma4(vv, splat4(hdr[3]), lds4(Vt + VT_N_BV + own));
-      if (own_row) {
+      if (own_row && !IG_LP_NOKV) {
         *reinterpret_cast<float4*>(nK + (size_t)row * D + own) = make_float4(kk[0], kk[1], kk[2], kk[3]);
         *reinterpret_cast<float4*>(nV + (size_t)row * D + own) = make_float4(vv[0], vv[1], vv[2], vv[3]);
       }
@@ -279,8 +304,12 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
       v4h ah[8], al[8];
 #pragma unroll
       for (int ct = 0; ct < 8; ++ct) {
+#if IG_LP_NOAUX
+        asm volatile("" : "=v"(ah[ct]), "=v"(al[ct]));
+#else
         ah[ct] = *reinterpret_cast<const v4h*>(Wk + (ct * 2) * 256);
         al[ct] = *reinterpret_cast<const v4h*>(Wk + (ct * 2 + 1) * 256);
+#endif
       }
       *reinterpret_cast<float4*>(AG + j * LP_LDA + own) = make_float4(q[0], q[1], q[2], q[3]);
       float m = fmaxf(fmaxf(fabsf(q[0]), fabsf(q[1])), fmaxf(fabsf(q[2]), fabsf(q[3])));
@@ -339,7 +368,7 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
       };
       for (int ri = 0; ri < (R == 16 ? 2 : 1); ++ri) {
         const int rl = ri == 0 ? eR[0] : eR[1];
-        const int E = ri == 0 ? eE[0] : eE[1];
+        const int E = IG_LP_NOEDGE ? 0 : (ri == 0 ? eE[0] : eE[1]);
         const int e_base = ri == 0 ? eB[0] : eB[1];
         int sv = ri == 0 ? eS[0] : eS[1];
         float* uz = UZ + rl * LP_LDU;
@@ -384,8 +413,12 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
       const unsigned short* Wv = post + (size_t)(w >> 1) * QUARTER + (size_t)((w & 1) * 4) * 2 * 512 + lane * 8;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+#if IG_LP_NOAUX
+        asm volatile("" : "=v"(p3h[s]), "=v"(p3l[s]));
+#else
         p3h[s] = *reinterpret_cast<const v8h*>(Wv + (s * 2) * 512);
         p3l[s] = *reinterpret_cast<const v8h*>(Wv + (s * 2 + 1) * 512);
+#endif
       }
     }
     wg_barrier();
@@ -543,7 +576,7 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
     float* nK = kind == 0 ? nullptr : kind == 1 ? Ka : last ? nullptr : a.ringK[i + 1] + a.slot_off;
     float* nV = kind == 0 ? nullptr : kind == 1 ? Va : last ? nullptr : a.ringV[i + 1] + a.slot_off;
     STAMP(30 + kind);
-    if (kind == 2) {
+    if (kind == 2 && !IG_LP_NOSYNC) {
       // the scene's K / V rows of this layer: every workgroup of the scene has written its 16 before any reads them
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __syncthreads();

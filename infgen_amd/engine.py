@@ -1092,7 +1092,17 @@ class RolloutEngine:
             if t > 0:
                 yield from self._insert_step(t)
             self._decoded_rows.add_(self.n_agents.sum())       # A_t: rows decoded at this step, incl. the inserted ones
+            tight = use_groups and os.environ.get('INFGEN_ROW_GROUPS_TIGHT', '1') != '0'
+            if tight:
+                # the step's insertions are done: the motion stage runs on exactly the rows that hold agents now - the ten rows of
+                # head-room the sub-loop's lists carry put one more 16-row group per scene into 60 % of the node / edge launches
+                _lib.check(lib.infgen_active_row_groups(_lib.ptr(self.n_agents), self.S, self.A_cap, 0,
+                                                        _lib.ptr(I['groups']), _lib.ptr(I['n_groups']), self.ops.stream),
+                           'infgen_active_row_groups')
+                self._ctx.opts.row_group_margin = 0
             self.step(t)
+            if tight:
+                self._ctx.opts.row_group_margin = 10
 
     def _run_graph(self, t0, t1):
         """the decode steps as a HIP-graph replay.  Replays launched into the LEGACY DEFAULT stream fault now and then on this
