@@ -583,7 +583,14 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
       if (tid == 0) {
         __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int target = (i + 1) * gps;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+        // (a launch whose workgroups are not all resident - more concurrent k_layers_p launches than CUs, see api.hip / engine.py
+        // rollout_many - would wait here for ever and take the GPU with it: after ~0.2 s of spinning the kernel traps instead, the
+        // next HIP call of the process fails loudly)
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 22)) __builtin_trap();
+        }
       }
       __syncthreads();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

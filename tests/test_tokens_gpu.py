@@ -1,5 +1,11 @@
 """GPU: device-side agent tokenisation through the C ABI against the golden vectors of the
-reference's own TokenProcessor._match_agent_token and against the oracle on fresh seeded tracks."""
+reference's own TokenProcessor._match_agent_token and against the oracle on fresh seeded tracks.
+
+Why a tie criterion and not array_equal on the ids: the reference's cos / sin come from torch's CPU kernels, which on an MKL build
+(the build container's) are Intel MKL VML's vsSin / vsCos - closed source, 2.3 % of the arguments an ulp away from Sleef's u10
+kernels and 4.9 % from the correctly rounded value (tools/sincos_provenance/, profiles/r04_sincos_provenance.log).
+There is no platform-independent bit pattern to restate; where an id differs, the two candidates must tie in the reference's own
+matching cost."""
 import os
 
 import numpy as np
