@@ -40,6 +40,9 @@
 #ifndef IG_LP_NOMFMA
 #define IG_LP_NOMFMA 0
 #endif
+#ifndef IG_LP_X32
+#define IG_LP_X32 7              // bit 0: W1 on 16x16x32 products (one scale per row of LN_ffpre(x)); bit 1: q / k / v, gate-x, self too
+#endif                          // (LN_dst(x)); bit 2: W2 (the hidden layer's row maxima exchanged first)
 #ifndef IG_LP_NOAUX
 #define IG_LP_NOAUX 0            // (timing) no W'kr / W'vr loads, IG_LP_NOSYNC no scene counter, IG_LP_NOKV no K / V stores
 #endif
@@ -108,6 +111,37 @@ __device__ __forceinline__ void publish_stats(f32x4 v, float2* ST, int w, int la
   const float m2 = xor_lanes(fmaf(d0, d0, d1 * d1) + fmaf(d2, d2, d3 * d3));
   if ((lane >> 4) == 0) ST[(lane & 15) * 8 + w] = make_float2(mt, m2);
 }
+// (x32 path) the same plus the tile's largest |value - tile mean| + |tile mean| bound pieces: (min, max) of the tile, in a second
+// array - every wave derives the SAME bound of the row's LayerNorm output from the eight pairs
+__device__ __forceinline__ void publish_minmax(f32x4 v, float2* MM, int w, int lane) {
+  const float mx = xor_lanes_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+  const float mn = -xor_lanes_max(-fminf(fminf(v[0], v[1]), fminf(v[2], v[3])));
+  if ((lane >> 4) == 0) MM[(lane & 15) * 8 + w] = make_float2(mn, mx);
+}
+__device__ __forceinline__ float row_dev(const float2* MM, int j, float mean) {
+  const float4* p = reinterpret_cast<const float4*>(MM + j * 8);
+  const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+  const float lo = fminf(fminf(fminf(a.x, a.z), fminf(b.x, b.z)), fminf(fminf(c.x, c.z), fminf(d.x, d.z)));
+  const float hi = fmaxf(fmaxf(fmaxf(a.y, a.w), fmaxf(b.y, b.w)), fmaxf(fmaxf(c.y, c.w), fmaxf(d.y, d.w)));
+  return fmaxf(hi - mean, mean - lo);
+}
+// A GEMM operand whose rows have ONE scale for all eight tiles multiplies on v_mfma_f32_16x16x32_f16 (tiles 2 s, 2 s + 1 are the
+// halves of k-step s): 12 instead of 24 matrix instructions per GEMM and wave.  LayerNorm outputs get that scale without another
+// exchange: |LN(x)_i| <= dev * rstd * max|gamma| + max|beta|, dev = max_i |x_i - mean| from the per-tile (min, max) that travel
+// with the statistics, max|gamma| / max|beta| from the pack header (packing.py) - every wave derives the same power of two.  (A
+// value far below the bound keeps its 22 bits unless its low half goes subnormal: absolute error <= 2^-39 of the bound.)
+__device__ __forceinline__ unsigned scale_bits(float bound) {
+  unsigned eb = __float_as_uint(bound) >> 23;
+  return min(max(eb, 15u), 253u);
+}
+__device__ __forceinline__ float scale_inv(unsigned eb) { return __uint_as_float((eb - 14u) << 23); }
+__device__ __forceinline__ void publish_frag_common(f32x4 v, uint4* FR, unsigned eb, int w, int lane) {
+  const float sc = __uint_as_float((268u - eb) << 23);
+  unsigned h0, l0, h1, l1;
+  split_pair(v[0] * sc, v[1] * sc, h0, l0);
+  split_pair(v[2] * sc, v[3] * sc, h1, l1);
+  FR[w * 64 + lane] = make_uint4(h0, h1, l0, l1);
+}
 // merged over the eight tiles: mean and 1 / sqrt(var + eps) of row j (biased variance, eps 1e-5: split.cuh ln_stats)
 __device__ __forceinline__ void row_stats(const float2* ST, int j, float& mean, float& rstd) {
   const float4* p = reinterpret_cast<const float4*>(ST + j * 8);
@@ -170,6 +204,31 @@ __device__ __forceinline__ f32x4 gemm_tiles(const AFragP& f, const uint4* FR, co
   return o;
 }
 
+// x32 path: out tile w (unscaled) = W[16 w .., :] x B, B read from the published fragments (tiles 2 s | 2 s + 1 = k-step s)
+__device__ __forceinline__ f32x4 gemm32(const AFragP& f, const uint4* FR, int lane) {
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc[4];
+  u32x4 bh[4], bl[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4 t0 = FR[(2 * s) * 64 + lane], t1 = FR[(2 * s + 1) * 64 + lane];
+    bh[s] = u32x4{t0.x, t0.y, t1.x, t1.y};
+    bl[s] = u32x4{t0.z, t0.w, t1.z, t1.w};
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.h[s], __builtin_bit_cast(v8h, bh[s]), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.h[s], __builtin_bit_cast(v8h, bl[s]), acc[s], 0, 0, 0);
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.l[s], __builtin_bit_cast(v8h, bh[s]), acc[s], 0, 0, 0);
+  const f32x4 o = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __builtin_amdgcn_sched_barrier(0);
+  return o;
+}
+
 }  // namespace
 
 template <bool R24>
@@ -182,6 +241,8 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
   __shared__ __attribute__((aligned(16))) uint4 FRp[2][512];
   __shared__ __attribute__((aligned(16))) float SCx[128], SCp[2][128], SCH[4][128];
   __shared__ __attribute__((aligned(16))) float2 STp[2][128];
+  __shared__ __attribute__((aligned(16))) float2 MMp[2][128];           // (x32 path) per-tile (min, max), with the statistics
+  __shared__ __attribute__((aligned(16))) float HM[128];                 // (x32 path) the hidden layer's per-(row, wave) maxima
   uint4* FRH = reinterpret_cast<uint4*>(UZ);                            // [4][512] (32 KB of the 66 KB tile)
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -203,6 +264,7 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
   const int own = 16 * w + 4 * rg;                                      // this lane's four features
   int* ctr = a.sync + scene;
   int fp = 0, sp = 0;                                                   // ping-pong indices of FRp / SCp and STp
+  float inv_x = 1.0f;                                                   // (x32 path) inverse scale of the rows' LN_dst(x) fragments
   // diagnostics (INFGEN_LP_TRACE): s_memtime stamps of workgroup 0's wave 0 at the phase boundaries -> a.trace[]
   int n_trace = 0;
   auto STAMP = [&](int id) __attribute__((always_inline)) {
@@ -277,19 +339,27 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
     const float* hdr = Vt + VT_N_HDR;
     STAMP(16);
     publish_stats(x, STp[sp], w, lane);
+    if (IG_LP_X32 & 2) publish_minmax(x, MMp[sp], w, lane);
     wg_barrier();
     STAMP(17);
     float mean, rstd;
-    row_stats(STp[sp], j, mean, rstd); sp ^= 1;
+    row_stats(STp[sp], j, mean, rstd);
     const f32x4 xn = ln_own(x, mean, rstd, Vt + VT_N_LN_G + own, Vt + VT_N_LN_B + own);
-    publish_frag(xn, FRx, SCx, w, lane);
+    if (IG_LP_X32 & 2) {
+      const unsigned ebx = scale_bits(fmaf(row_dev(MMp[sp], j, mean) * rstd, hdr[12], hdr[13]));
+      inv_x = scale_inv(ebx);
+      publish_frag_common(xn, FRx, ebx, w, lane);
+    } else {
+      publish_frag(xn, FRx, SCx, w, lane);
+    }
+    sp ^= 1;
     wg_barrier();
     STAMP(18);
-    f32x4 q = gemm_tiles(fa, FRx, SCx, lane);
+    f32x4 q = (IG_LP_X32 & 2) ? gemm32(fa, FRx, lane) * splat4(inv_x) : gemm_tiles(fa, FRx, SCx, lane);
     q = fma4(q, splat4(hdr[0]), lds4(Vt + VT_N_BQ + own));
     if (nK) {
-      f32x4 kk = gemm_tiles(fb, FRx, SCx, lane);
-      f32x4 vv = gemm_tiles(fc, FRx, SCx, lane);
+      f32x4 kk = (IG_LP_X32 & 2) ? gemm32(fb, FRx, lane) * splat4(inv_x) : gemm_tiles(fb, FRx, SCx, lane);
+      f32x4 vv = (IG_LP_X32 & 2) ? gemm32(fc, FRx, lane) * splat4(inv_x) : gemm_tiles(fc, FRx, SCx, lane);
       kk = kk * splat4(hdr[2]);
       vv = fma4(vv, splat4(hdr[3]), lds4(Vt + VT_N_BV + own));
       if (own_row && !IG_LP_NOKV) {
@@ -463,9 +533,9 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
     {
       const f32x4 ga = gemm_tiles(fa, FRp[fp], SCp[fp], lane);
       fa.load(post + 16 * QUARTER, w, lane);                          // Wo
-      const f32x4 gx = gemm_tiles(fb, FRx, SCx, lane);
+      const f32x4 gx = (IG_LP_X32 & 2) ? gemm32(fb, FRx, lane) * splat4(inv_x) : gemm_tiles(fb, FRx, SCx, lane);
       fb.load(post + 20 * QUARTER, w, lane);                          // W1, chunk 0
-      const f32x4 sf = gemm_tiles(fc, FRx, SCx, lane);
+      const f32x4 sf = (IG_LP_X32 & 2) ? gemm32(fc, FRx, lane) * splat4(inv_x) : gemm_tiles(fc, FRx, SCx, lane);
       fc.load(post + (size_t)28 * QUARTER, w, lane);                  // W1, chunk 1
       fp ^= 1;
       const f32x4 bg = lds4(Vt + VT_BG + own), bs = lds4(Vt + VT_BS + own);
@@ -495,36 +565,64 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
     }
     {
       publish_stats(x, STp[sp], w, lane);
+      if (IG_LP_X32 & 1) publish_minmax(x, MMp[sp], w, lane);
       wg_barrier();
       STAMP(10);
       float mean, rstd;
-      row_stats(STp[sp], j, mean, rstd); sp ^= 1;
+      row_stats(STp[sp], j, mean, rstd);
       const f32x4 fin = ln_own(x, mean, rstd, Vt + VT_LNF_G + own, Vt + VT_LNF_B + own);
-      publish_frag(fin, FRp[fp], SCp[fp], w, lane);
+      float inv_f = 1.0f;
+      if (IG_LP_X32 & 1) {
+        const unsigned ebf = scale_bits(fmaf(row_dev(MMp[sp], j, mean) * rstd, hdr[10], hdr[11]));
+        inv_f = scale_inv(ebf);
+        publish_frag_common(fin, FRp[fp], ebf, w, lane);
+      } else {
+        publish_frag(fin, FRp[fp], SCp[fp], w, lane);
+      }
+      sp ^= 1;
       wg_barrier();
       STAMP(11);
+      f32x4 hd4[4];
+      float inv_h = 1.0f;
       // FFN: the four 128-wide chunks of the hidden layer (tile w of each), published as fragments behind ONE barrier
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
-        f32x4 hd = cc == 1 ? gemm_tiles(fc, FRp[fp], SCp[fp], lane) : cc == 2 ? gemm_tiles(fa, FRp[fp], SCp[fp], lane)
-                                                                                : gemm_tiles(fb, FRp[fp], SCp[fp], lane);
+        f32x4 hd;
+        if (IG_LP_X32 & 1) hd = (cc == 1 ? gemm32(fc, FRp[fp], lane) : cc == 2 ? gemm32(fa, FRp[fp], lane) : gemm32(fb, FRp[fp], lane)) * splat4(inv_f);
+        else hd = cc == 1 ? gemm_tiles(fc, FRp[fp], SCp[fp], lane) : cc == 2 ? gemm_tiles(fa, FRp[fp], SCp[fp], lane)
+                                                                          : gemm_tiles(fb, FRp[fp], SCp[fp], lane);
         if (cc == 0) fb.load(post + (size_t)44 * QUARTER, w, lane);   // W1, chunk 3
         if (cc == 1) fc.load(post + (size_t)24 * QUARTER, w, lane);   // W2, chunk 0
         if (cc == 2) fa.load(post + (size_t)32 * QUARTER, w, lane);   // W2, chunk 1
         if (cc == 3) fb.load(post + (size_t)40 * QUARTER, w, lane);   // W2, chunk 2
         hd = fma4(hd, splat4(hdr[8]), lds4(Vt + VT_B1 + 128 * cc + own));
         hd = __builtin_elementwise_max(hd, splat4(0.f));
-        publish_frag(hd, FRH + cc * 512, SCH[cc], w, lane);
+        if (IG_LP_X32 & 4) hd4[cc] = hd;
+        else publish_frag(hd, FRH + cc * 512, SCH[cc], w, lane);
       }
       fp ^= 1;
+      if (IG_LP_X32 & 4) {
+        // one scale per row for the whole hidden layer: the waves exchange their per-row maxima first (one more barrier)
+        const f32x4 m4 = __builtin_elementwise_max(__builtin_elementwise_max(hd4[0], hd4[1]), __builtin_elementwise_max(hd4[2], hd4[3]));
+        const float mo = xor_lanes_max(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])));      // (ReLU outputs: no fabs)
+        if (rg == 0) HM[j * 8 + w] = mo;
+        wg_barrier();
+        const float4 hm0 = *reinterpret_cast<const float4*>(HM + j * 8), hm1 = *reinterpret_cast<const float4*>(HM + j * 8 + 4);
+        const unsigned ebh = scale_bits(fmaxf(fmaxf(fmaxf(hm0.x, hm0.y), fmaxf(hm0.z, hm0.w)), fmaxf(fmaxf(hm1.x, hm1.y), fmaxf(hm1.z, hm1.w))));
+        inv_h = scale_inv(ebh);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) publish_frag_common(hd4[cc], FRH + cc * 512, ebh, w, lane);
+      }
       STAMP(12);
       wg_barrier();
       STAMP(13);
       f32x4 f = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
-        const f32x4 part = cc == 1 ? gemm_tiles(fa, FRH + cc * 512, SCH[cc], lane) : cc == 2 ? gemm_tiles(fb, FRH + cc * 512, SCH[cc], lane)
-                                                                                          : gemm_tiles(fc, FRH + cc * 512, SCH[cc], lane);
+        f32x4 part;
+        if (IG_LP_X32 & 4) part = (cc == 1 ? gemm32(fa, FRH + cc * 512, lane) : cc == 2 ? gemm32(fb, FRH + cc * 512, lane) : gemm32(fc, FRH + cc * 512, lane)) * splat4(inv_h);
+        else part = cc == 1 ? gemm_tiles(fa, FRH + cc * 512, SCH[cc], lane) : cc == 2 ? gemm_tiles(fb, FRH + cc * 512, SCH[cc], lane)
+                                                                                  : gemm_tiles(fc, FRH + cc * 512, SCH[cc], lane);
         // W2 chunk 3, then the next layer's Wq, Wk, Wv - unconditional (a sublayer without a pre part / without k, v re-reads
         // matrices it ignores): a conditional load is a basic block of its own whose results hipcc merges with copies and waits
         if (cc == 0) fc.load(post + (size_t)48 * QUARTER, w, lane);

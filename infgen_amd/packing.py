@@ -86,6 +86,10 @@ def pack_attention_layer(sd, prefix: str, has_pos_emb: bool = True) -> np.ndarra
     sc = [pow2(wq), pow2(wkr_) if has_pos_emb else 1.0, pow2(wk), pow2(wv), pow2(wvr_) if has_pos_emb else 1.0,
           pow2(wg), pow2(ws), pow2(wo), pow2(w1), pow2(w2)]
     hdr[:10] = [1.0 / v for v in sc]
+    # [10..13]: largest |gamma|, |beta| of ff_prenorm and of attn_prenorm_x_dst - k_layers_p bounds a row's LayerNorm output with them
+    # (one power-of-two scale per row for the fp16 split of a GEMM operand, csrc/layers_p.hip: scale_bits)
+    hdr[10], hdr[11] = np.abs(g('ff_prenorm.weight')).max(), np.abs(g('ff_prenorm.bias')).max()
+    hdr[12], hdr[13] = np.abs(g('attn_prenorm_x_dst.weight')).max(), np.abs(g('attn_prenorm_x_dst.bias')).max()
     pre = [pack_matrix_h(wq * sc[0], natural_k=False), pack_wkr_h(wkr_ * sc[1]),
            pack_matrix_h(wk * sc[2], natural_k=False), pack_matrix_h(wv * sc[3], natural_k=False)]
     post = [pack_wvr_h(wvr_ * sc[4]), pack_matrix_h(wg[:, :128] * sc[5], natural_k=False),
