@@ -65,7 +65,10 @@ namespace {
 
 constexpr int LP_LDU = H * D + 4;          // row stride of the U / Z tile in floats (k_edge_fused's)
 constexpr int LP_LDA = D + 4;
-constexpr int LP_G = 6;                    // edges per trip of the edge loop
+#ifndef IG_LP_G
+#define IG_LP_G 6
+#endif
+constexpr int LP_G = IG_LP_G;              // edges per trip of the edge loop
 
 struct AFragP {                // the four k-steps of ONE feature tile of a 128 x 128 matrix (attn_hs.hip: AFrag)
   v8h h[4], l[4];
