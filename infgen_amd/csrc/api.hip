@@ -1049,9 +1049,11 @@ static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless) {
   // groups the XCDs' L2s saturate (every workgroup streams each sublayer's 1.1 MB of weight fragments: 35 MB per XCD and sublayer
   // at 256 groups) and the per-sublayer launches are faster again: 8 / 16 / 32 / 48 / 64 scenes of 64 agents 12.98 / 14.31 /
   // 17.27 / 20.50 / 23.90 ms per rollout against 15.41 / 16.44 / 18.01 / 20.08 / 22.15 (INFGEN_LP_MAX_GROUPS moves the limit)
+  // (a row-group list of an insertion context is ignored: the launch visits every group - the ones without agents have empty edge
+  // lists and run in parallel on CUs that would idle)
   const int max_groups = lp_max_groups();
   return g_layers_p && !edgeless && O().edge_fuse != 0 && O().attn_mode != 0 && O().gemm_terms == 3 && O().fourier_mode != 0 &&
-         !(O().overlap && g_side) && !O().row_groups && r->A_cap % 16 == 0 && rows / 16 <= n_cu && rows / 16 <= max_groups &&
+         !(O().overlap && g_side) && r->A_cap % 16 == 0 && rows / 16 <= n_cu && rows / 16 <= max_groups &&
          rows / 16 <= 256 && r->num_layers <= LP_MAX_LAYERS && r->U && r->SIG;
 }
 
