@@ -263,26 +263,28 @@ class InfGenDecoder(nn.Module):
             if shape not in zero:
                 zero[shape] = torch.zeros(*shape, device=dev)
             return zero[shape]
-        for d, o in zip(datas, outs):
-            n_map = o.pop('x_pt')
-            r = dict(o)
+        T_cols = w.cfg.num_columns
+        for i_, (d, o) in enumerate(zip(datas, outs)):
+            r = o                                   # (a LazyOut: per-scene views are cut when a key is read, not here)
             # without insertion (or in the batched entry) these stay what the reference initialises them to (:1746-1750, :1730)
             for k_, shp_ in (('next_state_prob_seed', (11, steps)), ('next_pos_rel_prob_seed', (11, steps, G)),
                              ('grid_agent_occ_seed', (11, steps, G)), ('grid_pt_occ_seed', (11, steps, G)),
                              ('grid_agent_occ_gt_seed', (11, steps, G))):
                 if k_ not in r:
                     r[k_] = z(*shp_)
-            r.setdefault('agent_labels', [[None] * w.cfg.num_columns for _ in range(o['pos_a'].shape[0])])
+            if 'agent_labels' not in r:
+                r.set_lazy('agent_labels', (lambda n=eng.hosts[i_]['A'] + o['num_inserted']: [[None] * T_cols for _ in range(n)]))
             r['log_message'] = ('No agents inserted!' if o['num_inserted'] == 0 else
                                 f"Number of total inserted agents: {o['num_inserted']}")
             # the callee mutates data['batch_size_a'] like the reference (agent_decoder.py:1649)
             try:
-                filt = eng.hosts[len(res)]['filt']
-                av0 = int(np.asarray(scenes[len(res)]['agent']['av_index']).reshape(-1)[0])
-                d['batch_size_a'] -= int((~filt[:av0]).sum())
+                filt = eng.hosts[i_]['filt']
+                av0 = int(np.asarray(scenes[i_]['agent']['av_index']).reshape(-1)[0])
+                removed = int((~filt[:av0]).sum())
+                if removed:
+                    d['batch_size_a'] -= removed
             except (KeyError, TypeError):
                 pass
-            r['_x_pt'] = n_map
             res.append(r)
         return res if batch is not None else res[0]
 
@@ -315,18 +317,18 @@ class InfGenDecoder(nn.Module):
         Greedy unless ``agent_encoder.motion_beam_size > 1``; then tokens are drawn by inverse CDF over the
         top-k probabilities with ``sample_uniforms`` ([steps][1][A]) or torch.rand when omitted."""
         r = self._run(data, sample_uniforms=sample_uniforms)
-        x_pt = r.pop('_x_pt')
+        x_pt = r.pop('x_pt')
         map_enc = {'x_pt': x_pt, 'map_next_token_idx': torch.zeros(0, 10, dtype=torch.long, device=x_pt.device),
                    'map_next_token_prob': torch.zeros(0, self.map_encoder.token_size, device=x_pt.device),
                    'map_next_token_idx_gt': torch.zeros(0, dtype=torch.long, device=x_pt.device),
                    'map_next_token_eval_mask': torch.zeros(0, dtype=torch.bool, device=x_pt.device)}
-        return {**map_enc, **r, **{k: data[k] for k in self.data_keys if k in data}}
+        return r.merged(first=map_enc, last={k: data[k] for k in self.data_keys if k in data})
 
     @torch.no_grad()
     def inference_no_map(self, data, map_enc) -> Dict[str, torch.Tensor]:
         r = self._run(data, x_pt=map_enc['x_pt'])
-        r.pop('_x_pt')
-        return {**map_enc, **r}
+        r.pop('x_pt')
+        return r.merged(first=map_enc)
 
     @torch.no_grad()
     def inference_rollouts(self, data, n: int) -> List[Dict[str, torch.Tensor]]:
@@ -351,6 +353,5 @@ class InfGenDecoder(nn.Module):
                     'map_next_token_idx_gt': torch.zeros(0, dtype=torch.long, device=dev),
                     'map_next_token_eval_mask': torch.zeros(0, dtype=torch.bool, device=dev)}
         for d, r in zip(datas, rs):
-            x_pt = r.pop('_x_pt')
-            out.append({'x_pt': x_pt, **map_keys, **r, **{k: d[k] for k in self.data_keys if k in d}})
+            out.append(r.merged(first=map_keys, last={k: d[k] for k in self.data_keys if k in d}))
         return out
