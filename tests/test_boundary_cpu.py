@@ -349,3 +349,28 @@ def test_stacked_host_setup_equals_the_per_scene_path():
     check(uniform, True)
     ragged = uniform[:7] + [synth.make_scene(77, 24, 100, cfg, vocab=vocab, grid=grid)] + uniform[7:]
     check(ragged, False)
+
+
+def test_lazy_out_behaves_like_the_dict_it_replaces():
+    """engine.LazyOut (the per-scene result of outputs_device / inference_batch): values are cut on first access, every dict
+    operation that could observe one resolves it - same keys, same values as the plain dict of rounds 1 - 3"""
+    from infgen_amd.engine import LazyOut
+    calls = []
+
+    def thunk(v):
+        return lambda: (calls.append(v), v)[1]
+    o = LazyOut({'a': 1}, {'b': thunk(2), 'c': thunk(3)})
+    assert set(o) == {'a', 'b', 'c'} and len(o) == 3 and 'b' in o and 'z' not in o and not calls
+    assert o['b'] == 2 and calls == [2] and o['b'] == 2 and calls == [2]          # resolved once
+    assert o.get('c') == 3 and o.get('z', 9) == 9
+    m = LazyOut({'a': 1}, {'b': thunk(20)}).merged(first={'x': 0, 'a': 5}, last={'y': 7})
+    assert 20 not in calls and list(m)[0] == 'x' and m['a'] == 1 and m['y'] == 7 and m['b'] == 20
+    assert dict(LazyOut({'a': 1}, {'b': thunk(30)})) == {'a': 1, 'b': 30}
+    assert {**LazyOut({'a': 1}, {'b': thunk(40)})} == {'a': 1, 'b': 40}
+    p = LazyOut({}, {'k': thunk(50)})
+    assert p.pop('k') == 50 and 'k' not in p and p.pop('k', None) is None
+    q = LazyOut({}, {'k': thunk(60)})
+    q['k'] = 61                                                                    # overwriting a pending value drops its thunk
+    assert q['k'] == 61 and 60 not in calls
+    assert q.setdefault('n', 5) == 5 and q.setdefault('n', 6) == 5
+    assert sorted(LazyOut({'a': 1}, {'b': thunk(70)}).items()) == [('a', 1), ('b', 70)]
