@@ -100,6 +100,8 @@ typedef struct InfgenOptions {
   int edge_loop;        /* infgen_set_edge_loop */
   int overlap;          /* infgen_set_overlap (the side stream itself is shared: keep 0 when contexts run concurrently) */
   int row_group_margin; /* rows a decode step may append (infgen_set_row_limits) */
+  int layers_p;         /* infgen_set_layers_p: 1 = small launches run a decode step's sublayers in one launch (k_layers_p) */
+  int _pad0;
   const int* row_groups; const int* n_row_groups;   /* optional list of the 16-row groups that hold agents (infgen_set_row_groups) */
 } InfgenOptions;
 
@@ -237,7 +239,8 @@ int infgen_set_overlap(int mode);
  * in one launch of k_layers_p (one resident workgroup per group, wave = feature tile; the scene's groups meet at a counter before
  * each agent sublayer) instead of 36 launches of k_edge_fused + k_attn_hs - same operators (infgen/modules/layers.py:61-113),
  * rounding-level differences only.  Needs fused edge attention (infgen_set_edge_fuse != 0), the split GEMM kernels and no
- * row-group list; otherwise the per-sublayer launches run. */
+ * row-group list; otherwise the per-sublayer launches run.  Process-wide default like the other infgen_set_*: a context with
+ * opts.use != 0 takes InfgenOptions.layers_p instead. */
 int infgen_set_layers_p(int mode);
 /* same with the kernel variant forced: wide = 1 -> one 8-wave workgroup per destination (long edge lists, few rows),
  * wide = 0 -> one wave per destination; infgen_edge_attn picks wide when rows <= 256 */

@@ -64,10 +64,10 @@ class Insertion(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [('use', _i), ('attn_mode', _i), ('gemm_terms', _i), ('fourier_mode', _i), ('edge_fuse', _i), ('edge_loop', _i),
-                ('overlap', _i), ('row_group_margin', _i), ('row_groups', _p), ('n_row_groups', _p)]
+                ('overlap', _i), ('row_group_margin', _i), ('layers_p', _i), ('_pad0', _i), ('row_groups', _p), ('n_row_groups', _p)]
 
 
-OPTIONS_VALUE_BYTES = C.sizeof(_i) * 8        # the eight integer switches of Options (the two pointers follow)
+OPTIONS_VALUE_BYTES = C.sizeof(_i) * 10       # the integer switches of Options (the two pointers follow)
 
 
 class Rollout(C.Structure):

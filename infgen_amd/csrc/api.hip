@@ -31,8 +31,9 @@ extern "C" const char* infgen_last_error(void) { return g_err.c_str(); }
 // called with a context whose opts.use != 0 installs that context's block for the duration of the call (thread-local), so
 // contexts of one process do not see each other's settings.
 namespace {
+int layers_p_default() { const char* e = getenv("INFGEN_LAYERS_P"); return e ? (atoi(e) != 0) : 1; }
 InfgenOptions g_def = {0, /*attn_mode*/ 2, /*gemm_terms*/ 3, /*fourier_mode*/ 1, /*edge_fuse*/ 1, /*edge_loop*/ 6, /*overlap*/ 0,
-                       /*row_group_margin*/ 0, nullptr, nullptr};
+                       /*row_group_margin*/ 0, /*layers_p*/ layers_p_default(), 0, nullptr, nullptr};
 int g_def_group_rows = 0;                  // rows of the layout the process-wide group list belongs to
 const int* g_def_limit_n_agents = nullptr; // process-wide row limits (infgen_set_row_limits)
 int g_def_limit_A_cap = 0;
@@ -1026,10 +1027,9 @@ static int fourier_nomulti() {
 }
 
 // ---- k_layers_p (layers_p.hip): every sublayer of a step in one launch, one resident workgroup per 16-row group
-static int g_layers_p = -1;                 // -1: INFGEN_LAYERS_P (default on)
-extern "C" int infgen_set_layers_p(int mode) {
+extern "C" int infgen_set_layers_p(int mode) {        // (process-wide default, like the other infgen_set_*: contexts carry their own copy)
   if (mode != 0 && mode != 1) return fail("infgen_set_layers_p", "mode must be 0 or 1");
-  g_layers_p = mode;
+  g_def.layers_p = mode;
   return 0;
 }
 static int lp_max_groups() {
@@ -1038,7 +1038,6 @@ static int lp_max_groups() {
 }
 // the launch shape qualifies (the kernel keeps U / Z on chip like k_edge_fused: step_mode treats it as a fused launch)
 static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless) {
-  if (g_layers_p < 0) g_layers_p = getenv("INFGEN_LAYERS_P") ? (atoi(getenv("INFGEN_LAYERS_P")) != 0) : 1;
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0; hipDeviceProp_t prop;
@@ -1052,7 +1051,7 @@ static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless) {
   // (a row-group list of an insertion context is ignored: the launch visits every group - the ones without agents have empty edge
   // lists and run in parallel on CUs that would idle)
   const int max_groups = lp_max_groups();
-  return g_layers_p && !edgeless && O().edge_fuse != 0 && O().attn_mode != 0 && O().gemm_terms == 3 && O().fourier_mode != 0 &&
+  return O().layers_p && !edgeless && O().edge_fuse != 0 && O().attn_mode != 0 && O().gemm_terms == 3 && O().fourier_mode != 0 &&
          !(O().overlap && g_side) && r->A_cap % 16 == 0 && rows / 16 <= n_cu && rows / 16 <= max_groups &&
          rows / 16 <= 256 && r->num_layers <= LP_MAX_LAYERS && r->U && r->SIG;
 }
