@@ -1051,7 +1051,7 @@ static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless) {
   // (a row-group list of an insertion context is ignored: the launch visits every group - the ones without agents have empty edge
   // lists and run in parallel on CUs that would idle)
   const int max_groups = lp_max_groups();
-  return O().layers_p && !edgeless && O().edge_fuse != 0 && O().attn_mode != 0 && O().gemm_terms == 3 && O().fourier_mode != 0 &&
+  return O().layers_p && O().edge_fuse != 0 && O().attn_mode != 0 && O().gemm_terms == 3 && O().fourier_mode != 0 &&
          !(O().overlap && g_side) && r->A_cap % 16 == 0 && rows / 16 <= n_cu && rows / 16 <= max_groups &&
          rows / 16 <= 256 && r->num_layers <= LP_MAX_LAYERS && r->U && r->SIG;
 }
