@@ -43,6 +43,9 @@
 #ifndef IG_LP_X32
 #define IG_LP_X32 7              // bit 0: W1 on 16x16x32 products (one scale per row of LN_ffpre(x)); bit 1: q / k / v, gate-x, self too
 #endif                          // (LN_dst(x)); bit 2: W2 (the hidden layer's row maxima exchanged first)
+#ifndef IG_LP_SYNC1
+#define IG_LP_SYNC1 1              // one wave carries the agent-scope fences of the scene counter (0: every wave, the first version: +5 % of the launch)
+#endif
 #ifndef IG_LP_NOAUX
 #define IG_LP_NOAUX 0            // (timing) no W'kr / W'vr loads, IG_LP_NOSYNC no scene counter, IG_LP_NOKV no K / V stores
 #endif
@@ -679,6 +682,26 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
     STAMP(30 + kind);
     if (kind == 2 && !IG_LP_NOSYNC) {
       // the scene's K / V rows of this layer: every workgroup of the scene has written its 16 before any reads them
+#if IG_LP_SYNC1
+      // ONE wave carries the agent-scope fences: the others' K / V stores are complete when they reach the barrier (vmcnt(0)), the
+      // L2 write-back / the L1 + L2 invalidate act on caches the whole workgroup shares, and the barriers order the rest
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (w == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (tid == 0) {
+          __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int target = (i + 1) * gps;
+          unsigned spins = 0;
+          while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 22)) __builtin_trap();
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+#else
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __syncthreads();
       if (tid == 0) {
@@ -695,6 +718,7 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
       }
       __syncthreads();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     }
     STAMP(0);
     sublayer(es, es_next, Ksrc, Vsrc, kind == 0, P, NP, nK, nV);
