@@ -1033,7 +1033,7 @@ extern "C" int infgen_set_layers_p(int mode) {        // (process-wide default, 
   return 0;
 }
 static int lp_max_groups() {
-  static const int v = getenv("INFGEN_LP_MAX_GROUPS") ? atoi(getenv("INFGEN_LP_MAX_GROUPS")) : 128;
+  static const int v = getenv("INFGEN_LP_MAX_GROUPS") ? atoi(getenv("INFGEN_LP_MAX_GROUPS")) : 256;
   return v;
 }
 // the launch shape qualifies (the kernel keeps U / Z on chip like k_edge_fused: step_mode treats it as a fused launch)
@@ -1044,10 +1044,11 @@ static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) n_cu = 1;
     else n_cu = prop.multiProcessorCount;
   }
-  // all workgroups must be resident at once (they meet at per-scene counters): at most one 16-row group per CU.  Beyond ~128
-  // groups the XCDs' L2s saturate (every workgroup streams each sublayer's 1.1 MB of weight fragments: 35 MB per XCD and sublayer
-  // at 256 groups) and the per-sublayer launches are faster again: 8 / 16 / 32 / 48 / 64 scenes of 64 agents 12.98 / 14.31 /
-  // 17.27 / 20.50 / 23.90 ms per rollout against 15.41 / 16.44 / 18.01 / 20.08 / 22.15 (INFGEN_LP_MAX_GROUPS moves the limit)
+  // all workgroups must be resident at once (they meet at per-scene counters): at most one workgroup per CU (120 KB of LDS each).
+  // Up to that limit the one-launch kernel wins at every size measured (scenes of 64 agents, ms per rollout, k_layers_p vs the
+  // per-sublayer launches): 8 scenes 10.7 / 15.4, 16: 11.7 / 16.4, 32: 13.7 / 18.0 (8 rows per workgroup), 48: 16.8 / 20.1,
+  // 64: 18.4 / 22.2 (16 rows, 256 workgroups).  (With every wave executing the scene counter's agent-scope fences the crossover
+  // sat at ~40 scenes: 2,048 L2 write-backs per layer.)  INFGEN_LP_MAX_GROUPS lowers the limit.
   // (a row-group list of an insertion context is ignored: the launch visits every group - the ones without agents have empty edge
   // lists and run in parallel on CUs that would idle)
   const int max_groups = lp_max_groups();

@@ -1474,7 +1474,7 @@ def rollout_many(engines: Sequence[RolloutEngine], streams: Optional[Sequence[to
     # the CUs, so together they must not exceed them either (two launches each half resident would wait for each other for ever)
     def _lp_wgs(e):
         for r in (8, 16):
-            if e.rows % r == 0 and e.rows // r <= 128:
+            if e.rows % r == 0 and e.rows // r <= 256:
                 return e.rows // r
         return 0
     guard = sum(_lp_wgs(e) for e in engines) > 256
