@@ -1123,9 +1123,13 @@ static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, vo
   const int rows = r->S * r->A_cap;
   LayersPArgs a;
   a.rows = rows; a.A_cap = r->A_cap; a.num_layers = r->num_layers;
-  // 8 rows per workgroup while that keeps the launch within the group limit (twice the workgroups, half the edge loop each)
-  static const int lp_rows8 = getenv("INFGEN_LP_ROWS8") ? atoi(getenv("INFGEN_LP_ROWS8")) : 1;
-  a.rows_per_wg = (lp_rows8 && r->A_cap % 8 == 0 && rows / 8 <= lp_max_groups()) ? 8 : 16;
+  // fewer rows per workgroup while the launch stays within the limit: 8 (one row per wave in the edge loop) up to 256 workgroups,
+  // 4 (a row's edge list halved between two waves) up to 128
+  static const int lp_rows_min = getenv("INFGEN_LP_ROWS8") ? (atoi(getenv("INFGEN_LP_ROWS8")) ? 8 : 16)
+                               : getenv("INFGEN_LP_ROWS_MIN") ? atoi(getenv("INFGEN_LP_ROWS_MIN")) : 4;
+  a.rows_per_wg = 16;
+  for (int rr = 8; rr >= 4 && rr >= lp_rows_min; rr >>= 1)
+    if (r->A_cap % rr == 0 && rows / rr <= (rr == 4 ? lp_max_groups() / 2 : lp_max_groups())) a.rows_per_wg = rr;
   const int gps = r->A_cap / a.rows_per_wg;
   const int n_wg = rows / a.rows_per_wg;
   a.xcd_order = n_wg % (8 * gps) == 0 ? 1 : 0;
@@ -1153,8 +1157,10 @@ static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, vo
   if (hipMemsetAsync(a.sync, 0, (size_t)r->S * sizeof(int), (hipStream_t)stream) != hipSuccess)
     return fail("infgen_decode_layers", "memset failed");
   { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
-    if (sm.r24) hipLaunchKernelGGL(k_layers_p<true>, dim3(n_wg), dim3(512), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_layers_p<false>, dim3(n_wg), dim3(512), 0, (hipStream_t)stream, a); }
+    auto kern = a.rows_per_wg == 4 ? (sm.r24 ? k_layers_p<true, 4> : k_layers_p<false, 4>)
+              : a.rows_per_wg == 8 ? (sm.r24 ? k_layers_p<true, 8> : k_layers_p<false, 8>)
+                                   : (sm.r24 ? k_layers_p<true, 16> : k_layers_p<false, 16>);
+    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(512), 0, (hipStream_t)stream, a); }
   if (lp_trace) {          // synchronous dump of the last launch's stamps (diagnostic runs only)
     static int dumps = 0;
     if (dumps++ == lp_trace) {

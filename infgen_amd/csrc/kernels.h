@@ -470,7 +470,7 @@ template <int TERMS> __global__ void k_attn_hs(AttnHArgs a);             // attn
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);
 template <int G, bool R24, int HALVES, int WAVES> __global__ void k_edge_fused(EdgeFusedArgs a);        // edge_fused.hip (R24: rhat rows in the packed format)
-template <bool R24> __global__ void k_layers_p(LayersPArgs a);          // layers_p.hip
+template <bool R24, int ROWS> __global__ void k_layers_p(LayersPArgs a);          // layers_p.hip
 template <int G> __global__ void k_edge_fused_p(EdgeFusedArgs a);      // persistent workgroups, decoupled halves
 __global__ void k_edge_attn_wide(EdgeAttnArgs a);
 __global__ void k_attn_post(AttnPostArgs a);

@@ -237,7 +237,7 @@ __device__ __forceinline__ f32x4 gemm32(const AFragP& f, const uint4* FR, int la
 
 }  // namespace
 
-template <bool R24>
+template <bool R24, int ROWS>
 __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
   __shared__ __attribute__((aligned(16))) float UZ[16 * LP_LDU];        // u, then z; the FFN's hidden-layer fragments in between
   __shared__ __attribute__((aligned(16))) float AG[16 * LP_LDA];        // q tile, then agg
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
   const int j = lane & 15, rg = lane >> 4;
   // R rows per workgroup: 16, or 8 for the smallest batches (twice the workgroups: ONE row per wave in the edge loop, the phase the
   // agent sublayers spend most of their time in; lanes j >= 8 then shadow rows j - 8 - same loads, no stores, never read)
-  const int R = a.rows_per_wg;
+  constexpr int R = ROWS;                                               // (compile time: a run-time row count costs ~3 %)
   const int gps = a.A_cap / R;                                          // workgroups per scene
   const int L = a.num_layers;
   // a scene's workgroups on ONE XCD (consecutive workgroups go to consecutive XCDs): its K / V rows and its counter share an L2
@@ -327,14 +327,22 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
       rank += (ck > cnt || (ck == cnt && k < rl)) ? 1 : 0;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int want = i == 0 ? w : 15 - w;                       // (R = 8: the second row does not exist, the edge loop skips it)
+    for (int i = 0; i < (R == 16 ? 2 : 1); ++i) {
+      // R = 16: rows of rank w and 15 - w; R = 8: rank w only; R = 4: rank w >> 1, and the row's list is halved between waves 2 q
+      // and 2 q + 1 (first half | second half), whose partial softmax states are merged afterwards
+      const int want = R == 4 ? (w >> 1) : (i == 0 ? w : 15 - w);
       const unsigned long long m = __ballot(rank == want && lane < 16);
       const int r = __builtin_ctzll(m);
       eR[i] = r;
-      eE[i] = __builtin_amdgcn_readlane(cnt, r);
-      eB[i] = __builtin_amdgcn_readlane(off, r);
-      eS[i] = es.src[eB[i] + max(min(lane, eE[i] - 1), 0)];      // (an empty list reads the entry at its offset: in bounds, unused)
+      int E = __builtin_amdgcn_readlane(cnt, r), B = __builtin_amdgcn_readlane(off, r);
+      if constexpr (R == 4) {
+        const int first = (E + 1) >> 1;
+        B += (w & 1) ? first : 0;
+        E = (w & 1) ? E - first : first;
+      }
+      eE[i] = E;
+      eB[i] = B;
+      eS[i] = es.src[B + max(min(lane, E - 1), 0)];              // (an empty list reads the entry at its offset: in bounds, unused)
     }
   };
 
@@ -468,6 +476,33 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
             }
 #pragma unroll
             for (int s = 0; s < LP_G; ++s) acc.step(kb[s], vb[s], rb[s], i0 + s < mc, b3);
+          }
+        }
+        if constexpr (R == 4) {
+          // two waves share the row: the odd one parks its un-normalised state in spare rows of the U / Z tile (rows 4 .. 11 are
+          // unused with four rows per workgroup), the even one merges it into its own (running maxima may differ) and finalises
+          float* ps = UZ + (4 + 2 * (w >> 1)) * LP_LDU;
+          if (w & 1) {
+#pragma unroll
+            for (int hd = 0; hd < H; ++hd) *reinterpret_cast<float2*>(ps + hd * D + 2 * lane) = make_float2(acc.zz[hd][0], acc.zz[hd][1]);
+            *reinterpret_cast<float2*>(ps + LP_LDU + 2 * lane) = make_float2(acc.ag[0], acc.ag[1]);
+            ps[LP_LDU + 128 + lane] = acc.m;
+            ps[LP_LDU + 192 + lane] = acc.lsum;
+          }
+          wg_barrier();
+          if (w & 1) continue;
+          const float m1 = ps[LP_LDU + 128 + lane], l1 = ps[LP_LDU + 192 + lane];
+          const float mm = fmaxf(acc.m, m1);
+          const float s0 = acc.m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(acc.m - mm);
+          const float s1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m1 - mm);
+          acc.lsum = fmaf(l1, s1, acc.lsum * s0);
+          const float2 a1 = *reinterpret_cast<const float2*>(ps + LP_LDU + 2 * lane);
+          acc.ag = pk2{fmaf(a1.x, s1, acc.ag[0] * s0), fmaf(a1.y, s1, acc.ag[1] * s0)};
+#pragma unroll
+          for (int hd = 0; hd < H; ++hd) {
+            const float h0 = readlane_f(s0, 8 * hd), h1 = readlane_f(s1, 8 * hd);
+            const float2 z1 = *reinterpret_cast<const float2*>(ps + hd * D + 2 * lane);
+            acc.zz[hd] = pk2{fmaf(z1.x, h1, acc.zz[hd][0] * h0), fmaf(z1.y, h1, acc.zz[hd][1] * h0)};
           }
         }
         const float inv = 1.0f / (acc.lsum + 1e-16f);
@@ -726,7 +761,11 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
   if (own_row) *reinterpret_cast<float4*>(a.X + (size_t)row * D + own) = make_float4(x[0], x[1], x[2], x[3]);
 }
 
-template __global__ void k_layers_p<true>(LayersPArgs);
-template __global__ void k_layers_p<false>(LayersPArgs);
+template __global__ void k_layers_p<true, 16>(LayersPArgs);
+template __global__ void k_layers_p<false, 16>(LayersPArgs);
+template __global__ void k_layers_p<true, 8>(LayersPArgs);
+template __global__ void k_layers_p<false, 8>(LayersPArgs);
+template __global__ void k_layers_p<true, 4>(LayersPArgs);
+template __global__ void k_layers_p<false, 4>(LayersPArgs);
 
 }  // namespace ig
