@@ -1032,6 +1032,18 @@ extern "C" int infgen_set_layers_p(int mode) {        // (process-wide default, 
   g_def.layers_p = mode;
   return 0;
 }
+// scenes per launch when the batch needs more than one (0: not eligible): whole scenes, at most `limit` 16-row groups per launch,
+// at most INFGEN_LP_MAX_CHUNKS (2) launches - measured with scenes of 64 agents: 96 / 128 scenes 36.6 / 39.6 ms per rollout through the
+// per-sublayer launches, whose layers cost 26 - 28 ms there against 2 x 10 ms of two 64-scene launches; from three chunks on the
+// big-batch kernels are as fast
+static int lp_chunk_scenes(const InfgenRollout* r, int limit) {
+  static const int max_chunks = getenv("INFGEN_LP_MAX_CHUNKS") ? atoi(getenv("INFGEN_LP_MAX_CHUNKS")) : 2;
+  const int gps = r->A_cap / 16;
+  if (gps <= 0 || gps > limit) return 0;
+  const int per = limit / gps;                       // scenes per launch
+  const int chunks = (r->S + per - 1) / per;
+  return chunks <= max_chunks ? per : 0;
+}
 static int lp_max_groups() {
   static const int v = getenv("INFGEN_LP_MAX_GROUPS") ? atoi(getenv("INFGEN_LP_MAX_GROUPS")) : 256;
   return v;
@@ -1053,8 +1065,8 @@ static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless) {
   // lists and run in parallel on CUs that would idle)
   const int max_groups = lp_max_groups();
   return O().layers_p && O().edge_fuse != 0 && O().attn_mode != 0 && O().gemm_terms == 3 && O().fourier_mode != 0 &&
-         !(O().overlap && g_side) && r->A_cap % 16 == 0 && rows / 16 <= n_cu && rows / 16 <= max_groups &&
-         rows / 16 <= 256 && r->num_layers <= LP_MAX_LAYERS && r->U && r->SIG;
+         !(O().overlap && g_side) && r->A_cap % 16 == 0 && lp_chunk_scenes(r, max_groups < n_cu ? max_groups : n_cu) > 0 &&
+          r->num_layers <= LP_MAX_LAYERS && r->U && r->SIG;
 }
 
 // ---- a decode step in two halves: the edge sets of a column with their embeddings, and the 18 sublayers that consume them
@@ -1123,16 +1135,6 @@ static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, vo
   const int rows = r->S * r->A_cap;
   LayersPArgs a;
   a.rows = rows; a.A_cap = r->A_cap; a.num_layers = r->num_layers;
-  // fewer rows per workgroup while the launch stays within the limit: 8 (one row per wave in the edge loop) up to 256 workgroups,
-  // 4 (a row's edge list halved between two waves) up to 128
-  static const int lp_rows_min = getenv("INFGEN_LP_ROWS8") ? (atoi(getenv("INFGEN_LP_ROWS8")) ? 8 : 16)
-                               : getenv("INFGEN_LP_ROWS_MIN") ? atoi(getenv("INFGEN_LP_ROWS_MIN")) : 4;
-  a.rows_per_wg = 16;
-  for (int rr = 8; rr >= 4 && rr >= lp_rows_min; rr >>= 1)
-    if (r->A_cap % rr == 0 && rows / rr <= (rr == 4 ? lp_max_groups() / 2 : lp_max_groups())) a.rows_per_wg = rr;
-  const int gps = r->A_cap / a.rows_per_wg;
-  const int n_wg = rows / a.rows_per_wg;
-  a.xcd_order = n_wg % (8 * gps) == 0 ? 1 : 0;
   a.X = r->X;
   for (int i = 0; i < r->num_layers; ++i) {
     a.attn_t[i] = r->attn_t[i]; a.attn_m[i] = r->attn_m[i]; a.attn_a[i] = r->attn_a[i];
@@ -1156,11 +1158,32 @@ static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, vo
   }
   if (hipMemsetAsync(a.sync, 0, (size_t)r->S * sizeof(int), (hipStream_t)stream) != hipSuccess)
     return fail("infgen_decode_layers", "memset failed");
-  { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
-    auto kern = a.rows_per_wg == 4 ? (sm.r24 ? k_layers_p<true, 4> : k_layers_p<false, 4>)
-              : a.rows_per_wg == 8 ? (sm.r24 ? k_layers_p<true, 8> : k_layers_p<false, 8>)
-                                   : (sm.r24 ? k_layers_p<true, 16> : k_layers_p<false, 16>);
-    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(512), 0, (hipStream_t)stream, a); }
+  // fewer rows per workgroup while the launch stays within the limit: 8 (one row per wave in the edge loop) up to 256 workgroups,
+  // 4 (a row's edge list halved between two waves) up to 128
+  static const int lp_rows_min = getenv("INFGEN_LP_ROWS8") ? (atoi(getenv("INFGEN_LP_ROWS8")) ? 8 : 16)
+                               : getenv("INFGEN_LP_ROWS_MIN") ? atoi(getenv("INFGEN_LP_ROWS_MIN")) : 4;
+  a.rows_per_wg = 16;
+  for (int rr = 8; rr >= 4 && rr >= lp_rows_min; rr >>= 1)
+    if (r->A_cap % rr == 0 && rows / rr <= (rr == 4 ? lp_max_groups() / 2 : lp_max_groups())) a.rows_per_wg = rr;
+  const int gps = r->A_cap / a.rows_per_wg;
+  // a batch beyond one launch's workgroups: chunks of whole scenes, one launch after the other (each launch's workgroups are all
+  // resident; the stream orders them)
+  int n_cu = 256;
+  { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount; }
+  const int limit = lp_max_groups() < n_cu ? lp_max_groups() : n_cu;
+  const int per = rows / a.rows_per_wg <= limit ? r->S : lp_chunk_scenes(r, limit);
+  if (per <= 0) return fail("infgen_decode_layers", "k_layers_p: batch does not fit");
+  auto kern = a.rows_per_wg == 4 ? (sm.r24 ? k_layers_p<true, 4> : k_layers_p<false, 4>)
+            : a.rows_per_wg == 8 ? (sm.r24 ? k_layers_p<true, 8> : k_layers_p<false, 8>)
+                                 : (sm.r24 ? k_layers_p<true, 16> : k_layers_p<false, 16>);
+  for (int s0 = 0; s0 < r->S; s0 += per) {
+    const int ns = r->S - s0 < per ? r->S - s0 : per;
+    const int n_wg = ns * gps;
+    a.row0 = s0 * r->A_cap;
+    a.xcd_order = n_wg % (8 * gps) == 0 ? 1 : 0;
+    ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
+    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(512), 0, (hipStream_t)stream, a);
+  }
   if (lp_trace) {          // synchronous dump of the last launch's stamps (diagnostic runs only)
     static int dumps = 0;
     if (dumps++ == lp_trace) {

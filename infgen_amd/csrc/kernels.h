@@ -126,6 +126,7 @@ constexpr int LP_MAX_LAYERS = 8;
 struct LayersPArgs {
   int rows, A_cap, num_layers;
   int xcd_order;                     // 1: a scene's workgroups share an XCD (workgroups a multiple of 8 * A_cap / rows_per_wg)
+  int row0;                          // first row of this launch (a batch beyond one launch's workgroup limit runs as chunks of whole scenes)
   int rows_per_wg;                   // 16, or 8 (the smallest batches: one row per wave in the edge loop, lanes j >= 8 are shadows)
   float* X;                          // [rows][128] in / out: the layer stack's input rows (raw features) -> its output
   const float* attn_t[LP_MAX_LAYERS]; const float* attn_m[LP_MAX_LAYERS]; const float* attn_a[LP_MAX_LAYERS];

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
     const int per = 8 * gps, bq = grp / per, br = grp % per;
     grp = bq * per + (br % 8) * gps + br / 8;
   }
-  const int r0 = R * grp, row = r0 + (j & (R - 1));
+  const int r0 = a.row0 + R * grp, row = r0 + (j & (R - 1));        // (row0: first row of this launch's chunk of scenes)
   const bool own_row = j < R;                                           // (this lane's row is not a shadow: it may store)
   const int scene = r0 / a.A_cap;
   const int own = 16 * w + 4 * rg;                                      // this lane's four features
