@@ -1472,11 +1472,14 @@ def rollout_many(engines: Sequence[RolloutEngine], streams: Optional[Sequence[to
         return
     # k_layers_p's workgroups of one launch meet at per-scene counters and must all be resident; launches of SEVERAL streams share
     # the CUs, so together they must not exceed them either (two launches each half resident would wait for each other for ever)
-    def _lp_wgs(e):
-        for r in (8, 16):
-            if e.rows % r == 0 and e.rows // r <= 256:
-                return e.rows // r
-        return 0
+    def _lp_wgs(e):                      # workgroups of one k_layers_p launch of this engine (csrc/api.hip: layers_p_launch)
+        if e.rows % 16 or e.rows // 16 > 512:
+            return 0
+        if e.rows % 4 == 0 and e.rows // 4 <= 128:
+            return e.rows // 4
+        if e.rows % 8 == 0 and e.rows // 8 <= 256:
+            return e.rows // 8
+        return min(e.rows // 16, 256)
     guard = sum(_lp_wgs(e) for e in engines) > 256
     if guard:
         _lib.check(engines[0].lib.infgen_set_layers_p(0), 'infgen_set_layers_p')
