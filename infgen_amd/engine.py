@@ -447,6 +447,7 @@ class RolloutEngine:
 
         # ------------------------------------------------ host-side scene setup
         self._stacked = None
+        self._hosts_light = False
         hosts = self._setup_scenes(scenes)
         self.hosts = hosts
         amax = max(h['A'] for h in hosts)
@@ -599,6 +600,7 @@ class RolloutEngine:
         assert self.fits(scenes), 'batch does not fit this engine (RolloutEngine.fits)'
         self.scenes = scenes
         self._stacked = None
+        self._hosts_light = False
         self.hosts = hosts = self._setup_scenes(scenes)
         arr = self._scene_arrays(hosts)
         for k in self._SCENE_ARRAYS:
@@ -617,6 +619,137 @@ class RolloutEngine:
         self._epi = None
         self._mg_checked = False           # the new map may hold more pt <-> pt edges than the buffers
         self._prologue_done = False
+
+    # ------------------------------------------------------------------ a batch that is already on the device
+    def fits_device(self, k: Mapping) -> bool:
+        """``fits`` for a stacked device batch (``_setup_device``): shapes only, no host copy"""
+        ag, pt = k['agent'], k['pt_token']
+        if int(ag['state_idx'].shape[0]) != self.S or self.teacher_token is not None:
+            return False
+        A, T0, M = int(ag['state_idx'].shape[1]), int(ag['state_idx'].shape[2]), int(pt['position'].shape[1])
+        head = (self.A_cap - self._amax0) if self.insertion else 0
+        return A + head <= self.A_cap and M <= self.M_cap and T0 <= self.T and A >= 1
+
+    def reload_device(self, k: Mapping, scenes, sample_uniforms: Optional[np.ndarray] = None,
+                      insert_uniforms: Optional[np.ndarray] = None, x_pt_override: Optional[Sequence] = None) -> bool:
+        """``reload`` for a batch whose scenes arrive as DEVICE tensors of one shape, stacked per key (``k``: what
+        ``modules.infgen_decoder.stack_datas`` returns): the setup statements of ``_setup_scenes_stacked`` / ``_scene_arrays`` and
+        the epilogue's input arrays run as torch ops on the device and write this engine's buffers - no device -> host -> device
+        round trip of the scene arrays (~70 ms of a 512-scene call before the first launch).  ``scenes`` is the (lazy) host form
+        of the same batch, only read if somebody asks for the host-side ``outputs()``.  Returns False, having changed nothing,
+        when a row would be filtered (the per-scene host path handles that: ``reload``)."""
+        assert self.fits_device(k), 'batch does not fit this engine (RolloutEngine.fits_device)'
+        if not self._setup_device(k):
+            return False
+        self.scenes = scenes
+        self._stacked = None
+        if self.sample_k > 1:
+            assert sample_uniforms is not None, 'top-k sampling needs caller-supplied uniforms'
+            self.sample_u.copy_(torch.from_numpy(self._uniform_rows(sample_uniforms, self.hosts[0]['A'])))
+        if self.insert_k > 1:
+            assert insert_uniforms is not None, 'cell sampling needs caller-supplied uniforms [steps][10][S]'
+            self._insert_u.copy_(torch.from_numpy(np.ascontiguousarray(insert_uniforms, dtype=np.float32)))
+        self._x_pt_override = x_pt_override
+        self._init = None
+        self._wgraph = None
+        self._mg_checked = False
+        self._prologue_done = False
+        return True
+
+    def _setup_device(self, k: Mapping) -> bool:
+        """reference agent_decoder.py:1609-1719 (pad, zero the future, masks) for a one-shape batch on the device; the same
+        statements as ``_setup_scenes_stacked`` (tests/test_boundary_cpu.py compares the two array by array on CPU tensors)"""
+        cfg = self.cfg
+        T, hc, H, S, A_cap, M_cap = cfg.num_columns, cfg.hist_columns, cfg.num_historical_steps, self.S, self.A_cap, self.M_cap
+        ag, pt = k['agent'], k['pt_token']
+        state0 = ag['state_idx'].long()                                                   # [S, A, T0]
+        A, T0, M = int(state0.shape[1]), int(state0.shape[2]), int(pt['position'].shape[1])
+        dev = state0.device
+        av = ag['av_index'].reshape(S, -1)[:, 0].long()
+        # the one host copy of the way in: the ego rows + "is any row filtered?" (then the host path takes the batch)
+        chk = torch.cat([av, (state0[:, :, hc - 1] == INVALID).any().long()[None]]).cpu().numpy()
+        if chk[-1]:
+            return False
+        av_host = chk[:-1]
+
+        def pad(x, val):
+            if x.shape[2] == T:
+                return x.clone()
+            shp = tuple(x.shape[:2]) + (T - x.shape[2],) + tuple(x.shape[3:])
+            return torch.cat([x, torch.full(shp, val, dtype=x.dtype, device=dev)], dim=2)
+        pos = pad(ag['token_pos'].float(), 0.0)
+        head = pad(ag['token_heading'].float(), 0.0)
+        token = pad(ag['token_idx'].long(), -1)
+        state = pad(state0, INVALID)
+        grid = pad(ag['grid_token_idx'].long(), -1)
+        valid = pad(ag['raw_agent_valid_mask'].bool(), True)
+        pos[:, :, hc:] = 0; head[:, :, hc:] = 0; token[:, :, hc:] = -1; state[:, :, hc:] = INVALID; grid[:, :, hc:] = -1
+        valid[:, :, hc:] = True
+        valid &= ag['valid_mask'][:, :, H - 1].bool()[..., None]
+        is_bos, is_eos = state == ENTER, state == EXIT
+        bos = torch.where(is_bos.any(2), is_bos.int().argmax(2), 0)
+        eos = torch.where(is_eos.any(2), is_eos.int().argmax(2), T - 1)
+        cols = torch.arange(T, device=dev)[None, None, :]
+        motion = (cols > bos[..., None]) & (cols <= eos[..., None])
+        motion[:, :, H // cfg.shift:] = False
+        tmask = torch.where(motion, valid, True)
+        nonmotion = ~motion
+        nonmotion[:, :, H // cfg.shift:] = False
+        imask = ~nonmotion
+        imask |= state == ENTER
+        imask[torch.arange(S, device=dev), av] = True
+        tmask[:, :, hc:] = True
+        imask[:, :, hc:] = True
+        catflag = state != INVALID
+
+        def put(dst, src, fill=0):          # [S, A, T, ...] -> the engine's [S, T, A_cap, ...]
+            dst.fill_(fill)
+            dst[:, :, :A] = src.transpose(1, 2)
+        put(self.pos, pos); put(self.head, head); put(self.state, state); put(self.token, token, -1); put(self.gridtok, grid, -1)
+        put(self.tmask, tmask); put(self.imask, imask); put(self.catflag, catflag)
+        self.atype.zero_(); self.atype[:, :A] = ag['type']
+        self.bos.zero_(); self.bos[:, :A] = bos
+        self._shape10.fill_(INVALID_SHAPE); self._shape10[:, :A] = ag['shape'][:, :, H - 1]
+        self.n_agents.fill_(A); self.n_map.fill_(M); self.av.copy_(av)
+        self.map_pos.zero_(); self.map_pos[:, :M] = pt['position'][:, :, :2]
+        self.map_orient.zero_(); self.map_orient[:, :M] = pt['orientation']
+        light = torch.gather(k['light_type'].long(), 1, k['edge_index'][:, 1].long())
+        for dst, src in zip(self._map_cat, (pt['token_idx'], pt['type'], pt['pl_type'], light)):
+            dst.zero_()
+            dst[:, :M] = src
+        # the epilogue's inputs (outputs_device: E)
+        P = int(ag['position'].shape[2])
+        Rg = P - H
+        z = lambda *shape, dt=torch.float32: torch.zeros(*shape, dtype=dt, device=dev)
+        htok, hst = z(S, A_cap, hc, dt=torch.int64), z(S, A_cap, hc, dt=torch.int64)
+        htok[:, :A] = ag['token_idx'][:, :, :hc]; hst[:, :A] = state0[:, :, :hc]
+        p0, h0, shp = z(S, A_cap, 2), z(S, A_cap), z(S, A_cap, 3)
+        p0[:, :A] = ag['position'][:, :, 0, :2]; h0[:, :A] = ag['heading'][:, :, 0]; shp[:, :A] = ag['shape'][:, :, hc - 1]
+        gt = z(S, A_cap, Rg, 2); gt[:, :A] = ag['position'][:, :, H:, :2]
+        val = z(S, A_cap, T, dt=torch.bool); val[:, :A] = valid
+        ids = z(S, A_cap, dt=torch.int64)
+        i0 = ag['id'].long()
+        ids[:, :A] = i0
+        ids[:, A:] = i0.max(dim=1).values[:, None] + 1 + torch.arange(A_cap - A, device=dev)[None, :]
+        n0_host = np.full(S, A, np.int64)
+        self._gt_len = [Rg] * S
+        self._epi = dict(htok=htok, hst=hst, p0=p0, h0=h0, ids=ids, shp=shp, gt=gt, val=val, n0=torch.full((S,), A, device=dev),
+                         n0_host=n0_host, eval_shape=torch.tensor([[4.3, 1.8, 1.0], [0.5, 0.5, 1.0], [1.9, 0.5, 1.0]], device=dev))
+        filt = np.ones(A, bool)
+        self.hosts = [dict(A=A, M=M, av=int(av_host[s]), filt=filt) for s in range(S)]
+        self._hosts_light = True             # (the host-side ``outputs()`` rebuilds the full per-scene dicts when asked)
+        return True
+
+    def _full_hosts(self):
+        """the per-scene host dicts with every array of ``_setup_scene`` (a device-side reload keeps only A / M / av / filt)"""
+        if getattr(self, '_hosts_light', False):
+            self.scenes = list(self.scenes)
+            epi = self._epi
+            self.hosts = self._setup_scenes(self.scenes)
+            self._stacked = None
+            self._epi = epi
+            self._hosts_light = False
+        return self.hosts
 
     def _uniform_rows(self, sample_uniforms, amax) -> np.ndarray:
         steps, S, A_cap = self.cfg.num_decode_steps, self.S, self.A_cap
@@ -1251,6 +1384,7 @@ class RolloutEngine:
         """the reference's return dict per scene (agent_decoder.py:2303-2389); rows appended by the
         insertion loop follow the initial ones like in the reference"""
         torch.cuda.synchronize(self.device)
+        self._full_hosts()
         cfg, hc, H = self.cfg, self.hc, self.cfg.num_historical_steps
         pos, head = self.pos.cpu().numpy(), self.head.cpu().numpy()
         state, token = self.state.cpu().numpy(), self.token.cpu().numpy()
@@ -1330,6 +1464,37 @@ class RolloutEngine:
             outs.append(o)
         return outs
 
+    def _epi_from_hosts(self):
+        """padded copies of the inputs the device epilogue reads (``outputs_device``), from the per-scene host dicts: one upload
+        per array (``_setup_device`` builds the same arrays on the device)"""
+        cfg, hc, H, dev = self.cfg, self.hc, self.cfg.num_historical_steps, self.device
+        S, A_cap, T, R = self.S, self.A_cap, self.T, self.R
+        # padded copies of the inputs the epilogue reads (one upload per array)
+        z = lambda *shape, dt=np.float32: np.zeros(shape, dt)
+        Rg = max(int(np.asarray(sc['agent']['position']).shape[1]) - H for sc in self.scenes)
+        htok, hst = z(S, A_cap, hc, dt=np.int64), z(S, A_cap, hc, dt=np.int64)
+        p0, h0, ids, shp = z(S, A_cap, 2), z(S, A_cap), z(S, A_cap, dt=np.int64), z(S, A_cap, 3)
+        gt, val, n0 = z(S, A_cap, Rg, 2), z(S, A_cap, T, dt=bool), z(S, dt=np.int64)
+        for s, (h, sc_) in enumerate(zip(self.hosts, self.scenes)):
+            sc, f, A0 = sc_['agent'], h['filt'], h['A']
+            n0[s] = A0
+            htok[s, :A0] = np.asarray(sc['token_idx'])[f][:, :hc]
+            hst[s, :A0] = np.asarray(sc['state_idx'])[f][:, :hc]
+            pos = np.asarray(sc['position'])[f]
+            p0[s, :A0] = pos[:, 0, :2]
+            g = pos[:, H:, :2]
+            gt[s, :A0, :g.shape[1]] = g
+            h0[s, :A0] = np.asarray(sc['heading'])[f][:, 0]
+            i0 = np.asarray(sc['id'])[f]
+            ids[s, :A0] = i0
+            ids[s, A0:] = (i0.max() if len(i0) else -1) + 1 + np.arange(A_cap - A0)
+            shp[s, :A0] = np.asarray(sc['shape'])[f][:, hc - 1]
+            val[s, :A0] = h['valid']
+        t = lambda a: torch.from_numpy(a).to(dev)
+        self._gt_len = [int(np.asarray(sc['agent']['position']).shape[1]) - H for sc in self.scenes]
+        return dict(htok=t(htok), hst=t(hst), p0=t(p0), h0=t(h0), ids=t(ids), shp=t(shp), gt=t(gt), val=t(val), n0=t(n0),
+                         n0_host=n0, eval_shape=t(np.asarray([[4.3, 1.8, 1.0], [0.5, 0.5, 1.0], [1.9, 0.5, 1.0]], np.float32)))
+
     def outputs_device(self, detach: bool = False) -> List[Dict[str, torch.Tensor]]:
         """``outputs`` without the host round trip: the same per-scene dicts as device tensors (views of the batch arrays where
         the layout allows), the epilogue of agent_decoder.py:2303-2389 evaluated for all scenes at once on the device.
@@ -1340,31 +1505,7 @@ class RolloutEngine:
         cfg, hc, H, dev = self.cfg, self.hc, self.cfg.num_historical_steps, self.device
         S, A_cap, T, R = self.S, self.A_cap, self.T, self.R
         if getattr(self, '_epi', None) is None:
-            # padded copies of the inputs the epilogue reads (one upload per array)
-            z = lambda *shape, dt=np.float32: np.zeros(shape, dt)
-            Rg = max(int(np.asarray(sc['agent']['position']).shape[1]) - H for sc in self.scenes)
-            htok, hst = z(S, A_cap, hc, dt=np.int64), z(S, A_cap, hc, dt=np.int64)
-            p0, h0, ids, shp = z(S, A_cap, 2), z(S, A_cap), z(S, A_cap, dt=np.int64), z(S, A_cap, 3)
-            gt, val, n0 = z(S, A_cap, Rg, 2), z(S, A_cap, T, dt=bool), z(S, dt=np.int64)
-            for s, (h, sc_) in enumerate(zip(self.hosts, self.scenes)):
-                sc, f, A0 = sc_['agent'], h['filt'], h['A']
-                n0[s] = A0
-                htok[s, :A0] = np.asarray(sc['token_idx'])[f][:, :hc]
-                hst[s, :A0] = np.asarray(sc['state_idx'])[f][:, :hc]
-                pos = np.asarray(sc['position'])[f]
-                p0[s, :A0] = pos[:, 0, :2]
-                g = pos[:, H:, :2]
-                gt[s, :A0, :g.shape[1]] = g
-                h0[s, :A0] = np.asarray(sc['heading'])[f][:, 0]
-                i0 = np.asarray(sc['id'])[f]
-                ids[s, :A0] = i0
-                ids[s, A0:] = (i0.max() if len(i0) else -1) + 1 + np.arange(A_cap - A0)
-                shp[s, :A0] = np.asarray(sc['shape'])[f][:, hc - 1]
-                val[s, :A0] = h['valid']
-            t = lambda a: torch.from_numpy(a).to(dev)
-            self._gt_len = [int(np.asarray(sc['agent']['position']).shape[1]) - H for sc in self.scenes]
-            self._epi = dict(htok=t(htok), hst=t(hst), p0=t(p0), h0=t(h0), ids=t(ids), shp=t(shp), gt=t(gt), val=t(val), n0=t(n0),
-                             n0_host=n0, eval_shape=t(np.asarray([[4.3, 1.8, 1.0], [0.5, 0.5, 1.0], [1.9, 0.5, 1.0]], np.float32)))
+            self._epi = self._epi_from_hosts()
         E = self._epi
         n_fin = self.n_agents.long()
         row = torch.arange(A_cap, device=dev)[None, :]
@@ -1383,7 +1524,7 @@ class RolloutEngine:
         ntok[:, :, :hc] = torch.where(init[..., None], E['htok'], ntok[:, :, :hc])
         nstate[:, :, :hc] = torch.where(init[..., None], E['hst'], nstate[:, :, :hc])
         cols = torch.arange(T, device=dev)[None, None, :]
-        ntok[(~init)[..., None] & (cols <= self.bos.long()[..., None])] = -1
+        ntok.masked_fill_((~init)[..., None] & (cols <= self.bos.long()[..., None]), -1)      # (a masked assignment would wait for the device)
         zf = lambda *shape: torch.zeros(*shape, device=dev)
         pt = torch.cat([zf(S, A_cap, H, 2), self.pred_traj], dim=2)
         ph = torch.cat([zf(S, A_cap, H), self.pred_head], dim=2)
@@ -1409,7 +1550,9 @@ class RolloutEngine:
         if self.ins is not None:
             pshape = torch.where(init[..., None], E['shp'], self.ins['shape_all'].view(S, A_cap, 3))
         eval_shape = E['eval_shape'][atype]
-        n_host = n_fin.cpu().numpy()                                                  # the only host copy: final agent counts
+        # the only host copy: the final agent counts - known without asking when nothing can be inserted (then the call returns
+        # with the epilogue enqueued behind the rollout and nothing waited for)
+        n_host = n_fin.cpu().numpy() if self.insertion else E['n0_host']
         outs = []
         batch = dict(agent_id=E['ids'], pos_a=pos_a, head_a=head_a, pred_traj=pt, pred_head=ph, pred_state=ps, pred_valid=pvalid,
                      pred_type=atype, pred_shape=pshape, eval_shape=eval_shape, next_token_idx=ntok, next_state_idx=nstate)

@@ -115,6 +115,64 @@ def scenes_from_datas(datas) -> List[Dict[str, Dict[str, np.ndarray]]]:
     return out
 
 
+_STACK_AGENT_KEYS = ('state_idx', 'valid_mask', 'id', 'raw_agent_valid_mask', 'token_pos', 'token_idx', 'token_heading', 'shape',
+                     'type', 'grid_token_idx', 'position', 'heading', 'av_index')
+_STACK_PT_KEYS = ('position', 'orientation', 'type', 'pl_type', 'token_idx')
+
+
+def stack_datas(datas, min_scenes: int = 8, any_device: bool = False):
+    """a batch of ``data`` objects whose arrays are DEVICE tensors of one shape -> one stacked device tensor per key (what
+    ``RolloutEngine.reload_device`` takes), or None when the batch is not of that kind (host arrays, ragged shapes, several
+    devices, fewer than ``min_scenes`` scenes): then ``scenes_from_datas`` + the host setup take it.  No host copy.
+    ``any_device``: CPU tensors count too (the CPU test of the device-side setup)."""
+    if len(datas) < min_scenes:
+        return None
+    key = ('pt_token', 'to', 'map_polygon')
+
+    def edge(d):
+        try:
+            return d[key]['edge_index']
+        except (KeyError, TypeError):
+            return d['pt_token__to__map_polygon']['edge_index']
+
+    def stack(vals):
+        v0 = vals[0]
+        if not all(isinstance(v, torch.Tensor) and v.device == v0.device and v.shape == v0.shape for v in vals):
+            raise TypeError('not a one-shape batch of tensors on one device')
+        return torch.stack(vals)
+    try:
+        agent = {k: stack([d['agent'][k].reshape(-1)[:1] if k == 'av_index' else d['agent'][k] for d in datas])
+                 for k in _STACK_AGENT_KEYS}
+        if agent['state_idx'].device.type != 'cuda' and not any_device:
+            return None
+        return {'agent': agent, 'pt_token': {k: stack([d['pt_token'][k] for d in datas]) for k in _STACK_PT_KEYS},
+                'light_type': stack([d['map_polygon']['light_type'] for d in datas]),
+                'edge_index': stack([edge(d) for d in datas])}
+    except (KeyError, TypeError, AttributeError, RuntimeError):
+        return None
+
+
+class _LazyScenes:
+    """``scenes_from_datas(datas)``, made when first read (the device-side reload of a reused engine never reads it)"""
+
+    def __init__(self, datas):
+        self._datas, self._scenes = datas, None
+
+    def _get(self):
+        if self._scenes is None:
+            self._scenes = scenes_from_datas(self._datas)
+        return self._scenes
+
+    def __len__(self):
+        return len(self._datas)
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __iter__(self):
+        return iter(self._get())
+
+
 class InfGenDecoder(nn.Module):
 
     def __init__(self, decoder_type: str, dataset: str, input_dim: int, hidden_dim: int, num_historical_steps: int,
@@ -157,6 +215,7 @@ class InfGenDecoder(nn.Module):
                             seed_size=seed_size, buffer_size=buffer_size, disable_insertion=disable_insertion,
                             state_token=dict(state_token))
         self._packed = None
+        self._last_w = None
         self._packed_ver = None
         self._engines = {}          # RolloutEngine per batch layout, reused across calls (RolloutEngine.reload)
 
@@ -186,13 +245,17 @@ class InfGenDecoder(nn.Module):
              batch_seed_outputs: bool = False):
         ae = self.agent_encoder
         datas = list(batch) if batch is not None else [data]
-        scenes = scenes_from_datas(datas)
-        w = self._weights()
+        # a batch of device tensors of one shape is set up on the device (RolloutEngine.reload_device); its host form is only made
+        # when something reads it (a new engine, a filtered row, the host-side outputs)
+        stk = stack_datas(datas) if batch is not None else None
+        scenes = _LazyScenes(datas) if stk is not None else scenes_from_datas(datas)
+        w = self._last_w = self._weights()
+        ag0 = datas[0]['agent']
         if ae.num_recurrent_steps_val == -1:
             # sticky like the reference (agent_decoder.py:1633-1635)
-            ae.num_recurrent_steps_val = scenes[0]['agent']['position'].shape[1] - ae.num_historical_steps
+            ae.num_recurrent_steps_val = int(ag0['position'].shape[1]) - ae.num_historical_steps
             w.cfg.num_recurrent_steps_val = ae.num_recurrent_steps_val
-        vocab = {k: scenes[0]['agent'][f'trajectory_token_{k}'] for k in ('veh', 'ped', 'cyc')}
+        vocab = {k: _np(ag0[f'trajectory_token_{k}']) for k in ('veh', 'ped', 'cyc')}
         map_vocab = _np(self.map_encoder.map_token['traj_src']).astype(np.float32)
         grid = ae.attr_tokenizer.grid.detach().cpu().numpy()
         xo = None
@@ -205,7 +268,7 @@ class InfGenDecoder(nn.Module):
             # stochastic decode like the reference's default (top-k multinomial), driven by torch's RNG: one uniform per decode
             # step and agent row - with insertion on for every row a scene can ever hold (a row without its own uniform would
             # be decoded greedily)
-            amax = max(int(np.asarray(s_['agent']['state_idx']).shape[0]) for s_ in scenes)
+            amax = max(int(d_['agent']['state_idx'].shape[0]) for d_ in datas)
             ucols = amax if w.cfg.disable_insertion else int(_lib.load().infgen_layout_query(_lib.Q_MAX_AGENTS))
             sample_uniforms = torch.rand(w.cfg.num_decode_steps, len(scenes), ucols).numpy()
         ik = int(getattr(ae, 'insert_beam_size', 1))
@@ -229,7 +292,10 @@ class InfGenDecoder(nn.Module):
                 ik if insert_uniforms is not None else 1, bool(int(os.getenv('DEBUG', 0))), batch is None, map_only, xo is None,
                 bool(batch_seed_outputs))
         eng = self._engines.get(ekey)
-        if eng is not None and eng.fits(scenes):
+        if (stk is not None and eng is not None and eng.fits_device(stk) and
+                eng.reload_device(stk, scenes, sample_uniforms=sample_uniforms, insert_uniforms=insert_uniforms, x_pt_override=xo)):
+            pass
+        elif eng is not None and eng.fits(scenes):
             eng.reload(scenes, sample_uniforms=sample_uniforms, insert_uniforms=insert_uniforms, x_pt_override=xo)
         else:
             eng = make_engine()
@@ -279,10 +345,11 @@ class InfGenDecoder(nn.Module):
             # the callee mutates data['batch_size_a'] like the reference (agent_decoder.py:1649)
             try:
                 filt = eng.hosts[i_]['filt']
-                av0 = int(np.asarray(scenes[i_]['agent']['av_index']).reshape(-1)[0])
-                removed = int((~filt[:av0]).sum())
-                if removed:
-                    d['batch_size_a'] -= removed
+                if not filt.all():
+                    av0 = int(np.asarray(scenes[i_]['agent']['av_index']).reshape(-1)[0])
+                    removed = int((~filt[:av0]).sum())
+                    if removed:
+                        d['batch_size_a'] -= removed
             except (KeyError, TypeError):
                 pass
             res.append(r)
@@ -347,7 +414,7 @@ class InfGenDecoder(nn.Module):
         scene), otherwise they are the zero arrays the reference initialises them to (agent_decoder.py:1746-1750)."""
         rs = self._run(None, batch=datas, batch_seed_outputs=seed_outputs)
         out = []
-        dev, ts = self._weights().device, self.map_encoder.token_size
+        dev, ts = self._last_w.device, self.map_encoder.token_size
         map_keys = {'map_next_token_idx': torch.zeros(0, 10, dtype=torch.long, device=dev),
                     'map_next_token_prob': torch.zeros(0, ts, device=dev),
                     'map_next_token_idx_gt': torch.zeros(0, dtype=torch.long, device=dev),

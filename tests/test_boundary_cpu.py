@@ -351,6 +351,77 @@ def test_stacked_host_setup_equals_the_per_scene_path():
     check(ragged, False)
 
 
+def test_device_side_setup_equals_the_host_setup():
+    """RolloutEngine._setup_device (the drop-in entry's reload of a batch that arrives as device tensors: the setup statements
+    and the epilogue's inputs as torch ops) writes exactly the arrays the host path uploads - run here on CPU tensors against
+    _setup_scenes / _scene_arrays / _epi_from_hosts, history edge cases included; a batch with a filtered row is refused"""
+    from infgen_amd import engine, synth
+    from infgen_amd.modules.infgen_decoder import stack_datas, _LazyScenes
+    from test_modules_gpu import _to_data
+    cfg = synth.standard_config()
+    vocab = synth.make_agent_vocab(cfg.token_size)
+    grid = synth.build_grid(cfg.grid_range, cfg.grid_interval, cfg.pl2seed_radius)
+    scenes = [synth.make_scene(900 + i, 40, 200, cfg, ego_last=(i % 2 == 0), edge_cases=(i % 3 == 0), vocab=vocab, grid=grid)
+              for i in range(12)]
+    scenes = [sc for sc in scenes if (np.asarray(sc['agent']['state_idx'])[:, 1] != 0).all()]
+    assert len(scenes) >= 8
+    dev = torch.device('cpu')
+    datas = [_to_data(sc, dev) for sc in scenes]
+    assert stack_datas(datas) is None                      # CPU tensors: the product path keeps its host setup
+    k = stack_datas(datas, any_device=True)
+    assert k is not None and k['agent']['state_idx'].shape[0] == len(scenes)
+    assert stack_datas(datas[:4], any_device=True) is None
+    assert stack_datas(datas + [_to_data(synth.make_scene(77, 24, 100, cfg, vocab=vocab, grid=grid), dev)], any_device=True) is None
+
+    def blank(S):
+        e = engine.RolloutEngine.__new__(engine.RolloutEngine)
+        e.cfg, e.T, e.hc, e.device = cfg, cfg.num_columns, cfg.hist_columns, dev
+        e.S, e.A_cap, e.M_cap, e.R = S, 64, 224, cfg.num_recurrent_steps_val
+        e.insertion, e.teacher_token, e._amax0, e._stacked = False, None, 40, None
+        return e
+    S = len(scenes)
+    host = blank(S)
+    host.scenes = scenes
+    host.hosts = host._setup_scenes(scenes)
+    arr = host._scene_arrays(host.hosts)
+    epi_h = host._epi_from_hosts()
+    d = blank(S)
+    T, A_cap, M_cap = d.T, d.A_cap, d.M_cap
+    junk = lambda *shape, dt: torch.full(shape, 7, dtype=dt)         # stale contents of a reused engine's buffers
+    d.pos, d.head = junk(S, T, A_cap, 2, dt=torch.float32), junk(S, T, A_cap, dt=torch.float32)
+    d.state, d.token, d.gridtok = (junk(S, T, A_cap, dt=torch.int32) for _ in range(3))
+    d.tmask, d.imask, d.catflag = (junk(S, T, A_cap, dt=torch.uint8) for _ in range(3))
+    d.atype, d.bos, d._shape10 = junk(S, A_cap, dt=torch.int32), junk(S, A_cap, dt=torch.int32), junk(S, A_cap, 3, dt=torch.float32)
+    d.n_agents, d.n_map, d.av = (junk(S, dt=torch.int32) for _ in range(3))
+    d.map_pos, d.map_orient = junk(S, M_cap, 2, dt=torch.float32), junk(S, M_cap, dt=torch.float32)
+    d._map_cat = tuple(junk(S, M_cap, dt=torch.int64) for _ in range(4))
+    assert d.fits_device(k)
+    assert d._setup_device(k) is True
+    for name in engine.RolloutEngine._SCENE_ARRAYS:
+        got = getattr(d, name).numpy()
+        assert got.dtype == arr[name].dtype and np.array_equal(got, arr[name]), name
+    for got, name in zip(d._map_cat, ('map_tok', 'map_type', 'map_pl', 'map_light')):
+        assert np.array_equal(got.numpy(), arr[name]), name
+    assert d._epi.keys() == epi_h.keys()
+    for name, v in epi_h.items():
+        got = d._epi[name]
+        got, v = (np.asarray(got), np.asarray(v)) if not isinstance(v, torch.Tensor) else (got.numpy(), v.numpy())
+        assert got.dtype == v.dtype and np.array_equal(got, v), name
+    assert d._gt_len == host._gt_len
+    assert [(h['A'], h['M'], h['av']) for h in d.hosts] == [(h['A'], h['M'], h['av']) for h in host.hosts]
+    # the host-side outputs() of such an engine rebuilds the full per-scene dicts from the lazily made host scenes
+    d.scenes = _LazyScenes(datas)
+    full = d._full_hosts()
+    assert set(full[0]) == set(host.hosts[0]) and np.array_equal(full[3]['tmask'], host.hosts[3]['tmask'])
+    # a filtered row (invalid at the last history column): refused before anything is written
+    bad = [dict(x) for x in datas]
+    bad[2] = dict(bad[2]); bad[2]['agent'] = dict(bad[2]['agent'])
+    st = bad[2]['agent']['state_idx'].clone(); st[5, cfg.hist_columns - 1] = 0
+    bad[2]['agent']['state_idx'] = st
+    before = d.pos.clone()
+    assert d._setup_device(stack_datas(bad, any_device=True)) is False and torch.equal(d.pos, before)
+
+
 def test_lazy_out_behaves_like_the_dict_it_replaces():
     """engine.LazyOut (the per-scene result of outputs_device / inference_batch): values are cut on first access, every dict
     operation that could observe one resolves it - same keys, same values as the plain dict of rounds 1 - 3"""

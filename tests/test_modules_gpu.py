@@ -128,6 +128,56 @@ def test_infgen_decoder_inference_with_insertion(monkeypatch):
     assert not torch.equal(out2['next_pos_rel_prob_seed'], snap['next_pos_rel_prob_seed'])
 
 
+@pytest.mark.parametrize('insertion', [False, True])
+def test_inference_batch_device_side_reload_equals_the_host_path(insertion, monkeypatch):
+    """the drop-in entry sets a one-shape batch of device tensors up ON the device when it reuses an engine
+    (RolloutEngine.reload_device: no device -> host -> device round trip of the scene arrays).  Every returned array must equal
+    what the host setup gives for the same batch - here the first call (new engine: host setup) against the second (reload on
+    the device) and against a decoder that is kept on the host path."""
+    from infgen_amd import synth
+    from infgen_amd.modules import infgen_decoder as idm
+    c = load_case('ins_forced_a16_m256' if insertion else 'c1_a8_m128')
+    cfg = c['cfg']
+    if insertion:
+        monkeypatch.setenv('DEBUG', '1')
+    dev = torch.device('cuda:0')
+    dec = _decoder(cfg)
+    dec.agent_encoder.disable_insertion = not insertion
+    _load(dec, c['sd'])
+    dec = dec.to(dev).eval()
+    A, M = (16, 256) if insertion else (11, 90)
+    mk = lambda seeds: [synth.make_scene(s, A, M, cfg, ego_last=(s % 2 == 0), vocab=c['vocab'], grid=c['grid']) for s in seeds]
+    first, second = mk(range(500, 509)), mk(range(600, 609))
+    keep = [sc for sc in first + second if (np.asarray(sc['agent']['state_idx'])[:, cfg.hist_columns - 1] != 0).all()]
+    assert len(keep) >= 16                                    # (no filtered rows: the batches stay on the device path)
+    first, second = keep[:8], keep[8:16]
+    dec.inference_batch([_to_data(s, dev) for s in first])             # builds the engine (host setup)
+    eng = next(iter(dec._engines.values()))
+    assert not getattr(eng, '_hosts_light', False)
+    outs = dec.inference_batch([_to_data(s, dev) for s in second])     # reuses it: set up on the device
+    assert next(iter(dec._engines.values())) is eng and eng._hosts_light is True
+    outs = [dict(o) for o in outs]
+    monkeypatch.setattr(idm, 'stack_datas', lambda datas, **kw: None)
+    ref = dec.inference_batch([_to_data(s, dev) for s in second])      # the same engine through the host-side reload
+    assert eng._hosts_light is False
+    assert len(outs) == len(ref) == 8
+    for o, r in zip(outs, ref):
+        assert set(o) == set(r)
+        for k in r:
+            if isinstance(r[k], torch.Tensor):
+                assert o[k].dtype == r[k].dtype and o[k].shape == r[k].shape and torch.equal(o[k], r[k]), k
+            else:
+                assert o[k] == r[k], k
+    # ... and the host-side outputs() of an engine that was reloaded on the device rebuilds its per-scene host dicts
+    monkeypatch.undo()
+    if insertion:
+        monkeypatch.setenv('DEBUG', '1')
+    dec.inference_batch([_to_data(s, dev) for s in first])
+    assert eng._hosts_light is True
+    host = eng.outputs()
+    assert eng._hosts_light is False and len(host) == 8 and host[0]['pos_a'].shape[0] >= A
+
+
 def test_operator_modules_match_oracle():
     """AttentionLayer / FourierEmbedding / MLPEmbedding / MLPLayer forward(...) with the reference's
     argument conventions (edge_index = [src; dst] COO in arbitrary order)."""
