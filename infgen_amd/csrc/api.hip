@@ -850,12 +850,12 @@ static int validate(const InfgenRollout* r, const char* where) {
   return 0;
 }
 
-static int build_edges_impl(const InfgenRollout* r, int c, int edgeless, void* stream, bool zero_totals);
+static int build_edges_impl(const InfgenRollout* r, int c, int edgeless, void* stream, bool zero_totals, unsigned long long* clear_keys = nullptr);
 extern "C" int infgen_build_edges(const InfgenRollout* r, int c, int edgeless, void* stream) {
   return build_edges_impl(r, c, edgeless, stream, true);
 }
 // zero_totals = false: the three totals were cleared by the previous step's k_integrate (IntegrateArgs.edge_totals)
-static int build_edges_impl(const InfgenRollout* r, int c, int edgeless, void* stream, bool zero_totals) {
+static int build_edges_impl(const InfgenRollout* r, int c, int edgeless, void* stream, bool zero_totals, unsigned long long* clear_keys) {
   RET_IF(validate(r, "infgen_build_edges"));
   OptScope _opts(r);
   hipStream_t s = (hipStream_t)stream;
@@ -870,16 +870,25 @@ static int build_edges_impl(const InfgenRollout* r, int c, int edgeless, void* s
   BuildEdgesArgs a;
   a.st = scene_of(r); a.c = c; a.edgeless = edgeless; a.r_map = r->r_map; a.r_agent = r->r_agent;
   a.rows = r->S * r->A_cap; a.t = ebuf(r->et); a.m = ebuf(r->em); a.a = ebuf(r->ea);
+  a.clear_keys = clear_keys;
   a.prof = (g_prof.mask & ((1u << INFGEN_KID_EDGE_ATTN) | (1u << INFGEN_KID_BUILD_EDGES))) ? g_prof.rows_dev : nullptr;
   { ProfScope _ps(INFGEN_KID_BUILD_EDGES, stream);
     a.map_lds = r->M_cap < 4096 ? r->M_cap : 4096;
     const size_t lds = (size_t)a.map_lds * 8;
-    if (r->A_cap <= 256) hipLaunchKernelGGL(k_build_edges<256>, dim3(r->S, 3), dim3(256), lds, s, a);
+    // few scenes: 16 waves per workgroup whatever A_cap (INFGEN_BE_WIDE_SCENES: the largest batch that takes them, default 128)
+    static const int wide_scenes = getenv("INFGEN_BE_WIDE_SCENES") ? atoi(getenv("INFGEN_BE_WIDE_SCENES")) : 128;
+    if (r->A_cap <= 256 && r->S > wide_scenes) hipLaunchKernelGGL(k_build_edges<256>, dim3(r->S, 3), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(k_build_edges<1024>, dim3(r->S, 3), dim3(1024), lds, s, a); }
   return check_launch("infgen_build_edges");
 }
 
 static RawFeatArgs rawfeat_args(const InfgenRollout* r, int col);
+// workgroups per scene of k_integrate: 16 rows each for few scenes (INFGEN_INT_GROUP_SCENES: the largest batch, default 128), else 1.
+// With more than one the arg-max keys are reset by the k_build_edges that follows (build_edges_impl: clear_keys), not by k_integrate.
+static int integrate_groups(const InfgenRollout* r) {
+  static const int max_scenes = getenv("INFGEN_INT_GROUP_SCENES") ? atoi(getenv("INFGEN_INT_GROUP_SCENES")) : 128;
+  return (r->S <= max_scenes && r->A_cap % 16 == 0 && r->A_cap > 16) ? r->A_cap / 16 : 1;
+}
 static int integrate_impl(const InfgenRollout* r, int t, void* stream, unsigned long long* heads_part, bool zero_totals, bool prep);
 extern "C" int infgen_integrate(const InfgenRollout* r, int t, void* stream) {
   return integrate_impl(r, t, stream, nullptr, false, false);
@@ -898,10 +907,11 @@ static int integrate_impl(const InfgenRollout* r, int t, void* stream, unsigned 
   a.teacher_pos = r->teacher_pos; a.teacher_head = r->teacher_head;
   a.vocab = r->vocab; a.token_size = r->token_size; a.grid_xy = r->grid_xy; a.grid_size = r->grid_size;
   a.pred_traj = r->pred_traj; a.pred_head = r->pred_head; a.pred_state = r->pred_state;
+  a.groups = integrate_groups(r);
   { ProfScope _ps(INFGEN_KID_INTEGRATE, stream);
-    // 16 waves per scene whatever A_cap: the grid-cell search is one wave per agent (4 instead of 16 agents per wave with 256
-    // threads: 0.95 -> 0.56 ms per rollout at 8 scenes, 1.23 -> 0.98 at 512)
-    hipLaunchKernelGGL(k_integrate<1024>, dim3(r->S), dim3(1024), 0, (hipStream_t)stream, a); }
+    // 16 waves per workgroup whatever A_cap: the grid-cell search is one wave per agent (4 instead of 16 agents per wave with 256
+    // threads: 0.95 -> 0.56 ms per rollout at 8 scenes, 1.23 -> 0.98 at 512); few scenes: 16 rows per workgroup, one wave each
+    hipLaunchKernelGGL(k_integrate<1024>, dim3(r->S, a.groups), dim3(1024), 0, (hipStream_t)stream, a); }
   return check_launch("infgen_integrate");
 }
 
@@ -1092,9 +1102,10 @@ static bool fourier_multi_ok(int rows, int edgeless) {
 // edge sets of column c + their Fourier embeddings.  zero_totals = false: the totals were cleared by k_integrate; with_xa: the
 // x_a_emb embedding of the rows' raw features (raw2 / cat -> fus_in, infgen_raw_feature's middle launch) rides along as a
 // fourth set of the multi launch
-static int prepare_edges(const InfgenRollout* r, int c, int edgeless, void* stream, bool zero_totals, bool with_xa) {
+static int prepare_edges(const InfgenRollout* r, int c, int edgeless, void* stream, bool zero_totals, bool with_xa,
+                         unsigned long long* clear_keys = nullptr) {
   const int rows = r->S * r->A_cap;
-  RET_IF(build_edges_impl(r, c, edgeless, stream, zero_totals));
+  RET_IF(build_edges_impl(r, c, edgeless, stream, zero_totals, clear_keys));
   const StepMode sm = step_mode(r, rows, edgeless);
   const bool overlap = sm.overlap; const int r24 = sm.r24; const float* dt = sm.dt;
   if (overlap) {
@@ -1312,7 +1323,7 @@ extern "C" int infgen_rollout_run(const InfgenRollout* r, int t0, int t1, void* 
     // (the last step keeps its edge totals, like infgen_decode_step: RolloutEngine.edge_totals() / overflow checks read them)
     RET_IF(integrate_impl(r, t, stream, split ? keys : nullptr, t + 1 < t1, true));
     if (t + 1 < t1) {
-      RET_IF(prepare_edges(r, c + 1, 0, stream, false, true));
+      RET_IF(prepare_edges(r, c + 1, 0, stream, false, true, split && integrate_groups(r) > 1 ? keys : nullptr));
     } else {          // after the last step only the raw feature of the new column is left (kept: the context's X stays what
                       // infgen_decode_step leaves)
       RET_IF(infgen_fourier_embed(r->raw2, 2, nullptr, rows, r->four_xa, r->cat, 128, r->fus_in + 128, 512, 0, stream));

@@ -98,20 +98,21 @@ __device__ __forceinline__ size_t sidx(const SceneState& st, int s, int col, int
   return ((size_t)s * st.T + col) * st.A_cap + a;
 }
 
-// block-wide exclusive scan of one int per thread (BT threads); returns exclusive prefix, total in *tot
+// block-wide exclusive scan of one int per thread (BT threads); returns exclusive prefix, total in *tot.  n (<= BT, uniform): threads
+// n.. hold zeros - the doubling stops at n (two barriers per step: 64 rows in a 1024-thread workgroup take 6 steps, not 10)
 template <int BT>
-__device__ __forceinline__ int block_excl_scan(int v, int* sh /*[BT+1]*/, int* tot) {
+__device__ __forceinline__ int block_excl_scan(int v, int* sh /*[BT+1]*/, int* tot, int n = BT) {
   const int t = threadIdx.x;
   sh[t] = v;
   __syncthreads();
-  for (int o = 1; o < BT; o <<= 1) {
+  for (int o = 1; o < n; o <<= 1) {
     int x = (t >= o) ? sh[t - o] : 0;
     __syncthreads();
     sh[t] += x;
     __syncthreads();
   }
   const int incl = sh[t];
-  *tot = sh[BT - 1];
+  *tot = sh[n - 1];
   __syncthreads();
   return incl - v;
 }
@@ -125,7 +126,9 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh /*[BT+1]*/, int* t
 // src holds the row index into the K/V source array of that edge type:
 //   temporal: (j % ring) * rows + row ; map: s * M_cap + m ; agent: s * A_cap + j
 // ------------------------------------------------------------------------------------------
-// one thread per agent row of the scene: BT = 256 threads for A_cap <= 256, 1024 beyond (long rollouts with insertion)
+// one thread per agent row of the scene: BT = 256 threads for A_cap <= 256, 1024 beyond (long rollouts with insertion) - and for
+// few scenes at any A_cap: the map and agent parts are one wave per destination row, 16 waves take a quarter of 4 waves' trips
+// (same lists in the same order: the ranks come from ballots and the row offsets from the scan over the rows)
 constexpr int MAP_LDS = 4096; // map-token positions staged in LDS by k_build_edges
 
 template <int BT>
@@ -146,6 +149,7 @@ __global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
   const int rows_total = a.rows;
   const int row = s * st.A_cap + t;
   const int part = blockIdx.y;        // the three sets of a scene are built by three workgroups (grid S x 3): independent lists
+  if (a.clear_keys && part == 0 && t < st.A_cap) a.clear_keys[row] = 0ull;
   if (a.edgeless) {
     if (part == 0 && t < st.A_cap) {
       a.t.off[row] = 0; a.t.cnt[row] = 0;
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
       cnt = __popc(ok_mask);
     }
     int tot;
-    const int excl = block_excl_scan<BT>(cnt, scan, &tot);
+    const int excl = block_excl_scan<BT>(cnt, scan, &tot, min(st.A_cap, BT));
     if (t == 0) { base_t = atomicAdd(a.t.total, tot); if (a.prof) atomicAdd(a.prof + 8, (unsigned long long)tot); }
     __syncthreads();
     if (t < st.A_cap) {
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
     __syncthreads();
     const int cnt = (t < st.A_cap) ? mapcnt[t] : 0;
     int tot;
-    const int excl = block_excl_scan<BT>(cnt, scan, &tot);
+    const int excl = block_excl_scan<BT>(cnt, scan, &tot, min(st.A_cap, BT));
     if (t == 0) { base_m = atomicAdd(a.m.total, tot); if (a.prof) atomicAdd(a.prof + 9, (unsigned long long)tot); }
     __syncthreads();
     if (t < st.A_cap) {
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
     __syncthreads();
     const int cnt = (t < st.A_cap) ? acnt[t] : 0;
     int tot;
-    const int excl = block_excl_scan<BT>(cnt, scan, &tot);
+    const int excl = block_excl_scan<BT>(cnt, scan, &tot, min(st.A_cap, BT));
     if (t == 0) { base_a = atomicAdd(a.a.total, tot); if (a.prof) atomicAdd(a.prof + 10, (unsigned long long)tot); }
     __syncthreads();
     if (t < st.A_cap) {
@@ -443,30 +447,44 @@ __global__ __launch_bounds__(NT) void k_map_graph(MapGraphArgs a) {
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void rawfeat_prep_item(const RawFeatArgs& a, int row, int slot, int c4);     // (defined below)
 constexpr int GRID_LDS = 2048;   // grid cells staged in LDS (1961 for the 150 m / 3 m / 75 m grid)
+// a.groups > 1 (few scenes): the scene's rows are dealt to `groups` workgroups (grid S x groups), A_cap / groups rows each - the
+// grid-cell search is one wave per agent and 16 waves searching for 64 agents one after the other were most of the launch (41 us at
+// 8 scenes on 8 of 256 CUs).  Every workgroup also integrates the ego's step for itself (the search is relative to the ego's NEW
+// pose) without storing it; the arg-max keys are then cleared by the next launch (k_build_edges: clear_keys), not here - another
+// workgroup may still have to read the ego's.
 template <int BT>
 __global__ __launch_bounds__(BT) void k_integrate(IntegrateArgs a) {
   __shared__ float npx[BT], npy[BT], nth[BT];
   __shared__ int nst[BT];
+  __shared__ float ego[3];
   __shared__ __attribute__((aligned(8))) float2 gxy[GRID_LDS];
   const bool grid_in_lds = a.grid_size <= GRID_LDS;
   if (grid_in_lds)
     for (int g = threadIdx.x; g < a.grid_size; g += BT) gxy[g] = *reinterpret_cast<const float2*>(a.grid_xy + 2 * g);
   const SceneState& st = a.st;
-  const int s = blockIdx.x, t = threadIdx.x;
+  const int s = blockIdx.x, tl = threadIdx.x;
+  const int groups = a.groups > 1 ? a.groups : 1;
+  const int per = st.A_cap / groups;                 // rows of this workgroup: [a0, a0 + per)
+  const int a0 = (int)blockIdx.y * per;
   const int A = st.n_agents[s];
   const int av = st.av_index[s];
   const int c = a.c, n = a.c + 1;
+  const bool own = tl < per;                          // this thread integrates row a0 + tl ...
+  const bool dup = groups > 1 && tl == per && (av < a0 || av >= a0 + per);     // ... or the ego of another workgroup, unstored
+  const int t = own ? a0 + tl : av;
   // the split arg-max keys of k_heads (ordered 64-bit (max, first index) keys): decoded here instead of by k_heads_finish, and
   // cleared for the next decode step - for EVERY row of the scene (an appended row must not inherit an older maximum)
   int tok_dec = 0;
-  if (a.heads_part && t < st.A_cap) {
+  if (a.heads_part && (own || dup)) {
     const int row = s * st.A_cap + t;
     tok_dec = (int)(0xffffffffu - (unsigned)(a.heads_part[row] & 0xffffffffull));
-    a.heads_part[row] = 0ull;
-    a.next_token_w[row] = tok_dec;
+    if (own) {
+      if (groups == 1) a.heads_part[row] = 0ull;
+      a.next_token_w[row] = tok_dec;
+    }
   }
-  if (a.edge_totals && s == 0 && t < 3) a.edge_totals[t] = 0;       // the next column's k_build_edges starts from zero
-  if (t < A) {
+  if (a.edge_totals && s == 0 && blockIdx.y == 0 && tl < 3) a.edge_totals[tl] = 0;       // the next column's k_build_edges starts from zero
+  if ((own || dup) && t < A) {
     const int row = s * st.A_cap + t;
     int tok = a.heads_part ? tok_dec : a.next_token[row];
     int ns = a.next_state[row];
@@ -494,27 +512,32 @@ __global__ __launch_bounds__(BT) void k_integrate(IntegrateArgs a) {
       const float mx = (((cx[0] + cx[1]) + cx[2]) + cx[3]) / 4.0f;
       const float my = (((cy[0] + cy[1]) + cy[2]) + cy[3]) / 4.0f;
       const float hh = atan2f(cy[0] - cy[3], cx[0] - cx[3]);
-      const size_t o = ((size_t)row * a.R + a.t * 5 + (k - 1));
-      a.pred_traj[2 * o] = mx; a.pred_traj[2 * o + 1] = my;
-      a.pred_head[o] = hh;
-      a.pred_state[o] = (float)ns;
+      if (own) {
+        const size_t o = ((size_t)row * a.R + a.t * 5 + (k - 1));
+        a.pred_traj[2 * o] = mx; a.pred_traj[2 * o + 1] = my;
+        a.pred_head[o] = hh;
+        a.pred_state[o] = (float)ns;
+      }
       if (k == 5) { lx = mx; ly = my; lth = hh; }
     }
     if (a.teacher_pos) {        // the stored pose is the teacher's (pred_traj / pred_head above keep this step's own result)
       const size_t in_ = sidx(st, s, n, t);
       lx = a.teacher_pos[2 * in_]; ly = a.teacher_pos[2 * in_ + 1]; lth = a.teacher_head[in_];
     }
-    npx[t] = lx; npy[t] = ly; nth[t] = lth; nst[t] = ns;
+    if (own) { npx[tl] = lx; npy[tl] = ly; nth[tl] = lth; nst[tl] = ns; }
+    if (t == av) { ego[0] = lx; ego[1] = ly; ego[2] = lth; }
   }
   __syncthreads();
   // grid token of every agent: one wave per agent, lanes over grid cells
   {
-    const float ex = npx[av], ey = npy[av];
-    const float phi = -(nth[av] - HALF_PI_F);
+    const float ex = ego[0], ey = ego[1];
+    const float phi = -(ego[2] - HALF_PI_F);
     const float cs = cosf(phi), sn = sinf(phi);
     const int lane = lane_id();
-    for (int ag = wave_id(); ag < A; ag += BT / 64) {
-      const float dx = npx[ag] - ex, dy = npy[ag] - ey;
+    const int a1 = min(A, a0 + per);
+    for (int ag = a0 + wave_id(); ag < a1; ag += BT / 64) {
+      const int al = ag - a0;
+      const float dx = npx[al] - ex, dy = npy[al] - ey;
       const float rx = dx * cs + dy * (-sn);
       const float ry = dx * sn + dy * cs;
       float best = INFINITY;
@@ -534,12 +557,12 @@ __global__ __launch_bounds__(BT) void k_integrate(IntegrateArgs a) {
       }
       if (lane == 0) {
         const size_t in_ = sidx(st, s, n, ag);
-        const int ns = nst[ag];
+        const int ns = nst[al];
         const bool inv = ns == INVALID;
         st.state[in_] = ns;
-        st.pos[2 * in_] = inv ? 0.f : npx[ag];
-        st.pos[2 * in_ + 1] = inv ? 0.f : npy[ag];
-        st.head[in_] = inv ? 0.f : nth[ag];
+        st.pos[2 * in_] = inv ? 0.f : npx[al];
+        st.pos[2 * in_ + 1] = inv ? 0.f : npy[al];
+        st.head[in_] = inv ? 0.f : nth[al];
         int cell = bi;
         if (a.teacher_grid && a.teacher_grid[in_] >= -1) cell = a.teacher_grid[in_];
         st.grid[in_] = inv ? -1 : cell;
@@ -551,10 +574,10 @@ __global__ __launch_bounds__(BT) void k_integrate(IntegrateArgs a) {
     }
   }
   if (a.do_prep) {
-    // the raw-feature gather of the column just written (k_rawfeat_prep), all rows of this scene: one launch less per step
+    // the raw-feature gather of the column just written (k_rawfeat_prep), the rows of this workgroup: one launch less per step
     __syncthreads();
-    for (int item = t; item < st.A_cap * 32; item += BT) {
-      const int row = s * st.A_cap + (item >> 5);
+    for (int item = tl; item < per * 32; item += BT) {
+      const int row = s * st.A_cap + a0 + (item >> 5);
       rawfeat_prep_item(a.prep, row, row, item & 31);
     }
   }

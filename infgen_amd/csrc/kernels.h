@@ -334,6 +334,7 @@ struct BuildEdgesArgs {
   EdgeBuf t, m, a;
   unsigned long long* prof;         // optional profiling counters (api.hip Prof::rows_dev): [8 + kind] += edges of the scene
   int map_lds;                      // float2 slots of dynamic LDS for the scene's map-token positions (0 .. 4096)
+  unsigned long long* clear_keys;   // optional [rows]: k_heads' split arg-max keys, reset here when the k_integrate before ran in row groups
 };
 
 struct RawFeatArgs {
@@ -367,6 +368,7 @@ struct IntegrateArgs {
   int* next_token_w;                // where the decoded tokens go (the context's next_token array)
   int* edge_totals;                 // the three edge totals of the context, zeroed for the next column's k_build_edges
   RawFeatArgs prep; int do_prep;    // the raw-feature gather (k_rawfeat_prep) of the new column, all rows of the scene
+  int groups;                       // > 1: grid S x groups, A_cap / groups rows per workgroup (few scenes); the keys are then NOT reset here
   const float* vocab;               // [3][token_size][6][4][2]
   int token_size;
   const float* grid_xy; int grid_size;    // [G][2]
