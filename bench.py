@@ -320,7 +320,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--scenes', type=int, default=512, help='scenes per GPU (weak scaling)')
+    ap.add_argument('--scenes', type=int, default=1024, help='scenes per GPU (weak scaling; 512 until round 4: 25.7 M, 1024: 27.2 M)')
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
                     help='strong: a fixed batch of --total-scenes scenes dealt to the ranks (scene i -> rank i mod N)')
     ap.add_argument('--total-scenes', type=int, default=64, help='batch size of --scaling strong (BASELINE C3: 64)')

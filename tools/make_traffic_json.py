@@ -2,7 +2,7 @@
 the dispatches of the pass): bytes per launch, FETCH corrected by the factors tools/calibrate_fetch.sh measured.
 usage: make_traffic_json.py <pmc_FETCH_SIZE.summary.csv> <pmc_WRITE_SIZE.summary.csv> <fetch_factor_8B> <fetch_factor_16B> <tag>
        [<pmc_FETCH_SIZE.bygrid.csv> <pmc_WRITE_SIZE.bygrid.csv>]   -> also `k_edge_attn_step`: the decode-step launches alone"""
-import csv, json, sys
+import csv, json, os, sys
 fetch, write, f8, f16, tag = sys.argv[1], sys.argv[2], float(sys.argv[3]), float(sys.argv[4]), sys.argv[5]
 names = {'k_edge_fused': ('k_edge_attn', f8), 'k_attn_h': ('k_attn_post', f16), 'k_fourier_h': ('k_fourier', f16)}
 
@@ -49,6 +49,6 @@ for kid in fe:
 json.dump(dict(source=f'{tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of `python bench.py --no-cpu-baseline '
                       f'--no-parity --steps 1 --warmup 1` (tools/prof_round.sh); FETCH_SIZE divided by the counted / actual factor '
                       f'of a known-size streaming read of the same width (tools/calibrate_fetch.sh), WRITE_SIZE as counted',
-               scenes_per_gpu=512, agents=64, map_tokens=1024, insertion=False, rollout_steps=80, kernels=kern),
+               scenes_per_gpu=int(os.environ.get('SCENES', 1024)), agents=64, map_tokens=1024, insertion=False, rollout_steps=80, kernels=kern),
           open('profiles/traffic.json', 'w'), indent=1)
 print(json.dumps(kern, indent=1))
