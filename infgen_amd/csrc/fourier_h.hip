@@ -63,6 +63,24 @@ __device__ __forceinline__ void sincos_fast(float z, float& s, float& c) {
   s = __uint_as_float(sv ^ (((unsigned)qi & 2u) << 30));
   c = __uint_as_float(cv ^ ((((unsigned)qi + 1u) & 2u) << 30));
 }
+// Round 4: the same pair through the hardware's v_sin_f32 / v_cos_f32 (argument in revolutions, valid on [-256, 256]).  The reference
+// takes sin / cos of the ROUNDED fp32 product z = x f 2 pi, so z itself is reduced: r = z / (2 pi) - rint(z / (2 pi)) with 1 / (2 pi) as
+// two floats and the products inside fused multiply-adds (z * c_hi is exact there: 24 x 24 bits; the result is rounded once at
+// |r| <= 0.5, 3e-8 of a revolution = 1.9e-7 rad, for every |z| < 1e8).  Four vector instructions and two transcendental ones per
+// pair instead of ~30: the sine / cosine features were a quarter of the kernel's vector work, and the kernel is bound by that work
+// (tools/bench_fourier.py with the matrix phases removed: 292 of 409 us; with the vector phases removed: 195).  Measured against fp64
+// (tools/hw_sincos_probe.hip): max |error| 2.6e-7 (sincos_fast: 6e-8) - under the 2^-21 per product of the three-term split that
+// consumes the features, and 30 x under the 2^-17 of the packed 24-bit output rows.  IG_FH_HWSIN=0 restores sincos_fast.
+#ifndef IG_FH_HWSIN
+#define IG_FH_HWSIN 1
+#endif
+__device__ __forceinline__ void sincos_hw(float z, float& s, float& c) {
+  const float k = rintf(z * 0.15915494f);
+  float r = __builtin_fmaf(z, 0.15915494f, -k);              // 0x3e22f983
+  r = __builtin_fmaf(z, 6.4206382e-09f, r);                  // 1 / (2 pi) - 0x3e22f983
+  s = __builtin_amdgcn_sinf(r);
+  c = __builtin_amdgcn_cosf(r);
+}
 // (results by value: reference arguments of a non-inlined function would go through scratch memory)
 __device__ __noinline__ f32x2 sincos_big(float z) {
   const double zd = (double)z;
@@ -92,7 +110,11 @@ __device__ __forceinline__ void sincos_group(float x, const float (&fr)[8], floa
   for (int p = 0; p < 8; ++p) {
     z[p] = x * fr[p] * 2.0f * PI_F;
     zmax = fmaxf(zmax, fabsf(z[p]));          // (a NaN argument gives NaN on the fast path as well)
+#if IG_FH_HWSIN
+    sincos_hw(z[p], sn[p], cs[p]);
+#else
     sincos_fast(z[p], sn[p], cs[p]);
+#endif
   }
   if (__builtin_expect(__any(!(zmax < 1.0e5f)), 0)) {
 #pragma unroll

@@ -63,6 +63,9 @@ __device__ __forceinline__ float xor_lanes_max(float v) {
 #ifndef IG_GQ_INTERLEAVE
 #define IG_GQ_INTERLEAVE 0
 #endif
+#ifndef IG_GU_NOREAD      // timing experiment (wrong results): gemm_unit reads its A fragments from LDS once per GEMM instead of eight times
+#define IG_GU_NOREAD 0
+#endif
 __device__ __forceinline__ void lds_dma16(const void* gptr, unsigned lds_byte_addr_uniform) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                :: "s"(lds_byte_addr_uniform), "v"(gptr) : "memory");     // (M0 is reserved - not a legal clobber; nothing else in these kernels uses it: tests/test_boundary_cpu.py scans for that)
@@ -195,7 +198,7 @@ struct GemmUnit {
   template <bool LAST>
   __device__ __forceinline__ void group(f32x4 (&acc)[8], int grp, u32x4 Bh, u32x4 Bl) {
     const int buf = grp & 1, o = 4 * (grp & 1);
-    if (!LAST) request(grp + 1, buf ^ 1);
+    if (!LAST && !IG_GU_NOREAD) request(grp + 1, buf ^ 1);
     const v8h bh = __builtin_bit_cast(v8h, Bh);
     const v8h bl = __builtin_bit_cast(v8h, Bl);
 #pragma unroll
@@ -222,6 +225,7 @@ __device__ __forceinline__ void gemm_unit(f32x4 (&acc)[8], const unsigned short*
   GemmUnit<TERMS> u;
   u.p = Wu + lane * 8;
   u.request(0, 0);
+  if (IG_GU_NOREAD) u.request(1, 1);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int grp = 0; grp < 7; ++grp) u.template group<false>(acc, grp, Bh[grp >> 1], Bl[grp >> 1]);

@@ -8,7 +8,7 @@ __global__ void k(const float* z, float* s, float* c, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float x = z[i];
-  const float c_hi = 0.15915494f, c_lo = 4.4614608e-09f;          // 1 / (2 pi) = c_hi + c_lo (c_hi = 0x3e22f983)
+  const float c_hi = 0.15915494f, c_lo = 6.4206382e-09f;          // 1 / (2 pi) = c_hi + c_lo (c_hi = 0x3e22f983)
   const float t = x * c_hi;
   const float k_ = rintf(t);
   float r = __builtin_fmaf(x, c_hi, -k_);
