@@ -319,10 +319,14 @@ static int fourier_embed_impl(const float* raw, int n, const int* count_dev, int
     ProfScope _ps(INFGEN_KID_FOURIER, stream);
     hipLaunchKernelGGL(k_fourier, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a);
   } else {
-    int grid = ceil_div(e_cap, FH_TILE);     // 128-row tiles (8 waves x 16 rows), persistent
+    // large sets: the three-wave-group variant (fourier_h12.hip); INFGEN_FH12_MIN = smallest capacity that takes it (0: never)
+    static const int fh12_min = getenv("INFGEN_FH12_MIN") ? atoi(getenv("INFGEN_FH12_MIN")) : 150000;
+    const bool wide = fh12_min > 0 && e_cap >= fh12_min && O().gemm_terms != 1 && FH_WAVES == 8;
+    int grid = ceil_div(e_cap, wide ? FH12_TILE : FH_TILE);     // 128-row tiles (8 waves x 16 rows), persistent
     if (grid > 256 * FH_WG_PER_CU) grid = 256 * FH_WG_PER_CU;          // one workgroup per CU (fourier_h.hip explains why)
     ProfScope _ps(INFGEN_KID_FOURIER, stream);
-    if (O().gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h<1>, dim3(grid), dim3(FH_NT), 0, (hipStream_t)stream, a);
+    if (wide) hipLaunchKernelGGL(k_fourier_h12<3>, dim3(grid), dim3(FH12_NT), 0, (hipStream_t)stream, a);
+    else if (O().gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h<1>, dim3(grid), dim3(FH_NT), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_fourier_h<3>, dim3(grid), dim3(FH_NT), 0, (hipStream_t)stream, a);
   }
   return check_launch("infgen_fourier_embed");

@@ -452,6 +452,8 @@ __global__ void k_linear_multi(LinearMultiArgs m);
 __global__ void k_fourier(FourierArgs a);
 template <int TERMS> __global__ void k_fourier_h(FourierArgs a);
 template <int TERMS> __global__ void k_fourier_h_multi(FourierMultiArgs m);
+template <int TERMS> __global__ void k_fourier_h12(FourierArgs a);      // fourier_h12.hip: three wave groups, 192-edge tiles
+constexpr int FH12_NT = 768, FH12_TILE = 192;
 __global__ void k_match_tokens(MatchTokensArgs a);   // token_kernels.hip
 template <int TERMS> __global__ void k_mlpemb_h(MlpEmbHArgs a);           // mlp_h.hip
 __global__ void k_box_corners(NearestArgs a);        // metric_kernels.hip

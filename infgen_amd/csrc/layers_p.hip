@@ -158,7 +158,7 @@ __device__ __forceinline__ void row_stats(const float2* ST, int j, float& mean, 
   const float within = ((a.y + a.w) + (b.y + b.w)) + ((c.y + c.w) + (d.y + d.w));
   const float between = (fmaf(e0, e0, e1 * e1) + fmaf(e2, e2, e3 * e3)) + (fmaf(e4, e4, e5 * e5) + fmaf(e6, e6, e7 * e7));
   const float var_eps = fmaf(16.0f, between, within) * (1.0f / 128.0f) + LN_EPS;
-  rstd = 1.0f / sqrtf(var_eps);
+  rstd = ln_rstd(var_eps);
 }
 __device__ __forceinline__ f32x4 ln_own(f32x4 v, float mean, float rstd, const float* g, const float* b) {
   const f32x4 y = (v - splat4(mean)) * splat4(rstd);

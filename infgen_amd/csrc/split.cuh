@@ -58,7 +58,7 @@ __device__ __forceinline__ float xor_lanes_max(float v) {
 #define IG_DMA_BUILTIN 0
 #endif
 #ifndef IG_LN_RSQ
-#define IG_LN_RSQ 0
+#define IG_LN_RSQ 1
 #endif
 #ifndef IG_GQ_INTERLEAVE
 #define IG_GQ_INTERLEAVE 0
@@ -298,6 +298,19 @@ __device__ __forceinline__ f32x4 lds4(const float* p) {
   return f32x4{v.x, v.y, v.z, v.w};
 }
 
+// 1 / sqrt(var + eps): v_rsq_f32 (1 ulp) + one Newton step instead of the correctly rounded square root and division (~25 dependent
+// instructions of a chain that a lone wave pays in full: s_memtime traces of k_fourier_h); var + eps >= 1e-5, far from the denormal
+// range; the result is within an ulp of the correctly rounded one (IG_LN_RSQ=0: sqrtf and a division; round 4, with the vector
+// phases of k_fourier_h shortened: +0.7 % per 1024-scene rollout, it was +0.3 % in round 3 and off)
+__device__ __forceinline__ float ln_rstd(float var_eps) {
+#if IG_LN_RSQ
+  const float y = __builtin_amdgcn_rsqf(var_eps);
+  const float e = __builtin_fmaf(-(var_eps * y), y, 1.0f);
+  return __builtin_fmaf(0.5f * y, e, y);
+#else
+  return 1.0f / sqrtf(var_eps);
+#endif
+}
 // (two halves so that a kernel can put a slot barrier between them: ln_stats centres v and returns 1 / sqrt(var + eps), ln_apply
 // scales and applies the affine part / ReLU; ln_regs = both, the same operations in the same order)
 __device__ __forceinline__ float ln_stats(f32x4 (&v)[8]) {
@@ -314,15 +327,7 @@ __device__ __forceinline__ float ln_stats(f32x4 (&v)[8]) {
   }
   q4 += q5;
   const float var_eps = xor_lanes((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 128.0f) + LN_EPS;
-#if IG_LN_RSQ
-  // v_rsq_f32 (1 ulp) + one Newton step instead of the correctly rounded square root and division (~25 dependent instructions of a
-  // chain that a lone wave pays in full: s_memtime traces of k_fourier_h); var + eps >= 1e-5, far from the denormal range
-  const float y = __builtin_amdgcn_rsqf(var_eps);
-  const float e = __builtin_fmaf(-(var_eps * y), y, 1.0f);
-  return __builtin_fmaf(0.5f * y, e, y);
-#else
-  return 1.0f / sqrtf(var_eps);
-#endif
+  return ln_rstd(var_eps);
 }
 template <bool AFFINE, bool RELU>
 __device__ __forceinline__ void ln_apply(f32x4 (&v)[8], float rstd, const float* gtab, const float* btab, int rg) {

@@ -163,6 +163,38 @@ def test_fourier_time_gap_table(env, terms):
         assert np.abs(a1 - ref2).max() <= 2e-4
 
 
+def test_fourier_three_wave_group_variant_gives_the_same_rows(env):
+    """large edge sets take k_fourier_h12 (three wave groups, 192-edge tiles; csrc/fourier_h12.hip), chosen by the set's
+    CAPACITY: the same 90,001 counted rows through a small-capacity launch (k_fourier_h) and a large-capacity one must be
+    bitwise equal - fp32 rows and packed 24-bit rows, n = 3 and 4"""
+    from infgen_amd import _lib
+    lib, dev = env['lib'], env['dev']
+    E, cap_small, cap_large = 90001, 100000, 400000
+    for n, prefix in ((3, 'agent_encoder.r_a2a_emb'), (4, 'agent_encoder.r_t_emb')):
+        rng = np.random.default_rng(n)
+        raw = np.zeros((cap_large, 4), np.float32)
+        raw[:, 0] = rng.uniform(0, 60, cap_large)
+        raw[:, 1:n] = rng.uniform(-np.pi, np.pi, (cap_large, n - 1))
+        if n == 4:
+            raw[:, 3] = -rng.integers(1, 13, cap_large)
+        rawd = _dev(raw, dev)
+        pack = _dev(env['packing'].pack_fourier(env['sd'], prefix, n), dev)
+        count = torch.tensor([E], device=dev, dtype=torch.int32)
+        outs = []
+        for cap in (cap_small, cap_large):
+            o32 = torch.zeros(cap_large, 128, device=dev)
+            _lib.check(lib.infgen_fourier_embed(_lib.ptr(rawd), n, _lib.ptr(count), cap, _lib.ptr(pack), None, 0, _lib.ptr(o32), 128, 1,
+                                                env['ops'].stream))
+            o24 = torch.zeros(cap_large, 96, device=dev)            # 384 bytes per row
+            _lib.check(lib.infgen_fourier_embed_r24(_lib.ptr(rawd), n, _lib.ptr(count), cap, _lib.ptr(pack), o24.data_ptr(),
+                                                    env['ops'].stream))
+            outs.append((o32, o24))
+        torch.cuda.synchronize()
+        assert float(outs[0][0][:E].abs().max()) > 0 and float(outs[0][0][E:].abs().max()) == 0
+        for a_, b_ in zip(outs[0], outs[1]):
+            assert torch.equal(a_.view(torch.int32), b_.view(torch.int32)), n
+
+
 def test_fourier_split_is_deterministic(env):
     """350k rows (every CU busy for ~10 tiles), four launches: bitwise identical, and equal to the fp32-MFMA kernel
     within the split's accuracy.  Guards the one-workgroup-per-CU placement of k_fourier_h (csrc/fourier_h.hip)."""
