@@ -12,6 +12,8 @@
 // the eight waves: vector work is cheap here, the chain is what costs).  Per accumulator the products are issued in
 // k_attn_h's order (k-step major; hi x hi, hi x lo, lo x hi), so the GEMM results are bit-identical to k_attn_h's.
 //   z-GEMM / u-GEMM: head h is feature tile h - wave w takes head w (k_edge_fused's per-(row, head) scaling for u).
+// (the LayerNorm tables stay read-where-used here: with split.cuh's ln_fetch the kernel needs 40 registers more than it has)
+#define IG_LN_PREFETCH 0
 #include "kernels.h"
 #include "layout.h"
 #include "tile.cuh"

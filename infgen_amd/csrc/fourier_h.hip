@@ -199,7 +199,7 @@ template __global__ void k_fourier_h<1>(FourierArgs);
 
 }  // namespace ig
 
-#if IG_FH_TRACE
+#if IG_FH_TRACE && !defined(k_fourier_h)          // (not again in the translation unit of the 12-wave variant, fourier_h12.hip)
 extern "C" int infgen_debug_fh_trace(unsigned long long* host512) {
   return (int)hipMemcpyFromSymbol(host512, HIP_SYMBOL(ig::g_fh_trace), 512 * sizeof(unsigned long long));
 }

@@ -340,10 +340,42 @@ __device__ __forceinline__ void ln_apply(f32x4 (&v)[8], float rstd, const float*
     v[t] = y;
   }
 }
+// The affine tables of a LayerNorm in registers.  ln_apply reads gamma / beta of a feature tile right where it uses them, and hipcc
+// keeps one or two of those sixteen LDS reads in flight (`s_waitcnt lgkmcnt(1)` in front of every pair of products): sixteen exposed
+// LDS round trips per LayerNorm, each queued behind the fragment reads of the SIMD's other wave - the LayerNorm phases of k_fourier_h
+// took ~4,000 cycles for ~300 instructions (s_memtime slot traces, round 4).  ln_fetch requests all sixteen in one block (gamma and
+// beta of a tile next to each other: the first product waits for two reads, not nine); callers put it in front of the statistics'
+// dependency chain, fenced with a scheduling barrier, so the reads land under it.  Same values, same operations: bitwise equal.
+#ifndef IG_LN_PREFETCH
+#define IG_LN_PREFETCH 1
+#endif
+struct LnTab { f32x4 g[8], b[8]; };
+__device__ __forceinline__ void ln_fetch(LnTab& tb, const float* gtab, const float* btab, int rg) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { tb.g[t] = lds4(gtab + 16 * t + 4 * rg); tb.b[t] = lds4(btab + 16 * t + 4 * rg); }
+}
+template <bool RELU>
+__device__ __forceinline__ void ln_apply_tab(f32x4 (&v)[8], float rstd, const LnTab& tb) {
+  const f32x4 r4 = splat4(rstd);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    f32x4 y = fma4(v[t] * r4, tb.g[t], tb.b[t]);
+    if (RELU) y = __builtin_elementwise_max(y, splat4(0.f));
+    v[t] = y;
+  }
+}
 template <bool AFFINE, bool RELU>
 __device__ __forceinline__ void ln_regs(f32x4 (&v)[8], const float* gtab, const float* btab, int rg) {
-  const float rstd = ln_stats(v);
-  ln_apply<AFFINE, RELU>(v, rstd, gtab, btab, rg);
+  if constexpr (AFFINE && IG_LN_PREFETCH) {
+    LnTab tb;
+    ln_fetch(tb, gtab, btab, rg);
+    __builtin_amdgcn_sched_barrier(0);
+    const float rstd = ln_stats(v);
+    ln_apply_tab<RELU>(v, rstd, tb);
+  } else {
+    const float rstd = ln_stats(v);
+    ln_apply<AFFINE, RELU>(v, rstd, gtab, btab, rg);
+  }
 }
 
 // C registers -> B fragments of the next GEMM: k-step s takes tiles 2 s (slots 0..3) and 2 s + 1 (slots 4..7)
