@@ -98,8 +98,13 @@ struct EdgeAcc {
     float val = fmaf(q.y, k2[1], q.x * k2[0]);
     if constexpr (HASR) {
       pk2 pp[H / 2];
+#ifdef IG_EDGE_SDROP          // timing experiment (wrong results): the u . rhat products of two of the eight heads only
+      pp[0] = pk_fma(uy[0], bc_v(r2[1]), ux[0] * bc_v(r2[0]));
+      pp[1] = pp[2] = pp[3] = pp[0];
+#else
 #pragma unroll
       for (int j = 0; j < H / 2; ++j) pp[j] = pk_fma(uy[j], bc_v(r2[1]), ux[j] * bc_v(r2[0]));
+#endif
       // halving exchange over lane bits 5 and 4 (gfx950 half / row swaps): after swapping the upper half of X with the
       // lower half of Y, X + Y holds the X sum in the lower lanes and the Y sum in the upper ones
       float k4[4];
@@ -146,11 +151,16 @@ struct EdgeAcc {
     ag = pk2{fmaf(pe, v2[0], ag[0]), fmaf(pe, v2[1], ag[1])};      // two scalar FMAs: a register pair for pe would cost the same
 #endif
     if constexpr (HASR) {
-      float ph[H];
+#ifdef IG_EDGE_ZDROP          // timing experiment (wrong results): one of the eight z accumulations only
+      constexpr int HZ = 1;
+#else
+      constexpr int HZ = H;
+#endif
+      float ph[HZ];
 #pragma unroll
-      for (int h = 0; h < H; ++h) ph[h] = readlane_f(pe, 8 * h);
+      for (int h = 0; h < HZ; ++h) ph[h] = readlane_f(pe, 8 * h);
 #pragma unroll
-      for (int h = 0; h < H; ++h) zz[h] = pk_fma(bc_s(ph[h]), r2, zz[h]);
+      for (int h = 0; h < HZ; ++h) zz[h] = pk_fma(bc_s(ph[h]), r2, zz[h]);
     }
   }
 };
