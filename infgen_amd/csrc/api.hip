@@ -825,9 +825,10 @@ extern "C" int infgen_map_graph(int S, int M_cap, const int* n_map, const float*
   if (S <= 0 || M_cap <= 0) return 0;
   if (hipMemsetAsync(total, 0, sizeof(int), (hipStream_t)stream) != hipSuccess)
     return fail("infgen_map_graph", "memset failed");
-  MapGraphArgs a{S, M_cap, n_map, pos, orient, radius, max_nbr, EdgeBuf{off, cnt, src, raw, total, cap}};
+  MapGraphArgs a{S, M_cap, n_map, pos, orient, radius, max_nbr, EdgeBuf{off, cnt, src, raw, total, cap}, 0};
+  a.lds_tokens = (M_cap <= 4096 && M_cap % (4 * MAP_GRAPH_C) == 0) ? M_cap : 0;      // (else: the global-memory scan)
   { ProfScope _ps(INFGEN_KID_MAP_GRAPH, stream);
-    hipLaunchKernelGGL(k_map_graph, dim3(ceil_div(S * M_cap, 4)), dim3(NT), 0, (hipStream_t)stream, a); }
+    hipLaunchKernelGGL(k_map_graph, dim3(ceil_div(S * M_cap, 4 * MAP_GRAPH_C)), dim3(NT), (size_t)a.lds_tokens * 12, (hipStream_t)stream, a); }
   return check_launch("infgen_map_graph");
 }
 

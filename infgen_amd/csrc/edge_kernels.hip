@@ -361,42 +361,70 @@ template __global__ void k_build_edges<1024>(BuildEdgesArgs);
 // raw = (|d|, angle(orient_vec[dst], d), wrap(orient[src] - orient[dst]), 0)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_map_graph(MapGraphArgs a) {
+  // MG_C centre tokens per wave, one after the other, and the scene's token positions / orientations staged in LDS once per
+  // workgroup (its 4 x MG_C centres belong to one scene when M_cap is a multiple of that, as the engine's layouts are): a wave's
+  // scan is 16 dependent trips over the scene's 1024 tokens, and with every trip a global load (rounds 1 - 3: one centre per wave,
+  // 3.7 ms per 1024-scene launch) the launch was the sum of those latencies; one atomic per workgroup reserves the slots of all its lists.
+  constexpr int MG_C = MAP_GRAPH_C;
   __shared__ int wcnt[4];
   __shared__ int wbase[4];
+  constexpr int MG_LIST = 128;                                           // emitted sources of one centre (max_nbr <= 128: the list path)
+  __shared__ int nbr_list[4][MG_LIST];
+  extern __shared__ __attribute__((aligned(8))) float2 mg_xy[];          // [lds_tokens] positions, then [lds_tokens] orientations
   const int lane = lane_id(), w = wave_id();
-  const int gw = blockIdx.x * 4 + w;
-  const int s = gw / a.M_cap, i = gw % a.M_cap;
-  const bool live = s < a.S;
-  const int M = live ? a.n_map[s] : 0;
-  const int row = s * a.M_cap + i;
-  const float* mp = a.pos + (size_t)(live ? s : 0) * a.M_cap * 2;
-  const float* mo = a.orient + (size_t)(live ? s : 0) * a.M_cap;
-  const bool centre = live && i < M;
-  float cx = 0.f, cy = 0.f, co = 0.f;
-  if (centre) { cx = mp[2 * i]; cy = mp[2 * i + 1]; co = mo[i]; }
+  const int gw0 = (blockIdx.x * 4 + w) * MG_C;
   const float r2 = a.radius * a.radius;
-  // pass 1: count kept neighbours (self excluded); every lane remembers in which 64-token chunks it emits (bit per chunk: up to
-  // 4096 tokens per scene), so that pass 2 neither reloads nor re-tests the tokens that are not emitted
-  int found = 0, kept = 0;
-  unsigned long long emit_chunks = 0;
-  const bool masks_ok = M <= 4096;
-  if (centre) {
-    for (int m0 = 0; m0 < M && found < a.max_nbr + 1; m0 += 64) {
-      const int m = m0 + lane;
-      bool in = false;
-      if (m < M) {
-        const float dx = cx - mp[2 * m], dy = cy - mp[2 * m + 1];
-        in = (dx * dx + dy * dy) < r2;
-      }
-      const unsigned long long bal = __ballot(in);
-      const int before = __popcll(bal & ((1ull << lane) - 1ull));
-      const bool emit = in && (found + before < a.max_nbr + 1) && (m != i);
-      if (emit && masks_ok) emit_chunks |= 1ull << (m0 >> 6);
-      kept += (int)__popcll(__ballot(emit));
-      found += (int)__popcll(bal);
+  const bool in_lds = a.lds_tokens >= a.M_cap && a.M_cap % (4 * MG_C) == 0;
+  float* mg_o = reinterpret_cast<float*>(mg_xy + a.lds_tokens);
+  if (in_lds) {
+    const int s_wg = (blockIdx.x * 4 * MG_C) / a.M_cap;
+    if (s_wg < a.S) {
+      const int M = a.n_map[s_wg];
+      const float* mp = a.pos + (size_t)s_wg * a.M_cap * 2;
+      const float* mo = a.orient + (size_t)s_wg * a.M_cap;
+      for (int m = threadIdx.x; m < M; m += NT) { mg_xy[m] = *reinterpret_cast<const float2*>(mp + 2 * m); mg_o[m] = mo[m]; }
     }
+    __syncthreads();
   }
-  if (lane == 0) wcnt[w] = kept;
+  int kept_c[MG_C];
+  unsigned long long chunks_c[MG_C];
+  int kept_sum = 0;
+#pragma unroll
+  for (int c = 0; c < MG_C; ++c) {
+    const int gw = gw0 + c;
+    const int s = gw / a.M_cap, i = gw % a.M_cap;
+    const bool live = s < a.S;
+    const int M = live ? a.n_map[s] : 0;
+    const float* mp = a.pos + (size_t)(live ? s : 0) * a.M_cap * 2;
+    const bool centre = live && i < M;
+    float cx = 0.f, cy = 0.f;
+    if (centre) { cx = mp[2 * i]; cy = mp[2 * i + 1]; }
+    // pass 1: count kept neighbours (self excluded); every lane remembers in which 64-token chunks it emits (bit per chunk: up to
+    // 4096 tokens per scene), so that pass 2 neither reloads nor re-tests the tokens that are not emitted
+    int found = 0, kept = 0;
+    unsigned long long emit_chunks = 0;
+    const bool masks_ok = M <= 4096;
+    if (centre) {
+      for (int m0 = 0; m0 < M && found < a.max_nbr + 1; m0 += 64) {
+        const int m = m0 + lane;
+        bool in = false;
+        if (m < M) {
+          const float2 q = in_lds ? mg_xy[m] : *reinterpret_cast<const float2*>(mp + 2 * m);
+          const float dx = cx - q.x, dy = cy - q.y;
+          in = (dx * dx + dy * dy) < r2;
+        }
+        const unsigned long long bal = __ballot(in);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        const bool emit = in && (found + before < a.max_nbr + 1) && (m != i);
+        if (emit && masks_ok) emit_chunks |= 1ull << (m0 >> 6);
+        kept += (int)__popcll(__ballot(emit));
+        found += (int)__popcll(bal);
+      }
+    }
+    kept_c[c] = kept; chunks_c[c] = emit_chunks;
+    kept_sum += kept;
+  }
+  if (lane == 0) wcnt[w] = kept_sum;
   __syncthreads();
   if (threadIdx.x == 0) {
     const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
@@ -404,39 +432,87 @@ __global__ __launch_bounds__(NT) void k_map_graph(MapGraphArgs a) {
     wbase[0] = base; wbase[1] = base + wcnt[0]; wbase[2] = wbase[1] + wcnt[1]; wbase[3] = wbase[2] + wcnt[2];
   }
   __syncthreads();
-  if (!live) return;
-  const int e0 = wbase[w];
-  if (lane == 0) { a.e.off[row] = e0; a.e.cnt[row] = (e0 + kept <= a.e.cap) ? kept : 0; }
-  if (!centre || kept == 0 || e0 + kept > a.e.cap) return;   // overflow: total > cap is reported by the host
-  const float ocs = cosf(co), osn = sinf(co);
-  found = 0;
-  int written = 0;
-  for (int m0 = 0; m0 < M && (masks_ok ? written < kept : found < a.max_nbr + 1); m0 += 64) {
-    const int m = m0 + lane;
-    bool emit;
-    if (masks_ok) {
-      emit = (emit_chunks >> (m0 >> 6)) & 1ull;
-    } else {
-      bool in = false;
-      if (m < M) {
-        const float dx = cx - mp[2 * m], dy = cy - mp[2 * m + 1];
-        in = (dx * dx + dy * dy) < r2;
+  int e0 = wbase[w];
+#pragma unroll
+  for (int c = 0; c < MG_C; ++c) {
+    const int gw = gw0 + c;
+    const int s = gw / a.M_cap, i = gw % a.M_cap;
+    if (s >= a.S) break;
+    const int M = a.n_map[s];
+    const int row = s * a.M_cap + i;
+    const float* mp = a.pos + (size_t)s * a.M_cap * 2;
+    const float* mo = a.orient + (size_t)s * a.M_cap;
+    const bool centre = i < M;
+    const int kept = kept_c[c];
+    const unsigned long long emit_chunks = chunks_c[c];
+    const bool masks_ok = M <= 4096;
+    const int e_row = e0;
+    e0 += kept;
+    if (lane == 0) { a.e.off[row] = e_row; a.e.cnt[row] = (e_row + kept <= a.e.cap) ? kept : 0; }
+    if (!centre || kept == 0 || e_row + kept > a.e.cap) continue;   // overflow: total > cap is reported by the host
+    const float cx = mp[2 * i], cy = mp[2 * i + 1], co = mo[i];
+    const float ocs = cosf(co), osn = sinf(co);
+    int found = 0;
+    int written = 0;
+    if (masks_ok && kept <= MG_LIST) {
+      // the emitted sources are first compacted into a list (their ranks come from ballots, a few instructions per 64-token
+      // chunk), then the features - a square root, an atan2 and an angle wrap per edge - are evaluated with the lanes full: the
+      // ~22 neighbours of a centre sit in ~10 different chunks, and evaluating them chunk by chunk ran the ~90-instruction
+      // feature block ten times per centre with two or three live lanes (most of the launch: the scan itself is ~20
+      // instructions per chunk)
+      for (int m0 = 0; m0 < M && written < kept; m0 += 64) {
+        const bool emit = (emit_chunks >> (m0 >> 6)) & 1ull;
+        const unsigned long long ebal = __ballot(emit);
+        if (emit) nbr_list[w][written + __popcll(ebal & ((1ull << lane) - 1ull))] = m0 + lane;
+        written += (int)__popcll(ebal);
       }
-      const unsigned long long bal = __ballot(in);
-      const int before = __popcll(bal & ((1ull << lane) - 1ull));
-      emit = in && (found + before < a.max_nbr + 1) && (m != i);
-      found += (int)__popcll(bal);
+      // (one wave: its LDS writes are visible to its own later reads in program order)
+      __builtin_amdgcn_wave_barrier();
+      for (int k0 = 0; k0 < kept; k0 += 64) {
+        const int k = k0 + lane;
+        if (k < kept) {
+          const int m = nbr_list[w][k];
+          const float2 q = in_lds ? mg_xy[m] : *reinterpret_cast<const float2*>(mp + 2 * m);
+          const float qo = in_lds ? mg_o[m] : mo[m];
+          const float dx = q.x - cx, dy = q.y - cy;
+          const int e = e_row + k;
+          a.e.src[e] = s * a.M_cap + m;
+          *reinterpret_cast<float4*>(a.e.raw + 4 * (size_t)e) =
+              make_float4(norm2(dx, dy), angle_between(ocs, osn, dx, dy), wrap_angle(qo - co), 0.f);
+        }
+      }
+      continue;
     }
-    const unsigned long long ebal = __ballot(emit);
-    const int ebefore = __popcll(ebal & ((1ull << lane) - 1ull));
-    if (emit) {
-      const int e = e0 + written + ebefore;
-      const float dx = mp[2 * m] - cx, dy = mp[2 * m + 1] - cy;
-      a.e.src[e] = s * a.M_cap + m;
-      *reinterpret_cast<float4*>(a.e.raw + 4 * (size_t)e) =
-          make_float4(norm2(dx, dy), angle_between(ocs, osn, dx, dy), wrap_angle(mo[m] - co), 0.f);
+    for (int m0 = 0; m0 < M && (masks_ok ? written < kept : found < a.max_nbr + 1); m0 += 64) {
+      const int m = m0 + lane;
+      bool emit;
+      if (masks_ok) {
+        emit = (emit_chunks >> (m0 >> 6)) & 1ull;
+      } else {
+        bool in = false;
+        if (m < M) {
+          const float2 q = in_lds ? mg_xy[m] : *reinterpret_cast<const float2*>(mp + 2 * m);
+          const float dx = cx - q.x, dy = cy - q.y;
+          in = (dx * dx + dy * dy) < r2;
+        }
+        const unsigned long long bal = __ballot(in);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        emit = in && (found + before < a.max_nbr + 1) && (m != i);
+        found += (int)__popcll(bal);
+      }
+      const unsigned long long ebal = __ballot(emit);
+      const int ebefore = __popcll(ebal & ((1ull << lane) - 1ull));
+      if (emit) {
+        const int e = e_row + written + ebefore;
+        const float2 q = in_lds ? mg_xy[m] : *reinterpret_cast<const float2*>(mp + 2 * m);
+        const float qo = in_lds ? mg_o[m] : mo[m];
+        const float dx = q.x - cx, dy = q.y - cy;
+        a.e.src[e] = s * a.M_cap + m;
+        *reinterpret_cast<float4*>(a.e.raw + 4 * (size_t)e) =
+            make_float4(norm2(dx, dy), angle_between(ocs, osn, dx, dy), wrap_angle(qo - co), 0.f);
+      }
+      written += (int)__popcll(ebal);
     }
-    written += (int)__popcll(ebal);
   }
 }
 

@@ -440,10 +440,12 @@ struct SampleArgs {
   int* token;                                // [rows] out
 };
 
+constexpr int MAP_GRAPH_C = 8;          // centre tokens per wave of k_map_graph (32 per workgroup: one LDS staging of the scene's tokens, one atomic)
 struct MapGraphArgs {
   int S, M_cap; const int* n_map;
   const float* pos; const float* orient; float radius; int max_nbr;
   EdgeBuf e;
+  int lds_tokens;          // tokens the launch's dynamic LDS holds (12 bytes each; 0: every trip reads global memory)
 };
 
 template <int W> __global__ void k_stream_read(const float* p, size_t n_floats, float* out);   // gemm_kernels.hip
