@@ -894,16 +894,17 @@ static int integrate_groups(const InfgenRollout* r) {
   static const int max_scenes = getenv("INFGEN_INT_GROUP_SCENES") ? atoi(getenv("INFGEN_INT_GROUP_SCENES")) : 128;
   return (r->S <= max_scenes && r->A_cap % 16 == 0 && r->A_cap > 16) ? r->A_cap / 16 : 1;
 }
-static int integrate_impl(const InfgenRollout* r, int t, void* stream, unsigned long long* heads_part, bool zero_totals, bool prep);
+static int integrate_impl(const InfgenRollout* r, int t, void* stream, unsigned long long* heads_part, bool zero_totals, bool prep, bool zero_sync = false);
 extern "C" int infgen_integrate(const InfgenRollout* r, int t, void* stream) {
   return integrate_impl(r, t, stream, nullptr, false, false);
 }
-static int integrate_impl(const InfgenRollout* r, int t, void* stream, unsigned long long* heads_part, bool zero_totals, bool prep) {
+static int integrate_impl(const InfgenRollout* r, int t, void* stream, unsigned long long* heads_part, bool zero_totals, bool prep, bool zero_sync) {
   RET_IF(validate(r, "infgen_integrate"));
   OptScope _opts(r);
   IntegrateArgs a;
   a.heads_part = heads_part; a.next_token_w = r->next_token;
   a.edge_totals = zero_totals ? r->et.total : nullptr;
+  a.zero_sync = zero_sync ? reinterpret_cast<int*>(r->SIG) : nullptr;       // (k_layers_p's per-scene counters: layers_p_launch)
   a.do_prep = prep ? 1 : 0;
   if (prep) a.prep = rawfeat_args(r, 2 + t);
   a.st = scene_of(r); a.c = 1 + t; a.t = t; a.R = r->R; a.force_valid = r->force_valid;
@@ -1147,7 +1148,8 @@ static int prepare_edges(const InfgenRollout* r, int c, int edgeless, void* stre
   return 0;
 }
 
-static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, void* stream) {
+// sync_clear = false: the scenes' counters are already zero (the k_integrate of the previous decode step cleared them: IntegrateArgs.zero_sync)
+static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, void* stream, bool sync_clear = true) {
   const int rows = r->S * r->A_cap;
   LayersPArgs a;
   a.rows = rows; a.A_cap = r->A_cap; a.num_layers = r->num_layers;
@@ -1172,7 +1174,7 @@ static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, vo
     (void)hipMemsetAsync(trace_dev, 0, 2048 * sizeof(unsigned long long), (hipStream_t)stream);
     a.trace = trace_dev;
   }
-  if (hipMemsetAsync(a.sync, 0, (size_t)r->S * sizeof(int), (hipStream_t)stream) != hipSuccess)
+  if (sync_clear && hipMemsetAsync(a.sync, 0, (size_t)r->S * sizeof(int), (hipStream_t)stream) != hipSuccess)
     return fail("infgen_decode_layers", "memset failed");
   // fewer rows per workgroup while the launch stays within the limit: 8 (one row per wave in the edge loop) up to 256 workgroups,
   // 4 (a row's edge list halved between two waves) up to 128
@@ -1213,10 +1215,10 @@ static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, vo
   return check_launch("infgen_decode_layers(k_layers_p)");
 }
 
-static int layers_core(const InfgenRollout* r, int c, int edgeless, void* stream) {
+static int layers_core(const InfgenRollout* r, int c, int edgeless, void* stream, bool lp_sync_clear = true) {
   const int rows = r->S * r->A_cap;
   const StepMode sm = step_mode(r, rows, edgeless);
-  if (sm.lp && sm.fuse) return layers_p_launch(r, c, sm, stream);
+  if (sm.lp && sm.fuse) return layers_p_launch(r, c, sm, stream, lp_sync_clear);
   const bool overlap = sm.overlap, fuse = sm.fuse; const int r24 = sm.r24;
   const size_t slot = (size_t)(c % r->ring) * rows * D;
   const int L = r->num_layers;
@@ -1318,15 +1320,17 @@ extern "C" int infgen_rollout_run(const InfgenRollout* r, int t0, int t1, void* 
   if (hipMemsetAsync(keys, 0, (size_t)rows * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess)
     return fail("infgen_rollout_run", "memset failed");
   RET_IF(prepare_edges(r, 1 + t0, 0, stream, true, false));
+  const StepMode sm0 = step_mode(r, rows, 0);
+  const bool lp_steps = sm0.lp && sm0.fuse && r->SIG != nullptr;       // the steps' sublayers run as k_layers_p launches
   for (int t = t0; t < t1; ++t) {
     const int c = 1 + t;
-    RET_IF(layers_core(r, c, 0, stream));
+    RET_IF(layers_core(r, c, 0, stream, t == t0 || !lp_steps));      // (later steps: the counters of k_layers_p were cleared by k_integrate)
     float* lg = (r->store_logits && r->logits) ? r->logits + (size_t)t * rows * r->token_size : nullptr;
     bool split = false;
     RET_IF(heads_impl(r->X, rows, r->tok_head_pack, r->st_head_pack, r->token_size, lg, r->next_token, r->next_state, keys, stream,
                       true, &split));
     // (the last step keeps its edge totals, like infgen_decode_step: RolloutEngine.edge_totals() / overflow checks read them)
-    RET_IF(integrate_impl(r, t, stream, split ? keys : nullptr, t + 1 < t1, true));
+    RET_IF(integrate_impl(r, t, stream, split ? keys : nullptr, t + 1 < t1, true, t + 1 < t1 && lp_steps));
     if (t + 1 < t1) {
       RET_IF(prepare_edges(r, c + 1, 0, stream, false, true, split && integrate_groups(r) > 1 ? keys : nullptr));
     } else {          // after the last step only the raw feature of the new column is left (kept: the context's X stays what

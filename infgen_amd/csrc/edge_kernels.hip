@@ -560,6 +560,7 @@ __global__ __launch_bounds__(BT) void k_integrate(IntegrateArgs a) {
     }
   }
   if (a.edge_totals && s == 0 && blockIdx.y == 0 && tl < 3) a.edge_totals[tl] = 0;       // the next column's k_build_edges starts from zero
+  if (a.zero_sync && blockIdx.y == 0 && tl == 0) a.zero_sync[s] = 0;
   if ((own || dup) && t < A) {
     const int row = s * st.A_cap + t;
     int tok = a.heads_part ? tok_dec : a.next_token[row];

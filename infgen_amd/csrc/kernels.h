@@ -367,6 +367,7 @@ struct IntegrateArgs {
   unsigned long long* heads_part;   // k_heads' split arg-max keys [rows]: decoded here (k_heads_finish) and reset for the next step
   int* next_token_w;                // where the decoded tokens go (the context's next_token array)
   int* edge_totals;                 // the three edge totals of the context, zeroed for the next column's k_build_edges
+  int* zero_sync;                   // optional [S]: the per-scene counters of the next step's k_layers_p launch, zeroed here
   RawFeatArgs prep; int do_prep;    // the raw-feature gather (k_rawfeat_prep) of the new column, all rows of the scene
   int groups;                       // > 1: grid S x groups, A_cap / groups rows per workgroup (few scenes); the keys are then NOT reset here
   const float* vocab;               // [3][token_size][6][4][2]
