@@ -154,14 +154,20 @@ __device__ __forceinline__ void gemm_quarter(f32x4 (&acc)[8], const unsigned sho
     for (int t = 0; t < 4; ++t) acc[4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[1][t], bh, acc[4 + t], 0, 0, 0);
   }
   __builtin_amdgcn_sched_barrier(0);
+#elif defined(IG_GQ_NOMFMA)      // timing experiment (wrong results): no fragment reads, no products
+  asm volatile("" : "+v"(acc[0]), "+v"(acc[7]));
 #else
 #pragma unroll
   for (int g = 0; g < 8; g += 4) {
     v8h ah[4], al[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+#ifdef IG_GQ_NOREAD            // timing experiment (wrong results): the products without their A-fragment reads from LDS
+      ah[t] = bh; al[t] = bl;
+#else
       ah[t] = *reinterpret_cast<const v8h*>(p + (g + t) * 1024);
       if constexpr (TERMS == 3) al[t] = *reinterpret_cast<const v8h*>(p + (g + t) * 1024 + 512);
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
