@@ -412,6 +412,40 @@ def test_warm_workgroups_are_bitwise_neutral(monkeypatch):
         _lib.check(lib.infgen_set_layers_p(1))
 
 
+def test_few_scene_kernel_shapes_are_bitwise_neutral():
+    """up to 128 scenes k_integrate runs one workgroup per 16 rows (every workgroup integrates the ego's step for itself; the arg-max
+    keys are then cleared by the next k_build_edges) and k_build_edges 16 waves per workgroup; larger batches keep one workgroup
+    per scene / 4 waves (csrc/api.hip: integrate_groups, INFGEN_BE_WIDE_SCENES - read once per process, so the comparison is
+    between a batch below and a batch above the limit).  Same rows in, bitwise the same rollouts out - and the fixture's."""
+    from infgen_amd import engine, synth, _lib
+    lib = _lib.load()
+    c = load_case('a24_m256_edge')
+    cfg = c['cfg']
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], cfg, dev)
+    _lib.check(lib.infgen_set_layers_p(0))                      # (both batches through the per-sublayer launches)
+    try:
+        few = [c['scene']] + [synth.make_scene(8600 + i, 24, 256, cfg, ego_last=(i % 2 == 0), vocab=c['vocab'], grid=c['grid']) for i in range(7)]
+        many = few + [synth.make_scene(8700 + i, 20, 256, cfg, ego_last=True, vocab=c['vocab'], grid=c['grid']) for i in range(125)]
+        a = engine.RolloutEngine(w, few, c['vocab'], c['map_vocab'], c['grid'], store_logits=True)      # 8 scenes: the few-scene shapes
+        b = engine.RolloutEngine(w, many, c['vocab'], c['map_vocab'], c['grid'], store_logits=True)     # 133 scenes: the big-batch shapes
+        assert a.S <= 128 < b.S
+        a.rollout(); b.rollout()
+        torch.cuda.synchronize()
+        assert a.edge_totals() != b.edge_totals()
+        for x, y in zip(a.outputs(), b.outputs()[:8]):
+            # what the two kernels produce - poses, states, grid cells behind them, the edge sets behind the tokens - bitwise;
+            # the logits also pass through kernels chosen by the row count (256 rows: k_edge_attn with U / Z in memory; 4,256 rows:
+            # k_edge_fused): rounding-level differences on logits of magnitude ~30
+            for k in ('next_token_idx', 'next_state_idx', 'pos_a', 'head_a', 'pred_traj', 'pred_head'):
+                assert np.array_equal(x[k], y[k]), k
+            assert np.abs(x['logits'] - y['logits']).max() <= 1e-3
+        assert np.array_equal(a.outputs()[0]['next_token_idx'], c['z']['next_token_idx'])
+        assert np.array_equal(a.gridtok.cpu().numpy(), b.gridtok.cpu().numpy()[:8])
+    finally:
+        _lib.check(lib.infgen_set_layers_p(1))
+
+
 def test_rollout_many_streams_equals_single_engine():
     """engine.rollout_many: engines on their own streams, sequenced cooperatively by one host thread (each yields where it
     needs the device's insertion decisions) - the same scenes give the same rollouts as one engine after the other"""
