@@ -8,6 +8,9 @@ timeout 900 python bench.py > $O/bench_s1024.json 2> $O/bench_s1024.err
 timeout 600 python bench.py --scenes 512 $B > $O/bench_s512.json 2> $O/bench_s512.err
 for s in 8 64; do timeout 300 python bench.py --scenes $s --steps 20 --warmup 3 $B > $O/bench_s$s.json 2> $O/bench_s$s.err; done
 timeout 600 python bench.py --insertion --scenes 512 $B > $O/bench_ins_s512.json 2> $O/bench_ins_s512.err
+timeout 900 python bench.py --insertion $B > $O/bench_ins_s1024.json 2> $O/bench_ins_s1024.err
+timeout 900 python bench.py --insertion --streams 2 $B > $O/bench_ins_s1024_streams2.json 2> $O/bench_ins_s1024_streams2.err
+timeout 1500 python bench.py --insertion --rollout-steps 800 --scenes 256 --insert-headroom 320 --steps 1 --warmup 1 $B --no-parity > $O/bench_c4shape_s256.json 2> $O/bench_c4shape_s256.err
 timeout 900 python bench.py --insertion --rollout-steps 800 --scenes 128 --insert-headroom 320 --steps 2 --warmup 1 $B > $O/bench_c4shape_s128.json 2> $O/bench_c4shape_s128.err
 timeout 900 python bench.py --agents 256 --map-tokens 4096 --rollout-steps 800 --scenes 32 --steps 2 --warmup 1 $B > $O/bench_c5shape_s32.json 2> $O/bench_c5shape_s32.err
 timeout 300 python tools/bench_dropin.py 512 > $O/dropin.log 2>&1
