@@ -1,7 +1,7 @@
 # the round's closing measurements on the final build: profiles (kernel stats + PMC passes of the default workload), the default
 # bench line, the secondary lines, the drop-in entry, a determinism soak
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04z; mkdir -p $O
+O=gpurun_out/suite; mkdir -p $O
 bash tools/prof_round.sh > $O/prof_round.log 2>&1
 B="--no-cpu-baseline --no-literal --no-strict"
 timeout 900 python bench.py > $O/bench_s1024.json 2> $O/bench_s1024.err
