@@ -1134,10 +1134,14 @@ static int prepare_edges(const InfgenRollout* r, int c, int edgeless, void* stre
       m.set[3] = FourierArgs{r->raw2, 2, nullptr, rows, r->four_xa, r->cat, 128, r->fus_in + 128, 512, 0, pr, 0, nullptr, 0};
     int cap = r->et.cap > r->em.cap ? r->et.cap : r->em.cap;
     if (r->ea.cap > cap) cap = r->ea.cap;
-    int grid = ceil_div(cap, FH_TILE);
+    // (INFGEN_FH12_MULTI_ROWS: smallest launch, in rows, whose multi-set launch takes the three-wave-group kernel; default: never)
+    static const int fh12_rows = getenv("INFGEN_FH12_MULTI_ROWS") ? atoi(getenv("INFGEN_FH12_MULTI_ROWS")) : 0;
+    const bool wide = fh12_rows > 0 && rows >= fh12_rows && O().gemm_terms != 1 && FH_WAVES == 8;
+    int grid = ceil_div(cap, wide ? FH12_TILE : FH_TILE);
     if (grid > 256 * FH_WG_PER_CU) grid = 256 * FH_WG_PER_CU;
     { ProfScope _ps(INFGEN_KID_FOURIER, stream);
-      if (O().gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h_multi<1>, dim3(grid, with_xa ? 4 : 3), dim3(FH_NT), 0, (hipStream_t)stream, m);
+      if (wide) hipLaunchKernelGGL(k_fourier_h12_multi<3>, dim3(grid, with_xa ? 4 : 3), dim3(FH12_NT), 0, (hipStream_t)stream, m);
+      else if (O().gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h_multi<1>, dim3(grid, with_xa ? 4 : 3), dim3(FH_NT), 0, (hipStream_t)stream, m);
       else hipLaunchKernelGGL(k_fourier_h_multi<3>, dim3(grid, with_xa ? 4 : 3), dim3(FH_NT), 0, (hipStream_t)stream, m); }
     RET_IF(check_launch("infgen_decode_layers(fourier)"));
   } else if (!edgeless) {

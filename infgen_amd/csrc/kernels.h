@@ -456,6 +456,7 @@ __global__ void k_fourier(FourierArgs a);
 template <int TERMS> __global__ void k_fourier_h(FourierArgs a);
 template <int TERMS> __global__ void k_fourier_h_multi(FourierMultiArgs m);
 template <int TERMS> __global__ void k_fourier_h12(FourierArgs a);      // fourier_h12.hip: three wave groups, 192-edge tiles
+template <int TERMS> __global__ void k_fourier_h12_multi(FourierMultiArgs m);
 constexpr int FH12_NT = 768, FH12_TILE = 192;
 __global__ void k_match_tokens(MatchTokensArgs a);   // token_kernels.hip
 template <int TERMS> __global__ void k_mlpemb_h(MlpEmbHArgs a);           // mlp_h.hip
