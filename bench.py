@@ -600,6 +600,28 @@ def main():
                 os.environ['INFGEN_NO_R24'] = old_env
         torch.cuda.empty_cache()
 
+    # ---- config.two_streams: the same batch as two engines (half the scenes each) on two HIP streams, sequenced by one host thread
+    # (engine.rollout_many): one engine's HBM-bound edge launches run under the other's matrix / vector-bound ones.  Reported next to
+    # the headline, not as it: with two streams the per-kernel HIP-event durations overlap, and the roofline of the line is the
+    # single-stream kernel's.
+    two = None
+    if not args.no_strict and args.gemm_terms == 3 and not args.insertion and ns == 1 and len(scenes) >= 128:
+        log('two-stream leg')
+        half = (len(scenes) + 1) // 2
+        es = [engine.RolloutEngine(w, scenes[i * half:(i + 1) * half], vocab, map_vocab, grid, store_logits=False, use_graph=False)
+              for i in range(2)]
+        st2 = [torch.cuda.Stream(device=dev) for _ in es]
+        run2 = lambda: engine.rollout_many(es, st2)
+        run2()
+        torch.cuda.synchronize(dev)
+        tsteps = max(1, min(3, args.steps))
+        t = timed(ranks, run2, tsteps)
+        t, n = igdist.reduce_run(t, float(sum(e.agent_steps() for e in es) * tsteps), dev)
+        two = {'value': n / t, 'ms_per_step': 1e3 * t / tsteps, 'steps': tsteps, 'engines': 2, 'scenes_per_engine': half,
+               'note': 'the same scenes as two engines on two HIP streams (bench.py --streams 2 times exactly this as the headline)'}
+        del es
+        torch.cuda.empty_cache()
+
     # ---- config.c3_literal: BASELINE C3 as written - 64 scenes in total, dealt to the ranks like the reference's
     # DistributedSampler (scene i -> rank i mod N); at N = 1 also the 8 scenes one GPU of an 8-way shard owns
     c3 = args.agents == 64 and args.map_tokens == 1024 and args.rollout_steps == 80 and not args.insertion
@@ -671,6 +693,7 @@ def main():
                 'parallelism': f'scenes sharded over {world} rank(s), no data-path collective',
                 'c3_literal': literal,
                 'strict_fp32': strict,
+                'two_streams': two,
                 'insertion_balance': balance,
             },
             'roofline': roof,
