@@ -855,12 +855,14 @@ static int validate(const InfgenRollout* r, const char* where) {
   return 0;
 }
 
-static int build_edges_impl(const InfgenRollout* r, int c, int edgeless, void* stream, bool zero_totals, unsigned long long* clear_keys = nullptr);
+static int build_edges_impl(const InfgenRollout* r, int c, int edgeless, void* stream, bool zero_totals, unsigned long long* clear_keys = nullptr,
+                            bool clear_sync = false);
 extern "C" int infgen_build_edges(const InfgenRollout* r, int c, int edgeless, void* stream) {
   return build_edges_impl(r, c, edgeless, stream, true);
 }
 // zero_totals = false: the three totals were cleared by the previous step's k_integrate (IntegrateArgs.edge_totals)
-static int build_edges_impl(const InfgenRollout* r, int c, int edgeless, void* stream, bool zero_totals, unsigned long long* clear_keys) {
+static int build_edges_impl(const InfgenRollout* r, int c, int edgeless, void* stream, bool zero_totals, unsigned long long* clear_keys,
+                            bool clear_sync) {
   RET_IF(validate(r, "infgen_build_edges"));
   OptScope _opts(r);
   hipStream_t s = (hipStream_t)stream;
@@ -876,6 +878,7 @@ static int build_edges_impl(const InfgenRollout* r, int c, int edgeless, void* s
   a.st = scene_of(r); a.c = c; a.edgeless = edgeless; a.r_map = r->r_map; a.r_agent = r->r_agent;
   a.rows = r->S * r->A_cap; a.t = ebuf(r->et); a.m = ebuf(r->em); a.a = ebuf(r->ea);
   a.clear_keys = clear_keys;
+  a.clear_sync = clear_sync ? reinterpret_cast<int*>(r->SIG) : nullptr;      // (k_layers_p's per-scene counters: layers_p_launch)
   a.prof = (g_prof.mask & ((1u << INFGEN_KID_EDGE_ATTN) | (1u << INFGEN_KID_BUILD_EDGES))) ? g_prof.rows_dev : nullptr;
   { ProfScope _ps(INFGEN_KID_BUILD_EDGES, stream);
     a.map_lds = r->M_cap < 4096 ? r->M_cap : 4096;
@@ -1109,9 +1112,9 @@ static bool fourier_multi_ok(int rows, int edgeless) {
 // x_a_emb embedding of the rows' raw features (raw2 / cat -> fus_in, infgen_raw_feature's middle launch) rides along as a
 // fourth set of the multi launch
 static int prepare_edges(const InfgenRollout* r, int c, int edgeless, void* stream, bool zero_totals, bool with_xa,
-                         unsigned long long* clear_keys = nullptr) {
+                         unsigned long long* clear_keys = nullptr, bool clear_sync = false) {
   const int rows = r->S * r->A_cap;
-  RET_IF(build_edges_impl(r, c, edgeless, stream, zero_totals, clear_keys));
+  RET_IF(build_edges_impl(r, c, edgeless, stream, zero_totals, clear_keys, clear_sync));
   const StepMode sm = step_mode(r, rows, edgeless);
   const bool overlap = sm.overlap; const int r24 = sm.r24; const float* dt = sm.dt;
   if (overlap) {
@@ -1275,8 +1278,10 @@ extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless,
   RET_IF(validate(r, "infgen_decode_layers"));
   OptScope _opts(r);
   ProfPhase _pp(edgeless ? g_prof.phase : 1);        // (the edgeless column-0 chain belongs to the prologue)
-  RET_IF(prepare_edges(r, c, edgeless, stream, true, false));
-  return layers_core(r, c, edgeless, stream);
+  const StepMode sm = step_mode(r, r->S * r->A_cap, edgeless);
+  const bool lp = sm.lp && sm.fuse && r->SIG != nullptr;      // (k_build_edges zeroes k_layers_p's counters: infgen_rollout_run)
+  RET_IF(prepare_edges(r, c, edgeless, stream, true, false, nullptr, lp));
+  return layers_core(r, c, edgeless, stream, !lp);
 }
 
 extern "C" int infgen_decode_step(const InfgenRollout* r, int t, void* stream) {
@@ -1323,12 +1328,14 @@ extern "C" int infgen_rollout_run(const InfgenRollout* r, int t0, int t1, void* 
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(r->tmp2);     // (free scratch under attn_mode != 0)
   if (hipMemsetAsync(keys, 0, (size_t)rows * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess)
     return fail("infgen_rollout_run", "memset failed");
-  RET_IF(prepare_edges(r, 1 + t0, 0, stream, true, false));
   const StepMode sm0 = step_mode(r, rows, 0);
   const bool lp_steps = sm0.lp && sm0.fuse && r->SIG != nullptr;       // the steps' sublayers run as k_layers_p launches
+  // (their per-scene counters are zeroed by the kernel in front of every launch - k_build_edges before the first step, k_integrate
+  // before the later ones - not by a fill: one launch less per step, and no memset node between the kernels of a captured graph)
+  RET_IF(prepare_edges(r, 1 + t0, 0, stream, true, false, nullptr, lp_steps));
   for (int t = t0; t < t1; ++t) {
     const int c = 1 + t;
-    RET_IF(layers_core(r, c, 0, stream, t == t0 || !lp_steps));      // (later steps: the counters of k_layers_p were cleared by k_integrate)
+    RET_IF(layers_core(r, c, 0, stream, !lp_steps));
     float* lg = (r->store_logits && r->logits) ? r->logits + (size_t)t * rows * r->token_size : nullptr;
     bool split = false;
     RET_IF(heads_impl(r->X, rows, r->tok_head_pack, r->st_head_pack, r->token_size, lg, r->next_token, r->next_state, keys, stream,

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
   const int row = s * st.A_cap + t;
   const int part = blockIdx.y;        // the three sets of a scene are built by three workgroups (grid S x 3): independent lists
   if (a.clear_keys && part == 0 && t < st.A_cap) a.clear_keys[row] = 0ull;
+  if (a.clear_sync && part == 0 && t == 0) a.clear_sync[s] = 0;
   if (a.edgeless) {
     if (part == 0 && t < st.A_cap) {
       a.t.off[row] = 0; a.t.cnt[row] = 0;

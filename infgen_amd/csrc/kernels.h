@@ -335,6 +335,7 @@ struct BuildEdgesArgs {
   unsigned long long* prof;         // optional profiling counters (api.hip Prof::rows_dev): [8 + kind] += edges of the scene
   int map_lds;                      // float2 slots of dynamic LDS for the scene's map-token positions (0 .. 4096)
   unsigned long long* clear_keys;   // optional [rows]: k_heads' split arg-max keys, reset here when the k_integrate before ran in row groups
+  int* clear_sync;                  // optional [S]: the per-scene counters of the k_layers_p launch that follows, zeroed here
 };
 
 struct RawFeatArgs {
