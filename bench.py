@@ -48,6 +48,7 @@ from infgen_amd import engine, synth, _lib  # noqa: E402
 from infgen_amd import dist as igdist  # noqa: E402
 
 # peaks: /opt/skills/guides/MI355X_MICROARCH.md
+PROF_STRIDE = 5            # of the dominant kernel's decode-step launches in the timed region every fifth carries HIP events
 HBM_PEAK_GBS = 8000.0
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32
 F16_DENSE_PEAK_TFLOPS = 2500.0
@@ -471,12 +472,16 @@ def main():
     per_kernel = _lib.prof_collect()
     dominant = args.roofline_kernel or max(per_kernel, key=lambda k: per_kernel[k]['ms'])
     log('per-kernel ms of one rollout: ' + ', '.join(f'{k}={v["ms"]:.2f}' for k, v in per_kernel.items()))
-    # roofline leg 2: events only around the dominant kernel's launches, inside the timed region
+    # roofline leg 2: events only around the dominant kernel's launches, inside the timed region - and only around every
+    # PROF_STRIDE-th of its decode-step launches (an event pair costs ~5 us of launch-stream time: ~3 ms per rollout with all 306
+    # bracketed).  5 is coprime to the 18 launches of a step (6 layers x temporal, map, agent): every position is sampled equally often
     _lib.prof_enable(1 << _lib.KERNEL_IDS.index(dominant))
+    _lib.prof_set_stride(PROF_STRIDE)
     dt_local = timed(ranks, eng.rollout, args.steps)
     log(f'timed region done: {1e3 * dt_local / args.steps:.2f} ms per step')
     dt = dt_local
     timed_k = _lib.prof_collect()
+    seen_k = _lib.prof_seen()[dominant]
     dom = timed_k[dominant]
     _lib.prof_enable(0)
 
@@ -517,6 +522,11 @@ def main():
         nedge = ed['temporal'] + ed['map'] + ed['agent']
         nbytes = L * KV_ROW_BYTES * (ed['temporal'] + ed['map'] + rows_t)
         calls, secs = max(1, dom['step_calls']), max(1e-9, dom['step_ms'] * 1e-3)
+        # (calls / secs: the bracketed launches; nedge / nbytes / rows_t are scaled to them - the sample is uniform over the step's
+        # positions, so bytes per bracketed launch = bytes per launch)
+        in_region = max(calls, seen_k['seen_step'])
+        sampled = calls / in_region
+        nedge, nbytes, rows_t = nedge * sampled, nbytes * sampled, rows_t * sampled
         hbm_frac = nbytes / secs / (HBM_PEAK_GBS * 1e9)
         # what this design has to move for the same launches: + the 24-bit rhat row per edge, + q in / agg out per row
         rhat_b = 384.0
@@ -535,7 +545,7 @@ def main():
                 'traffic_model_bytes_per_launch': model / calls,
                 'traffic_model_frac': model / secs / (HBM_PEAK_GBS * 1e9),
                 'edges_per_launch': nedge * L / calls,
-                'launches': dom['step_calls'], 'avg_launch_us': 1e6 * secs / calls,
+                'launches': dom['step_calls'], 'launches_in_timed_region': in_region, 'avg_launch_us': 1e6 * secs / calls,
                 'other_launches': {'what': 'map encoder pt <-> pt sublayers + edgeless column-0 chain (prologue)',
                                    'launches': dom['calls'] - dom['step_calls'],
                                    'avg_launch_us': 1e3 * (dom['ms'] - dom['step_ms']) / max(1, dom['calls'] - dom['step_calls'])},

@@ -488,6 +488,11 @@ int infgen_prof_collect(double* total_ms, int* calls, double* total_macs, unsign
  * step_ms / step_calls [INFGEN_KID_COUNT]; the remainder is the prologue (map encoder, column-0 chain) and operator-level calls */
 int infgen_prof_collect_steps(double* total_ms, int* calls, double* total_macs, unsigned long long* counters,
                               double* step_ms, int* step_calls);
+/* after infgen_prof_enable: bracket only every stride-th launch of the selected kernels INSIDE decode steps (an event pair costs
+ * ~5 us of launch-stream time; launches outside decode steps are all bracketed).  infgen_prof_seen: launches of every kernel since
+ * infgen_prof_enable, bracketed or not - seen / seen_step [INFGEN_KID_COUNT] (either may be NULL). */
+int infgen_prof_set_stride(int stride);
+int infgen_prof_seen(int* seen, int* seen_step);
 
 #ifdef __cplusplus
 }

@@ -170,6 +170,8 @@ SYMBOLS = {
     'infgen_prof_collect': (_i, [C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]),
     'infgen_prof_collect_steps': (_i, [C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_ulonglong),
                                        C.POINTER(C.c_double), C.POINTER(_i)]),
+    'infgen_prof_set_stride': (_i, [_i]),
+    'infgen_prof_seen': (_i, [C.POINTER(_i), C.POINTER(_i)]),
 }
 
 Q_ATTN_PACK_SIZE, Q_FOURIER_N2, Q_FOURIER_N3, Q_FOURIER_N4, Q_TILE_ROWS, Q_EDGE_ATTN_CAP, Q_MAX_AGENTS, \
@@ -253,6 +255,19 @@ def prof_enable(mask: int, max_launches: int = 20000) -> None:
     global _prof_mask
     check(load().infgen_prof_enable(mask, max_launches), 'infgen_prof_enable')
     _prof_mask = int(mask)
+
+
+def prof_set_stride(stride: int) -> None:
+    """after prof_enable: only every stride-th launch inside decode steps carries an event pair (bench.py's timed region)"""
+    check(load().infgen_prof_set_stride(int(stride)), 'infgen_prof_set_stride')
+
+
+def prof_seen():
+    """-> {kernel: dict(seen, seen_step)}: launches of the selected kernels since prof_enable, bracketed or not"""
+    n = len(KERNEL_IDS)
+    seen, seen_step = (_i * n)(), (_i * n)()
+    check(load().infgen_prof_seen(seen, seen_step), 'infgen_prof_seen')
+    return {k: dict(seen=seen[i], seen_step=seen_step[i]) for i, k in enumerate(KERNEL_IDS)}
 
 
 def prof_active() -> bool:

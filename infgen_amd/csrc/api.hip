@@ -83,6 +83,9 @@ struct Prof {
   std::vector<int> phase_of;                // 0: prologue / operator-level call, 1: inside a decode step (infgen_decode_step, infgen_rollout_run)
   std::vector<double> macs;                 // algorithmic multiply-accumulates of the launch (0: not a GEMM kernel)
   int phase = 0;
+  int stride = 1;                           // of the launches inside decode steps every stride-th is bracketed (infgen_prof_set_stride)
+  int seen[INFGEN_KID_COUNT] = {};          // launches of the selected kernels since infgen_prof_enable, bracketed or not
+  int seen_step[INFGEN_KID_COUNT] = {};     // ... of them inside decode steps
   size_t used = 0;
   unsigned long long* rows_dev = nullptr;   // [16] device counters: [n] rows processed by k_fourier with n input dims (n < 8);
                                             // [8 + kind] edges built by k_build_edges (kind 0 temporal, 1 map, 2 agent)
@@ -93,7 +96,10 @@ struct ProfScope {
   hipStream_t s;
   ProfScope(int kid, void* stream, double macs = 0.0) : s((hipStream_t)stream) {
     if ((g_prof.mask >> kid) & 1u) {
-      if (g_prof.used < g_prof.e0.size()) {
+      ++g_prof.seen[kid];
+      // an event pair costs ~5 us of launch-stream time: inside the timed region only every stride-th decode-step launch carries one
+      const bool take = g_prof.phase != 1 || (g_prof.seen_step[kid]++ % g_prof.stride) == 0;
+      if (take && g_prof.used < g_prof.e0.size()) {
         slot = (int)g_prof.used++;
         g_prof.kid[slot] = kid;
         g_prof.phase_of[slot] = g_prof.phase;
@@ -130,6 +136,22 @@ extern "C" int infgen_prof_enable(unsigned mask, int max_launches) {
   if (g_prof.rows_dev) (void)hipMemset(g_prof.rows_dev, 0, 16 * sizeof(unsigned long long));
   g_prof.mask = mask;
   g_prof.used = 0;
+  g_prof.stride = 1;
+  for (int k = 0; k < INFGEN_KID_COUNT; ++k) g_prof.seen[k] = g_prof.seen_step[k] = 0;
+  return 0;
+}
+// after infgen_prof_enable: bracket only every stride-th launch of the selected kernels inside decode steps (launches outside
+// them are all bracketed); infgen_prof_seen returns how many launches there were, bracketed or not
+extern "C" int infgen_prof_set_stride(int stride) {
+  if (stride < 1) return fail("infgen_prof_set_stride", "stride must be >= 1");
+  g_prof.stride = stride;
+  return 0;
+}
+extern "C" int infgen_prof_seen(int* seen, int* seen_step) {
+  for (int k = 0; k < INFGEN_KID_COUNT; ++k) {
+    if (seen) seen[k] = g_prof.seen[k];
+    if (seen_step) seen_step[k] = g_prof.seen_step[k];
+  }
   return 0;
 }
 
