@@ -1260,7 +1260,13 @@ static int layers_core(const InfgenRollout* r, int c, int edgeless, void* stream
   // warm requests (tile.cuh: WarmArgs): an edge launch pulls what the node launch after it reads (the layer's post part without
   // W'vr, the next layer's pre part), a node launch the whole post part of the layer after it (W'vr first: the next edge launch)
   const int QB = 16384;                              // bytes of a quarter-matrix (split.cuh: QUARTER fp16 elements)
+  // the edgeless column-0 chain through the fused kernels: a row without edges aggregates exactly zero (agg = z = sigma = 0, so
+  // agg + W'vr z + b' sigma = +0 in every column) - AGG is zeroed once and the 18 edge launches (54 us each at 1024 scenes) are skipped
+  const bool skip_edges = edgeless && fuse;
+  if (skip_edges && hipMemsetAsync(r->AGG, 0, (size_t)rows * D * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return fail("infgen_decode_layers", "memset failed");
   auto edge = [&](const float* pack, const float* Ks, const float* Vs, const InfgenEdgeBuf& e, int kv_once = 0, const float* next_pack = nullptr) {
+    if (skip_edges) return 0;
     if (fuse && O().attn_mode != 0)
       warm_request(pack + AH_POST + 4 * (QB / 4), 48 * QB, next_pack ? next_pack + AH_PRE : nullptr, 16 * QB);
     return fuse ? edge_fused_launch(rows, r->Q, pack, Ks, Vs, e.off, e.cnt, e.src, e.rhat, r->AGG, r->A_cap, kv_once, stream, r24)
