@@ -32,9 +32,6 @@
 #include "edge_attn.cuh"
 
 #ifndef IG_LP_NOLOAD
-#define IG_LP_NOLOAD 0
-#endif
-#ifndef IG_LP_NOLOAD
 #define IG_LP_NOLOAD 0           // timing experiments (wrong results): 1 no weight-fragment loads, IG_LP_NOMFMA no products in the
 #endif                          // GEMM stages, IG_LP_NOEDGE empty edge lists - what each costs in wall time
 #ifndef IG_LP_NOMFMA
@@ -76,10 +73,6 @@ constexpr int LP_G = IG_LP_G;              // edges per trip of the edge loop
 struct AFragP {                // the four k-steps of ONE feature tile of a 128 x 128 matrix (attn_hs.hip: AFrag)
   v8h h[4], l[4];
   __device__ __forceinline__ void load(const unsigned short* W, int w, int lane) {
-#if IG_LP_NOLOAD
-    asm volatile("" : "+v"(h[0]), "+v"(l[0]));
-    return;
-#endif
 #if IG_LP_NOLOAD          // timing experiment (wrong results): the node part without its weight stream
     asm volatile("" : "+v"(h[0]), "+v"(l[0]));
     return;
