@@ -929,3 +929,38 @@ def test_layers_p_one_launch_per_decode_step():
     steps = c['cfg'].num_decode_steps
     assert counts[1]['k_edge_attn']['step_calls'] == steps and counts[1]['k_attn_post']['step_calls'] == 0
     assert counts[0]['k_edge_attn']['step_calls'] == 18 * steps and counts[0]['k_attn_post']['step_calls'] == 18 * steps
+
+
+def test_profiler_stride_samples_the_step_launches_evenly():
+    """bench.py's timed region brackets every fifth decode-step launch of the dominant kernel (infgen_prof_set_stride; an event
+    pair costs launch-stream time): the launches are all COUNTED (infgen_prof_seen), the bracketed ones are every stride-th of the
+    launches inside decode steps - all positions of a step's 18 sublayers equally often - and every launch outside them"""
+    from infgen_amd import engine, _lib
+    lib = _lib.load()
+    c = load_case('a24_m256_edge')
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], c['cfg'], dev)
+    e = engine.RolloutEngine(w, [c['scene']], c['vocab'], c['map_vocab'], c['grid'], store_logits=False, use_graph=False)
+    e.rollout()
+    steps = c['cfg'].num_decode_steps
+    kid = 1 << _lib.KERNEL_IDS.index('k_edge_attn')
+    try:
+        _lib.check(lib.infgen_set_layers_p(0))                 # 18 edge launches per step
+        _lib.prof_enable(kid)
+        e.rollout()
+        full, seen_full = _lib.prof_collect()['k_edge_attn'], _lib.prof_seen()['k_edge_attn']
+        _lib.prof_enable(kid)
+        _lib.prof_set_stride(5)
+        for _ in range(5):
+            e.rollout()
+        part, seen_part = _lib.prof_collect()['k_edge_attn'], _lib.prof_seen()['k_edge_attn']
+    finally:
+        _lib.prof_enable(0)
+        _lib.check(lib.infgen_set_layers_p(1))
+    assert full['step_calls'] == seen_full['seen_step'] == 18 * steps and full['calls'] == seen_full['seen']
+    assert seen_part['seen_step'] == 5 * 18 * steps and seen_part['seen'] == 5 * seen_full['seen']
+    assert part['step_calls'] == 18 * steps                                        # a fifth of the 5 rollouts' step launches
+    assert part['calls'] - part['step_calls'] == 5 * (full['calls'] - full['step_calls'])      # outside the steps: every launch
+    # the same average duration within noise (single scene: ~20 us launches)
+    a, b = full['step_ms'] / full['step_calls'], part['step_ms'] / part['step_calls']
+    assert abs(a - b) <= 0.25 * a, (a, b)
