@@ -238,10 +238,19 @@ int infgen_set_overlap(int mode);
 /* 1 (default; INFGEN_LAYERS_P=0 in the environment: off): launches of up to 256 16-row groups run ALL 18 sublayers of a decode step
  * in one launch of k_layers_p (one resident workgroup per group, wave = feature tile; the scene's groups meet at a counter before
  * each agent sublayer) instead of 36 launches of k_edge_fused + k_attn_hs - same operators (infgen/modules/layers.py:61-113),
- * rounding-level differences only.  Needs fused edge attention (infgen_set_edge_fuse != 0), the split GEMM kernels and no
- * row-group list; otherwise the per-sublayer launches run.  Process-wide default like the other infgen_set_*: a context with
- * opts.use != 0 takes InfgenOptions.layers_p instead. */
+ * rounding-level differences only.  Needs fused edge attention (infgen_set_edge_fuse != 0) and the split GEMM kernels; otherwise
+ * the per-sublayer launches run (a row-group list of an insertion context is ignored by this kernel: it visits every group).
+ * Process-wide default like the other infgen_set_*: a context with opts.use != 0 takes InfgenOptions.layers_p instead.
+ * Concurrency: a launch never exceeds the workgroups the device keeps resident for this kernel (occupancy query x CUs), the
+ * launches of different streams of one process are ordered behind each other by the library, and the wait at the counters has no
+ * time limit - contexts may run concurrently on several streams or host threads, next to other kernels (tests/test_rollout_gpu.py).
+ * mode 2: the same through hipLaunchCooperativeKernel (device-wide cooperative queue: also safe next to ANOTHER PROCESS that runs
+ * such kernels on the same GPU; ~25 us more per launch; a runtime that refuses the launch gets the per-sublayer launches from
+ * then on).  (A stream that is being captured into a HIP graph takes a plain launch with a bounded wait: graph replay is an
+ * opt-in mode whose caller owns the GPU.)
+ * infgen_layers_p_capacity: workgroups one such launch may have on the current device (0: the kernel is unavailable here). */
 int infgen_set_layers_p(int mode);
+int infgen_layers_p_capacity(void);
 /* same with the kernel variant forced: wide = 1 -> one 8-wave workgroup per destination (long edge lists, few rows),
  * wide = 0 -> one wave per destination; infgen_edge_attn picks wide when rows <= 256 */
 int infgen_edge_attn_mode(int rows, const float* Q, const float* U, const float* Ksrc, const float* Vsrc,

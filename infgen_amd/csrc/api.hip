@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <string>
 #include <vector>
+#include <atomic>
+#include <mutex>
 #include "kernels.h"
 #include "../../include/infgen_hip.h"
 
@@ -31,7 +33,7 @@ extern "C" const char* infgen_last_error(void) { return g_err.c_str(); }
 // called with a context whose opts.use != 0 installs that context's block for the duration of the call (thread-local), so
 // contexts of one process do not see each other's settings.
 namespace {
-int layers_p_default() { const char* e = getenv("INFGEN_LAYERS_P"); return e ? (atoi(e) != 0) : 1; }
+int layers_p_default() { const char* e = getenv("INFGEN_LAYERS_P"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : v > 2 ? 2 : v; }
 InfgenOptions g_def = {0, /*attn_mode*/ 2, /*gemm_terms*/ 3, /*fourier_mode*/ 1, /*edge_fuse*/ 1, /*edge_loop*/ 6, /*overlap*/ 0,
                        /*row_group_margin*/ 0, /*layers_p*/ layers_p_default(), 0, nullptr, nullptr};
 int g_def_group_rows = 0;                  // rows of the layout the process-wide group list belongs to
@@ -1069,7 +1071,7 @@ static int fourier_nomulti() {
 
 // ---- k_layers_p (layers_p.hip): every sublayer of a step in one launch, one resident workgroup per 16-row group
 extern "C" int infgen_set_layers_p(int mode) {        // (process-wide default, like the other infgen_set_*: contexts carry their own copy)
-  if (mode != 0 && mode != 1) return fail("infgen_set_layers_p", "mode must be 0 or 1");
+  if (mode < 0 || mode > 2) return fail("infgen_set_layers_p", "mode must be 0, 1 or 2");
   g_def.layers_p = mode;
   return 0;
 }
@@ -1090,13 +1092,67 @@ static int lp_max_groups() {
   return v;
 }
 // the launch shape qualifies (the kernel keeps U / Z on chip like k_edge_fused: step_mode treats it as a fused launch)
-static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless) {
-  static int n_cu = 0;
-  if (!n_cu) {
+// k_layers_p's workgroups meet at counters in global memory, so a launch needs ALL of them resident at some point:
+//  * the grid is checked against the device's resident capacity for this kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs:
+//    layers_p_shape) - what fits becomes resident as soon as kernels of other streams leave the CUs, so the wait at the counters
+//    has no limit (no trap);
+//  * launches of different streams of this process are ordered behind each other (two half-resident launches would wait for each
+//    other for ever): g_lp_mu / g_lp_ev below;
+//  * layers_p == 2 additionally launches through hipLaunchCooperativeKernel (the runtime's own residency contract, and the
+//    cooperative queue is device-wide - this also covers another PROCESS running such a kernel on the same GPU); measured cost of
+//    the queue hand-over: 8 scenes 9.54 -> 9.97 ms per rollout, 64 scenes 17.01 -> 17.36 (tools/lp_coop_ab.sh).  A refused
+//    cooperative launch falls back to the per-sublayer kernels for good (g_lp_refused).
+static std::atomic<bool> g_lp_refused{false};
+static std::mutex g_lp_mu;                  // orders the k_layers_p launches of the process's streams
+static hipEvent_t g_lp_ev = nullptr;        // recorded behind the last k_layers_p launch
+static hipStream_t g_lp_last = nullptr;     // ... on this stream
+static bool g_lp_any = false;
+struct LpDevice { int n_cu = 1; int coop = 0; int wg_per_cu = 0; };
+static const LpDevice& lp_device() {
+  static LpDevice d = [] {
+    LpDevice v;
     int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) n_cu = 1;
-    else n_cu = prop.multiProcessorCount;
-  }
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+      v.n_cu = prop.multiProcessorCount;
+      (void)hipDeviceGetAttribute(&v.coop, hipDeviceAttributeCooperativeLaunch, dev);
+      // resident workgroups per CU of the largest variant (the 120 KB of LDS set it: 1)
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v.wg_per_cu, k_layers_p<true, 16>, 512, 0) != hipSuccess) v.wg_per_cu = 0;
+      (void)hipGetLastError();
+    }
+    return v;
+  }();
+  return d;
+}
+extern "C" int infgen_layers_p_capacity(void) {       // workgroups one k_layers_p launch may have on this device (0: not available)
+  const LpDevice& d = lp_device();
+  if (d.wg_per_cu <= 0) return 0;
+  return d.n_cu * (d.wg_per_cu > 1 ? 1 : d.wg_per_cu);      // (the launch shapes assume one workgroup per CU)
+}
+// k_layers_p bounds a row's LayerNorm output with header slots 10..13 of the attention packs; a pack without them (an older or
+// foreign packer: slot 14 != AH_HDR_VERSION) would scale its operands by 2^126.  Checked once per pack pointer (a 64-byte
+// device -> host copy at a context's first launch); contexts with such a pack take the per-sublayer launches.
+static bool lp_packs_ok(const InfgenRollout* r) {
+  static std::mutex mu;
+  static std::vector<std::pair<const float*, bool>> seen;
+  std::lock_guard<std::mutex> lk(mu);
+  auto ok = [&](const float* pack) {
+    if (!pack) return false;
+    for (const auto& e : seen) if (e.first == pack) return e.second;
+    float hdr[16] = {};
+    const bool good = hipMemcpy(hdr, pack + AH_HDR, sizeof(hdr), hipMemcpyDeviceToHost) == hipSuccess && hdr[14] == AH_HDR_VERSION &&
+                      hdr[10] > 0.f && hdr[12] > 0.f;
+    if (seen.size() > 4096) seen.clear();
+    seen.emplace_back(pack, good);
+    return good;
+  };
+  for (int i = 0; i < r->num_layers; ++i)
+    if (!ok(r->attn_t[i]) || !ok(r->attn_m[i]) || !ok(r->attn_a[i])) return false;
+  return true;
+}
+static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless) {
+  const LpDevice& lpd = lp_device();
+  if (lpd.wg_per_cu <= 0 || (O().layers_p == 2 && (!lpd.coop || g_lp_refused.load()))) return false;
+  const int n_cu = lpd.n_cu;
   // all workgroups must be resident at once (they meet at per-scene counters): at most one workgroup per CU (120 KB of LDS each).
   // Up to that limit the one-launch kernel wins at every size measured (scenes of 64 agents, ms per rollout, k_layers_p vs the
   // per-sublayer launches): 8 scenes 10.7 / 15.4, 16: 11.7 / 16.4, 32: 13.7 / 18.0 (8 rows per workgroup), 48: 16.8 / 20.1,
@@ -1107,7 +1163,7 @@ static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless) {
   const int max_groups = lp_max_groups();
   return O().layers_p && O().edge_fuse != 0 && O().attn_mode != 0 && O().gemm_terms == 3 && O().fourier_mode != 0 &&
          !(O().overlap && g_side) && r->A_cap % 16 == 0 && lp_chunk_scenes(r, max_groups < n_cu ? max_groups : n_cu) > 0 &&
-          r->num_layers <= LP_MAX_LAYERS && r->U && r->SIG;
+          r->num_layers <= LP_MAX_LAYERS && r->U && r->SIG && lp_packs_ok(r);
 }
 
 // ---- a decode step in two halves: the edge sets of a column with their embeddings, and the 18 sublayers that consume them
@@ -1177,6 +1233,7 @@ static int prepare_edges(const InfgenRollout* r, int c, int edgeless, void* stre
   return 0;
 }
 
+constexpr int LP_REFUSED = -12345;      // layers_p_launch: the runtime refused the cooperative launch, nothing was enqueued
 // sync_clear = false: the scenes' counters are already zero (the k_integrate of the previous decode step cleared them: IntegrateArgs.zero_sync)
 static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, void* stream, bool sync_clear = true) {
   const int rows = r->S * r->A_cap;
@@ -1215,21 +1272,54 @@ static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, vo
   const int gps = r->A_cap / a.rows_per_wg;
   // a batch beyond one launch's workgroups: chunks of whole scenes, one launch after the other (each launch's workgroups are all
   // resident; the stream orders them)
-  int n_cu = 256;
-  { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount; }
+  const int n_cu = lp_device().n_cu;
   const int limit = lp_max_groups() < n_cu ? lp_max_groups() : n_cu;
   const int per = rows / a.rows_per_wg <= limit ? r->S : lp_chunk_scenes(r, limit);
   if (per <= 0) return fail("infgen_decode_layers", "k_layers_p: batch does not fit");
   auto kern = a.rows_per_wg == 4 ? (sm.r24 ? k_layers_p<true, 4> : k_layers_p<false, 4>)
             : a.rows_per_wg == 8 ? (sm.r24 ? k_layers_p<true, 8> : k_layers_p<false, 8>)
                                  : (sm.r24 ? k_layers_p<true, 16> : k_layers_p<false, 16>);
+  // A stream that is being captured into a HIP graph cannot take a cooperative launch or the cross-stream ordering below: the
+  // (opt-in) graph modes keep the plain launch with the spin limit - their caller owns the GPU
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  static const unsigned spin_env = getenv("INFGEN_LP_SPIN_LIMIT") ? (unsigned)strtoul(getenv("INFGEN_LP_SPIN_LIMIT"), nullptr, 0) : 0u;
+  a.spin_limit = capturing ? (1u << 22) : spin_env;
+  std::unique_lock<std::mutex> lk(g_lp_mu, std::defer_lock);
+  if (!capturing) {
+    lk.lock();
+    if (!g_lp_ev && hipEventCreateWithFlags(&g_lp_ev, hipEventDisableTiming) != hipSuccess)
+      return fail("infgen_decode_layers", "event creation failed");
+    // a launch from ANOTHER stream than the previous one waits for that stream's work enqueued so far (which includes its
+    // k_layers_p launch): the event is recorded only now, on the switch - a single-stream caller never pays for it
+    if (g_lp_any && g_lp_last != (hipStream_t)stream &&
+        (hipEventRecord(g_lp_ev, g_lp_last) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, g_lp_ev, 0) != hipSuccess))
+      return fail("infgen_decode_layers", "k_layers_p: ordering behind the previous launch failed");
+  }
+  const bool lp_coop = O().layers_p == 2;
   for (int s0 = 0; s0 < r->S; s0 += per) {
     const int ns = r->S - s0 < per ? r->S - s0 : per;
     const int n_wg = ns * gps;
     a.row0 = s0 * r->A_cap;
     a.xcd_order = n_wg % (8 * gps) == 0 ? 1 : 0;
     ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
-    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(512), 0, (hipStream_t)stream, a);
+    if (capturing || !lp_coop) {
+      hipLaunchKernelGGL(kern, dim3(n_wg), dim3(512), 0, (hipStream_t)stream, a);
+    } else {
+      void* params[] = {&a};
+      const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), dim3(n_wg), dim3(512), params, 0, (hipStream_t)stream);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (s0 > 0) return fail("infgen_decode_layers", "k_layers_p: cooperative launch of a later chunk refused");
+        g_lp_refused.store(true);          // this and every later call: the per-sublayer launches
+        return LP_REFUSED;
+      }
+    }
+  }
+  if (!capturing) {
+    g_lp_last = (hipStream_t)stream;
+    g_lp_any = true;
+    lk.unlock();
   }
   if (lp_trace) {          // synchronous dump of the last launch's stamps (diagnostic runs only)
     static int dumps = 0;
@@ -1247,7 +1337,12 @@ static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, vo
 static int layers_core(const InfgenRollout* r, int c, int edgeless, void* stream, bool lp_sync_clear = true) {
   const int rows = r->S * r->A_cap;
   const StepMode sm = step_mode(r, rows, edgeless);
-  if (sm.lp && sm.fuse) return layers_p_launch(r, c, sm, stream, lp_sync_clear);
+  if (sm.lp && sm.fuse) {
+    const int rc = layers_p_launch(r, c, sm, stream, lp_sync_clear);
+    if (rc != LP_REFUSED) return rc;
+    // the runtime refused the cooperative launch: the per-sublayer launches below, with the fused edge kernel (the step's rhat
+    // rows are already in its format); later calls do not try again (layers_p_shape)
+  }
   const bool overlap = sm.overlap, fuse = sm.fuse; const int r24 = sm.r24;
   const size_t slot = (size_t)(c % r->ring) * rows * D;
   const int L = r->num_layers;

@@ -136,6 +136,8 @@ struct LayersPArgs {
   float* Ka[2]; float* Va[2];        // agent-set K / V rows, double buffered by layer parity
   EdgeSet et, em, ea;
   int* sync;                         // [scenes] zeroed before the launch: arrivals of a scene's workgroups per layer
+  unsigned spin_limit;               // 0: wait at the scene counters without limit (cooperative launch: residency is guaranteed);
+                                     // n: trap after n polls (diagnostics, and launches captured into a HIP graph)
   unsigned long long* trace;         // diagnostics (INFGEN_LP_TRACE=1): [1024][2] (stamp id, s_memtime) of workgroup 0
 };
 

@@ -723,7 +723,7 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
           unsigned spins = 0;
           while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 22)) __builtin_trap();
+            if (a.spin_limit && ++spins > a.spin_limit) __builtin_trap();
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -735,13 +735,14 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
       if (tid == 0) {
         __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int target = (i + 1) * gps;
-        // (a launch whose workgroups are not all resident - more concurrent k_layers_p launches than CUs, see api.hip / engine.py
-        // rollout_many - would wait here for ever and take the GPU with it: after ~0.2 s of spinning the kernel traps instead, the
-        // next HIP call of the process fails loudly)
+        // (the launch is a COOPERATIVE one - api.hip: layers_p_launch - so every workgroup is resident or will be as soon as kernels
+        // of other streams leave the CUs, and the library serialises k_layers_p launches across streams: the wait is bounded by
+        // other work's duration and has no limit.  a.spin_limit != 0 - diagnostic builds / runs, and launches captured into a HIP
+        // graph, which cannot be cooperative - traps after that many polls instead of waiting for ever)
         unsigned spins = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
           __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 22)) __builtin_trap();
+          if (a.spin_limit && ++spins > a.spin_limit) __builtin_trap();
         }
       }
       __syncthreads();

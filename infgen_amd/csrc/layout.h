@@ -37,7 +37,7 @@ enum AttnLayout : int {
   AL_SIZE_F32 = AL_LN_FFPOST_B + 128,
   // ---- fp16-split section (k_attn_h, attn_h.hip): inverse weight scales, then quarter-matrices (8192 fp16 =
   // 4096 floats each; packing.pack_matrix_h / pack_wvr_h / pack_wkr_h) in consumption order
-  AH_HDR = AL_SIZE_F32,                  // [16]: 1/scale of  0 wq  1 wkr  2 wk  3 wv  4 wvr  5 wg  6 ws  7 wo  8 w1  9 w2; 10, 11 max |gamma|, |beta| of ff_prenorm; 12, 13 of attn_prenorm_x_dst
+  AH_HDR = AL_SIZE_F32,                  // [16]: 1/scale of  0 wq  1 wkr  2 wk  3 wv  4 wvr  5 wg  6 ws  7 wo  8 w1  9 w2; 10, 11 max |gamma|, |beta| of ff_prenorm; 12, 13 of attn_prenorm_x_dst; 14: AH_HDR_VERSION
   AH_PRE = AH_HDR + 16,                  // 16 quarters: Wq (4)  W'kr (4: two heads each)  Wk (4)  Wv (4)
   AH_POST = AH_PRE + 16 * 4096,          // 52 quarters: W'vr (4: two heads each)  Wg[:, :128] (4)  Wg[:, 128:] (4)  Ws (4)
                                          //   Wo (4)  then per 128-wide FFN chunk c: W1[128c:128c+128, :] (4)  W2[:, 128c:128c+128] (4)
@@ -94,5 +94,8 @@ enum FourierHLayout : int {
 __host__ __device__ inline int fourier_pack_size(int n) {
   return fourier_pack_size_f32(n) + FH_VEC_SIZE + 2 * (2 * n + 1) * FH_HALF_MAT_FLOATS;
 }
+
+// value of header slot 14 of an attention pack whose slots 10..13 (LayerNorm bounds for k_layers_p) are filled (packing.py)
+constexpr float AH_HDR_VERSION = 2.0f;
 
 }  // namespace ig

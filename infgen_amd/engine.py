@@ -78,7 +78,31 @@ class LazyOut(dict):
         yield from list(self._lazy)
 
     def keys(self):
-        return list(self.__iter__())
+        # a real view (set operations such as ``d.keys() & other`` work); the pending keys are resolved first - every caller that
+        # only wants the names uses ``in`` / iteration, which stay lazy
+        self._force_all()
+        return super().keys()
+
+    def update(self, *args, **kw):
+        for k, v in dict(*args, **kw).items():
+            self[k] = v
+
+    def __ior__(self, other):
+        self.update(other)
+        return self
+
+    def __or__(self, other):
+        out = self.copy()
+        out.update(other)
+        return out
+
+    def clear(self):
+        self._lazy.clear()
+        super().clear()
+
+    def popitem(self):
+        self._force_all()
+        return super().popitem()
 
     def values(self):
         self._force_all()
@@ -1613,24 +1637,9 @@ def rollout_many(engines: Sequence[RolloutEngine], streams: Optional[Sequence[to
         for e in engines:
             e.rollout()
         return
-    # k_layers_p's workgroups of one launch meet at per-scene counters and must all be resident; launches of SEVERAL streams share
-    # the CUs, so together they must not exceed them either (two launches each half resident would wait for each other for ever)
-    def _lp_wgs(e):                      # workgroups of one k_layers_p launch of this engine (csrc/api.hip: layers_p_launch)
-        if e.rows % 16 or e.rows // 16 > 512:
-            return 0
-        if e.rows % 4 == 0 and e.rows // 4 <= 128:
-            return e.rows // 4
-        if e.rows % 8 == 0 and e.rows // 8 <= 256:
-            return e.rows // 8
-        return min(e.rows // 16, 256)
-    guard = sum(_lp_wgs(e) for e in engines) > 256
-    if guard:
-        _lib.check(engines[0].lib.infgen_set_layers_p(0), 'infgen_set_layers_p')
-    try:
-        return _rollout_many_streams(engines, streams, dev)
-    finally:
-        if guard and os.environ.get('INFGEN_LAYERS_P', '1') != '0':
-            _lib.check(engines[0].lib.infgen_set_layers_p(1), 'infgen_set_layers_p')
+    # (k_layers_p launches of several streams: the library launches the kernel cooperatively and orders such launches of different
+    # streams behind each other - csrc/api.hip: layers_p_launch - so engines of any size may share the GPU)
+    return _rollout_many_streams(engines, streams, dev)
 
 
 def _rollout_many_streams(engines, streams, dev):

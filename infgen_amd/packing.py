@@ -90,6 +90,9 @@ def pack_attention_layer(sd, prefix: str, has_pos_emb: bool = True) -> np.ndarra
     # (one power-of-two scale per row for the fp16 split of a GEMM operand, csrc/layers_p.hip: scale_bits)
     hdr[10], hdr[11] = np.abs(g('ff_prenorm.weight')).max(), np.abs(g('ff_prenorm.bias')).max()
     hdr[12], hdr[13] = np.abs(g('attn_prenorm_x_dst.weight')).max(), np.abs(g('attn_prenorm_x_dst.bias')).max()
+    # [14]: version of this header (csrc/layout.h: AH_HDR_VERSION).  The library checks it before it lets k_layers_p use [10..13]: a
+    # pack from an older packer has zeros there, the bound would be 0 and the operand scale 2^126
+    hdr[14] = ATTN_HDR_VERSION
     pre = [pack_matrix_h(wq * sc[0], natural_k=False), pack_wkr_h(wkr_ * sc[1]),
            pack_matrix_h(wk * sc[2], natural_k=False), pack_matrix_h(wv * sc[3], natural_k=False)]
     post = [pack_wvr_h(wvr_ * sc[4]), pack_matrix_h(wg[:, :128] * sc[5], natural_k=False),
@@ -167,6 +170,7 @@ def pack_fourier(sd, prefix: str, n: int) -> np.ndarray:
     return out
 
 
+ATTN_HDR_VERSION = 2.0      # csrc/layout.h: AH_HDR_VERSION
 H_TARGET = 32000.0      # |scaled operand| bound: fp16 max is 65504
 LN_MAX = 11.3           # max |(x - mean) / std| over 128 values is sqrt(127)
 

@@ -445,3 +445,16 @@ def test_lazy_out_behaves_like_the_dict_it_replaces():
     assert q['k'] == 61 and 60 not in calls
     assert q.setdefault('n', 5) == 5 and q.setdefault('n', 6) == 5
     assert sorted(LazyOut({'a': 1}, {'b': thunk(70)}).items()) == [('a', 1), ('b', 70)]
+    # the bulk operations go through the same bookkeeping (update over a pending key, clear, popitem, |=, key views)
+    u = LazyOut({'a': 1}, {'b': thunk(80), 'c': thunk(81)})
+    u.update(b=5)
+    assert len(u) == 3 and sorted(u) == ['a', 'b', 'c'] and u['b'] == 5 and 80 not in calls
+    u |= {'c': 6, 'd': 7}
+    assert u['c'] == 6 and 81 not in calls and len(u) == 4
+    assert (u | {'e': 1})['e'] == 1 and 'e' not in u
+    assert u.keys() & {'a', 'z'} == {'a'}
+    k = LazyOut({}, {'p': thunk(90)})
+    assert k.popitem() == ('p', 90) and len(k) == 0
+    c = LazyOut({'a': 1}, {'b': thunk(91)})
+    c.clear()
+    assert len(c) == 0 and 'b' not in c and list(c) == [] and 91 not in calls

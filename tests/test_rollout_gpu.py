@@ -964,3 +964,122 @@ def test_profiler_stride_samples_the_step_launches_evenly():
     # the same average duration within noise (single scene: ~20 us launches)
     a, b = full['step_ms'] / full['step_calls'], part['step_ms'] / part['step_calls']
     assert abs(a - b) <= 0.25 * a, (a, b)
+
+
+def _eight_scene_engine(c, dev, seed0=8600, **kw):
+    from infgen_amd import engine, synth
+    cfg = c['cfg']
+    w = engine.PackedWeights(c['sd'], cfg, dev)
+    scenes = [c['scene']] + [synth.make_scene(seed0 + i, a, m, cfg, ego_last=(i % 2 == 0), vocab=c['vocab'], grid=c['grid'], slip=0.3)
+                             for i, (a, m) in enumerate([(64, 1024), (9, 100), (40, 300), (64, 700), (33, 512), (17, 64), (50, 900)])]
+    return engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=True, use_graph=False, **kw)
+
+
+@pytest.mark.parametrize('mode', [1, 2])
+def test_layers_p_next_to_a_long_kernel_on_another_stream(mode):
+    """VERDICT r4 item 3 / ADVICE r4: k_layers_p's workgroups meet at counters in global memory, so all of them must become
+    resident.  A launch never exceeds the device's resident capacity and waits without a limit (mode 1; mode 2: the same through
+    hipLaunchCooperativeKernel): an 8-scene engine (32 - 128 workgroups per launch) runs 20 rollouts while a second stream keeps
+    most CUs busy with long kernels of another library (torch matmuls, ~10 ms each) - no trap, and tokens / states / poses /
+    logits bitwise equal to the quiet run"""
+    from infgen_amd import _lib
+    lib = _lib.load()
+    assert lib.infgen_layers_p_capacity() > 0, 'k_layers_p would never run on this device'
+    c = load_case('c3_a64_m1024')
+    dev = torch.device('cuda:0')
+    e = _eight_scene_engine(c, dev, options={'layers_p': mode})
+    keys = ('pos', 'head', 'state', 'token', 'X', 'logits')
+    e.rollout()
+    torch.cuda.synchronize()
+    quiet = {k: getattr(e, k).clone() for k in keys}
+    assert np.array_equal(e.outputs()[0]['next_token_idx'], c['z']['next_token_idx'])
+    # the kernel in question really is the one that runs (one edge-side launch per decode step)
+    _lib.prof_enable(1 << _lib.KERNEL_IDS.index('k_edge_attn'))
+    e.rollout()
+    assert _lib.prof_collect()['k_edge_attn']['step_calls'] == c['cfg'].num_decode_steps
+    _lib.prof_enable(0)
+    side = torch.cuda.Stream(device=dev)
+    a = torch.randn(8192, 8192, device=dev)
+    b = torch.randn(8192, 8192, device=dev)
+    torch.cuda.synchronize()
+    for it in range(20):
+        with torch.cuda.stream(side):
+            for _ in range(6):                      # fp32 8192^3: ~10 ms each on every CU, queued ahead of and beside the rollout
+                a = torch.mm(a, b) * 1e-2
+        e.rollout()
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(getattr(e, k), quiet[k]), (it, k)
+
+
+@pytest.mark.parametrize('mode', [1, 2])
+def test_layers_p_engines_on_two_streams_from_two_host_threads(mode):
+    """two engines whose decode steps are k_layers_p launches, driven concurrently from two host threads on two streams (the
+    documented use of contexts, include/infgen_hip.h): the library orders the k_layers_p launches of different streams behind each
+    other, so both finish and reproduce their single-engine results bitwise - 10 rollouts each"""
+    import threading
+    from infgen_amd import _lib
+    c = load_case('c3_a64_m1024')
+    dev = torch.device('cuda:0')
+    keys = ('pos', 'head', 'state', 'token', 'X', 'logits')
+    engs = [_eight_scene_engine(c, dev, options={'layers_p': mode}), _eight_scene_engine(c, dev, seed0=9100, options={'layers_p': mode})]
+    quiet = []
+    for e in engs:
+        e.rollout()
+        torch.cuda.synchronize()
+        quiet.append({k: getattr(e, k).clone() for k in keys})
+    streams = [torch.cuda.Stream(device=dev) for _ in engs]
+    errors = []
+
+    def work(i):
+        try:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[i]):
+                for it in range(10):
+                    engs[i].rollout()
+                    streams[i].synchronize()
+                    for k in keys:
+                        if not torch.equal(getattr(engs[i], k), quiet[i][k]):
+                            errors.append((i, it, k))
+        except Exception as ex:          # noqa: BLE001
+            errors.append((i, repr(ex)))
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ths), 'an engine did not finish (k_layers_p launches waiting for each other?)'
+    assert not errors, errors[:5]
+    # the same two engines through rollout_many on two streams (one host thread)
+    from infgen_amd import engine
+    engine.rollout_many(engs, streams)
+    torch.cuda.synchronize()
+    for i, e in enumerate(engs):
+        for k in keys:
+            assert torch.equal(getattr(e, k), quiet[i][k]), (i, k)
+
+
+def test_layers_p_is_refused_for_packs_without_the_layernorm_bounds():
+    """k_layers_p scales a GEMM operand by a bound it reads from header slots 10..13 of the attention pack; a pack from
+    an older packer has zeros there (scale 2^126 -> inf / NaN).  The library checks the header version (slot 14) and gives such a
+    context the per-sublayer launches: same tokens, 18 edge launches per step instead of one"""
+    from infgen_amd import engine, _lib
+    lib = _lib.load()
+    c = load_case('a24_m256_edge')
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], c['cfg'], dev)
+    hdr = lib.infgen_attn_pack_offset(b'h_hdr')
+    assert hdr > 0
+    for pk in list(w.attn_t) + list(w.attn_m) + list(w.attn_a):
+        assert float(pk[hdr + 14]) == 2.0                       # the current packer's version stamp
+    w.attn_a[0] = w.attn_a[0].clone()                           # a fresh pointer: the library caches its verdict per pack
+    w.attn_a[0][hdr + 10:hdr + 15] = 0.0                        # what the previous packer wrote
+    e = engine.RolloutEngine(w, [c['scene']], c['vocab'], c['map_vocab'], c['grid'], store_logits=False, use_graph=False)
+    _lib.prof_enable(1 << _lib.KERNEL_IDS.index('k_edge_attn'))
+    try:
+        e.rollout()
+        n = _lib.prof_collect()['k_edge_attn']['step_calls']
+    finally:
+        _lib.prof_enable(0)
+    assert n == 18 * c['cfg'].num_decode_steps, n
+    assert np.array_equal(e.outputs()[0]['next_token_idx'], c['z']['next_token_idx'])
