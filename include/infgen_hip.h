@@ -215,6 +215,16 @@ int infgen_edge_attn_fused(int rows, const float* Q, const float* pack, const fl
 int infgen_fourier_embed_r24(const float* raw, int n_dims, const int* count_dev, int e_cap, const float* pack, void* out, void* stream);
 int infgen_edge_attn_fused_r24(int rows, const float* Q, const float* pack, const float* Ksrc, const float* Vsrc,
                                const int* off, const int* cnt, const int* src, const void* rhat24, float* AGG, void* stream);
+/* ... and in the "H8" form: per row 128 x fp16 of 2048 r (round to nearest) followed by 128 x OCP fp8 e4m3 of the remainder
+ * 2048 r - fp16(2048 r), 384 bytes (relative error 2^-16 for |r| >= 2^-6, absolute 2^-21 below).  Both planes are operands of the
+ * fp16 matrix pipe as they are: infgen_edge_attn_fused_h8 (k_edge_mfma) forms the scores u_h . r and the aggregates sum_e p_h r of
+ * 16 edges at a time as MFMAs instead of ~70 vector instructions per edge (reference infgen/modules/layers.py:78-92,109; same
+ * results as infgen_edge_attn_fused up to rounding).  infgen_fourier_embed_h8 writes the rows (split Fourier kernel only),
+ * infgen_rhat_to_h8 converts fp32 rows [rows][128]. */
+int infgen_fourier_embed_h8(const float* raw, int n_dims, const int* count_dev, int e_cap, const float* pack, void* out, void* stream);
+int infgen_edge_attn_fused_h8(int rows, const float* Q, const float* pack, const float* Ksrc, const float* Vsrc,
+                              const int* off, const int* cnt, const int* src, const void* rhat_h8, float* AGG, void* stream);
+int infgen_rhat_to_h8(const float* rhat, int rows, void* out, void* stream);
 int infgen_set_edge_fuse(int mode);
 /* the process-wide defaults (what the infgen_set_* functions edited so far), e.g. to seed a context's own InfgenOptions */
 int infgen_get_options(InfgenOptions* out);

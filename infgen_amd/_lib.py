@@ -127,6 +127,9 @@ SYMBOLS = {
     'infgen_edge_attn_fused': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'infgen_edge_attn_fused_r24': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'infgen_fourier_embed_r24': (_i, [_p, _i, _p, _i, _p, _p, _p]),
+    'infgen_edge_attn_fused_h8': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'infgen_fourier_embed_h8': (_i, [_p, _i, _p, _i, _p, _p, _p]),
+    'infgen_rhat_to_h8': (_i, [_p, _i, _p, _p]),
     'infgen_embedding_sum4': (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _p, _p]),
     'infgen_fourier_last_dim_table': (_i, [_p, _i, _p, _p]),
     'infgen_fourier_embed_tab': (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _p]),

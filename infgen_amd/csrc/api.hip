@@ -547,6 +547,38 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
     grid = ceil_div(grid, grp) * grp;
   }
   if (no_xcd & 2) a.kv_once = 0;
+  if (r24 == 2) {
+    // H8 rows: the matrix-pipe edge loop (edge_mfma.hip), one 8-wave workgroup per 16-row group at every size
+    EdgeFusedArgs m = a;
+    int mg = ceil_div(rows, 16);
+    m.tiles_per_scene = 0;
+    if (!m.groups && rows_per_scene > 16 && rows_per_scene % 16 == 0 && !(no_xcd & 1)) {
+      m.tiles_per_scene = rows_per_scene / 16;
+      const int grp = 8 * m.tiles_per_scene;
+      mg = ceil_div(mg, grp) * grp;
+    }
+    m.n_virtual = mg;
+    t_warm = WarmArgs{};
+    static unsigned long long* em_trace = nullptr;
+    if (dbg & 128) {
+      if (!em_trace && hipMalloc(&em_trace, 64 * sizeof(unsigned long long)) != hipSuccess) return fail("infgen_edge_attn_fused_h8", "trace buffer");
+      (void)hipMemsetAsync(em_trace, 0, 64 * sizeof(unsigned long long), (hipStream_t)stream);
+      m.dbgbuf = reinterpret_cast<unsigned*>(em_trace);
+    }
+    { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
+      if (m.kv_once) hipLaunchKernelGGL(k_edge_mfma<true>, dim3(mg), dim3(512), 0, (hipStream_t)stream, m);
+      else hipLaunchKernelGGL(k_edge_mfma<false>, dim3(mg), dim3(512), 0, (hipStream_t)stream, m); }
+    if (dbg & 128) {
+      static int dumps = 0;
+      if (dumps++ < 2) {
+        unsigned long long hst[64];
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        (void)hipMemcpy(hst, em_trace, sizeof(hst), hipMemcpyDeviceToHost);
+        for (int i = 1; i < 13; ++i) fprintf(stderr, "[em trace] %d +%lld\n", i, hst[i] && hst[0] ? (long long)(hst[i] - hst[0]) : -1ll);
+      }
+    }
+    return check_launch("infgen_edge_attn_fused_h8");
+  }
   a.n_virtual = grid;
   if (small && !persist) grid = warm_take(a.warm, grid); else t_warm = WarmArgs{};
   if (persist && !r24) {
@@ -612,6 +644,24 @@ extern "C" int infgen_edge_attn_fused_r24(int rows, const float* Q, const float*
                                           const int* off, const int* cnt, const int* src, const void* rhat24,
                                           float* AGG, void* stream) {
   return edge_fused_launch(rows, Q, pack, Ksrc, Vsrc, off, cnt, src, static_cast<const float*>(rhat24), AGG, 0, 0, stream, 1);
+}
+
+// ... and in the H8 form (include/infgen_hip.h), whose consumer runs the products with the rows on the matrix pipe (k_edge_mfma)
+extern "C" int infgen_fourier_embed_h8(const float* raw, int n, const int* count_dev, int e_cap, const float* pack, void* out,
+                                       void* stream) {
+  return fourier_embed_impl(raw, n, count_dev, e_cap, pack, nullptr, 0, static_cast<float*>(out), 128, 1, 2, stream);
+}
+
+extern "C" int infgen_edge_attn_fused_h8(int rows, const float* Q, const float* pack, const float* Ksrc, const float* Vsrc,
+                                         const int* off, const int* cnt, const int* src, const void* rhat_h8,
+                                         float* AGG, void* stream) {
+  return edge_fused_launch(rows, Q, pack, Ksrc, Vsrc, off, cnt, src, static_cast<const float*>(rhat_h8), AGG, 0, 0, stream, 2);
+}
+
+extern "C" int infgen_rhat_to_h8(const float* rhat, int rows, void* out, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(k_rhat_to_h8, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, rhat, rows, static_cast<char*>(out));
+  return check_launch("infgen_rhat_to_h8");
 }
 
 // one wave per destination; few destinations (<= 256 rows) get the 8-wave split so that the chip is not idle

@@ -370,6 +370,11 @@ class Ops:
         if wide == 'fused':         # u is the layer pack: U / Z / SIG stay on chip, agg already holds the positional part
             _lib.check(self.lib.infgen_edge_attn_fused(rows, _lib.ptr(q), _lib.ptr(u), *args[3:10], self.stream),
                        'infgen_edge_attn_fused')
+        elif wide == 'mfma':        # the same with the rows of rhat in the H8 form and the edge loop on the matrix pipe (k_edge_mfma)
+            h8 = torch.empty(max(rhat.shape[0], 1) * 384, device=rhat.device, dtype=torch.uint8)
+            _lib.check(self.lib.infgen_rhat_to_h8(_lib.ptr(rhat), rhat.shape[0], h8.data_ptr(), self.stream), 'infgen_rhat_to_h8')
+            _lib.check(self.lib.infgen_edge_attn_fused_h8(rows, _lib.ptr(q), _lib.ptr(u), *args[3:8], h8.data_ptr(), _lib.ptr(agg),
+                                                          self.stream), 'infgen_edge_attn_fused_h8')
         elif wide is None:
             _lib.check(self.lib.infgen_edge_attn(*args, self.stream), 'infgen_edge_attn')
         else:
@@ -396,7 +401,7 @@ class Ops:
         agg = sc.get('AGG', torch.empty(rows, D, device=dev))
         z = sc.get('Z', torch.empty(rows, 8 * D, device=dev))
         sig = sc.get('SIG', torch.empty(rows, 8, device=dev))
-        fused = wide == 'fused'
+        fused = wide in ('fused', 'mfma')
         if x_src is None:
             k = torch.empty(rows, D, device=dev)
             v = torch.empty(rows, D, device=dev)

@@ -1,0 +1,55 @@
+"""k_edge_mfma vs k_edge_fused on an agent <-> agent shaped edge set (scenes of 64 rows, ~27 sources per row out of the scene's 64):
+errors of agg' and time per launch.  python tools/probe_edge_mfma.py [scenes] [mean_degree]"""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+from conftest import make_weights
+from infgen_amd import _lib, packing, engine
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+deg = float(sys.argv[2]) if len(sys.argv) > 2 else 27.6
+dev = torch.device('cuda:0')
+lib = _lib.load()
+ops = engine.Ops(dev)
+sd = make_weights(seed=3)
+pack = torch.from_numpy(packing.pack_attention_layer(sd, 'agent_encoder.a2a_attn_layers.1')).to(dev)
+rng = np.random.default_rng(5)
+A = 64
+rows = S * A
+p = deg / (A - 1)
+adj = rng.random((S, A, A)) < p
+adj[:, np.arange(A), np.arange(A)] = False
+cnt = adj.sum(-1).reshape(-1).astype(np.int32)
+off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int32)
+s_idx, d_idx, j_idx = np.nonzero(adj)            # row-major: sorted by (scene, dst), sources ascending
+src = (s_idx * A + j_idx).astype(np.int32)
+E = len(src)
+print('rows', rows, 'edges', E, 'mean degree', E / rows, 'max', cnt.max())
+g = torch.Generator(device='cpu').manual_seed(1)
+r = torch.nn.functional.layer_norm(torch.randn(E, 128, generator=g), (128,)).to(dev)
+q = torch.randn(rows, 128, generator=g).to(dev)
+k = torch.randn(rows, 128, generator=g).to(dev)
+v = torch.randn(rows, 128, generator=g).to(dev)
+offd, cntd, srcd = (torch.from_numpy(a).to(dev) for a in (off, cnt, src))
+h8 = torch.empty(E * 384, device=dev, dtype=torch.uint8)
+r24 = torch.empty(E * 384, device=dev, dtype=torch.uint8)
+_lib.check(lib.infgen_rhat_to_h8(r.data_ptr(), E, h8.data_ptr(), ops.stream))
+aggs = {}
+def run(kind, n=1):
+    agg = aggs.setdefault(kind, torch.empty(rows, 128, device=dev))
+    for _ in range(n):
+        if kind == 'fused':
+            _lib.check(lib.infgen_edge_attn_fused(rows, q.data_ptr(), pack.data_ptr(), k.data_ptr(), v.data_ptr(), offd.data_ptr(),
+                                                  cntd.data_ptr(), srcd.data_ptr(), r.data_ptr(), agg.data_ptr(), ops.stream))
+        else:
+            _lib.check(lib.infgen_edge_attn_fused_h8(rows, q.data_ptr(), pack.data_ptr(), k.data_ptr(), v.data_ptr(), offd.data_ptr(),
+                                                     cntd.data_ptr(), srcd.data_ptr(), h8.data_ptr(), agg.data_ptr(), ops.stream))
+    return agg
+for kind in ('fused', 'mfma'):
+    run(kind); torch.cuda.synchronize()
+    t0 = time.perf_counter(); run(kind, 20); torch.cuda.synchronize()
+    print(kind, 'us per launch', (time.perf_counter() - t0) / 20 * 1e6)
+a, b = aggs['fused'], aggs['mfma']
+print('max |fused|', float(a.abs().max()), 'max abs err', float((a - b).abs().max()), 'mean abs err', float((a - b).abs().mean()),
+      'nan', int(torch.isnan(b).sum()))
+worst = int((a - b).abs().max(dim=1).values.argmax())
+print('worst row', worst, 'cnt', int(cnt[worst]), a[worst, :6].tolist(), b[worst, :6].tolist())
