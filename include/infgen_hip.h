@@ -284,6 +284,11 @@ int infgen_embedding_sum4(const float* tab0, const long long* idx0, int n0, cons
 int infgen_map_graph(int S, int M_cap, const int* n_map, const float* pos, const float* orient, float radius,
                      int max_nbr, int* off, int* cnt, int* src, float* raw, int* total, int cap, void* stream);
 
+/* checks a freshly built context (sizes, required pointers) and examines its attention packs' headers (64-byte device -> host
+ * copies: synchronous; k_layers_p needs the LayerNorm bounds of header slots 10..13, version slot 14 - contexts whose packs lack
+ * them take the per-sublayer launches).  Optional: without it a pack is examined when its device address is first seen, which
+ * goes wrong if that address held another pack earlier in the process. */
+int infgen_rollout_validate(const InfgenRollout* r);
 int infgen_build_edges(const InfgenRollout* r, int c, int edgeless, void* stream);
 int infgen_integrate(const InfgenRollout* r, int t, void* stream);
 int infgen_raw_feature(const InfgenRollout* r, int col, void* stream);

@@ -117,6 +117,7 @@ SYMBOLS = {
     'infgen_set_edge_fuse': (_i, [_i]),
     'infgen_set_layers_p': (_i, [_i]),
     'infgen_layers_p_capacity': (_i, []),
+    'infgen_rollout_validate': (_i, [_p]),
     'infgen_set_edge_loop': (_i, [_i]),
     'infgen_get_options': (_i, [C.POINTER(Options)]),
     'infgen_thread_options': (_i, [C.POINTER(Options)]),

@@ -1181,13 +1181,13 @@ extern "C" int infgen_layers_p_capacity(void) {       // workgroups one k_layers
 // k_layers_p bounds a row's LayerNorm output with header slots 10..13 of the attention packs; a pack without them (an older or
 // foreign packer: slot 14 != AH_HDR_VERSION) would scale its operands by 2^126.  Checked once per pack pointer (a 64-byte
 // device -> host copy at a context's first launch); contexts with such a pack take the per-sublayer launches.
-static bool lp_packs_ok(const InfgenRollout* r) {
+static bool lp_packs_ok(const InfgenRollout* r, bool refresh = false) {
   static std::mutex mu;
   static std::vector<std::pair<const float*, bool>> seen;
   std::lock_guard<std::mutex> lk(mu);
   auto ok = [&](const float* pack) {
     if (!pack) return false;
-    for (const auto& e : seen) if (e.first == pack) return e.second;
+    for (auto& e : seen) if (e.first == pack) { if (!refresh) return e.second; e.first = nullptr; }      // (refresh: look again)
     float hdr[16] = {};
     const bool good = hipMemcpy(hdr, pack + AH_HDR, sizeof(hdr), hipMemcpyDeviceToHost) == hipSuccess && hdr[14] == AH_HDR_VERSION &&
                       hdr[10] > 0.f && hdr[12] > 0.f;
@@ -1198,6 +1198,13 @@ static bool lp_packs_ok(const InfgenRollout* r) {
   for (int i = 0; i < r->num_layers; ++i)
     if (!ok(r->attn_t[i]) || !ok(r->attn_m[i]) || !ok(r->attn_a[i])) return false;
   return true;
+}
+// A context's packs looked at afresh (a device address may have held another pack before): callers that build a context call
+// this once (infgen_amd/engine.py: _build_ctx); without it a pack is examined when its address is first seen.  Synchronous.
+extern "C" int infgen_rollout_validate(const InfgenRollout* r) {
+  RET_IF(validate(r, "infgen_rollout_validate"));
+  (void)lp_packs_ok(r, true);
+  return 0;
 }
 static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless) {
   const LpDevice& lpd = lp_device();
@@ -1217,7 +1224,7 @@ static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless) {
 }
 
 // ---- a decode step in two halves: the edge sets of a column with their embeddings, and the 18 sublayers that consume them
-struct StepMode { bool overlap, fuse, lp; int r24; const float* dt; };
+struct StepMode { bool overlap, fuse, lp; int r24; int ra; const float* dt; };
 static StepMode step_mode(const InfgenRollout* r, int rows, int edgeless) {
   StepMode m;
   m.overlap = O().overlap && g_side && !edgeless;
@@ -1227,6 +1234,10 @@ static StepMode step_mode(const InfgenRollout* r, int rows, int edgeless) {
   // (INFGEN_NO_R24=1, read per call: fp32 rows instead - tests/test_rollout_gpu.py compares the two)
   const char* no_r24 = getenv("INFGEN_NO_R24");
   m.r24 = m.fuse && O().fourier_mode != 0 && !(no_r24 && atoi(no_r24));
+  // the agent set's rows in the H8 form for k_edge_mfma (scores on the matrix pipe; opt-in: INFGEN_EDGE_MFMA=1, read per call -
+  // measured equal to k_edge_fused on 24-bit rows, profiles/r05_edge_mfma_*): big launches only, never inside k_layers_p
+  const char* em = getenv("INFGEN_EDGE_MFMA");
+  m.ra = (m.r24 && em && atoi(em) && !m.lp && rows > 4096) ? 2 : m.r24;
   // the temporal set's fourth input (the time gap, one of -1 .. -16) as a lookup of its branch (kernels.h: dt_mode)
   m.dt = O().fourier_mode != 0 ? r->four_t_dt : nullptr;
   return m;
@@ -1244,14 +1255,14 @@ static int prepare_edges(const InfgenRollout* r, int c, int edgeless, void* stre
   const int rows = r->S * r->A_cap;
   RET_IF(build_edges_impl(r, c, edgeless, stream, zero_totals, clear_keys, clear_sync));
   const StepMode sm = step_mode(r, rows, edgeless);
-  const bool overlap = sm.overlap; const int r24 = sm.r24; const float* dt = sm.dt;
+  const bool overlap = sm.overlap; const int r24 = sm.r24, ra = sm.ra; const float* dt = sm.dt;
   if (overlap) {
     hipStream_t ms = (hipStream_t)stream;
     if (hipEventRecord(g_ev_fork, ms) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork, 0) != hipSuccess)
       return fail("infgen_decode_layers", "fork failed");
     RET_IF(fourier_embed_impl(r->em.raw, 3, r->em.total, r->em.cap, r->four_m, nullptr, 0, r->em.rhat, 128, 1, r24, g_side));
     if (hipEventRecord(g_ev_m, g_side) != hipSuccess) return fail("infgen_decode_layers", "event failed");
-    RET_IF(fourier_embed_impl(r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, r24, g_side));
+    RET_IF(fourier_embed_impl(r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, ra, g_side));
     if (hipEventRecord(g_ev_a, g_side) != hipSuccess) return fail("infgen_decode_layers", "event failed");
     RET_IF(fourier_embed_impl(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, r24, stream, dt, dt != nullptr));
   } else if (fourier_multi_ok(rows, edgeless)) {
@@ -1260,7 +1271,7 @@ static int prepare_edges(const InfgenRollout* r, int c, int edgeless, void* stre
     FourierMultiArgs m;
     m.set[0] = FourierArgs{r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, pr, r24, dt, dt != nullptr};
     m.set[1] = FourierArgs{r->em.raw, 3, r->em.total, r->em.cap, r->four_m, nullptr, 0, r->em.rhat, 128, 1, pr, r24, nullptr, 0};
-    m.set[2] = FourierArgs{r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, pr, r24, nullptr, 0};
+    m.set[2] = FourierArgs{r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, pr, ra, nullptr, 0};
     if (with_xa)
       m.set[3] = FourierArgs{r->raw2, 2, nullptr, rows, r->four_xa, r->cat, 128, r->fus_in + 128, 512, 0, pr, 0, nullptr, 0};
     int cap = r->et.cap > r->em.cap ? r->et.cap : r->em.cap;
@@ -1278,7 +1289,7 @@ static int prepare_edges(const InfgenRollout* r, int c, int edgeless, void* stre
   } else if (!edgeless) {
     RET_IF(fourier_embed_impl(r->et.raw, 4, r->et.total, r->et.cap, r->four_t, nullptr, 0, r->et.rhat, 128, 1, r24, stream, dt, dt != nullptr));
     RET_IF(fourier_embed_impl(r->em.raw, 3, r->em.total, r->em.cap, r->four_m, nullptr, 0, r->em.rhat, 128, 1, r24, stream));
-    RET_IF(fourier_embed_impl(r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, r24, stream));
+    RET_IF(fourier_embed_impl(r->ea.raw, 3, r->ea.total, r->ea.cap, r->four_a, nullptr, 0, r->ea.rhat, 128, 1, ra, stream));
   }
   return 0;
 }
@@ -1410,11 +1421,11 @@ static int layers_core(const InfgenRollout* r, int c, int edgeless, void* stream
   const bool skip_edges = edgeless && fuse;
   if (skip_edges && hipMemsetAsync(r->AGG, 0, (size_t)rows * D * sizeof(float), (hipStream_t)stream) != hipSuccess)
     return fail("infgen_decode_layers", "memset failed");
-  auto edge = [&](const float* pack, const float* Ks, const float* Vs, const InfgenEdgeBuf& e, int kv_once = 0, const float* next_pack = nullptr) {
+  auto edge = [&](const float* pack, const float* Ks, const float* Vs, const InfgenEdgeBuf& e, int kv_once = 0, const float* next_pack = nullptr, int fmt = -1) {
     if (skip_edges) return 0;
     if (fuse && O().attn_mode != 0)
       warm_request(pack + AH_POST + 4 * (QB / 4), 48 * QB, next_pack ? next_pack + AH_PRE : nullptr, 16 * QB);
-    return fuse ? edge_fused_launch(rows, r->Q, pack, Ks, Vs, e.off, e.cnt, e.src, e.rhat, r->AGG, r->A_cap, kv_once, stream, r24)
+    return fuse ? edge_fused_launch(rows, r->Q, pack, Ks, Vs, e.off, e.cnt, e.src, e.rhat, r->AGG, r->A_cap, kv_once, stream, fmt < 0 ? r24 : fmt)
                 : infgen_edge_attn(rows, r->Q, r->U, Ks, Vs, e.off, e.cnt, e.src, e.rhat, r->AGG, r->Z, r->SIG, stream);
   };
   RET_IF(infgen_attn_pre(r->X, rows, r->attn_t[0], 0, r->Q, U, r->ringK[0] + slot, r->ringV[0] + slot, stream));
@@ -1435,7 +1446,7 @@ static int layers_core(const InfgenRollout* r, int c, int edgeless, void* stream
     // agent <-> agent
     if (overlap && i == 0 && hipStreamWaitEvent((hipStream_t)stream, g_ev_a, 0) != hipSuccess)
       return fail("infgen_decode_layers", "join failed");
-    RET_IF(edge(r->attn_a[i], r->Ka, r->Va, r->ea, 0, i + 1 < L ? r->attn_t[i + 1] : nullptr));
+    RET_IF(edge(r->attn_a[i], r->Ka, r->Va, r->ea, 0, i + 1 < L ? r->attn_t[i + 1] : nullptr, sm.ra));
     if (i + 1 < L) {
       warm_post(r->attn_t[i + 1]);
       RET_IF(infgen_attn_post_pre(r->X, rows, r->attn_a[i], r->AGG, Z, SIG, has_pos, r->attn_t[i + 1], r->Q, U,

@@ -1,26 +1,29 @@
-// k_edge_mfma: k_edge_fused (edge_fused.hip) with the relative-position part of the edge loop on the MATRIX pipe - the edge side
-// of one AttentionLayer (reference infgen/modules/layers.py:78-92,109: propagate + PyG softmax) for a tile of 16 destination rows.
+// k_edge_mfma: k_edge_fused (edge_fused.hip) with the SCORES of the relative-position term on the MATRIX pipe - the edge side of
+// one AttentionLayer (reference infgen/modules/layers.py:78-92,109: propagate + PyG softmax) for a tile of 16 destination rows.
 //
-// Per edge the vector-pipe loop (edge_attn.cuh: EdgeAcc) spends ~100 instructions, ~70 of them on the two products with the edge's
-// normalised relative-position row r^ (128 values): the eight scores u_h . r^ and the eight accumulations z_h += p_h r^.  With
-// sets of 20 - 60 edges per row (agent <-> agent, the map encoder's pt <-> pt) the launch is bound by exactly that
-// (profiles/r04f_pmc_sq_*: vector pipe 77 % active, matrix pipe 4 %).  Here a wave takes 16 edges of its row at a time:
+// Per edge the vector-pipe loop (edge_attn.cuh: EdgeAcc) spends ~100 instructions: ~40 on the eight scores u_h . r^ with the edge's
+// normalised relative-position row r^ (128 values; products + a three-level cross-lane reduction), ~25 on the online softmax
+// (a possible rescale of every accumulator per edge), ~25 on the eight accumulations z_h += p_h r^.  With sets of 20 - 60 edges
+// per row (agent <-> agent, the map encoder's pt <-> pt) the launch is bound by that (profiles/r04f_pmc_sq_*: vector pipe 77 %
+// active, matrix pipe 4 %).  Here a wave takes 16 edges of its row at a time:
 //
 //   scores   S^T[16 edges x 16] = R^[16 x 128] . U'[128 x 16]     (v_mfma_f32_16x16x32_f16, 4 k-steps, x 2 planes of R^)
 //            columns of U' = the row's absorbed query u_h = q_h W'_kr,h as fp16 hi (columns 0..7, head = column) and fp16 lo
-//            (columns 8..15): one DPP add per value (row_ror:8) gives hi.r + lo.r; q_h . k_src is added on the vector pipe
-//            (8 of the head's 16 dims per lane, the same DPP add joins the halves)
-//   softmax  online, log2 domain, reference moved only when exceeded by 2^8 (as EdgeAcc); 4 edges x 1 head per lane
-//   z        Z'[16 x 128] += P'[16 x 16 edges] . R^[16 edges x 128]  (v_mfma_f32_16x16x16_f16, 8 feature tiles x 2 planes)
-//            rows of P' = p_h as fp16 hi (rows 0..7) / lo (rows 8..15): the lane that owns (head, 4 edges) of S^T owns exactly the
-//            A fragment of that row - no data movement between the two products
-//   agg      sum_e p_h v_src on the vector pipe (the lane's 8 dims x 4 edges), reduced over the four lane groups at the row's end
+//            (columns 8..15): one DPP add per value (row_ror:8) gives hi.r + lo.r.  The A fragments - edge m's 8 features per
+//            k-step - are 16 contiguous bytes of the edge's row: they come straight from global memory, no LDS.
+//            q_h . k_src is added on the vector pipe (8 of the head's 16 dims x 4 edges per lane, the same DPP add joins the halves)
+//   softmax  once per TRIP: 4 edges x 1 head per lane, log2 domain, reference moved only when exceeded by 2^8 (as EdgeAcc)
+//   agg      sum_e p_h v_src in the same lane layout (8 dims x 4 edges), reduced over the four lane groups at the row's end
+//   z        z_h += p_h r^ stays on the vector pipe, edge by edge in EdgeAcc's lane layout (lane l owns columns 2 l, 2 l + 1),
+//            but with the trip's probabilities KNOWN: eight v_readlane from fixed lanes + eight packed FMAs per edge, no
+//            maximum, no exponential, no rescale in the loop
 //
-// R^ rows arrive in the "H8" format (kernels.h: fp16 of 2048 r^ + fp8 of the remainder, 384 B - k_fourier_h writes it), stream
-// global -> LDS untouched (LDS-DMA, 16 edges = 6 KB per wave) and are read twice from there: edge-major as A fragments of the
-// score product (ds_read_b128 / b64), feature-major for the z product through the transposing LDS reads of gfx950
-// (ds_read_b64_tr_b16 for the fp16 plane, ds_read_b64_tr_b8 + v_cvt_scalef32_pk_f16_fp8 for the fp8 plane).  The 16-byte chunks of
-// a row are XOR-swizzled by the DMA's source addresses so that both read patterns are bank-conflict free.
+// ~30 vector instructions per edge instead of ~100, in 128 registers and 75 KB of LDS: two 8-wave workgroups per CU like
+// k_edge_fused.  (A first form with z on the matrix pipe as well - rhat tile through LDS-DMA and the transposing LDS reads of
+// gfx950 - needed 255 registers and 6 KB of tile per wave; at 8 waves per CU it waited for memory: 358 us per agent-set launch
+// against k_edge_fused's 308.  profiles/r05_edge_mfma_v1_full_matrix_loop.txt, commit 0529c2c.)
+// R^ rows arrive in the "H8" format (kernels.h: fp16 of 2048 r^ + fp8 of the remainder, 384 B - k_fourier_h writes it); the z loop
+// reads a row's two planes again (L1 / L2) and rebuilds 2048 r^ = hi + lo exactly in fp32.
 // Phases 1 (u = q W'_kr) and 3 (agg + W'_vr z + b' sigma) are k_edge_fused's; phase 1 leaves U' as ready-made B fragments.
 // Every reduction has a fixed order: results are bitwise reproducible; they differ from k_edge_fused's by rounding only.
 #include "kernels.h"
@@ -36,44 +39,30 @@ constexpr int EM_WAVES = 8;
 constexpr int EM_NT = 64 * EM_WAVES;
 constexpr int EM_LDU = H * D + 4;           // floats per row image: U' fragments (4 KB), later the row's normalised z (fp32 [8][128])
 constexpr int EM_LDA = D + 4;
-constexpr int EM_HI = 16 * 256;             // bytes of a wave's R^ tile: fp16 plane, then fp8 plane
-constexpr int EM_LO = 16 * 128;
-constexpr int EM_TILE = EM_HI + EM_LO;
-constexpr float EM_PSCALE = 64.0f;          // p <= 2^8 (EA_TAU) -> 64 p <= 2^14 in fp16, its remainder stays a normal number for p >= 2^-9
+constexpr int EM_ZG = 8;                    // rows of the z loop requested together
 
-typedef short v4s_t __attribute__((vector_size(8)));
-typedef int v2i_t __attribute__((vector_size(8)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 
-// 16-byte chunk swizzle of the fp16 plane (16 chunks per 256-byte row): chunk c of edge row m lives at position c ^ em_key(m).
-// A bijection of 0..15 whose upper three bits are distinct over rows 0..7 and over rows 8..15 (the eight rows a half wave touches
-// in a transposing read) and whose values differing in bit 0 belong to rows of one ds_read_b128 lane group
-__device__ __forceinline__ int em_key(int m) { return (((m & 7) ^ ((m >> 3) << 2)) << 1) | (m >> 3); }
-
-__device__ __forceinline__ v8h cvt8(uint2 b) {
+__device__ __forceinline__ v8h cvt8(uint2 b) {          // eight fp8 (e4m3) -> fp16, exact
   const v2h a0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)b.x, 1.0f, false);
   const v2h a1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)b.x, 1.0f, true);
   const v2h a2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)b.y, 1.0f, false);
   const v2h a3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)b.y, 1.0f, true);
   return v8h{a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
 }
-__device__ __forceinline__ v4h cvt4(unsigned b) {
-  const v2h a0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)b, 1.0f, false);
-  const v2h a1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)b, 1.0f, true);
-  return v4h{a0[0], a0[1], a1[0], a1[1]};
-}
-__device__ __forceinline__ float swap32_sum(float x, float y) {      // lower lanes: x + x(lane + 32); upper lanes: y(lane - 32) + y
-  const u32x2_sw s = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-  return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+// columns 2 l, 2 l + 1 of an H8 row as 2048 r^ in fp32: fp16 pair + fp8 pair, both conversions and the sum exact
+__device__ __forceinline__ pk2 h8_to_f32(unsigned hi, unsigned lo) {
+  const v2h h = __builtin_bit_cast(v2h, hi);
+  const pk2 l = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false);
+  return pk2{(float)h[0] + l[0], (float)h[1] + l[1]};
 }
 
 // timing experiment (INFGEN_EDGE_DBG bit 7): s_memtime of wave 0 of workgroup 2600 (a later round: warm instruction cache) at the marked points -> a.dbgbuf [64] x 64 bit
 #define EM_STAMP(i) do { if ((a.dbg & 128) && blockIdx.x == 2600 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(a.dbgbuf)[i] = __builtin_readcyclecounter(); } while (0)
 template <bool KV_ONCE>
-__global__ __launch_bounds__(EM_NT, 2) void k_edge_mfma(EdgeFusedArgs a) {
+__global__ __launch_bounds__(EM_NT, 4) void k_edge_mfma(EdgeFusedArgs a) {
   __shared__ __attribute__((aligned(16))) float UZ[EM_ROWS * EM_LDU];
   __shared__ __attribute__((aligned(16))) float AG[EM_ROWS * EM_LDA];     // q tile (phase 1 -> 2), then agg (phase 2 -> 3)
-  __shared__ __attribute__((aligned(16))) char RB[EM_WAVES * EM_TILE];    // per wave: the R^ rows of 16 edges
   __shared__ float SG[EM_ROWS * H];
   __shared__ float SCL[EM_ROWS * H];                                      // 1 / (scale of U' x 2048) per (row, head)
   __shared__ int M_CNT[EM_ROWS], M_OFF[EM_ROWS];
@@ -153,7 +142,7 @@ __global__ __launch_bounds__(EM_NT, 2) void k_edge_mfma(EdgeFusedArgs a) {
     float um = 0.f;
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) {
-      acc[ct] *= f32x4{cq, cq, cq, cq};
+      acc[ct] *= splat4(cq);
       um = fmaxf(um, fmaxf(fmaxf(fabsf(acc[ct][0]), fabsf(acc[ct][1])), fmaxf(fabsf(acc[ct][2]), fabsf(acc[ct][3]))));
     }
     um = xor_lanes_max(um);
@@ -180,88 +169,16 @@ __global__ __launch_bounds__(EM_NT, 2) void k_edge_mfma(EdgeFusedArgs a) {
 
   // ---- phase 2: the edge loop, one wave per destination row, 16 edges per trip
   if (!(a.dbg & 64)) {
-    const int n = lane & 15;                 // column of S^T / row of P': head n & 7, fp16 hi (n < 8) or lo part
+    const int n = lane & 15;                 // column of S^T: head n & 7, fp16 hi (n < 8) or lo part of u; also: edge n of the trip (A fragments)
     const int hd = n & 7, half = n >> 3;
-    char* rb_hi = RB + w * EM_TILE;
-    char* rb_lo = rb_hi + EM_HI;
-    const unsigned lds_hi = __builtin_amdgcn_readfirstlane(lds_addr(rb_hi));
-    const unsigned lds_lo = lds_hi + EM_HI;
-    // LDS-DMA source offsets inside an H8 row: instruction k of the fp16 plane lands rows 4 k + (lane >> 4), 16-byte position
-    // lane & 15; of the fp8 plane rows 8 k + (lane >> 3), position lane & 7
-    int dma_hi_off[4], dma_lo_off[2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dma_hi_off[k] = ((lane & 15) ^ em_key(4 * k + g)) * 16;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) dma_lo_off[k] = H8_LO_PLANE + ((lane & 7) ^ ((8 * k + (lane >> 3)) >> 1)) * 16;
-    // A fragments of the score product: edge row n (= lane & 15), features 32 ks + 8 g .. + 7
-    const char* a_hi[4]; const char* a_lo[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      a_hi[ks] = rb_hi + n * 256 + ((4 * ks + g) ^ em_key(n)) * 16;
-      a_lo[ks] = rb_lo + n * 128 + ((4 * ks + g) ^ (n & 14)) * 8;
-    }
-    // B fragments of the z product through the transposing reads: this lane SUPPLIES the address of
-    //   fp16: edge row 4 g + (n >> 2), features 16 t + 4 (n & 3) .. + 3      (8 bytes)
-    //   fp8 : edge row 4 g + ((n >> 1) & 3), features 16 t + 8 (n & 1) .. + 7  (8 bytes; rows repeat: the read delivers eight)
-    // and RECEIVES feature 16 t + n of edges 4 g .. 4 g + 3
-    const int trow = 4 * g + (n >> 2), tq = n & 3;
-    const char* t_hi = rb_hi + trow * 256 + (tq & 1) * 8;
-    const int t_hi_key = em_key(trow) ^ (tq >> 1);
-    const int brow = 4 * g + ((n >> 1) & 3);
-    const char* t_lo = rb_lo + brow * 128;
-    const int t_lo_key = (brow & 14) ^ (n & 1);
     const char* rh = reinterpret_cast<const char*>(a.es.rhat);
-
-    // this wave's two rows (positions w and 15 - w of the sorted order), their lists and the source indices of their first 64 edges
-    int rlx[2], Ex[2], obx[2], svx[2];
-#pragma unroll
-    for (int ri = 0; ri < 2; ++ri) {
-      rlx[ri] = __builtin_amdgcn_readfirstlane((int)row_order[ri ? EM_ROWS - 1 - w : w]);
-      Ex[ri] = __builtin_amdgcn_readfirstlane(M_CNT[rlx[ri]]);
-      obx[ri] = __builtin_amdgcn_readfirstlane(M_OFF[rlx[ri]]);
-      svx[ri] = Ex[ri] > 0 ? a.es.src[obx[ri] + min(lane, Ex[ri] - 1)] : 0;
-    }
-    int si[4];
-    f32x4 kf[4][2], vf[4][2];
-    // requests of one 16-edge trip (E_, eb_, sv_: the list it belongs to; on = false: aimed at one line, see below)
-    auto load_si = [&](int sv_, int t0, int E_) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) si[i] = __shfl(sv_, min(t0 + 4 * g + i, E_ - 1) & 63, 64);
-    };
-    auto issue_dma = [&](int t0, int E_, int eb_, bool on) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int er = min(t0 + 4 * k + g, E_ - 1);
-        lds_dma16(on ? rh + (size_t)(eb_ + er) * H8_ROW_BYTES + dma_hi_off[k] : rh, lds_hi + k * 1024);
-      }
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int er = min(t0 + 8 * k + (lane >> 3), E_ - 1);
-        lds_dma16(on ? rh + (size_t)(eb_ + er) * H8_ROW_BYTES + dma_lo_off[k] : rh, lds_lo + k * 1024);
-      }
-    };
-    auto issue_kv = [&](const float* base, f32x4 (&dst)[4][2], bool on) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float* kp = on ? base + (size_t)si[i] * D + DH * hd + 8 * half : base;
-        if constexpr (KV_ONCE) {
-          dst[i][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kp));
-          dst[i][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kp + 4));
-        } else {
-          dst[i][0] = *reinterpret_cast<const f32x4*>(kp);
-          dst[i][1] = *reinterpret_cast<const f32x4*>(kp + 4);
-        }
-      }
-    };
     EM_STAMP(4);
-    bool inflight = false;                   // the current row's first trip has been requested (under the previous row's last trip)
     for (int ri = 0; ri < 2; ++ri) {
-      const int rl = ri ? rlx[1] : rlx[0];
-      const int E = ri ? Ex[1] : Ex[0];
-      const int e_base = ri ? obx[1] : obx[0];
-      int sv = ri ? svx[1] : svx[0];
-      // what follows this row in the wave's stream (ri == 0: the second row, if it has edges)
-      const int En = ri ? 0 : Ex[1], ebn = ri ? 0 : obx[1], svn = svx[1];
+      // the wave's rows: positions w and 15 - w of the sorted order
+      const int rl = __builtin_amdgcn_readfirstlane((int)row_order[ri ? EM_ROWS - 1 - w : w]);
+      const int E = __builtin_amdgcn_readfirstlane(M_CNT[rl]);
+      const int e_base = __builtin_amdgcn_readfirstlane(M_OFF[rl]);
+      int sv = E > 0 ? a.es.src[e_base + min(lane, E - 1)] : 0;            // source indices of up to 64 edges in one register
       const char* img = reinterpret_cast<const char*>(UZ + rl * EM_LDU);
       v8h ub[4];
 #pragma unroll
@@ -269,41 +186,44 @@ __global__ __launch_bounds__(EM_NT, 2) void k_edge_mfma(EdgeFusedArgs a) {
       const float4 q0 = *reinterpret_cast<const float4*>(AG + rl * EM_LDA + DH * hd + 8 * half);
       const float4 q1 = *reinterpret_cast<const float4*>(AG + rl * EM_LDA + DH * hd + 8 * half + 4);
       const float cs = SCL[rl * H + hd];
-      f32x4 zacc[8];
+      pk2 zz[H];                             // sum_e p_e,h 2048 r^_e: columns 2 lane, 2 lane + 1, every head
 #pragma unroll
-      for (int t = 0; t < 8; ++t) zacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      float ag8[8];
-#pragma unroll
-      for (int d = 0; d < 8; ++d) ag8[d] = 0.f;
+      for (int k = 0; k < H; ++k) zz[k] = pk2{0.f, 0.f};
+      pk2 ag = {0.f, 0.f};                   // sum_e p_e,head(l) v_src: columns 2 lane, 2 lane + 1 (head lane >> 3)
       float m = -INFINITY, lsum = 0.f;
 
-      // Software pipeline over the wave's 16-edge trips: the K rows of the NEXT trip (of this row, or the first of the wave's
-      // second row) are requested as soon as this trip's scores are formed, its rhat tile as soon as the last fragment of this
-      // trip has been read, its V rows after this trip's aggregation - one wait per trip.  Requests beyond the wave's last trip
-      // are unconditional (a conditional load is a basic block whose results hipcc merges with copies) but aimed at one line.
-      if (E > 0 && !inflight) {
-        load_si(sv, 0, E);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        issue_kv(a.Ksrc, kf, true);
-        issue_dma(0, E, e_base, true);
-        issue_kv(a.Vsrc, vf, true);
-      }
       for (int t0 = 0; t0 < E; t0 += 16) {
-        const int t1 = t0 + 16;
-        const bool more = t1 < E;                              // the next trip belongs to this row
-        const bool hop = !more && En > 0;                      // ... is the first of the wave's second row
-        const bool nx = more || hop;
-        const int nt0 = more ? t1 : 0, nE = more ? E : (hop ? En : 1), neb = more ? e_base : ebn;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // trip t0 has landed (LDS-DMA retires through vmcnt)
-
+        const int ne = min(16, E - t0);
+        if (t0 > 0 && (t0 & 63) == 0) sv = a.es.src[e_base + min(t0 + lane, E - 1)];       // lists beyond 64 edges: the next chunk of indices
+        // ---- requests of the trip: A fragments of the score product (edge n: 4 x 16 bytes of the fp16 plane, 4 x 8 of the fp8
+        // plane; slots beyond the list re-read its last edge), K and V rows of this lane's four edges (8 dims each)
+        const char* arow = rh + (size_t)(e_base + min(t0 + n, E - 1)) * H8_ROW_BYTES + 16 * g;
+        v8h ahi[4];
+        uint2 alo[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          ahi[ks] = *reinterpret_cast<const v8h*>(arow + 64 * ks);
+          alo[ks] = *reinterpret_cast<const uint2*>(arow + H8_LO_PLANE - 8 * g + 32 * ks);
+        }
+        f32x4 kf[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int sj = __shfl(sv, min(t0 + 4 * g + i, E - 1) & 63, 64);
+          const float* kp = a.Ksrc + (size_t)sj * D + DH * hd + 8 * half;
+          if constexpr (KV_ONCE) {
+            kf[i][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kp));
+            kf[i][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kp + 4));
+          } else {
+            kf[i][0] = *reinterpret_cast<const f32x4*>(kp);
+            kf[i][1] = *reinterpret_cast<const f32x4*>(kp + 4);
+          }
+        }
         // ---- scores
         f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const v8h*>(a_hi[ks]), ub[ks], sacc, 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[ks], ub[ks], sacc, 0, 0, 0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(cvt8(*reinterpret_cast<const uint2*>(a_lo[ks])), ub[ks], sacc, 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(cvt8(alo[ks]), ub[ks], sacc, 0, 0, 0);
         float val[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -312,90 +232,75 @@ __global__ __launch_bounds__(EM_NT, 2) void k_edge_mfma(EdgeFusedArgs a) {
           qk = fmaf(q1.x, kf[i][1].x, qk); qk = fmaf(q1.y, kf[i][1].y, qk); qk = fmaf(q1.z, kf[i][1].z, qk); qk = fmaf(q1.w, kf[i][1].w, qk);
           const float s = fmaf(sacc[i], cs, qk);               // this lane's part: (hi or lo of u) . r^  +  half of q . k
           const float tot = s + dpp_xor8(s);
-          val[i] = (t0 + 4 * g + i < E) ? tot * EA_LOG2E : -INFINITY;
+          val[i] = (4 * g + i < ne) ? tot * EA_LOG2E : -INFINITY;
         }
-        if (more && (t1 & 63) == 0) sv = a.es.src[e_base + min(t1 + lane, E - 1)];      // lists beyond 64 edges: the next chunk of indices
-        load_si(more ? sv : svn, nt0, nE);
-        asm volatile("" ::: "memory");
-        issue_kv(a.Ksrc, kf, nx);
-        asm volatile("" ::: "memory");
-        // ---- online softmax (log2 domain; the reference only moves when a score exceeds it by more than EA_TAU)
+        // ---- online softmax per trip (log2 domain; the reference only moves when a score exceeds it by more than EA_TAU)
         const float vmax = fmaxf(fmaxf(val[0], val[1]), fmaxf(val[2], val[3]));
         if (__any(vmax > m + EA_TAU)) {
           const float vm = xor_lanes_max(vmax);                // over the head's four lane groups (columns n and n ^ 8 already agree)
           const float mn = vm > m + EA_TAU ? vm : m;
           const float scl = __builtin_amdgcn_exp2f(m - mn);    // 0 at the first trip, 1 for heads that keep their reference
           lsum *= scl;
+          {
+            const float so = __shfl(scl, lane >> 3, 64);       // the factor of this lane's own head
+            ag = pk2{ag[0] * so, ag[1] * so};
+          }
 #pragma unroll
-          for (int d = 0; d < 8; ++d) ag8[d] *= scl;
-          float sh[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) sh[k] = readlane_f(scl, k);         // lane k: column k = head k
-          f32x4 f;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) f[i] = (g & 1) ? sh[4 + i] : sh[i];  // rows 4 g + i of Z' belong to head (4 g + i) & 7
-#pragma unroll
-          for (int t = 0; t < 8; ++t) zacc[t] *= f;
+          for (int k = 0; k < H; ++k) zz[k] *= bc_s(readlane_f(scl, k));      // lane k: column k = head k
           m = mn;
         }
         float p[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { p[i] = __builtin_amdgcn_exp2f(val[i] - m); lsum += p[i]; }
-        // ---- z: row n of P' = 64 p as fp16 hi (n < 8) or its remainder (n >= 8)
-        unsigned h01, l01, h23, l23;
-        split_pair(p[0] * EM_PSCALE, p[1] * EM_PSCALE, h01, l01);
-        split_pair(p[2] * EM_PSCALE, p[3] * EM_PSCALE, h23, l23);
-        const v4h pa = __builtin_bit_cast(v4h, half ? u32x2{l01, l23} : u32x2{h01, h23});
+        // ---- z and agg: edge by edge in the column layout (lane l: columns 2 l, 2 l + 1 of the edge's rhat and V rows).  The
+        // probability of (edge e, head k) sits in lane k + 16 (e >> 2), register e & 3: eight v_readlane from fixed lanes for z,
+        // one ds_bpermute for the lane's own head (agg).  EM_ZG edges' rows in flight.
+        const char* zrow = rh + (size_t)(e_base + t0) * H8_ROW_BYTES;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const v4s_t bh = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) v4s_t*)(t_hi + ((2 * t) ^ t_hi_key) * 16));
-          zacc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(pa, __builtin_bit_cast(v4h, bh), zacc[t], 0, 0, 0);
-          const v2i_t bl = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
-              (__attribute__((address_space(3))) v2i_t*)(t_lo + ((2 * t) ^ t_lo_key) * 8));
-          zacc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(pa, cvt4((unsigned)bl[0]), zacc[t], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every fragment of this trip has been read: the buffer may be refilled
-        issue_dma(nt0, nE, neb, nx);
-        // ---- agg: this lane's 8 dims of the head's value rows
+        for (int e0 = 0; e0 < 16; e0 += EM_ZG) {
+          if (e0 >= ne) break;
+          unsigned rhi[EM_ZG], rlo[EM_ZG];
+          pk2 vb[EM_ZG];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          ag8[0] = fmaf(p[i], vf[i][0].x, ag8[0]); ag8[1] = fmaf(p[i], vf[i][0].y, ag8[1]);
-          ag8[2] = fmaf(p[i], vf[i][0].z, ag8[2]); ag8[3] = fmaf(p[i], vf[i][0].w, ag8[3]);
-          ag8[4] = fmaf(p[i], vf[i][1].x, ag8[4]); ag8[5] = fmaf(p[i], vf[i][1].y, ag8[5]);
-          ag8[6] = fmaf(p[i], vf[i][1].z, ag8[6]); ag8[7] = fmaf(p[i], vf[i][1].w, ag8[7]);
+          for (int s_ = 0; s_ < EM_ZG; ++s_) {
+            const int ec = min(e0 + s_, ne - 1);
+            const char* rp = zrow + (size_t)ec * H8_ROW_BYTES;
+            rhi[s_] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(rp + 4 * lane));      // (the row's last use)
+            rlo[s_] = __builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(rp + H8_LO_PLANE + 2 * lane));
+            const int sj = __builtin_amdgcn_readlane(sv, (t0 + ec) & 63);
+            vb[s_] = ea_ld(a.Vsrc + (size_t)sj * D + 2 * lane, KV_ONCE);
+          }
+#pragma unroll
+          for (int s_ = 0; s_ < EM_ZG; ++s_) {
+            const int e = e0 + s_;               // (a slot beyond the list: its probability is exp2(-inf) = 0, its rows are the last edge's)
+            const pk2 r2 = h8_to_f32(rhi[s_], rlo[s_]);
+            const float pe = p[e & 3];
+            const float po = __shfl(pe, (lane >> 3) + 16 * (e >> 2), 64);       // this lane's head: lane >> 3
+            ag = pk2{fmaf(po, vb[s_][0], ag[0]), fmaf(po, vb[s_][1], ag[1])};
+            float ph[H];
+#pragma unroll
+            for (int k = 0; k < H; ++k) ph[k] = readlane_f(pe, k + 16 * (e >> 2));
+#pragma unroll
+            for (int k = 0; k < H; ++k) zz[k] = pk_fma(bc_s(ph[k]), r2, zz[k]);
+          }
         }
-        asm volatile("" ::: "memory");
-        issue_kv(a.Vsrc, vf, nx);
       }
-
-      inflight = E > 0 && En > 0;
       EM_STAMP(5 + 2 * ri);
+
       // ---- the row's results -> LDS (z over the row's own U' image)
       const float lt = xor_lanes(lsum);
       const float inv = 1.0f / (lt + 1e-16f);
-#pragma unroll
-      for (int d = 0; d < 8; ++d) ag8[d] = xor_lanes(ag8[d]) * inv;
-      if (g == 0) {
-        float* ap = AG + rl * EM_LDA + DH * hd + 8 * half;
-        *reinterpret_cast<float4*>(ap) = make_float4(ag8[0], ag8[1], ag8[2], ag8[3]);
-        *reinterpret_cast<float4*>(ap + 4) = make_float4(ag8[4], ag8[5], ag8[6], ag8[7]);
-        if (half == 0) SG[rl * H + hd] = lt * inv;
+      {
+        const float io = __shfl(inv, lane >> 3, 64);
+        *reinterpret_cast<float2*>(AG + rl * EM_LDA + 2 * lane) = make_float2(ag[0] * io, ag[1] * io);
       }
-      float ih[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) ih[k] = readlane_f(inv, k) * (1.0f / (EM_PSCALE * 2048.0f));
+      if (g == 0 && half == 0) SG[rl * H + hd] = lt * inv;
       float* zr = UZ + rl * EM_LDU;
-      const int hb = 4 * (g & 1), tb = 4 * (g >> 1);
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          // rows 4 g + i (hi part, g < 2) and 4 g + i + 8 (lo part) of Z' are 32 lanes apart: lower lanes take tile t, upper t + 4
-          const float z = swap32_sum(zacc[t][i], zacc[t + 4][i]);
-          const float fi = (g & 1) ? ih[4 + i] : ih[i];
-          zr[(hb + i) * D + 16 * (tb + t) + n] = z * fi;
-        }
+      for (int k = 0; k < H; ++k) {
+        const float ih = readlane_f(inv, k) * (1.0f / 2048.0f);
+        *reinterpret_cast<float2*>(zr + k * D + 2 * lane) = make_float2(zz[k][0] * ih, zz[k][1] * ih);
+      }
       EM_STAMP(6 + 2 * ri);
     }
   }

@@ -1296,6 +1296,7 @@ class RolloutEngine:
         c.sample_k, c.sample_u, c.logits_scratch = self.sample_k, P(self.sample_u), P(self.logits_scratch)
         self._ctx = c
         self._refresh_opts()
+        _lib.check(self.lib.infgen_rollout_validate(C.byref(c)), 'infgen_rollout_validate')      # (the packs' headers, looked at afresh)
 
     def _refresh_opts(self, groups: bool = False):
         """the context carries its own kernel switches (InfgenRollout.opts, re-entrant): explicit ``options`` of this engine,

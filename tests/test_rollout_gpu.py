@@ -1083,3 +1083,36 @@ def test_layers_p_is_refused_for_packs_without_the_layernorm_bounds():
         _lib.prof_enable(0)
     assert n == 18 * c['cfg'].num_decode_steps, n
     assert np.array_equal(e.outputs()[0]['next_token_idx'], c['z']['next_token_idx'])
+
+
+def test_rollout_with_the_matrix_pipe_edge_scores_reproduces_the_fixtures():
+    """INFGEN_EDGE_MFMA=1 (opt-in): the agent set's rhat rows in the H8 form (fp16 + fp8 planes) and its edge launches through
+    k_edge_mfma - scores u . r of 16 edges at a time on the matrix pipe (csrc/edge_mfma.hip; reference layers.py:78-92,109).
+    336 copies of the C1 fixture and of the A = 24 edge-case fixture (10,752 / 8,064 rows: the big-launch kernels): every copy
+    reproduces the reference's tokens and states, logits within the bar - and differ from the default path's, i.e. the kernel ran"""
+    import os
+    from infgen_amd import engine
+    dev = torch.device('cuda:0')
+    for name in ('c1_a8_m128', 'a24_m256_edge'):
+        c = load_case(name)
+        z = c['z']
+        w = engine.PackedWeights(c['sd'], c['cfg'], dev)
+        tol = 1e-3 * max(1.0, c['meta']['head_gain'] / 16)
+        lg = {}
+        try:
+            for mode in ('0', '1'):
+                os.environ['INFGEN_EDGE_MFMA'] = mode
+                e = engine.RolloutEngine(w, [c['scene']] * 336, c['vocab'], c['map_vocab'], c['grid'], store_logits=True, use_graph=False)
+                e.rollout()
+                outs = e.outputs_device()
+                ref_tok = torch.from_numpy(z['next_token_idx'].astype(np.int64)).to(dev)
+                ref_st = torch.from_numpy(z['next_state_idx'].astype(np.int64)).to(dev)
+                ref_lg = torch.from_numpy(z['logits']).to(dev)
+                for o in outs:
+                    assert torch.equal(o['next_token_idx'], ref_tok) and torch.equal(o['next_state_idx'], ref_st), (name, mode)
+                    assert float((o['logits'] - ref_lg).abs().max()) <= tol, (name, mode)
+                lg[mode] = outs[0]['logits'].clone()
+                del e, outs
+        finally:
+            os.environ.pop('INFGEN_EDGE_MFMA', None)
+        assert not torch.equal(lg['0'], lg['1']), name

@@ -31,8 +31,13 @@ k = torch.randn(rows, 128, generator=g).to(dev)
 v = torch.randn(rows, 128, generator=g).to(dev)
 offd, cntd, srcd = (torch.from_numpy(a).to(dev) for a in (off, cnt, src))
 h8 = torch.empty(E * 384, device=dev, dtype=torch.uint8)
-r24 = torch.empty(E * 384, device=dev, dtype=torch.uint8)
 _lib.check(lib.infgen_rhat_to_h8(r.data_ptr(), E, h8.data_ptr(), ops.stream))
+# the same rows in the packed 24-bit form k_edge_fused reads inside the rollout (kernels.h: R24): round to nearest even at bit 8
+b = r.view(torch.int32)
+u = b + 0x7f + ((b >> 8) & 1)
+r24 = torch.empty(E, 384, device=dev, dtype=torch.uint8)
+r24[:, :256] = ((u >> 16) & 0xffff).to(torch.int16).view(torch.uint8).reshape(E, 256)
+r24[:, 256:] = ((u >> 8) & 0xff).to(torch.uint8)
 aggs = {}
 def run(kind, n=1):
     agg = aggs.setdefault(kind, torch.empty(rows, 128, device=dev))
@@ -40,14 +45,18 @@ def run(kind, n=1):
         if kind == 'fused':
             _lib.check(lib.infgen_edge_attn_fused(rows, q.data_ptr(), pack.data_ptr(), k.data_ptr(), v.data_ptr(), offd.data_ptr(),
                                                   cntd.data_ptr(), srcd.data_ptr(), r.data_ptr(), agg.data_ptr(), ops.stream))
+        elif kind == 'fused_r24':
+            _lib.check(lib.infgen_edge_attn_fused_r24(rows, q.data_ptr(), pack.data_ptr(), k.data_ptr(), v.data_ptr(), offd.data_ptr(),
+                                                      cntd.data_ptr(), srcd.data_ptr(), r24.data_ptr(), agg.data_ptr(), ops.stream))
         else:
             _lib.check(lib.infgen_edge_attn_fused_h8(rows, q.data_ptr(), pack.data_ptr(), k.data_ptr(), v.data_ptr(), offd.data_ptr(),
                                                      cntd.data_ptr(), srcd.data_ptr(), h8.data_ptr(), agg.data_ptr(), ops.stream))
     return agg
-for kind in ('fused', 'mfma'):
+for kind in ('fused', 'fused_r24', 'mfma'):
     run(kind); torch.cuda.synchronize()
     t0 = time.perf_counter(); run(kind, 20); torch.cuda.synchronize()
     print(kind, 'us per launch', (time.perf_counter() - t0) / 20 * 1e6)
+print('r24 vs fp32 rows: max abs err', float((aggs['fused'] - aggs['fused_r24']).abs().max()))
 a, b = aggs['fused'], aggs['mfma']
 print('max |fused|', float(a.abs().max()), 'max abs err', float((a - b).abs().max()), 'mean abs err', float((a - b).abs().mean()),
       'nan', int(torch.isnan(b).sum()))
