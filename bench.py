@@ -67,6 +67,10 @@ ROW_FIXED_BYTES = 6144 + 12288 + 512 + 2048 + 192 + 80     # K/V written (tempor
 WEIGHT_BYTES_PER_STEP = 23.7e6      # motion-path weights, read once per decode step per GPU
 
 
+def c3_shapes(args):
+    return args.agents == 64 and args.map_tokens == 1024 and args.rollout_steps == 80
+
+
 def load_shapes():
     with open(os.path.join(REPO, 'tests', 'golden', 'state_dict_shapes.json')) as f:
         return {k: tuple(v) for k, v in json.load(f).items()}
@@ -632,6 +636,45 @@ def main():
         del es
         torch.cuda.empty_cache()
 
+    # ---- config.multi_rollout: the reference's validation workload - n_rollout_close_val sampled rollouts per scene
+    # (infgen/model/infgen.py:704-706; top-5 token draws) - as 32 scenes x 32 rollouts: RolloutEngine(copies=32) encodes every
+    # scene's map ONCE (one pt <-> pt graph, one map encoder pass, one set of map K / V rows per scene: what the reference's
+    # inference_no_map(data, map_enc), infgen_decoder.py:132-134, is for), next to the same 1024 rollouts run as independent scenes
+    multi = None
+    if c3_shapes(args) and not args.insertion and not args.no_strict and args.gemm_terms == 3 and ns == 1 and len(scenes) >= 32:
+        log('multi-rollout leg')
+        n_sc, n_ro = 32, 32
+        rng = np.random.default_rng(11)
+        u = rng.random((cfg.num_decode_steps, n_sc * n_ro, args.agents)).astype(np.float32)
+        msteps = max(1, min(3, args.steps))
+        res = {}
+        for tag in ('shared_map', 'independent'):
+            if tag == 'shared_map':
+                e = engine.RolloutEngine(w, scenes[:n_sc], vocab, map_vocab, grid, store_logits=False, use_graph=False,
+                                         sample_k=5, sample_uniforms=u, copies=n_ro)
+            else:
+                e = engine.RolloutEngine(w, [sc for sc in scenes[:n_sc] for _ in range(n_ro)], vocab, map_vocab, grid,
+                                         store_logits=False, use_graph=False, sample_k=5, sample_uniforms=u)
+            e.rollout()
+            torch.cuda.synchronize(dev)
+            t = timed(ranks, e.rollout, msteps)
+            t, n = igdist.reduce_run(t, float(e.agent_steps() * msteps), dev)
+            tok = e.token.clone()
+            mem = sum(x.numel() * 4 for x in e.mapK + e.mapV) + e.x_pt.numel() * 4
+            res[tag] = {'value': n / t, 'ms_per_step': 1e3 * t / msteps, 'map_side_bytes': int(mem), 'tokens': tok}
+            del e
+            torch.cuda.empty_cache()
+        same = bool(torch.equal(res['shared_map']['tokens'], res['independent']['tokens']))
+        multi = {'scenes': n_sc, 'rollouts_per_scene': n_ro, 'sample_k': 5, 'steps': msteps,
+                 'value': res['shared_map']['value'], 'ms_per_step': res['shared_map']['ms_per_step'],
+                 'independent_scenes_value': res['independent']['value'], 'independent_scenes_ms_per_step': res['independent']['ms_per_step'],
+                 'speedup': res['shared_map']['value'] / res['independent']['value'],
+                 'map_side_bytes': res['shared_map']['map_side_bytes'],
+                 'independent_map_side_bytes': res['independent']['map_side_bytes'],
+                 'same_tokens_as_independent_scenes': same,
+                 'note': '32 scenes x 32 top-5 sampled rollouts (caller-supplied uniforms, the same for both legs): one map encoding '
+                         'per scene (RolloutEngine(copies=32)) vs the same 1024 rollouts as independent scenes'}
+
     # ---- prologue_ms / decode_ms (throughput includes the map-encoder prologue, "report it separately too"): the
     # prologue (state reset, map encoder, map K / V, edgeless column-0 chain) of the same batch timed on its own; the decode
     # steps are the rest of the timed rollout
@@ -720,6 +763,7 @@ def main():
                 'c3_literal': literal,
                 'strict_fp32': strict,
                 'two_streams': two,
+                'multi_rollout': multi,
                 'insertion_balance': balance,
             },
             'roofline': roof,
@@ -732,6 +776,8 @@ def main():
         flat = {
             'strict_fp32_value': strict['value'] if strict else None,
             'two_streams_value': two['value'] if two else None,
+            'multi_rollout_value': multi['value'] if multi else None,
+            'multi_rollout_speedup_over_independent_scenes': multi['speedup'] if multi else None,
             'c3_literal_value': literal['value'] if literal else None,
             'c3_literal_ms': literal['ms_per_step'] if literal else None,
             'c3_8scene_value': literal['one_gpu_of_8way_shard']['value'] if literal and 'one_gpu_of_8way_shard' in literal else None,

@@ -161,6 +161,11 @@ typedef struct InfgenRollout {
    * accumulated pose drift and no radius / first-K decision can flip: logits are comparable row by row with a maximum, and the
    * one-step pose update is checked separately (tests/test_baseline_shapes_gpu.py) */
   const float* teacher_pos; const float* teacher_head;
+  /* optional [S]: the map-side scene of agent-side scene s (NULL: s itself).  Several scenes may share ONE set of map tokens - n_map,
+   * map_pos / map_orient, the rows [slot * M_cap, (slot + 1) * M_cap) of mapK / mapV (and of InfgenInsertion.mapK / mapV) are then
+   * indexed by slot = map_scene[s]: the n rollouts of one scene (reference infgen/model/infgen.py:704-706, inference_no_map
+   * infgen_decoder.py:132-134) encode their map once and keep one copy of its K / V rows */
+  const int* map_scene;
 } InfgenRollout;
 
 int infgen_linear(const float* X, int ldx, const int* gather, int rows, int K,

@@ -97,6 +97,7 @@ class Rollout(C.Structure):
         ('teacher_grid', _p),
         ('four_t_dt', _p),
         ('teacher_pos', _p), ('teacher_head', _p),
+        ('map_scene', _p),
     ]
 
 

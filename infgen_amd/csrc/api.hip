@@ -913,7 +913,7 @@ static SceneState scene_of(const InfgenRollout* r) {
   st.n_agents = r->n_agents; st.n_map = r->n_map; st.av_index = r->av_index;
   st.pos = r->pos; st.head = r->head; st.state = r->state; st.token = r->token; st.grid = r->grid;
   st.tmask = r->tmask; st.imask = r->imask; st.catflag = r->catflag; st.type = r->type; st.bos = r->bos;
-  st.map_pos = r->map_pos; st.map_orient = r->map_orient;
+  st.map_pos = r->map_pos; st.map_orient = r->map_orient; st.map_scene = r->map_scene;
   st.first_new = r->first_new; st.hv_ovr = r->hv_ovr;
   return st;
 }

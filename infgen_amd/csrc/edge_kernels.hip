@@ -229,9 +229,10 @@ __global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
 
   // ---------------- map -> agent (first 5 within radius, ascending index): one wave per agent
   if (part == 1) {
-    const int M = st.n_map[s];
+    const int ms = st.map_scene ? st.map_scene[s] : s;        // the scene's slot in the map-side arrays (copies of a scene share one)
+    const int M = st.n_map[ms];
     const float r2 = a.r_map * a.r_map;
-    const float* mp = st.map_pos + (size_t)s * st.M_cap * 2;
+    const float* mp = st.map_pos + (size_t)ms * st.M_cap * 2;
     const int lane = lane_id();
     const bool map_in_lds = M <= a.map_lds;
     if (map_in_lds) {
@@ -269,14 +270,14 @@ __global__ __launch_bounds__(BT) void k_build_edges(BuildEdgesArgs a) {
       a.m.off[row] = e;
       a.m.cnt[row] = cnt;
       const bool d_inv = stt[t] == INVALID;
-      const float* mo = st.map_orient + (size_t)s * st.M_cap;
+      const float* mo = st.map_orient + (size_t)ms * st.M_cap;
       for (int k = 0; k < cnt; ++k, ++e) {
         const int m = mapidx[t * 5 + k];
         float dx = mp[2 * m] - px[t], dy = mp[2 * m + 1] - py[t];
         float dth = wrap_angle(mo[m] - hd[t]);
         if (d_inv) { dx = MOTION_GAP; dy = MOTION_GAP; dth = HEADING_GAP; }
         if (e < a.m.cap) {
-          a.m.src[e] = s * st.M_cap + m;
+          a.m.src[e] = ms * st.M_cap + m;
           *reinterpret_cast<float4*>(a.m.raw + 4 * (size_t)e) =
               make_float4(norm2(dx, dy), angle_between(hc[t], hs[t], dx, dy), dth, 0.f);
         }
@@ -820,7 +821,8 @@ __global__ __launch_bounds__(128) void k_point_edges(PointEdgesArgs a) {
   const int c = a.c;
   const bool on = a.active == nullptr || a.active[s] != 0;
   const int A = st.n_agents[s];
-  const int N = is_map ? st.n_map[s] : A;
+  const int ms = st.map_scene ? st.map_scene[s] : s;          // the scene's slot in the map-side arrays
+  const int N = is_map ? st.n_map[ms] : A;
   const int K = is_map ? a.k_map : a.k_agent;
   const float r = is_map ? a.r_map : a.r_agent;
   const float r2 = r * r;
@@ -828,8 +830,8 @@ __global__ __launch_bounds__(128) void k_point_edges(PointEdgesArgs a) {
   const size_t ic = sidx(st, s, c, crow);
   const float cx = st.pos[2 * ic], cy = st.pos[2 * ic + 1], ch = st.head[ic];
   const float ccs = cosf(ch), csn = sinf(ch);
-  const float* mp = st.map_pos + (size_t)s * st.M_cap * 2;
-  const float* mo = st.map_orient + (size_t)s * st.M_cap;
+  const float* mp = st.map_pos + (size_t)ms * st.M_cap * 2;
+  const float* mo = st.map_orient + (size_t)ms * st.M_cap;
   int kept = 0;
   for (int pass = 0; pass < 2; ++pass) {
     int found = 0, written = 0, e0 = 0;
@@ -860,7 +862,7 @@ __global__ __launch_bounds__(128) void k_point_edges(PointEdgesArgs a) {
           const int e = e0 + written + __popcll(ebal & ((1ull << lane) - 1ull));
           const float dx = px - cx, dy = py - cy;
           const float oh = is_map ? mo[j] : st.head[sidx(st, s, c, j)];
-          eb.src[e] = (is_map ? s * st.M_cap : s * st.A_cap) + j;
+          eb.src[e] = (is_map ? ms * st.M_cap : s * st.A_cap) + j;
           *reinterpret_cast<float4*>(eb.raw + 4 * (size_t)e) =
               make_float4(norm2(dx, dy), angle_between(ccs, csn, dx, dy), wrap_angle(oh - ch), 0.f);
         }

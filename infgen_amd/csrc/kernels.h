@@ -313,6 +313,7 @@ struct SceneState {
   int* bos;                         // [S][A_cap] first 'enter' column (0 if none)
   const float* map_pos;             // [S][M_cap][2]
   const float* map_orient;          // [S][M_cap]
+  const int* map_scene;             // optional [S]: slot of scene s in the map-side arrays (n_map, map_pos, map_orient, map K / V rows)
   // scenario insertion (optional, may be null): rows >= first_new[s] inserted in the current step carry
   // the newest row's head vector during the motion stage (reference agent_decoder.py:2083, SURVEY a-Q13)
   const int* first_new;             // [S]

@@ -426,15 +426,23 @@ class RolloutEngine:
                  force_enter: bool = False, insert_headroom: Optional[int] = None,
                  sample_k: int = 1, sample_uniforms: Optional[np.ndarray] = None, options: Optional[Mapping[str, int]] = None,
                  insert_k: int = 1, insert_uniforms: Optional[np.ndarray] = None, seed_outputs: bool = False,
-                 use_graph: Optional[bool] = None):
+                 use_graph: Optional[bool] = None, copies: int = 1):
         self.w = weights
         self.options = dict(options) if options else None      # per-engine kernel switches (fields of InfgenOptions)
         self.cfg = cfg = weights.cfg
         self.device = dev = weights.device
         self.ops = Ops(dev)
         self.lib = self.ops.lib
+        # copies = n: every scene is decoded n times in lockstep (the reference's n_rollout_close_val loop, infgen/model/infgen.py:
+        # 704-706, whose inference_no_map(data, map_enc), infgen_decoder.py:132-134, exists so that the map is encoded once): the
+        # batch has S = len(scenes) * n agent-side scenes (scene i's copies are rows i n .. i n + n - 1: own state, own uniforms)
+        # over S0 = len(scenes) map-side scenes - ONE map-token graph, map encoding and set of map K / V rows per scene, found
+        # through InfgenRollout.map_scene
+        self.copies = int(copies)
+        assert self.copies >= 1
         self.scenes = scenes
-        self.S = S = len(scenes)
+        self.S0 = len(scenes)
+        self.S = S = len(scenes) * self.copies
         self.T = T = cfg.num_columns
         self.R = R = cfg.num_recurrent_steps_val
         self.hc = hc = cfg.hist_columns
@@ -477,7 +485,7 @@ class RolloutEngine:
         # ------------------------------------------------ host-side scene setup
         self._stacked = None
         self._hosts_light = False
-        hosts = self._setup_scenes(scenes)
+        hosts = self._replicate(self._setup_scenes(scenes))
         self.hosts = hosts
         amax = max(h['A'] for h in hosts)
         mmax = max(h['M'] for h in hosts)
@@ -495,11 +503,12 @@ class RolloutEngine:
             # 64 scenes 25.9 ms with and without it (the step is its kernels' dependency chains, not launch overhead)
             self.use_graph = os.environ.get('INFGEN_GRAPH') == '1' and not self.insertion
 
-        arr = self._scene_arrays(hosts)
+        arr = self._map_side(self._scene_arrays(hosts))
         t = lambda a: torch.from_numpy(a).to(dev)
         for k in self._SCENE_ARRAYS:
             setattr(self, k, t(arr[k]))
         self._map_cat = tuple(t(arr[k]) for k in ('map_tok', 'map_type', 'map_pl', 'map_light'))
+        self.map_scene = (torch.arange(S, device=dev, dtype=torch.int32) // self.copies).contiguous() if self.copies > 1 else None
         vocab_np = np.stack([vocab[k] for k in ('veh', 'ped', 'cyc')]).astype(np.float32)
         map_vocab_np = np.asarray(map_vocab, dtype=np.float32).reshape(map_vocab.shape[0], -1)
         grid_np = np.asarray(grid, dtype=np.float32)
@@ -536,8 +545,8 @@ class RolloutEngine:
         self.Ka, self.Va, self.AGG, self.Z, self.SIG = f(rows, D), f(rows, D), f(rows, D), f(rows, 8 * D), f(rows, 8)
         self.ringK = [f(self.ring, rows, D) for _ in range(L)]
         self.ringV = [f(self.ring, rows, D) for _ in range(L)]
-        self.mapK = [f(S * M_cap, D) for _ in range(L)]
-        self.mapV = [f(S * M_cap, D) for _ in range(L)]
+        self.mapK = [f(self.S0 * M_cap, D) for _ in range(L)]
+        self.mapV = [f(self.S0 * M_cap, D) for _ in range(L)]
         self.edges = {}
         totals = i32(3)        # the three edge totals back to back: infgen_build_edges clears them with one memset
         for k, (name, cap) in enumerate((('t', rows * self.W), ('m', rows * 5), ('a', rows * (A_cap - 1)))):
@@ -570,6 +579,22 @@ class RolloutEngine:
     # ------------------------------------------------------------------ scene arrays (host -> device)
     _SCENE_ARRAYS = ('pos', 'head', 'state', 'token', 'gridtok', 'tmask', 'imask', 'catflag', 'atype', 'bos', 'n_agents', 'n_map',
                      'av', 'map_pos', 'map_orient', '_shape10')
+
+    _MAP_SIDE = ('n_map', 'map_pos', 'map_orient', 'map_tok', 'map_type', 'map_pl', 'map_light')
+
+    def _replicate(self, hosts0):
+        """the per-scene host dicts of the agent-side batch: scene i's copies are adjacent (the dicts are shared, read-only)"""
+        if self.copies == 1:
+            return hosts0
+        self._stacked = None                   # (the stacked one-shape arrays describe the S0 distinct scenes)
+        return [h for h in hosts0 for _ in range(self.copies)]
+
+    def _map_side(self, arr):
+        """the map-side arrays of a batch with copies: one entry per DISTINCT scene (every copies-th of the replicated batch)"""
+        if self.copies > 1:
+            for k in self._MAP_SIDE:
+                arr[k] = np.ascontiguousarray(arr[k][::self.copies])
+        return arr
 
     def _scene_arrays(self, hosts) -> Dict[str, np.ndarray]:
         """the padded [S][T][A_cap] / [S][M_cap] arrays of a batch (section 4 of DESIGN.md) from the per-scene host dicts"""
@@ -615,7 +640,7 @@ class RolloutEngine:
     def fits(self, scenes: Sequence[Mapping]) -> bool:
         """can ``reload`` take this batch? (same scene count, agents + insertion head-room and map tokens inside the rows this
         engine allocated)"""
-        if len(scenes) != self.S or self.teacher_token is not None:
+        if len(scenes) != self.S0 or self.teacher_token is not None:
             return False
         amax = max(int((np.asarray(sc['agent']['state_idx'])[:, self.hc - 1] != INVALID).sum()) for sc in scenes)
         mmax = max(int(np.asarray(sc['pt_token']['position']).shape[0]) for sc in scenes)
@@ -630,8 +655,8 @@ class RolloutEngine:
         self.scenes = scenes
         self._stacked = None
         self._hosts_light = False
-        self.hosts = hosts = self._setup_scenes(scenes)
-        arr = self._scene_arrays(hosts)
+        self.hosts = hosts = self._replicate(self._setup_scenes(scenes))
+        arr = self._map_side(self._scene_arrays(hosts))
         for k in self._SCENE_ARRAYS:
             getattr(self, k).copy_(torch.from_numpy(arr[k]), non_blocking=False)
         for dst, k in zip(self._map_cat, ('map_tok', 'map_type', 'map_pl', 'map_light')):
@@ -653,8 +678,8 @@ class RolloutEngine:
     def fits_device(self, k: Mapping) -> bool:
         """``fits`` for a stacked device batch (``_setup_device``): shapes only, no host copy"""
         ag, pt = k['agent'], k['pt_token']
-        if int(ag['state_idx'].shape[0]) != self.S or self.teacher_token is not None:
-            return False
+        if self.copies > 1 or int(ag['state_idx'].shape[0]) != self.S or self.teacher_token is not None:
+            return False                        # (batches with copies take the host path: reload)
         A, T0, M = int(ag['state_idx'].shape[1]), int(ag['state_idx'].shape[2]), int(pt['position'].shape[1])
         head = (self.A_cap - self._amax0) if self.insertion else 0
         return A + head <= self.A_cap and M <= self.M_cap and T0 <= self.T and A >= 1
@@ -774,7 +799,7 @@ class RolloutEngine:
         if getattr(self, '_hosts_light', False):
             self.scenes = list(self.scenes)
             epi = self._epi
-            self.hosts = self._setup_scenes(self.scenes)
+            self.hosts = self._replicate(self._setup_scenes(self.scenes))
             self._stacked = None
             self._epi = epi
             self._hosts_light = False
@@ -978,8 +1003,9 @@ class RolloutEngine:
 
         if self._x_pt_override is not None:
             return self._prologue_with_given_map()
-        # ---- map encoder
-        mrows = S * M_cap
+        # ---- map encoder (once per DISTINCT scene)
+        S0 = self.S0
+        mrows = S0 * M_cap
         mtok, mtype, mpl, mlight = self._map_cat
         if self.x_pt is None:
             self.x_pt = torch.empty(mrows, D, device=dev)
@@ -1001,7 +1027,7 @@ class RolloutEngine:
                             cap=cap, K=torch.empty(mrows, D, device=dev), V=torch.empty(mrows, D, device=dev),
                             Q=torch.empty(mrows, D, device=dev), AGG=torch.empty(mrows, D, device=dev))
         g = self._mg
-        _lib.check(self.lib.infgen_map_graph(S, M_cap, _lib.ptr(self.n_map), _lib.ptr(self.map_pos),
+        _lib.check(self.lib.infgen_map_graph(S0, M_cap, _lib.ptr(self.n_map), _lib.ptr(self.map_pos),
                                              _lib.ptr(self.map_orient), float(cfg.pl2pl_radius), K, _lib.ptr(g['off']),
                                              _lib.ptr(g['cnt']), _lib.ptr(g['src']), _lib.ptr(g['raw']),
                                              _lib.ptr(g['total']), g['cap'], ops.stream), 'infgen_map_graph')
@@ -1053,11 +1079,12 @@ class RolloutEngine:
 
     def _prologue_with_given_map(self):
         """inference_no_map: x_pt comes from the caller (reference infgen_decoder.py:132-134)"""
-        S, M_cap, dev = self.S, self.M_cap, self.device
+        S0, M_cap, dev = self.S0, self.M_cap, self.device
         if self.x_pt is None:
-            self.x_pt = torch.zeros(S * M_cap, D, device=dev)
+            self.x_pt = torch.zeros(S0 * M_cap, D, device=dev)
+        assert len(self._x_pt_override) == S0, 'one x_pt per distinct scene'
         for s, xp in enumerate(self._x_pt_override):
-            M = self.hosts[s]['M']
+            M = self.hosts[s * self.copies]['M']
             self.x_pt[s * M_cap:s * M_cap + M] = xp.detach().to(dev, torch.float32)
         self._finish_prologue()
 
@@ -1138,7 +1165,7 @@ class RolloutEngine:
         ar = torch.arange(S, device=dev, dtype=torch.int32)
         self.ins = dict(
             occ=f(S, G), occ_emb=f(S, D), Kocc=[f(S, D) for _ in range(3)], Vocc=[f(S, D) for _ in range(3)],
-            mapK=[f(S * M_cap, D) for _ in range(3)], mapV=[f(S * M_cap, D) for _ in range(3)],
+            mapK=[f(self.S0 * M_cap, D) for _ in range(3)], mapV=[f(self.S0 * M_cap, D) for _ in range(3)],
             Ksa=[f(rows, D) for _ in range(3)], Vsa=[f(rows, D) for _ in range(3)],
             Kh=[f(rows, D) for _ in range(3)], Vh=[f(rows, D) for _ in range(3)],
             Xc=f(rows, D), AGG0=f(rows, D), Z0=f(rows, 8 * D), SIG0=f(rows, 8),
@@ -1272,6 +1299,7 @@ class RolloutEngine:
         c.pos, c.head, c.state, c.token, c.grid = P(self.pos), P(self.head), P(self.state), P(self.token), P(self.gridtok)
         c.tmask, c.imask, c.catflag, c.type, c.bos = P(self.tmask), P(self.imask), P(self.catflag), P(self.atype), P(self.bos)
         c.map_pos, c.map_orient = P(self.map_pos), P(self.map_orient)
+        c.map_scene = P(self.map_scene)
         for i in range(cfg.num_agent_layers):
             c.attn_t[i], c.attn_m[i], c.attn_a[i] = P(w.attn_t[i]), P(w.attn_m[i]), P(w.attn_a[i])
             c.ringK[i], c.ringV[i], c.mapK[i], c.mapV[i] = P(self.ringK[i]), P(self.ringV[i]), P(self.mapK[i]), P(self.mapV[i])
@@ -1430,7 +1458,7 @@ class RolloutEngine:
         for s, h in enumerate(self.hosts):
             A0, M = h['A'], h['M']
             A = int(n_fin[s])
-            sc = self.scenes[s]['agent']
+            sc = self.scenes[s // self.copies]['agent']
             filt = h['filt']
             pos_a = pos[s, :, :A].transpose(1, 0, 2).copy()
             head_a = head[s, :, :A].T.copy()
@@ -1490,7 +1518,8 @@ class RolloutEngine:
             if logits is not None:
                 o['logits'] = logits[:, s * self.A_cap:s * self.A_cap + A].copy()
             if x_pt is not None:
-                o['x_pt'] = x_pt[s * self.M_cap:s * self.M_cap + M].copy()
+                ms = s // self.copies
+                o['x_pt'] = x_pt[ms * self.M_cap:ms * self.M_cap + M].copy()
             outs.append(o)
         return outs
 
@@ -1502,10 +1531,11 @@ class RolloutEngine:
         # padded copies of the inputs the epilogue reads (one upload per array)
         z = lambda *shape, dt=np.float32: np.zeros(shape, dt)
         Rg = max(int(np.asarray(sc['agent']['position']).shape[1]) - H for sc in self.scenes)
+        row_scenes = self.scenes if self.copies == 1 else [sc for sc in self.scenes for _ in range(self.copies)]
         htok, hst = z(S, A_cap, hc, dt=np.int64), z(S, A_cap, hc, dt=np.int64)
         p0, h0, ids, shp = z(S, A_cap, 2), z(S, A_cap), z(S, A_cap, dt=np.int64), z(S, A_cap, 3)
         gt, val, n0 = z(S, A_cap, Rg, 2), z(S, A_cap, T, dt=bool), z(S, dt=np.int64)
-        for s, (h, sc_) in enumerate(zip(self.hosts, self.scenes)):
+        for s, (h, sc_) in enumerate(zip(self.hosts, row_scenes)):
             sc, f, A0 = sc_['agent'], h['filt'], h['A']
             n0[s] = A0
             htok[s, :A0] = np.asarray(sc['token_idx'])[f][:, :hc]
@@ -1521,7 +1551,7 @@ class RolloutEngine:
             shp[s, :A0] = np.asarray(sc['shape'])[f][:, hc - 1]
             val[s, :A0] = h['valid']
         t = lambda a: torch.from_numpy(a).to(dev)
-        self._gt_len = [int(np.asarray(sc['agent']['position']).shape[1]) - H for sc in self.scenes]
+        self._gt_len = [int(np.asarray(sc['agent']['position']).shape[1]) - H for sc in row_scenes]
         return dict(htok=t(htok), hst=t(hst), p0=t(p0), h0=t(h0), ids=t(ids), shp=t(shp), gt=t(gt), val=t(val), n0=t(n0),
                          n0_host=n0, eval_shape=t(np.asarray([[4.3, 1.8, 1.0], [0.5, 0.5, 1.0], [1.9, 0.5, 1.0]], np.float32)))
 
@@ -1618,7 +1648,7 @@ class RolloutEngine:
             if lg_all is not None:
                 o.set_lazy('logits', (lambda s=s, A=A: lg_all[:, s * A_capl:s * A_capl + A]))
             if x_pt_all is not None:
-                o.set_lazy('x_pt', (lambda s=s, M=M: x_pt_all[s * M_capl:s * M_capl + M]))
+                o.set_lazy('x_pt', (lambda ms=s // self.copies, M=M: x_pt_all[ms * M_capl:ms * M_capl + M]))
             outs.append(o)
         return outs
 

@@ -248,12 +248,15 @@ class InfGenDecoder(nn.Module):
 
     # ------------------------------------------------------------------ driver
     def _run(self, data, x_pt=None, map_only=False, batch: Optional[Sequence] = None, sample_uniforms=None,
-             batch_seed_outputs: bool = False):
+             batch_seed_outputs: bool = False, copies: int = 1):
         ae = self.agent_encoder
         datas = list(batch) if batch is not None else [data]
+        copies = int(copies)
+        # copies = n: every scene of the batch is decoded n times in lockstep over ONE map encoding (RolloutEngine(copies=n));
+        # the result list holds scene 0's n rollouts, then scene 1's, ...
         # a batch of device tensors of one shape is set up on the device (RolloutEngine.reload_device); its host form is only made
         # when something reads it (a new engine, a filtered row, the host-side outputs)
-        stk = stack_datas(datas) if batch is not None else None
+        stk = stack_datas(datas) if batch is not None and copies == 1 else None
         scenes = _LazyScenes(datas) if stk is not None else scenes_from_datas(datas)
         w = self._last_w = self._weights()
         ag0 = datas[0]['agent']
@@ -276,12 +279,12 @@ class InfGenDecoder(nn.Module):
             # be decoded greedily)
             amax = max(int(d_['agent']['state_idx'].shape[0]) for d_ in datas)
             ucols = amax if w.cfg.disable_insertion else int(_lib.load().infgen_layout_query(_lib.Q_MAX_AGENTS))
-            sample_uniforms = torch.rand(w.cfg.num_decode_steps, len(scenes), ucols).numpy()
+            sample_uniforms = torch.rand(w.cfg.num_decode_steps, len(scenes) * copies, ucols).numpy()
         ik = int(getattr(ae, 'insert_beam_size', 1))
         insert_uniforms = None
         if ik > 1 and not w.cfg.disable_insertion and not map_only:
             # the cell of an inserted agent from the insert_beam_size most probable ones (agent_decoder.py:1900-1904), torch's RNG
-            insert_uniforms = torch.rand(w.cfg.num_decode_steps, 10, len(scenes)).numpy()
+            insert_uniforms = torch.rand(w.cfg.num_decode_steps, 10, len(scenes) * copies).numpy()
         def make_engine(headroom=None):
             return RolloutEngine(w, scenes, vocab, map_vocab, grid, x_pt_override=xo, insert_headroom=headroom,
                                  force_enter=bool(int(os.getenv('DEBUG', 0))),    # DEBUG=1 forces 'enter' (agent_decoder.py:1888)
@@ -290,13 +293,14 @@ class InfGenDecoder(nn.Module):
                                  # the seed node's per-insertion outputs (plot inputs of the reference, 5.5 MB per scene): the
                                  # single-scene entry and the n-copies batch of inference_rollouts; the throughput entry
                                  # (inference_batch) returns the zero arrays the reference initialises them to
-                                 seed_outputs=(batch is None or batch_seed_outputs) and not w.cfg.disable_insertion and not map_only)
+                                 seed_outputs=(batch is None or batch_seed_outputs) and not w.cfg.disable_insertion and not map_only,
+                                 copies=copies)
         # one engine per batch layout is kept across calls: a second call of the same shape re-uploads the scene arrays into
         # the first call's device buffers instead of building (and allocating) an engine again
         ekey = (len(scenes), PackedWeights.tables_key(*(vocab[k_] for k_ in ('veh', 'ped', 'cyc')), grid, map_vocab),
                 bool(w.cfg.disable_insertion), w.cfg.num_recurrent_steps_val, k if not map_only else 1,
                 ik if insert_uniforms is not None else 1, bool(int(os.getenv('DEBUG', 0))), batch is None, map_only, xo is None,
-                bool(batch_seed_outputs))
+                bool(batch_seed_outputs), copies)
         eng = self._engines.get(ekey)
         if (stk is not None and eng is not None and eng.fits_device(stk) and
                 eng.reload_device(stk, scenes, sample_uniforms=sample_uniforms, insert_uniforms=insert_uniforms, x_pt_override=xo)):
@@ -336,6 +340,8 @@ class InfGenDecoder(nn.Module):
                 zero[shape] = torch.zeros(*shape, device=dev)
             return zero[shape]
         T_cols = w.cfg.num_columns
+        if copies > 1:                          # scene i's copies are adjacent in the engine's batch
+            datas = [d_ for d_ in datas for _ in range(copies)]
         for i_, (d, o) in enumerate(zip(datas, outs)):
             r = o                                   # (a LazyOut: per-scene views are cut when a key is read, not here)
             # without insertion (or in the batched entry) these stay what the reference initialises them to (:1746-1750, :1730)
@@ -352,9 +358,9 @@ class InfGenDecoder(nn.Module):
             try:
                 filt = eng.hosts[i_]['filt']
                 if not filt.all():
-                    av0 = int(np.asarray(scenes[i_]['agent']['av_index']).reshape(-1)[0])
+                    av0 = int(np.asarray(scenes[i_ // copies]['agent']['av_index']).reshape(-1)[0])
                     removed = int((~filt[:av0]).sum())
-                    if removed:
+                    if removed and i_ % copies == 0:          # (once per data object)
                         d['batch_size_a'] -= removed
             except (KeyError, TypeError):
                 pass
@@ -409,16 +415,19 @@ class InfGenDecoder(nn.Module):
         which calls ``inference(data.clone())`` n times) as one batch of n copies decoded in lockstep: with
         ``motion_beam_size`` / ``insert_beam_size`` > 1 every copy draws its own uniforms from torch's RNG, so the results are n
         samples; greedy copies are identical.  ``data`` itself is not mutated (the copies are)."""
-        copies = [data.clone() if hasattr(data, 'clone') else dict(data) for _ in range(int(n))]
+        # one engine batch of n copies of the scene over ONE map encoding (RolloutEngine(copies=n): the map-token graph, the map
+        # encoder and the map K / V rows exist once - the reference offers inference_no_map(data, map_enc) for the same purpose);
         # every rollout carries what ``inference`` returns for it: the seed node's outputs and the map_next_token_* keys too
-        return self.inference_batch(copies, seed_outputs=True)
+        return self.inference_batch([data.clone() if hasattr(data, 'clone') else dict(data)], seed_outputs=True, copies=int(n))
 
     @torch.no_grad()
-    def inference_batch(self, datas: Sequence, seed_outputs: bool = False) -> List[Dict[str, torch.Tensor]]:
+    def inference_batch(self, datas: Sequence, seed_outputs: bool = False, copies: int = 1) -> List[Dict[str, torch.Tensor]]:
         """throughput entry: many independent scenes decoded in lockstep on this GPU.  Every dict has the key set of
         ``inference``; the seed node's per-insertion arrays (``*_seed``) are recorded only with ``seed_outputs=True`` (5.5 MB per
         scene), otherwise they are the zero arrays the reference initialises them to (agent_decoder.py:1746-1750)."""
-        rs = self._run(None, batch=datas, batch_seed_outputs=seed_outputs)
+        rs = self._run(None, batch=datas, batch_seed_outputs=seed_outputs, copies=copies)
+        if copies > 1:                          # ``copies`` rollouts per scene over one map encoding: scene 0's first, then scene 1's ...
+            datas = [d for d in datas for _ in range(int(copies))]
         out = []
         dev, ts = self._last_w.device, self.map_encoder.token_size
         map_keys = {'map_next_token_idx': torch.zeros(0, 10, dtype=torch.long, device=dev),

@@ -1116,3 +1116,81 @@ def test_rollout_with_the_matrix_pipe_edge_scores_reproduces_the_fixtures():
         finally:
             os.environ.pop('INFGEN_EDGE_MFMA', None)
         assert not torch.equal(lg['0'], lg['1']), name
+
+
+def test_copies_share_one_map_encoding_and_equal_single_scene_runs():
+    """RolloutEngine(scenes, copies=n) decodes every scene n times in lockstep over ONE map encoding (the
+    reference runs n_rollout_close_val rollouts per scene, infgen/model/infgen.py:704-706, and offers inference_no_map(data,
+    map_enc), infgen_decoder.py:132-134, so that the map is encoded once).  Three ragged scenes x 4 copies with DIFFERENT
+    uniforms for the top-5 token draw: every copy equals the single-scene run with that copy's uniforms bit for bit (tokens,
+    states, poses; logits bitwise for the same batch shape is not required - compared within 1e-4), the copies differ from each
+    other, and the map-side buffers (x_pt, map K / V, the pt <-> pt graph) are sized for 3 scenes, not 12"""
+    from infgen_amd import engine, synth
+    c = load_case('c2_a32_m512')
+    cfg = c['cfg']
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], cfg, dev)
+    scenes = [c['scene']] + [synth.make_scene(9300 + i, a, m, cfg, ego_last=(i % 2 == 0), vocab=c['vocab'], grid=c['grid'], slip=0.3)
+                             for i, (a, m) in enumerate([(20, 300), (32, 512)])]
+    n = 4
+    steps = cfg.num_decode_steps
+    rng = np.random.default_rng(7)
+    amax = max(int(np.asarray(s_['agent']['state_idx']).shape[0]) for s_ in scenes)
+    u = rng.random((steps, len(scenes) * n, amax)).astype(np.float32)
+    e = engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=True, use_graph=False,
+                             sample_k=5, sample_uniforms=u, copies=n)
+    e.rollout()
+    outs = e.outputs()
+    assert len(outs) == len(scenes) * n
+    assert e.x_pt.shape[0] == len(scenes) * e.M_cap and e.mapK[0].shape[0] == len(scenes) * e.M_cap
+    assert e._mg['off'].shape[0] == len(scenes) * e.M_cap
+    for i, sc in enumerate(scenes):
+        toks = []
+        for k in range(n):
+            s = i * n + k
+            one = engine.RolloutEngine(w, [sc], c['vocab'], c['map_vocab'], c['grid'], store_logits=True, use_graph=False,
+                                       sample_k=5, sample_uniforms=u[:, s:s + 1], a_cap=e.A_cap, m_cap=e.M_cap)
+            one.rollout()
+            o1, on = one.outputs()[0], outs[s]
+            for key in ('next_token_idx', 'next_state_idx'):
+                assert np.array_equal(o1[key], on[key]), (i, k, key)
+            assert np.allclose(o1['pos_a'], on['pos_a'], atol=1e-4) and np.allclose(o1['logits'], on['logits'], atol=1e-4 * 4)
+            assert np.array_equal(o1['x_pt'], on['x_pt'])
+            toks.append(on['next_token_idx'])
+        assert any(not np.array_equal(toks[0], t) for t in toks[1:]), 'the copies drew the same tokens: uniforms not per copy?'
+    # a second rollout of the same engine (state reset from the device snapshot) repeats the first bit for bit
+    e.rollout()
+    again = e.outputs()
+    for a_, b_ in zip(outs, again):
+        assert np.array_equal(a_['next_token_idx'], b_['next_token_idx']) and np.array_equal(a_['pos_a'], b_['pos_a'])
+
+
+def test_copies_with_insertion_share_the_map_rows_of_the_seed_layers():
+    """copies + scenario insertion: the map K / V rows of the pt -> seed layers (InfgenInsertion.mapK / mapV) and the map -> seed
+    edges (k_point_edges) go through the same map_scene indirection - 3 ragged scenes x 2 greedy copies reproduce each scene
+    decoded alone (agents inserted at the same steps, same tokens; reference agent_decoder.py:1773-2105)"""
+    from infgen_amd import engine, synth
+    c = load_case('ins_natural_a20_m256')
+    cfg = c['cfg']
+    cfg.disable_insertion = False
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], cfg, dev)
+    scenes = [c['scene']] + [synth.make_scene(8100 + i, a, m, cfg, ego_last=(i % 2 == 0), vocab=c['vocab'], grid=c['grid'])
+                             for i, (a, m) in enumerate([(12, 128), (30, 300)])]
+    e = engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=False, a_cap=128, copies=2)
+    e.rollout()
+    outs = e.outputs()
+    assert len(outs) == 6 and e.ins['mapK'][0].shape[0] == 3 * e.M_cap
+    assert np.array_equal(outs[0]['next_token_idx'], c['z']['next_token_idx'])
+    n_ins = []
+    for i, sc in enumerate(scenes):
+        e1 = engine.RolloutEngine(w, [sc], c['vocab'], c['map_vocab'], c['grid'], store_logits=False, a_cap=128)
+        e1.rollout()
+        o1 = e1.outputs()[0]
+        for k in range(2):
+            ob = outs[2 * i + k]
+            assert o1['pos_a'].shape == ob['pos_a'].shape and o1['num_inserted'] == ob['num_inserted']
+            assert np.array_equal(o1['next_token_idx'], ob['next_token_idx'])
+            assert np.abs(o1['pos_a'] - ob['pos_a']).max() <= 1e-5
+        n_ins.append(o1['num_inserted'])
+    assert max(n_ins) > 0
