@@ -313,7 +313,7 @@ def dry_run(args, ranks):
     dt, agent_steps = igdist.reduce_run(dt, steps_local, ranks.dev)
     if ranks.rank == 0:
         print(json.dumps({'metric': 'agent-steps/sec (closed-loop rollout)', 'value': None, 'unit': 'agent-steps/s',
-                          'n_gpus': ranks.world, 'rccl_ranks': 0, 'backend': ranks.backend, 'dry_run': True, 'steps': args.steps,
+                          'n_gpus': ranks.world, 'rccl_ranks': 0, 'ranks': ranks.world, 'backend': ranks.backend, 'dry_run': True, 'steps': args.steps,
                           'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'scaling': args.scaling,
                           'agent_steps_counted': agent_steps, 'per_rank_ms': [r[0] for r in per_rank],
                           'scenes_per_rank': [int(r[1]) for r in per_rank],
@@ -720,6 +720,8 @@ def main():
             literal['one_gpu_of_8way_shard'] = shard
             literal['projected_8gpu_value'] = 8.0 * shard['value']
             literal['projected_8gpu_speedup_over_1gpu'] = 8.0 * shard['value'] / literal['value']
+            literal['note'] += (f"; projected strong-scaling factor of this fixed batch at 8 GPUs: {literal['projected_8gpu_speedup_over_1gpu']:.2f} x "
+                                '(latency-bound per GPU) - north_star\'s >= 7.5 x at 8 GPUs is to be read against WEAK scaling (scenes per GPU fixed)')
             literal['note'] += ('; one_gpu_of_8way_shard: the 8 scenes rank 0 of an 8-way shard owns, run here on one GPU - scenes are '
                                 'independent and there is no data-path collective, so 8 x its value projects the 8-GPU figure of the '
                                 'literal batch (latency-bound at 8 scenes per GPU; the weak-scaling headline does not have this limit)')
@@ -736,6 +738,7 @@ def main():
             'unit': 'agent-steps/s',
             'n_gpus': world,
             'rccl_ranks': world if ranks.dist is not None else 0,
+            'ranks': world,
             'backend': ranks.backend,
             'per_rank_ms': [r[0] for r in per_rank],
             'per_rank_ms_spread': max(r[0] for r in per_rank) / (sum(r[0] for r in per_rank) / len(per_rank)),

@@ -16,15 +16,19 @@ from conftest import load_case, make_weights
 pytestmark = pytest.mark.gpu
 
 
-def _assert_rows_within(row_err, tol, frac=0.999, cap_factor=50):
+def _assert_rows_within(row_err, tol, frac=0.999, cap_factor=50, max_outside=30):
     """long teacher-forced horizons: per (step, row) logits error within `tol` for >= 99.9 % of the rows.  The rest are rows next
     to a discrete boundary the accumulated pose drift (~1e-3 m after 100+ steps) crosses - an agent at 59.999 m of another (edge
     in or out of the 60 m radius), the fifth-nearest map token - where the reference's own CPU and GPU builds differ too; they stay
     isolated (no blow-up: bounded by cap_factor x tol) and the median sits at the kernels' noise level"""
     row_err = np.asarray(row_err)
     inside = float((row_err <= tol).mean())
-    print(f'rows {row_err.size}: within {tol:g}: {inside:.5f}, median {np.median(row_err):.2e}, max {row_err.max():.2e}')
+    n_out = int((row_err > tol).sum())
+    # the COUNT of rows outside the bar is printed and bounded (VERDICT r4 item 7: a fraction hides drift on a large run)
+    print(f'rows {row_err.size}: within {tol:g}: {inside:.5f} ({n_out} rows outside, bound {max_outside}), '
+          f'median {np.median(row_err):.2e}, max {row_err.max():.2e}')
     assert inside >= frac, inside
+    assert n_out <= max_outside, f'{n_out} rows outside {tol:g} (round 4 measured {max_outside // 3} or fewer)' 
     assert np.median(row_err) <= tol / 20
     assert row_err.max() <= cap_factor * tol
 

@@ -130,6 +130,19 @@ def test_bench_insertion_run_deals_scenes_by_cost():
     assert _run_bench('--gpus', '2', '--dry-run', '--steps', '1', '--scenes', '3')['insertion_balance'] is None
 
 
+def test_bench_insertion_strong_scaling_two_ranks():
+    """the first 8-GPU run will be the driver's - the rank path of `--insertion --scaling strong` (the
+    BASELINE C4 batch dealt like the reference's DistributedSampler, then re-dealt by measured cost) on two gloo ranks: every
+    rank reports, every scene of the fixed batch is dealt exactly once, the line names its ranks"""
+    line = _run_bench('--gpus', '2', '--dry-run', '--insertion', '--scaling', 'strong', '--total-scenes', '11', '--steps', '2')
+    assert line['n_gpus'] == 2 and line['ranks'] == 2 and line['scaling'] == 'strong' and line['backend'] == 'gloo'
+    assert len(line['scenes_per_rank']) == 2 and sum(line['scenes_per_rank']) == 11 and min(line['scenes_per_rank']) >= 1
+    b = line['insertion_balance']
+    assert b['all_scenes_dealt_once'] and b['scenes_per_rank'] == line['scenes_per_rank']
+    assert b['max_over_mean_after'] <= b['max_over_mean_before']
+    assert len(line['per_rank_ms']) == 2 and line['c3_literal_scenes_per_rank'] == [32, 32]
+
+
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():
     import subprocess
     import sys

@@ -120,14 +120,18 @@ def test_batched_scenes_equal_single_scene_runs():
         assert np.abs(outs[0]['logits'] - outb[i]['logits']).max() <= 1e-4
 
 
-def test_rollout_vs_oracle_fresh_seed():
-    """a scene/weight seed that has no committed fixture: HIP vs the CPU oracle run in-process"""
+@pytest.mark.parametrize('wseed,sseed', [(14, 4251), (16, 4253)])
+def test_rollout_vs_oracle_fresh_seed(wseed, sseed):
+    """scene / weight seeds that have no committed fixture: HIP vs the CPU oracle run in-process.  The seeds were picked so that
+    the oracle's own arg-max margin clears the bar at every (step, row) - 0.081 / 0.060 against 4 x 4e-3 - which is asserted,
+    so the token comparison below is unconditional over all 16 free-running steps (it used to sit behind an
+    `if` that a seed with one near-tie silently skipped)"""
     from infgen_amd import synth
     from oracle import rollout_oracle as ro
     c = load_case('a24_m256_edge')
     cfg = c['cfg']
-    sd = make_weights(seed=5, head_gain=64.0)
-    scene = synth.make_scene(4242, 20, 200, cfg, ego_last=True, edge_cases=True, vocab=c['vocab'], grid=c['grid'])
+    sd = make_weights(seed=wseed, head_gain=64.0)
+    scene = synth.make_scene(sseed, 20, 200, cfg, ego_last=True, edge_cases=True, vocab=c['vocab'], grid=c['grid'])
     tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
     ref = ro.run_scene(tsd, scene, cfg, c['vocab'], c['map_vocab'], c['grid'])
     case = dict(c, sd=sd, scene=scene)
@@ -137,10 +141,12 @@ def test_rollout_vs_oracle_fresh_seed():
     part = np.partition(lg, -2, axis=-1)
     margin = part[..., -1] - part[..., -2]
     tol = 4e-3
-    if margin.min() > 4 * tol:
-        assert np.array_equal(o['next_token_idx'], ref['next_token_idx'].numpy())
-    assert np.abs(o['logits'][0] - lg[0]).max() <= tol
-    assert np.array_equal(o['next_token_idx'][:, :3], ref['next_token_idx'].numpy()[:, :3])
+    assert margin.min() > 4 * tol, f'seed no longer has a clear margin: {margin.min()}'
+    assert np.array_equal(o['next_token_idx'], ref['next_token_idx'].numpy())
+    assert np.array_equal(o['next_state_idx'], ref['next_state_idx'].numpy())
+    err = float(np.abs(o['logits'] - lg).max())
+    print(f'fresh seeds ({wseed}, {sseed}): min arg-max margin {margin.min():.3f}, max logits error over all steps {err:.2e}')
+    assert err <= tol, err
 
 
 @pytest.mark.parametrize('name', ['ins_forced_a16_m256', 'ins_natural_a20_m256', 'ins_sampled_a16_m256'])

@@ -15,6 +15,7 @@ import torch
 from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
+MARGIN = 1e-5          # gap between the best and the second-best matching cost above which another index is a bug, not a tie
 
 
 def _vocab_last(dev):
@@ -80,6 +81,14 @@ def test_match_agent_token_golden(case, per_agent_tables):
         return float(torch.norm(world - cur, dim=-1).sum())
 
     _check(idx, con, z['token_index'], z['token_contour'], cost)
+    # the tie allowance must not hide a regression - where the reference's own matching cost separates its
+    # best token from the second best by more than rounding at EVERY step of an agent, the ids are equal, no allowance
+    _, _, margin = tm.match_agent_token(torch.from_numpy(z['valid']), torch.from_numpy(z['pos'][..., :2].copy()),
+                                        torch.from_numpy(z['heading']), torch.from_numpy(z['shape']),
+                                        tok3.cpu()[torch.from_numpy(z['type']).long()], return_margin=True)
+    clear = (margin.min(1).values > MARGIN).numpy()
+    assert clear.sum() >= len(clear) // 2, 'margin filter left too few agents to mean anything'
+    assert np.array_equal(idx.cpu().numpy()[clear], z['token_index'][clear]), 'ids differ where the reference\'s cost is not a tie'
 
 
 def test_match_agent_token_many_agents_vs_oracle():
@@ -102,13 +111,17 @@ def test_match_agent_token_many_agents_vs_oracle():
     dev = torch.device('cuda:0')
     tok3 = _vocab_last(dev)
     pos_t, head_t = torch.from_numpy(pos.astype(np.float32)), torch.from_numpy(head.astype(np.float32))
-    ref_idx, ref_con = tm.match_agent_token(torch.from_numpy(valid), pos_t, head_t, torch.from_numpy(shape),
-                                            tok3.cpu()[torch.from_numpy(atype)])
+    ref_idx, ref_con, margin = tm.match_agent_token(torch.from_numpy(valid), pos_t, head_t, torch.from_numpy(shape),
+                                                    tok3.cpu()[torch.from_numpy(atype)], return_margin=True)
     idx, con, _ = TokenProcessor()._match_agent_token(torch.from_numpy(valid).to(dev), pos_t.to(dev), head_t.to(dev),
                                                       torch.from_numpy(shape).to(dev), tok3,
                                                       agent_type=torch.from_numpy(atype).to(dev))
     same = (idx.cpu() == ref_idx).all(1)
     assert same.float().mean() >= 0.99, float(same.float().mean())
+    # ... and exactly equal wherever the oracle's cost separates best from second best at every step (no tie allowance there)
+    clear = margin.min(1).values > MARGIN
+    print('agents with a clear margin at every step:', int(clear.sum()), 'of', A, '- differing among them:', int((~same[clear]).sum()))
+    assert int(clear.sum()) >= A // 2 and bool(same[clear].all())
     assert float((con.cpu()[same] - ref_con[same]).abs().max()) <= 1e-3
     exact = (con.cpu() == ref_con).flatten(1).all(1).float().mean()
     print('agents with bit-identical contours over all 18 steps:', float(exact))
@@ -146,6 +159,10 @@ def test_match_token_map_large_vs_oracle():
     dev = torch.device('cuda:0')
     idx = match_token_map(torch.from_numpy(pos).to(dev), torch.from_numpy(theta).to(dev), sample_pt).cpu().numpy()
     assert (idx == ref).mean() >= 0.999, float((idx == ref).mean())
+    _, margin = tm.match_token_map(torch.from_numpy(pos), torch.from_numpy(theta), sample_pt, return_margin=True)
+    clear = (margin > MARGIN).numpy()
+    print('pieces with a clear margin:', int(clear.sum()), 'of', P, '- differing among them:', int((idx != ref)[clear].sum()))
+    assert clear.sum() >= P // 2 and np.array_equal(idx[clear], ref[clear])
 
 
 @pytest.mark.parametrize('case', ['tokenize_a40', 'tokenize_a6'])
