@@ -15,7 +15,12 @@ import torch
 from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
-MARGIN = 1e-5          # gap between the best and the second-best matching cost above which another index is a bug, not a tie
+# Gap between the best and the second-best matching cost (m, summed over the four corners) above which another index is a bug, not a
+# tie.  Not 1e-5: an ulp of difference in cos / sin / atan2 (see above) moves the matched pose, the poses chain over 18 steps, and
+# by the later steps the device's state is up to 1e-4 m away from the reference's - tools/diag_token_margin.py lists the 12 of 4096
+# agents that differ: ten at gaps <= 1e-5, two at gaps of 1.3e-5 / 1.1e-4 with 1e-4 m of drift in front of them.  1e-3 is ten times
+# the largest drift seen; a wrong rotation, corner order or tie rule shows at gaps of centimetres.
+MARGIN = 1e-3
 
 
 def _vocab_last(dev):
@@ -43,6 +48,20 @@ def _check(idx, con, ref_idx, ref_con, cost_fn):
         # (libm) can drift over the 18 chained steps
         assert np.abs(con[a, :o] - ref_con[a, :o]).max(initial=0.0) <= 1e-3
     return n_bad
+
+
+def _assert_equal_while_clear(idx, ref_idx, margin):
+    """every agent's ids up to (not including) its first step whose best / second-best gap is <= MARGIN: exactly the reference's -
+    until then both runs are in the same state (up to the drift MARGIN covers), so another index is a bug.  The tie allowance of
+    _check only ever applies from that step on."""
+    unclear = margin <= MARGIN
+    first = np.where(unclear.any(1), unclear.argmax(1), margin.shape[1])           # per agent: steps [0, first) are judged
+    judged = np.arange(margin.shape[1])[None, :] < first[:, None]
+    n = int(judged.sum())
+    bad = judged & (idx != ref_idx)
+    print(f'(agent, step) pairs judged without tie allowance: {n} of {margin.size}, differing: {int(bad.sum())}')
+    assert n >= margin.size // 4, 'margin filter left too few pairs to mean anything'
+    assert not bad.any(), np.argwhere(bad)[:5]
 
 
 @pytest.mark.parametrize('case', ['tok_a48', 'tok_a7'])
@@ -86,9 +105,7 @@ def test_match_agent_token_golden(case, per_agent_tables):
     _, _, margin = tm.match_agent_token(torch.from_numpy(z['valid']), torch.from_numpy(z['pos'][..., :2].copy()),
                                         torch.from_numpy(z['heading']), torch.from_numpy(z['shape']),
                                         tok3.cpu()[torch.from_numpy(z['type']).long()], return_margin=True)
-    clear = (margin.min(1).values > MARGIN).numpy()
-    assert clear.sum() >= len(clear) // 2, 'margin filter left too few agents to mean anything'
-    assert np.array_equal(idx.cpu().numpy()[clear], z['token_index'][clear]), 'ids differ where the reference\'s cost is not a tie'
+    _assert_equal_while_clear(idx.cpu().numpy(), z['token_index'], margin.numpy())
 
 
 def test_match_agent_token_many_agents_vs_oracle():
@@ -119,9 +136,7 @@ def test_match_agent_token_many_agents_vs_oracle():
     same = (idx.cpu() == ref_idx).all(1)
     assert same.float().mean() >= 0.99, float(same.float().mean())
     # ... and exactly equal wherever the oracle's cost separates best from second best at every step (no tie allowance there)
-    clear = margin.min(1).values > MARGIN
-    print('agents with a clear margin at every step:', int(clear.sum()), 'of', A, '- differing among them:', int((~same[clear]).sum()))
-    assert int(clear.sum()) >= A // 2 and bool(same[clear].all())
+    _assert_equal_while_clear(idx.cpu().numpy(), ref_idx.numpy(), margin.numpy())
     assert float((con.cpu()[same] - ref_con[same]).abs().max()) <= 1e-3
     exact = (con.cpu() == ref_con).flatten(1).all(1).float().mean()
     print('agents with bit-identical contours over all 18 steps:', float(exact))
@@ -160,7 +175,7 @@ def test_match_token_map_large_vs_oracle():
     idx = match_token_map(torch.from_numpy(pos).to(dev), torch.from_numpy(theta).to(dev), sample_pt).cpu().numpy()
     assert (idx == ref).mean() >= 0.999, float((idx == ref).mean())
     _, margin = tm.match_token_map(torch.from_numpy(pos), torch.from_numpy(theta), sample_pt, return_margin=True)
-    clear = (margin > MARGIN).numpy()
+    clear = (margin > 1e-5).numpy()              # (no chained state here: a single rotation per piece)
     print('pieces with a clear margin:', int(clear.sum()), 'of', P, '- differing among them:', int((idx != ref)[clear].sum()))
     assert clear.sum() >= P // 2 and np.array_equal(idx[clear], ref[clear])
 
