@@ -84,7 +84,6 @@ struct Prof {
   std::vector<int> kid;
   std::vector<int> phase_of;                // 0: prologue / operator-level call, 1: inside a decode step (infgen_decode_step, infgen_rollout_run)
   std::vector<double> macs;                 // algorithmic multiply-accumulates of the launch (0: not a GEMM kernel)
-  int phase = 0;
   int stride = 1;                           // of the launches inside decode steps every stride-th is bracketed (infgen_prof_set_stride)
   int seen[INFGEN_KID_COUNT] = {};          // launches of the selected kernels since infgen_prof_enable, bracketed or not
   int seen_step[INFGEN_KID_COUNT] = {};     // ... of them inside decode steps
@@ -93,6 +92,7 @@ struct Prof {
                                             // [8 + kind] edges built by k_build_edges (kind 0 temporal, 1 map, 2 agent)
 } g_prof;
 
+static thread_local int t_prof_phase = 0;       // 1: the calling thread is inside a decode step (ProfPhase below)
 struct ProfScope {
   int slot = -1;
   hipStream_t s;
@@ -100,11 +100,11 @@ struct ProfScope {
     if ((g_prof.mask >> kid) & 1u) {
       ++g_prof.seen[kid];
       // an event pair costs ~5 us of launch-stream time: inside the timed region only every stride-th decode-step launch carries one
-      const bool take = g_prof.phase != 1 || (g_prof.seen_step[kid]++ % g_prof.stride) == 0;
+      const bool take = t_prof_phase != 1 || (g_prof.seen_step[kid]++ % g_prof.stride) == 0;
       if (take && g_prof.used < g_prof.e0.size()) {
         slot = (int)g_prof.used++;
         g_prof.kid[slot] = kid;
-        g_prof.phase_of[slot] = g_prof.phase;
+        g_prof.phase_of[slot] = t_prof_phase;
         g_prof.macs[slot] = macs;
         (void)hipEventRecord(g_prof.e0[slot], s);
       }
@@ -113,10 +113,12 @@ struct ProfScope {
   ~ProfScope() { if (slot >= 0) (void)hipEventRecord(g_prof.e1[slot], s); }
 };
 // launches issued inside a decode step are tagged (bench.py separates the step's edge launches from the prologue's)
+// (per host thread: two threads driving two contexts save / restore their own tag - a shared one could be left at 1 by an
+// interleaved save / restore pair, after which every later prologue launch counted as a step launch)
 struct ProfPhase {
   int old;
-  explicit ProfPhase(int p) : old(g_prof.phase) { g_prof.phase = p; }
-  ~ProfPhase() { g_prof.phase = old; }
+  explicit ProfPhase(int p) : old(t_prof_phase) { t_prof_phase = p; }
+  ~ProfPhase() { t_prof_phase = old; }
 };
 }  // namespace
 
@@ -1461,7 +1463,7 @@ static int layers_core(const InfgenRollout* r, int c, int edgeless, void* stream
 extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless, void* stream) {
   RET_IF(validate(r, "infgen_decode_layers"));
   OptScope _opts(r);
-  ProfPhase _pp(edgeless ? g_prof.phase : 1);        // (the edgeless column-0 chain belongs to the prologue)
+  ProfPhase _pp(edgeless ? t_prof_phase : 1);        // (the edgeless column-0 chain belongs to the prologue)
   const StepMode sm = step_mode(r, r->S * r->A_cap, edgeless);
   const bool lp = sm.lp && sm.fuse && r->SIG != nullptr;      // (k_build_edges zeroes k_layers_p's counters: infgen_rollout_run)
   RET_IF(prepare_edges(r, c, edgeless, stream, true, false, nullptr, lp));
