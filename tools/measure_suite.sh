@@ -3,6 +3,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/suite; mkdir -p $O
 bash tools/prof_round.sh > $O/prof_round.log 2>&1
+bash tools/prof_sq.sh > $O/prof_sq.log 2>&1
 B="--no-cpu-baseline --no-literal --no-strict"
 timeout 900 python bench.py > $O/bench_s1024.json 2> $O/bench_s1024.err
 timeout 600 python bench.py --scenes 512 $B > $O/bench_s512.json 2> $O/bench_s512.err
