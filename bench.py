@@ -351,7 +351,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-literal', action='store_true', help='skip the config.c3_literal legs')
-    ap.add_argument('--no-strict', action='store_true', help='skip the config.strict_fp32 leg')
+    ap.add_argument('--no-strict', action='store_true', help='skip the secondary legs (strict_fp32, two_streams, multi_rollout, prologue)')
     ap.add_argument('--no-balance', action='store_true',
                     help='insertion on several ranks: keep the initial deal instead of the cost-sorted one (dist.scenes_for_rank_balanced)')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
@@ -679,7 +679,7 @@ def main():
     # prologue (state reset, map encoder, map K / V, edgeless column-0 chain) of the same batch timed on its own; the decode
     # steps are the rest of the timed rollout
     prologue = None
-    if ns == 1 and engines and not args.insertion:
+    if ns == 1 and engines and not args.insertion and not args.no_strict:      # (--no-strict: the timed region only, e.g. under rocprofv3)
         log('prologue leg')
         e0 = engines[0]
         psteps = max(1, min(3, args.steps))
