@@ -549,24 +549,6 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
     grid = ceil_div(grid, grp) * grp;
   }
   if (no_xcd & 2) a.kv_once = 0;
-  static const int em_form = getenv("INFGEN_EDGE_MFMA") ? atoi(getenv("INFGEN_EDGE_MFMA")) : 1;
-  if (r24 == 2 && em_form == 2 && !a.groups) {
-    // H8 rows, the all-matrix-pipe form (edge_mfma_z.hip): 4-wave workgroups of 8 rows, two per CU
-    EdgeFusedArgs m = a;
-    int mg = ceil_div(rows, 8);
-    m.tiles_per_scene = 0; m.groups = nullptr; m.n_groups = nullptr;
-    if (rows_per_scene > 8 && rows_per_scene % 8 == 0 && !(no_xcd & 1)) {
-      m.tiles_per_scene = rows_per_scene / 8;
-      const int grp = 8 * m.tiles_per_scene;
-      mg = ceil_div(mg, grp) * grp;
-    }
-    m.n_virtual = mg;
-    t_warm = WarmArgs{};
-    { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
-      if (m.kv_once) hipLaunchKernelGGL(k_edge_mfma_z<true>, dim3(mg), dim3(256), 0, (hipStream_t)stream, m);
-      else hipLaunchKernelGGL(k_edge_mfma_z<false>, dim3(mg), dim3(256), 0, (hipStream_t)stream, m); }
-    return check_launch("infgen_edge_attn_fused_h8");
-  }
   if (r24 == 2) {
     // H8 rows: the matrix-pipe edge loop (edge_mfma.hip), one 8-wave workgroup per 16-row group at every size
     EdgeFusedArgs m = a;

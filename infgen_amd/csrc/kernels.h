@@ -498,7 +498,6 @@ __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);
 template <bool KV_ONCE> __global__ void k_edge_mfma(EdgeFusedArgs a);   // edge_mfma.hip (rhat rows in the H8 format)
 __global__ void k_rhat_to_h8(const float* in, int rows, char* out);
-template <bool KV_ONCE> __global__ void k_edge_mfma_z(EdgeFusedArgs a); // edge_mfma_z.hip (the all-matrix-pipe form, 4-wave workgroups of 8 rows)
 template <int G, bool R24, int HALVES, int WAVES> __global__ void k_edge_fused(EdgeFusedArgs a);        // edge_fused.hip (R24: rhat rows in the packed format)
 template <bool R24, int ROWS> __global__ void k_layers_p(LayersPArgs a);          // layers_p.hip
 template <int G> __global__ void k_edge_fused_p(EdgeFusedArgs a);      // persistent workgroups, decoupled halves
