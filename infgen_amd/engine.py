@@ -418,6 +418,7 @@ class Ops:
 
 class RolloutEngine:
     """Device state + launch sequence for a batch of scenes."""
+    copies = 1          # rollouts per scene over one map encoding (instance attribute when given; see __init__)
 
     def __init__(self, weights: PackedWeights, scenes: Sequence[Mapping], vocab: Mapping[str, np.ndarray],
                  map_vocab: np.ndarray, grid: np.ndarray, a_cap: Optional[int] = None, m_cap: Optional[int] = None,
