@@ -202,6 +202,11 @@ def load() -> C.CDLL:
         raise InfgenHipError(
             f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             f'or `make -C infgen_amd/csrc` (there is no CPU fallback for the product path)')
+    # torch first: its wheel bundles its own libamdhip64 (ROCm 7.0), libinfgen_hip.so is linked against the system's (/opt/rocm).
+    # Whichever HIP runtime is mapped first serves both (same SONAME); with the library loaded BEFORE torch the process ends up with
+    # two runtimes and the library's sees no device ("no ROCm-capable device is detected" from the first launch - found with
+    # `python __graft_entry__.py smoke`, whose build() loads the library before smoke() imports torch)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is not exported
