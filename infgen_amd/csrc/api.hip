@@ -620,12 +620,27 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
     ++n_launch;
     return check_launch("infgen_edge_attn_fused");
   }
+  static unsigned long long* ef_trace = nullptr;       // (timing experiment: INFGEN_EDGE_DBG bit 7 with an -DIG_EF_TRACE=1 build)
+  if (dbg & 128) {
+    if (!ef_trace && hipMalloc(&ef_trace, 64 * sizeof(unsigned long long)) != hipSuccess) return fail("infgen_edge_attn_fused", "trace buffer");
+    (void)hipMemsetAsync(ef_trace, 0, 64 * sizeof(unsigned long long), (hipStream_t)stream);
+    a.dbgbuf = reinterpret_cast<unsigned*>(ef_trace);
+  }
   { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
     auto kern = small ? (r24 ? k_edge_fused<6, true, 1, 16> : k_edge_fused<6, false, 1, 16>)
               : two ? (r24 ? k_edge_fused<6, true, 1, 8> : k_edge_fused<6, false, 1, 8>)
               : r24 ? (G == 4 ? k_edge_fused<4, true, 2, 16> : G == 8 ? k_edge_fused<8, true, 2, 16> : k_edge_fused<6, true, 2, 16>)
                     : (G == 4 ? k_edge_fused<4, false, 2, 16> : G == 8 ? k_edge_fused<8, false, 2, 16> : k_edge_fused<6, false, 2, 16>);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(two ? 512 : 1024), 0, (hipStream_t)stream, a); }
+  if (dbg & 128) {
+    static int dumps = 0;
+    if (dumps++ < 3) {
+      unsigned long long hst[64];
+      (void)hipStreamSynchronize((hipStream_t)stream);
+      (void)hipMemcpy(hst, ef_trace, sizeof(hst), hipMemcpyDeviceToHost);
+      for (int i = 1; i < 8; ++i) fprintf(stderr, "[ef trace] %d +%lld\n", i, hst[i] && hst[0] ? (long long)(hst[i] - hst[0]) : -1ll);
+    }
+  }
   return check_launch("infgen_edge_attn_fused");
 }
 

@@ -38,6 +38,15 @@ constexpr int EF_LDA = D + 4;
 // WAVES = 16: one 1024-thread workgroup per CU; WAVES = 8 (HALVES = 1 only, 75 KB of LDS): two co-resident workgroups per CU, whose
 // matrix phases run under each other's edge loops - the configuration that gave wrong rows in round 2 and is exact since the
 // loop's per-lane broadcasts are real register pairs (edge_attn.cuh: bc_v)
+// timing experiment (build with -DIG_EF_TRACE=1, run with INFGEN_EDGE_DBG bit 7): s_memtime of wave 0 of workgroup 2600 -> a.dbgbuf
+#ifndef IG_EF_TRACE
+#define IG_EF_TRACE 0
+#endif
+#if IG_EF_TRACE
+#define EF_STAMP(i) do { if ((a.dbg & 128) && blockIdx.x == 2600 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(a.dbgbuf)[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define EF_STAMP(i) do {} while (0)
+#endif
 template <int G, bool R24, int HALVES, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 4) void k_edge_fused(EdgeFusedArgs a) {
   static_assert(WAVES == 16 || (WAVES == 8 && HALVES == 1), "8-wave workgroups take one 16-row group");
@@ -59,6 +68,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_edge_fused(EdgeFusedArgs a) {
     tile = bq * grp + (br % 8) * tps + br / 8;
   }
   if (tile >= ntiles) return;
+  EF_STAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -97,6 +107,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_edge_fused(EdgeFusedArgs a) {
     if (lane < ROWS) row_order[rank] = (unsigned char)rl;
   }
 
+  EF_STAMP(1);
   // ---- phase 1: u_h = q_h W'_kr,h (K = 16: v_mfma_f32_16x16x16_f16; B fragment = the head's 16 query values of row j)
   if (mat) {
     float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -137,7 +148,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_edge_fused(EdgeFusedArgs a) {
     for (int ct = 0; ct < 8; ++ct)
       *reinterpret_cast<float4*>(urow + 16 * ct) = make_float4(acc[ct][0] * cq, acc[ct][1] * cq, acc[ct][2] * cq, acc[ct][3] * cq);
   }
+  EF_STAMP(2);
   __syncthreads();
+  EF_STAMP(3);
 
   // ---- phase 2: edge loop, one wave per destination row
   {
@@ -205,6 +218,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_edge_fused(EdgeFusedArgs a) {
       if ((lane & 7) == 0) SG[rl * H + (lane >> 3)] = acc.lsum * inv;
     }
   }
+  EF_STAMP(4);
   // (phase 3's weight fragments are requested BEFORE the barrier: a wave that has finished its rows waits there anyway, and the
   // fragments' L2 latency runs under that wait)
   v8h p3h[4], p3l[4];
@@ -217,7 +231,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_edge_fused(EdgeFusedArgs a) {
       p3l[s] = *reinterpret_cast<const v8h*>(Wv + (s * 2 + 1) * 512);
     }
   }
+  EF_STAMP(5);
   __syncthreads();
+  EF_STAMP(6);
 
   // ---- phase 3: agg' = agg + W'_vr,h z_h + b'_h sigma_h  (k_attn_h's z-GEMM: |z| <= sqrt(127), static prescale 1024)
   if (mat) {
@@ -253,6 +269,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_edge_fused(EdgeFusedArgs a) {
       *reinterpret_cast<float4*>(a.AGG + (size_t)row * D + DH * h + 4 * g) = o;
     }
   }
+  EF_STAMP(7);
 }
 
 // G = edges per trip of the edge loop (their K / V / rhat rows are requested together)
