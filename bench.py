@@ -55,6 +55,12 @@ F16_DENSE_PEAK_TFLOPS = 2500.0
 # kernels on the fp16 matrix pipe with the three-term split: one algorithmic multiply-add costs three f16 MFMA
 # multiply-adds, so the ceiling for ALGORITHMIC flops at fp32 accuracy is the dense f16 peak / 3
 F16_SPLIT_PEAK_TFLOPS = F16_DENSE_PEAK_TFLOPS / 3.0
+# what "f32" means on the line: every tensor in HBM is fp32 (weights, activations, K / V, the relative-position rows), every
+# accumulation and every vector operation is fp32; inside the hot GEMM kernels an fp32 operand x enters the f16 matrix pipe as
+# the exact pair hi = rne16(x), lo = rne16(x - hi) (|x - hi - lo| <= 2^-23 |x|) and a product is hi hi + hi lo + lo hi in fp32
+ARITHMETIC_F32 = ('fp32 storage, fp32 accumulation; GEMM operands enter the f16 matrix pipe as round-to-nearest hi + lo fp16 pairs '
+                  '(<= 2^-23 per operand), three MFMA terms per product; error against fp64 measured <= 1.5 x the fp32-input MFMA '
+                  'kernels\' on every operator (tests/test_precision_gpu.py, profiles/r06_precision.json); fp32 rhat rows')
 
 # ---- SURVEY section 8d, per decode step of one scene (1 MAC = 2 FLOP, D = 128) ----------------------------------
 NODE_MAC_PER_ROW = 4_702_848        # 18 x 212,992 + 12 x 32,768 + 82,176 + 98,304 + 278,528 + 16,768
@@ -155,7 +161,7 @@ def cpu_baseline(args, budget_s):
 
 
 # ---------------------------------------------------------------------------------------- parity gate
-PARITY_COPIES = 336      # x 32 rows per scene = 10,752 rows: above every by-size switch of the library (k_edge_fused<6,true,2> from
+PARITY_COPIES = 336      # x 32 rows per scene = 10,752 rows: above every by-size switch of the library (k_edge_fused<6,false,1,8> from
                          # 4,097 rows, k_attn_h / k_heads_h / k_mlpemb_h from 10,241 rows) - the kernels the number is measured on
 
 
@@ -163,7 +169,7 @@ def parity_gate(dev):
     """parity reported with every perf number - the C1 fixture and the A = 24 edge-case fixture (outputs of the
     reference's own InfGenDecoder.inference) free-running through the library that is about to be timed: once as the single
     scene (the small-launch kernels) and once as a batch of PARITY_COPIES copies of the scene, which takes the launches
-    through the kernels of the timed region (large-batch variants, packed 24-bit rhat rows); every copy must reproduce the
+    through the kernels of the timed region (large-batch variants, fp32 rhat rows); every copy must reproduce the
     fixture"""
     sys.path.insert(0, os.path.join(REPO, 'tests'))
     from conftest import load_case
@@ -351,7 +357,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-literal', action='store_true', help='skip the config.c3_literal legs')
-    ap.add_argument('--no-strict', action='store_true', help='skip the secondary legs (strict_fp32, two_streams, multi_rollout, prologue)')
+    ap.add_argument('--no-strict', action='store_true', help='skip the secondary legs (fp32_mfma, rhat24, two_streams, multi_rollout, prologue)')
     ap.add_argument('--no-balance', action='store_true',
                     help='insertion on several ranks: keep the initial deal instead of the cost-sorted one (dist.scenes_for_rank_balanced)')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
@@ -532,8 +538,8 @@ def main():
         sampled = calls / in_region
         nedge, nbytes, rows_t = nedge * sampled, nbytes * sampled, rows_t * sampled
         hbm_frac = nbytes / secs / (HBM_PEAK_GBS * 1e9)
-        # what this design has to move for the same launches: + the 24-bit rhat row per edge, + q in / agg out per row
-        rhat_b = 384.0
+        # what this design has to move for the same launches: + the fp32 rhat row per edge, + q in / agg out per row
+        rhat_b = 512.0                     # fp32 rows (InfgenOptions.rhat_format = 0, the default)
         model = nbytes + L * rhat_b * nedge + 3 * L * 1024.0 * rows_t
         # the REFERENCE's per-edge projections (33,024 MAC per edge and layer) that these launches stand for, and what the absorbed
         # form executes instead: 2,304 per edge and layer + two 128 x 128 products per row and sublayer
@@ -584,35 +590,28 @@ def main():
     per_rank = igdist.gather_metrics([1e3 * dt_local / args.steps, float(n_scenes_local)], dev)
     dt, agent_steps = igdist.reduce_run(dt, agent_steps, dev)
 
-    # ---- config.strict_fp32: the same batch through the fp32-MFMA kernels with fp32 rhat rows (no fp16 split, no 24-bit rows)
-    strict = None
+    # ---- config.fp32_mfma: the same batch through the fp32-input MFMA kernels (v_mfma_f32_32x32x2_f32 in every GEMM kernel, the
+    # unsplit operands) - the arithmetic tests/test_precision_gpu.py measures the headline's split kernels against.  A per-engine
+    # option block (InfgenOptions), nothing process-wide is edited.
+    # ---- config.rhat24: the headline's kernels with the relative-position rows between the Fourier and the edge kernels packed
+    # into 24 bits (InfgenOptions.rhat_format = 1: 2^-17 per value - a reduced-precision mode, never the headline)
+    strict = r24leg = None
     if not args.no_strict and args.gemm_terms == 3 and not args.insertion and ns == 1:
-        log('strict fp32 leg')
-        o0 = _lib.Options()
-        _lib.check(lib.infgen_get_options(_lib.C.byref(o0)))
-        old_env = os.environ.get('INFGEN_NO_R24')
-        try:
-            _lib.check(lib.infgen_set_fourier_mode(0))
-            _lib.check(lib.infgen_set_attn_mode(0))
-            os.environ['INFGEN_NO_R24'] = '1'
-            e = engine.RolloutEngine(w, scenes, vocab, map_vocab, grid, store_logits=False, use_graph=False)
+        def opt_leg(options, what):
+            e = engine.RolloutEngine(w, scenes, vocab, map_vocab, grid, store_logits=False, use_graph=False, options=options)
             e.rollout()
             torch.cuda.synchronize(dev)
-            ssteps = max(1, min(2, args.steps))
+            ssteps = max(1, min(3, args.steps))
             t = timed(ranks, e.rollout, ssteps)
             t, n = igdist.reduce_run(t, float(e.agent_steps() * ssteps), dev)
-            strict = {'value': n / t, 'ms_per_step': 1e3 * t / ssteps, 'steps': ssteps,
-                      'arithmetic': 'v_mfma_f32_32x32x2_f32 (fp32 operands) in every GEMM kernel, fp32 rhat rows; '
-                                    'infgen_set_fourier_mode(0), infgen_set_attn_mode(0), INFGEN_NO_R24=1'}
             del e
-        finally:
-            _lib.check(lib.infgen_set_fourier_mode(o0.fourier_mode))
-            _lib.check(lib.infgen_set_attn_mode(o0.attn_mode))
-            if old_env is None:
-                os.environ.pop('INFGEN_NO_R24', None)
-            else:
-                os.environ['INFGEN_NO_R24'] = old_env
-        torch.cuda.empty_cache()
+            torch.cuda.empty_cache()
+            return {'value': n / t, 'ms_per_step': 1e3 * t / ssteps, 'steps': ssteps, 'options': options, 'arithmetic': what}
+        log('fp32-MFMA leg')
+        strict = opt_leg(dict(fourier_mode=0, attn_mode=0, rhat_format=0),
+                         'v_mfma_f32_32x32x2_f32 (fp32 operands) in every GEMM kernel, fp32 rhat rows')
+        log('24-bit rhat leg')
+        r24leg = opt_leg(dict(rhat_format=1), 'the headline\'s kernels with packed 24-bit rhat rows (2^-17 per value; reduced precision)')
 
     # ---- config.two_streams: the same batch as two engines (half the scenes each) on two HIP streams, sequenced by one host thread
     # (engine.rollout_many): one engine's HBM-bound edge launches run under the other's matrix / vector-bound ones.  Reported next to
@@ -748,8 +747,9 @@ def main():
             'higher_is_better': True,
             'scaling': args.scaling,
             'vs_baseline': None,
-            'dtype': ('f32 (emulated: fp16 MFMA, three-term hi/lo split, fp32 accumulate; rhat rows stored in 24 bits)'
-                      if args.gemm_terms == 3 else 'f16 (fp16 MFMA operands, fp32 accumulate; outside the 1e-3 parity bar)'),
+            'dtype': 'f32' if args.gemm_terms == 3 else 'f16',
+            'arithmetic': (ARITHMETIC_F32 if args.gemm_terms == 3 else
+                           'fp16 MFMA operands (hi term only), fp32 accumulate; outside the 1e-3 parity bar (BASELINE C5 reduced mode)'),
             'data': 'synthetic',
             'config': {
                 'workload': f'{shape}: configs/ours_{"long_term" if args.insertion else "standard"}.yaml hyper-parameters, '
@@ -764,7 +764,8 @@ def main():
                 'agent_token_steps_per_s': agent_steps / dt / cfg.shift,
                 'parallelism': f'scenes sharded over {world} rank(s), no data-path collective',
                 'c3_literal': literal,
-                'strict_fp32': strict,
+                'fp32_mfma': strict,
+                'rhat24': r24leg,
                 'two_streams': two,
                 'multi_rollout': multi,
                 'insertion_balance': balance,
@@ -777,7 +778,9 @@ def main():
         # figures next to the headline)
         ms = 1e3 * dt / args.steps
         flat = {
-            'strict_fp32_value': strict['value'] if strict else None,
+            'fp32_mfma_value': strict['value'] if strict else None,
+            'strict_fp32_value': strict['value'] if strict else None,       # (the key earlier rounds' lines used for the same leg)
+            'rhat24_value': r24leg['value'] if r24leg else None,
             'two_streams_value': two['value'] if two else None,
             'multi_rollout_value': multi['value'] if multi else None,
             'multi_rollout_speedup_over_independent_scenes': multi['speedup'] if multi else None,

@@ -101,7 +101,8 @@ typedef struct InfgenOptions {
   int overlap;          /* infgen_set_overlap (the side stream itself is shared: keep 0 when contexts run concurrently) */
   int row_group_margin; /* rows a decode step may append (infgen_set_row_limits) */
   int layers_p;         /* infgen_set_layers_p: 1 = small launches run a decode step's sublayers in one launch (k_layers_p) */
-  int _pad0;
+  int rhat_format;      /* infgen_set_rhat_format: 0 (default) fp32 rows of the normalised relative-position embedding between the
+                         * Fourier and the edge kernels, 1 packed 24-bit rows (384 B, 2^-17 relative: a reduced-precision mode) */
   const int* row_groups; const int* n_row_groups;   /* optional list of the 16-row groups that hold agents (infgen_set_row_groups) */
 } InfgenOptions;
 
@@ -182,6 +183,11 @@ typedef struct InfgenLinearDesc {
   float* Y; int ldy;
 } InfgenLinearDesc;
 int infgen_linear_multi(const InfgenLinearDesc* desc, int n, void* stream);
+/* MLPEmbedding.forward (infgen/modules/layers.py:163-192) for inputs of K0 = 128 j <= 512 columns: Linear LN ReLU Linear LN ReLU
+ * Linear, pack = infgen_amd.packing.pack_mlp_embedding (fp32 stages + split section).  attn_mode != 0: one launch on the fp16
+ * split (k_mlpemb_h); attn_mode 0: three fp32-MFMA launches through the scratch arrays tmp1 / tmp2 [rows][128]. */
+int infgen_mlp_embedding(const float* X, int ldx, int rows, int K0, const float* pack, float* tmp1, float* tmp2,
+                         float* Y, int ldy, void* stream);
 /* row-wise LayerNorm over 128 columns (torch.nn.LayerNorm, eps 1e-5); gamma == NULL: affine-free */
 int infgen_layernorm(const float* X, int rows, const float* gamma, const float* beta, float* Y, void* stream);
 int infgen_fourier_embed(const float* raw, int n_dims, const int* count_dev, int e_cap, const float* pack,
@@ -220,16 +226,11 @@ int infgen_edge_attn_fused(int rows, const float* Q, const float* pack, const fl
 int infgen_fourier_embed_r24(const float* raw, int n_dims, const int* count_dev, int e_cap, const float* pack, void* out, void* stream);
 int infgen_edge_attn_fused_r24(int rows, const float* Q, const float* pack, const float* Ksrc, const float* Vsrc,
                                const int* off, const int* cnt, const int* src, const void* rhat24, float* AGG, void* stream);
-/* ... and in the "H8" form: per row 128 x fp16 of 2048 r (round to nearest) followed by 128 x OCP fp8 e4m3 of the remainder
- * 2048 r - fp16(2048 r), 384 bytes (relative error 2^-16 for |r| >= 2^-6, absolute 2^-21 below).  Both planes are operands of the
- * fp16 matrix pipe as they are: infgen_edge_attn_fused_h8 (k_edge_mfma) forms the scores u_h . r and the aggregates sum_e p_h r of
- * 16 edges at a time as MFMAs instead of ~70 vector instructions per edge (reference infgen/modules/layers.py:78-92,109; same
- * results as infgen_edge_attn_fused up to rounding).  infgen_fourier_embed_h8 writes the rows (split Fourier kernel only),
- * infgen_rhat_to_h8 converts fp32 rows [rows][128]. */
-int infgen_fourier_embed_h8(const float* raw, int n_dims, const int* count_dev, int e_cap, const float* pack, void* out, void* stream);
-int infgen_edge_attn_fused_h8(int rows, const float* Q, const float* pack, const float* Ksrc, const float* Vsrc,
-                              const int* off, const int* cnt, const int* src, const void* rhat_h8, float* AGG, void* stream);
-int infgen_rhat_to_h8(const float* rhat, int rows, void* out, void* stream);
+/* Which of the two row formats infgen_decode_layers / infgen_rollout_run keep their own edge sets' rhat rows in between the Fourier
+ * and the edge launches: 0 (default) fp32 - the reference's arithmetic (infgen/modules/layers.py:61-113 is fp32 end to end) -,
+ * 1 the packed 24-bit rows above (-25 % of the rhat bytes, ~1 % of a rollout; outside the fp32 contract, a named secondary leg of
+ * bench.py).  Process-wide default; a context with opts.use != 0 takes InfgenOptions.rhat_format. */
+int infgen_set_rhat_format(int format);
 int infgen_set_edge_fuse(int mode);
 /* the process-wide defaults (what the infgen_set_* functions edited so far), e.g. to seed a context's own InfgenOptions */
 int infgen_get_options(InfgenOptions* out);

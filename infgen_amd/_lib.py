@@ -64,7 +64,7 @@ class Insertion(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [('use', _i), ('attn_mode', _i), ('gemm_terms', _i), ('fourier_mode', _i), ('edge_fuse', _i), ('edge_loop', _i),
-                ('overlap', _i), ('row_group_margin', _i), ('layers_p', _i), ('_pad0', _i), ('row_groups', _p), ('n_row_groups', _p)]
+                ('overlap', _i), ('row_group_margin', _i), ('layers_p', _i), ('rhat_format', _i), ('row_groups', _p), ('n_row_groups', _p)]
 
 
 OPTIONS_VALUE_BYTES = C.sizeof(_i) * 10       # the integer switches of Options (the two pointers follow)
@@ -120,6 +120,8 @@ SYMBOLS = {
     'infgen_layers_p_capacity': (_i, []),
     'infgen_rollout_validate': (_i, [_p]),
     'infgen_set_edge_loop': (_i, [_i]),
+    'infgen_set_rhat_format': (_i, [_i]),
+    'infgen_mlp_embedding': (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
     'infgen_get_options': (_i, [C.POINTER(Options)]),
     'infgen_thread_options': (_i, [C.POINTER(Options)]),
     'infgen_get_effective_options': (_i, [C.POINTER(Options)]),
@@ -129,9 +131,6 @@ SYMBOLS = {
     'infgen_edge_attn_fused': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'infgen_edge_attn_fused_r24': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'infgen_fourier_embed_r24': (_i, [_p, _i, _p, _i, _p, _p, _p]),
-    'infgen_edge_attn_fused_h8': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    'infgen_fourier_embed_h8': (_i, [_p, _i, _p, _i, _p, _p, _p]),
-    'infgen_rhat_to_h8': (_i, [_p, _i, _p, _p]),
     'infgen_embedding_sum4': (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _p, _p]),
     'infgen_fourier_last_dim_table': (_i, [_p, _i, _p, _p]),
     'infgen_fourier_embed_tab': (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _p]),

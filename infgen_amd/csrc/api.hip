@@ -35,7 +35,7 @@ extern "C" const char* infgen_last_error(void) { return g_err.c_str(); }
 namespace {
 int layers_p_default() { const char* e = getenv("INFGEN_LAYERS_P"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : v > 2 ? 2 : v; }
 InfgenOptions g_def = {0, /*attn_mode*/ 2, /*gemm_terms*/ 3, /*fourier_mode*/ 1, /*edge_fuse*/ 1, /*edge_loop*/ 6, /*overlap*/ 0,
-                       /*row_group_margin*/ 0, /*layers_p*/ layers_p_default(), 0, nullptr, nullptr};
+                       /*row_group_margin*/ 0, /*layers_p*/ layers_p_default(), /*rhat_format*/ 0, nullptr, nullptr};
 int g_def_group_rows = 0;                  // rows of the layout the process-wide group list belongs to
 const int* g_def_limit_n_agents = nullptr; // process-wide row limits (infgen_set_row_limits)
 int g_def_limit_A_cap = 0;
@@ -509,6 +509,13 @@ extern "C" int infgen_set_edge_fuse(int mode) {
   return 0;
 }
 
+// row format of the step's own rhat rows: 0 fp32 (default), 1 packed 24-bit (include/infgen_hip.h)
+extern "C" int infgen_set_rhat_format(int format) {
+  if (format != 0 && format != 1) return fail("infgen_set_rhat_format", "format must be 0 (fp32 rows) or 1 (packed 24-bit rows)");
+  g_def.rhat_format = format;
+  return 0;
+}
+
 // edges per trip of k_edge_fused's edge loop (their K / V / rhat rows are requested together): 4, 6 (default) or 8
 extern "C" int infgen_set_edge_loop(int v) {
   if (v != 4 && v != 6 && v != 8) return fail("infgen_set_edge_loop", "edges per trip must be 4, 6 or 8");
@@ -530,15 +537,14 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
   if (!pack || !rhat) return fail("infgen_edge_attn_fused", "needs the layer pack and rhat");
   static const int dbg = getenv("INFGEN_EDGE_DBG") ? atoi(getenv("INFGEN_EDGE_DBG")) : 0;
   static const int no_xcd = getenv("INFGEN_EDGE_NOXCD") ? atoi(getenv("INFGEN_EDGE_NOXCD")) : 0;
-  static const int persist = getenv("INFGEN_EDGE_P") ? atoi(getenv("INFGEN_EDGE_P")) : 0;
   static const int small_max = getenv("INFGEN_EDGE_SMALL") ? atoi(getenv("INFGEN_EDGE_SMALL")) : 4096;
   static const int wg2 = getenv("INFGEN_EDGE_WG2") ? atoi(getenv("INFGEN_EDGE_WG2")) : 1;
   const int G = O().edge_loop;
   // small launches: one 16-row group per workgroup (edge_fused.hip), twice the workgroups for the same rows
-  const bool small = rows <= small_max && G == 6 && !persist;
+  const bool small = rows <= small_max && G == 6;
   // large launches: 8-wave workgroups of one 16-row group, two per CU - one's matrix phases run under the other's edge loop
   // (128 vs 140 us per launch at 512 scenes; INFGEN_EDGE_WG2=0: one 16-wave workgroup of two groups per CU)
-  const bool two = !small && wg2 && G == 6 && !persist;
+  const bool two = !small && wg2 && G == 6;
   const int tr = (small || two) ? 16 : 32;          // rows per tile
   EdgeFusedArgs a{rows, Q, pack, Ksrc, Vsrc, EdgeSet{off, cnt, src, rhat}, AGG, nullptr, nullptr, dbg, 0, kv_once};
   int grid = ceil_div(rows, tr);           // with a group list at most that many
@@ -549,77 +555,8 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
     grid = ceil_div(grid, grp) * grp;
   }
   if (no_xcd & 2) a.kv_once = 0;
-  if (r24 == 2) {
-    // H8 rows: the matrix-pipe edge loop (edge_mfma.hip), one 8-wave workgroup per 16-row group at every size
-    EdgeFusedArgs m = a;
-    int mg = ceil_div(rows, 16);
-    m.tiles_per_scene = 0;
-    if (!m.groups && rows_per_scene > 16 && rows_per_scene % 16 == 0 && !(no_xcd & 1)) {
-      m.tiles_per_scene = rows_per_scene / 16;
-      const int grp = 8 * m.tiles_per_scene;
-      mg = ceil_div(mg, grp) * grp;
-    }
-    m.n_virtual = mg;
-    t_warm = WarmArgs{};
-    static unsigned long long* em_trace = nullptr;
-    if (dbg & 128) {
-      if (!em_trace && hipMalloc(&em_trace, 64 * sizeof(unsigned long long)) != hipSuccess) return fail("infgen_edge_attn_fused_h8", "trace buffer");
-      (void)hipMemsetAsync(em_trace, 0, 64 * sizeof(unsigned long long), (hipStream_t)stream);
-      m.dbgbuf = reinterpret_cast<unsigned*>(em_trace);
-    }
-    { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
-      if (m.kv_once) hipLaunchKernelGGL(k_edge_mfma<true>, dim3(mg), dim3(512), 0, (hipStream_t)stream, m);
-      else hipLaunchKernelGGL(k_edge_mfma<false>, dim3(mg), dim3(512), 0, (hipStream_t)stream, m); }
-    if (dbg & 128) {
-      static int dumps = 0;
-      if (dumps++ < 2) {
-        unsigned long long hst[64];
-        (void)hipStreamSynchronize((hipStream_t)stream);
-        (void)hipMemcpy(hst, em_trace, sizeof(hst), hipMemcpyDeviceToHost);
-        for (int i = 1; i < 13; ++i) fprintf(stderr, "[em trace] %d +%lld\n", i, hst[i] && hst[0] ? (long long)(hst[i] - hst[0]) : -1ll);
-      }
-    }
-    return check_launch("infgen_edge_attn_fused_h8");
-  }
   a.n_virtual = grid;
-  if (small && !persist) grid = warm_take(a.warm, grid); else t_warm = WarmArgs{};
-  if (persist && !r24) {
-    const int pg = grid < 256 ? grid : 256;
-    // INFGEN_EDGE_DBG bit 3 (diagnostic, synchronous): checksums of what each phase hands to the next, compared between the
-    // launches n and n - 3 (the map encoder's three sublayers repeat with identical inputs from one prologue to the next)
-    static unsigned* dbuf[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-    static long n_launch = 0;
-    const int slot = (int)(n_launch % 3), gen = (int)((n_launch / 3) & 1);
-    const size_t nb = (size_t)rows * 12 * sizeof(unsigned);
-    if (dbg & 8) {
-      if (!dbuf[slot][gen] && hipMalloc(&dbuf[slot][gen], nb) != hipSuccess) return fail("infgen_edge_attn_fused", "debug buffer");
-      (void)hipMemsetAsync(dbuf[slot][gen], 0, nb, (hipStream_t)stream);
-      a.dbgbuf = dbuf[slot][gen];
-    }
-    { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
-      if (persist == 2) hipLaunchKernelGGL(k_edge_fused_p<4>, dim3(pg), dim3(1024), 0, (hipStream_t)stream, a);
-      else hipLaunchKernelGGL(k_edge_fused_p<6>, dim3(pg), dim3(1024), 0, (hipStream_t)stream, a); }
-    if ((dbg & 8) && n_launch >= 3 && dbuf[slot][gen ^ 1]) {
-      std::vector<unsigned> x((size_t)rows * 12), y((size_t)rows * 12);
-      (void)hipStreamSynchronize((hipStream_t)stream);
-      (void)hipMemcpy(x.data(), dbuf[slot][gen], nb, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(y.data(), dbuf[slot][gen ^ 1], nb, hipMemcpyDeviceToHost);
-      long du = 0, dq = 0, dz = 0, dr = 0, dr_only = 0, dl = 0, dz_only = 0;
-      for (int r_ = 0; r_ < rows; ++r_) {
-        const unsigned* p = &x[(size_t)r_ * 12]; const unsigned* q = &y[(size_t)r_ * 12];
-        const bool bu = p[0] != q[0], bq = p[1] != q[1], bz = p[2] != q[2];
-        dl += p[3] != q[3]; dz_only += bz && p[3] == q[3];
-        bool br = false;
-        for (int k = 4; k < 12; ++k) br |= p[k] != q[k];
-        du += bu; dq += bq; dz += bz; dr += br; dr_only += br && !bz;
-      }
-      fprintf(stderr, "[edge_p dbg] launch %ld (sublayer %d): rows %d, differ vs previous prologue: u-read %ld, q-read %ld, loaded K/V/rhat %ld, "
-                      "loop result %ld (with identical loads %ld), z read by phase 3 %ld (with identical loop result %ld)\n",
-              n_launch, slot, rows, du, dq, dl, dz, dz_only, dr, dr_only);
-    }
-    ++n_launch;
-    return check_launch("infgen_edge_attn_fused");
-  }
+  if (small) grid = warm_take(a.warm, grid); else t_warm = WarmArgs{};
   static unsigned long long* ef_trace = nullptr;       // (timing experiment: INFGEN_EDGE_DBG bit 7 with an -DIG_EF_TRACE=1 build)
   if (dbg & 128) {
     if (!ef_trace && hipMalloc(&ef_trace, 64 * sizeof(unsigned long long)) != hipSuccess) return fail("infgen_edge_attn_fused", "trace buffer");
@@ -661,24 +598,6 @@ extern "C" int infgen_edge_attn_fused_r24(int rows, const float* Q, const float*
                                           const int* off, const int* cnt, const int* src, const void* rhat24,
                                           float* AGG, void* stream) {
   return edge_fused_launch(rows, Q, pack, Ksrc, Vsrc, off, cnt, src, static_cast<const float*>(rhat24), AGG, 0, 0, stream, 1);
-}
-
-// ... and in the H8 form (include/infgen_hip.h), whose consumer runs the products with the rows on the matrix pipe (k_edge_mfma)
-extern "C" int infgen_fourier_embed_h8(const float* raw, int n, const int* count_dev, int e_cap, const float* pack, void* out,
-                                       void* stream) {
-  return fourier_embed_impl(raw, n, count_dev, e_cap, pack, nullptr, 0, static_cast<float*>(out), 128, 1, 2, stream);
-}
-
-extern "C" int infgen_edge_attn_fused_h8(int rows, const float* Q, const float* pack, const float* Ksrc, const float* Vsrc,
-                                         const int* off, const int* cnt, const int* src, const void* rhat_h8,
-                                         float* AGG, void* stream) {
-  return edge_fused_launch(rows, Q, pack, Ksrc, Vsrc, off, cnt, src, static_cast<const float*>(rhat_h8), AGG, 0, 0, stream, 2);
-}
-
-extern "C" int infgen_rhat_to_h8(const float* rhat, int rows, void* out, void* stream) {
-  if (rows <= 0) return 0;
-  hipLaunchKernelGGL(k_rhat_to_h8, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, rhat, rows, static_cast<char*>(out));
-  return check_launch("infgen_rhat_to_h8");
 }
 
 // one wave per destination; few destinations (<= 256 rows) get the 8-wave split so that the chip is not idle
@@ -1041,28 +960,41 @@ extern "C" int infgen_raw_feature(const InfgenRollout* r, int col, void* stream)
   return raw_feature_fusion(r, stream);
 }
 
-// fusion_emb of the gathered rows (fus_in [rows][512]) -> X
-static int raw_feature_fusion(const InfgenRollout* r, void* stream) {
-  const int rows = r->S * r->A_cap;
-  const float* P = r->fusion_pack;
-  if (O().attn_mode != 0) {    // the three Linear stages of fusion_emb in one launch on the fp16 split (any row count: one
-                               // 25 us chain instead of three dependent fp32 launches of 30-40 us each)
-    MlpEmbHArgs m{r->fus_in, 512, rows, 512, P, r->X, 128};
+// MLPEmbedding (reference infgen/modules/layers.py:163-192) with K0 = 128 j inputs: Linear LN ReLU Linear LN ReLU Linear.  Split
+// arithmetic (attn_mode != 0): the three stages in one launch of k_mlpemb_h (any row count: one 25 us chain instead of three dependent
+// fp32 launches of 30-40 us each); attn_mode 0: three k_linear launches through tmp1 / tmp2 [rows][128]
+static int mlp_embedding_impl(const float* X, int ldx, int rows, int K0, const float* P, float* tmp1, float* tmp2, float* Y, int ldy,
+                              void* stream, const char* where) {
+  if (rows <= 0) return 0;
+  if (O().attn_mode != 0) {
+    MlpEmbHArgs m{X, ldx, rows, K0, P, Y, ldy};
     int grid = ceil_div(rows, 64);
     if (grid > 512) grid = 512;
-    { ProfScope _ps(INFGEN_KID_LINEAR, stream, (double)rows * (512 + 128 + 128) * 128.0);
+    { ProfScope _ps(INFGEN_KID_LINEAR, stream, (double)rows * (K0 + 128 + 128) * 128.0);
       if (O().gemm_terms == 1) hipLaunchKernelGGL(k_mlpemb_h<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m);
       else hipLaunchKernelGGL(k_mlpemb_h<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m); }
-    return check_launch("infgen_raw_feature/fusion");
+    return check_launch(where);
   }
-  const int o2 = mlpemb_off2(512), o3 = mlpemb_off3(512);
-  RET_IF(infgen_linear(r->fus_in, 512, nullptr, rows, 512, P, 128, P + 512 * 128, 128, nullptr, nullptr,
-                       P + 512 * 128 + 128, P + 512 * 128 + 256, 1, r->tmp1, 128, stream));
-  RET_IF(infgen_linear(r->tmp1, 128, nullptr, rows, 128, P + o2, 128, P + o2 + 16384, 128, nullptr, nullptr,
-                       P + o2 + 16384 + 128, P + o2 + 16384 + 256, 1, r->tmp2, 128, stream));
-  RET_IF(infgen_linear(r->tmp2, 128, nullptr, rows, 128, P + o3, 128, P + o3 + 16384, 128, nullptr, nullptr,
-                       nullptr, nullptr, 0, r->X, 128, stream));
+  if (!tmp1 || !tmp2) return fail(where, "the fp32 kernels need the two scratch arrays");
+  const int o2 = mlpemb_off2(K0), o3 = mlpemb_off3(K0);
+  RET_IF(infgen_linear(X, ldx, nullptr, rows, K0, P, 128, P + K0 * 128, 128, nullptr, nullptr,
+                       P + K0 * 128 + 128, P + K0 * 128 + 256, 1, tmp1, 128, stream));
+  RET_IF(infgen_linear(tmp1, 128, nullptr, rows, 128, P + o2, 128, P + o2 + 16384, 128, nullptr, nullptr,
+                       P + o2 + 16384 + 128, P + o2 + 16384 + 256, 1, tmp2, 128, stream));
+  RET_IF(infgen_linear(tmp2, 128, nullptr, rows, 128, P + o3, 128, P + o3 + 16384, 128, nullptr, nullptr,
+                       nullptr, nullptr, 0, Y, ldy, stream));
   return 0;
+}
+extern "C" int infgen_mlp_embedding(const float* X, int ldx, int rows, int K0, const float* pack, float* tmp1, float* tmp2,
+                                    float* Y, int ldy, void* stream) {
+  if (K0 <= 0 || K0 % 128 || K0 > 512) return fail("infgen_mlp_embedding", "K0 must be 128, 256, 384 or 512");
+  return mlp_embedding_impl(X, ldx, rows, K0, pack, tmp1, tmp2, Y, ldy, stream, "infgen_mlp_embedding");
+}
+
+// fusion_emb of the gathered rows (fus_in [rows][512]) -> X
+static int raw_feature_fusion(const InfgenRollout* r, void* stream) {
+  return mlp_embedding_impl(r->fus_in, 512, r->S * r->A_cap, 512, r->fusion_pack, r->tmp1, r->tmp2, r->X, 128, stream,
+                            "infgen_raw_feature/fusion");
 }
 
 // the same for a few rows only (insertion: the rows appended in this sub-loop iteration): row_list[k] = row, used where
@@ -1247,14 +1179,10 @@ static StepMode step_mode(const InfgenRollout* r, int rows, int edgeless) {
   m.overlap = O().overlap && g_side && !edgeless;
   m.lp = layers_p_shape(r, rows, edgeless);
   m.fuse = O().edge_fuse == 2 || (O().edge_fuse == 1 && (rows > 256 || m.lp));      // U / Z / SIG stay on chip inside k_edge_fused / k_layers_p
-  // the step's rhat rows never leave the library: packed 24-bit rows (kernels.h) when both ends are the kernels that know them
-  // (INFGEN_NO_R24=1, read per call: fp32 rows instead - tests/test_rollout_gpu.py compares the two)
-  const char* no_r24 = getenv("INFGEN_NO_R24");
-  m.r24 = m.fuse && O().fourier_mode != 0 && !(no_r24 && atoi(no_r24));
-  // the agent set's rows in the H8 form for k_edge_mfma (scores on the matrix pipe; opt-in: INFGEN_EDGE_MFMA=1, read per call -
-  // measured equal to k_edge_fused on 24-bit rows, profiles/r05_edge_mfma_*): big launches only, never inside k_layers_p
-  const char* em = getenv("INFGEN_EDGE_MFMA");
-  m.ra = (m.r24 && em && atoi(em) && !m.lp && rows > 4096) ? 2 : m.r24;
+  // the step's rhat rows never leave the library: fp32 rows by default (the reference's arithmetic); rhat_format 1: packed 24-bit
+  // rows (kernels.h) when both ends are the kernels that know them - a reduced-precision mode, tests/test_rollout_gpu.py compares the two
+  m.r24 = m.fuse && O().fourier_mode != 0 && O().rhat_format == 1;
+  m.ra = m.r24;
   // the temporal set's fourth input (the time gap, one of -1 .. -16) as a lookup of its branch (kernels.h: dt_mode)
   m.dt = O().fourier_mode != 0 ? r->four_t_dt : nullptr;
   return m;

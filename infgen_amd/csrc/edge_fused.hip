@@ -272,252 +272,6 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_edge_fused(EdgeFusedArgs a) {
   EF_STAMP(7);
 }
 
-// G = edges per trip of the edge loop (their K / V / rhat rows are requested together)
-// k_edge_fused_p: DIAGNOSTIC ONLY (INFGEN_EDGE_P=1|2, never the default) - a reproducer for the "wrong rows when wave groups of a CU
-// are in different phases" deviation of DESIGN.md section 5.1.  The same three phases with (1) persistent workgroups - gridDim.x workgroups walk the tile slots with stride
-// gridDim.x (a multiple of 8: a workgroup stays on its XCD) - and (2) the two 16-row halves of a workgroup DECOUPLED: each half
-// (8 waves) synchronises only with itself (a counter in LDS), so that the halves drift apart and one half's matrix phases
-// (37 us per launch when nothing overlaps them: loads of q and of the W'_kr / W'_vr fragments, MFMAs, LDS traffic) run under the
-// other half's memory-bound edge loop.  Phase 3 of a tile and phase 1 of the half's next tile touch the same LDS slices from
-// the same wave (head w of the half's 16 rows), so only two half-barriers per tile are needed.
-// Measured (tools/determinism_probe2.py, profiles/r02_decoupled_halves_probe.log): with the half-barriers ~85 % of the rows differ
-// from run to run (median 2.6e-5, up to 3e-2) although the LDS regions of the halves are disjoint and the generated code waits,
-// adds, spins and fences as written; with workgroup-wide barriers instead (INFGEN_EDGE_DBG=2: same persistent kernel, halves in
-// lockstep) it is exact and bitwise reproducible; plain shuffles instead of the permlane swaps, G = 4 (no spills) and a compiler
-// barrier after the spin loop change nothing.  It is also slower than k_edge_fused (51.9 vs 43.8 ms per rollout).
-__device__ __forceinline__ void half_barrier(int* ctr, int& epoch, int lane) {
-  ++epoch;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  if (lane == 0) atomicAdd(ctr, 1);
-  const int target = 8 * epoch;
-  while (__atomic_load_n(ctr, __ATOMIC_RELAXED) < target) __builtin_amdgcn_s_sleep(1);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // compiler barrier: no LDS access of the next phase above the spin loop
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-__device__ __forceinline__ unsigned wave_xor(unsigned v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v ^= (unsigned)__shfl_xor((int)v, o, 64);
-  return v;
-}
-
-template <int G>
-__global__ __launch_bounds__(EF_NT, 4) void k_edge_fused_p(EdgeFusedArgs a) {
-  __shared__ __attribute__((aligned(16))) float UZ[EF_ROWS * EF_LDU];
-  __shared__ __attribute__((aligned(16))) float AG[EF_ROWS * EF_LDA];     // q tile (phase 1 -> 2), then agg (phase 2 -> 3)
-  __shared__ float SG[EF_ROWS * H];
-  __shared__ int next_row2[2];
-  __shared__ int hbar[2];
-  const int ngroups = a.groups ? *a.n_groups : (a.rows + 15) / 16;        // 16-row groups; a tile takes two of them
-  const int ntiles = (ngroups + EF_HALVES - 1) / EF_HALVES;
-  // XCD-aware tile order: consecutive workgroups go to consecutive XCDs (b % 8), each with its own L2.  With tps tiles per
-  // scene, workgroups b, b + 8, ..., b + 8 (tps - 1) - one XCD - take the tiles of ONE scene, so that the scene's K / V rows
-  // (agent set: read by every row of the scene) are fetched into one L2 instead of tps of them.
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, w = tid >> 6;
-  const int j = lane & 15, g = lane >> 4;
-  const int h = w & 7, half = w >> 3, hp = h >> 1, hh = h & 1;
-  const int jl = 16 * half + j;                    // this lane's row of the LDS tiles in the matrix phases
-  if (tid < 2) { hbar[tid] = 0; next_row2[tid] = 0; }
-  __syncthreads();
-  int epoch = 0;
-  for (int vb = blockIdx.x; vb < a.n_virtual; vb += gridDim.x) {
-  int tile = vb;
-  if (a.tiles_per_scene > 1) {
-    const int tps = a.tiles_per_scene, grp = 8 * tps;
-    const int bq = tile / grp, br = tile % grp;
-    tile = bq * grp + (br % 8) * tps + br / 8;
-  }
-  const int gi_ = EF_HALVES * tile + half;
-  const int r0 = (tile < ntiles && gi_ < ngroups) ? 16 * (a.groups ? a.groups[gi_] : gi_) : -1;
-  const int row = r0 + j;
-  const bool valid = r0 >= 0 && row < a.rows;
-  const float* hdr = a.pack + AH_HDR;
-  if (h == 0 && lane == 0) next_row2[half] = 0;
-
-  // ---- phase 1: u_h = q_h W'_kr,h (K = 16: v_mfma_f32_16x16x16_f16; B fragment = the head's 16 query values of row j)
-  {
-    float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) qv = *reinterpret_cast<const float4*>(a.Q + (size_t)row * D + DH * h + 4 * g);
-    const unsigned short* Wk = reinterpret_cast<const unsigned short*>(a.pack + AH_PRE) + (size_t)(4 + hp) * QUARTER +
-                               (size_t)(hh * 8) * 2 * 256 + lane * 4;
-    v4h ah[8], al[8];
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-      ah[ct] = *reinterpret_cast<const v4h*>(Wk + (ct * 2) * 256);
-      al[ct] = *reinterpret_cast<const v4h*>(Wk + (ct * 2 + 1) * 256);
-    }
-    *reinterpret_cast<float4*>(AG + jl * EF_LDA + DH * h + 4 * g) = qv;
-    // per (row, head) power-of-two scale into the fp16 range, as frags_scaled does per row
-    float m = fmaxf(fmaxf(fabsf(qv.x), fabsf(qv.y)), fmaxf(fabsf(qv.z), fabsf(qv.w)));
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    unsigned ebits = __float_as_uint(m) >> 23;
-    ebits = min(max(ebits, 15u), 253u);
-    const float sc = __uint_as_float((268u - ebits) << 23), inv = __uint_as_float((ebits - 14u) << 23);
-    u32x2 qh, ql;
-    {
-      unsigned hi, lo;
-      split_pair(qv.x * sc, qv.y * sc, hi, lo); qh[0] = hi; ql[0] = lo;
-      split_pair(qv.z * sc, qv.w * sc, hi, lo); qh[1] = hi; ql[1] = lo;
-    }
-    const v4h vqh = __builtin_bit_cast(v4h, qh), vql = __builtin_bit_cast(v4h, ql);
-    const float cq = inv * hdr[1];
-    f32x4 acc[8];
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[ct], vqh, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[ct], vql, acc[ct], 0, 0, 0);
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(al[ct], vqh, acc[ct], 0, 0, 0);
-    float* urow = UZ + jl * EF_LDU + h * D + 4 * g;
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct)
-      *reinterpret_cast<float4*>(urow + 16 * ct) = make_float4(acc[ct][0] * cq, acc[ct][1] * cq, acc[ct][2] * cq, acc[ct][3] * cq);
-  }
-  if (a.dbg & 2) __syncthreads(); else half_barrier(&hbar[half], epoch, lane);
-
-  // ---- phase 2: edge loop, one wave per destination row of the half
-  {
-    const bool b3 = lane & 8;
-    const bool kv_once = a.kv_once != 0;
-    const unsigned lo8 = 8u * (unsigned)lane;
-    auto ld8 = [&](const float* base, bool nt) {
-      return ea_ld(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + lo8), nt);
-    };
-    // rows are dealt to the waves through an LDS counter (the agent set's lists vary in length)
-    auto take_row = [&]() {
-      int r = 0;
-      if (lane == 0) r = atomicAdd(&next_row2[half], 1);
-      return __builtin_amdgcn_readfirstlane(r);
-    };
-    for (int rq = take_row(); rq < 16; rq = take_row()) {
-      const int rl = 16 * half + rq;
-      const int drow = r0 + rq;
-      const bool live = r0 >= 0 && drow < a.rows && !(a.dbg & 1);
-      const int E = live ? __builtin_amdgcn_readfirstlane(a.es.cnt[drow]) : 0;
-      const int e_base = live ? __builtin_amdgcn_readfirstlane(a.es.off[drow]) : 0;
-      int sv = E > 0 ? a.es.src[e_base + min(lane, E - 1)] : 0;            // source indices of up to 64 edges in one register
-      float* uz = UZ + rl * EF_LDU;
-      EdgeAcc<true> acc;
-      acc.q = *reinterpret_cast<const float2*>(AG + rl * EF_LDA + 2 * lane);
-      acc.load_u(uz, lane);
-      acc.reset();
-      unsigned cld = 0;
-      if (a.dbgbuf && live) {                    // what this wave read of the row's u tile and q (written by the matrix phase)
-        unsigned cu = 0;
-#pragma unroll
-        for (int i = 0; i < H / 2; ++i)
-          cu ^= __float_as_uint(acc.ux[i][0]) ^ (__float_as_uint(acc.ux[i][1]) * 3u) ^ (__float_as_uint(acc.uy[i][0]) * 5u) ^ (__float_as_uint(acc.uy[i][1]) * 7u);
-        cu = wave_xor(cu * (2u * lane + 1u));
-        const unsigned cq_ = wave_xor((__float_as_uint(acc.q.x) ^ (__float_as_uint(acc.q.y) * 3u)) * (2u * lane + 1u));
-        if (lane == 0) { a.dbgbuf[(size_t)drow * 12 + 0] = cu; a.dbgbuf[(size_t)drow * 12 + 1] = cq_; }
-      }
-      for (int c0 = 0; c0 < E; c0 += 64) {
-        const int mc = min(64, E - c0);
-        if (c0 > 0) sv = a.es.src[e_base + c0 + min(lane, mc - 1)];        // lists beyond 64 edges: next chunk of indices
-        // G edges per trip: all their K / V / rhat rows are requested at the top of the trip (index clamped at the end of the
-        // list: no branch around the loads, the waits are counted ones) and consumed in turn; nothing is carried in registers
-        // from trip to trip (edge_attn.cuh explains why), the trip's fill latency is hidden by the SIMD's other waves.  (A
-        // tail trip of exactly the remaining length was tried: same time on lists of any raggedness - the loop is bound by
-        // its gathers, DESIGN.md section 9 - and ten spilled registers.)
-        for (int i0 = 0; i0 < mc; i0 += G) {
-          pk2 kb[G], vb[G], rb[G];
-#pragma unroll
-          for (int s = 0; s < G; ++s) {
-            const int ic = min(i0 + s, mc - 1);
-            const int sj = __builtin_amdgcn_readlane(sv, ic);
-            kb[s] = ld8(a.Ksrc + (size_t)sj * D, kv_once);
-            vb[s] = ld8(a.Vsrc + (size_t)sj * D, kv_once);
-            rb[s] = ld8(a.es.rhat + (size_t)(e_base + c0 + ic) * D, true);
-          }
-          if (a.dbgbuf) {                          // the values the loads of this trip delivered (live slots)
-#pragma unroll
-            for (int s = 0; s < G; ++s)
-              if (i0 + s < mc) {
-                const unsigned wgt = 2u * (unsigned)(c0 + i0 + s) + 1u;
-                cld ^= (__float_as_uint(kb[s][0]) ^ (__float_as_uint(kb[s][1]) * 3u) ^ (__float_as_uint(vb[s][0]) * 5u) ^
-                        (__float_as_uint(vb[s][1]) * 7u) ^ (__float_as_uint(rb[s][0]) * 9u) ^ (__float_as_uint(rb[s][1]) * 11u)) * wgt;
-              }
-          }
-#pragma unroll
-          for (int s = 0; s < G; ++s) acc.step(kb[s], vb[s], rb[s], i0 + s < mc, b3);
-        }
-      }
-      if (a.dbgbuf && live) { cld = wave_xor(cld * (2u * lane + 1u)); if (lane == 0) a.dbgbuf[(size_t)drow * 12 + 3] = cld; }
-      const float inv = 1.0f / (acc.lsum + 1e-16f);
-      if (a.dbgbuf && live) {                    // the loop's result in registers
-        unsigned cz = __float_as_uint(acc.ag[0]) ^ (__float_as_uint(acc.ag[1]) * 3u) ^ (__float_as_uint(acc.lsum) * 5u);
-#pragma unroll
-        for (int hd = 0; hd < H; ++hd) cz ^= (__float_as_uint(acc.zz[hd][0]) * (2u * hd + 7u)) ^ (__float_as_uint(acc.zz[hd][1]) * (2u * hd + 9u));
-        cz = wave_xor(cz * (2u * lane + 1u));
-        if (lane == 0) a.dbgbuf[(size_t)drow * 12 + 2] = cz;
-      }
-      *reinterpret_cast<float2*>(AG + rl * EF_LDA + 2 * lane) = make_float2(acc.ag[0] * inv, acc.ag[1] * inv);
-#pragma unroll
-      for (int hd = 0; hd < H; ++hd) {
-        const float ih = readlane_f(inv, 8 * hd);
-        *reinterpret_cast<float2*>(uz + hd * D + 2 * lane) = make_float2(acc.zz[hd][0] * ih, acc.zz[hd][1] * ih);
-      }
-      if ((lane & 7) == 0) SG[rl * H + (lane >> 3)] = acc.lsum * inv;
-    }
-  }
-  if (a.dbg & 2) __syncthreads(); else half_barrier(&hbar[half], epoch, lane);
-
-  // ---- phase 3: agg' = agg + W'_vr,h z_h + b'_h sigma_h  (k_attn_h's z-GEMM: |z| <= sqrt(127), static prescale 1024)
-  {
-    const float* zrow = UZ + jl * EF_LDU + h * D + 8 * g;
-    const unsigned short* Wv = reinterpret_cast<const unsigned short*>(a.pack + AH_POST) + (size_t)hp * QUARTER +
-                               (size_t)(hh * 4) * 2 * 512 + lane * 8;
-    v8h ah[4], al[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      ah[s] = *reinterpret_cast<const v8h*>(Wv + (s * 2) * 512);
-      al[s] = *reinterpret_cast<const v8h*>(Wv + (s * 2 + 1) * 512);
-    }
-    const float zs = 1024.0f, zinv = hdr[4] * (1.0f / 1024.0f);
-    unsigned czr = 0;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float4 z0 = *reinterpret_cast<const float4*>(zrow + 32 * s);
-      const float4 z1 = *reinterpret_cast<const float4*>(zrow + 32 * s + 4);
-      czr ^= (__float_as_uint(z0.x) ^ (__float_as_uint(z0.y) * 3u) ^ (__float_as_uint(z0.z) * 5u) ^ (__float_as_uint(z0.w) * 7u) ^
-              (__float_as_uint(z1.x) * 9u) ^ (__float_as_uint(z1.y) * 11u) ^ (__float_as_uint(z1.z) * 13u) ^ (__float_as_uint(z1.w) * 15u)) * (2u * s + 1u);
-      u32x4 bh, bl;
-      unsigned hi, lo;
-      split_pair(z0.x * zs, z0.y * zs, hi, lo); bh[0] = hi; bl[0] = lo;
-      split_pair(z0.z * zs, z0.w * zs, hi, lo); bh[1] = hi; bl[1] = lo;
-      split_pair(z1.x * zs, z1.y * zs, hi, lo); bh[2] = hi; bl[2] = lo;
-      split_pair(z1.z * zs, z1.w * zs, hi, lo); bh[3] = hi; bl[3] = lo;
-      const v8h vbh = __builtin_bit_cast(v8h, bh), vbl = __builtin_bit_cast(v8h, bl);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], vbh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], vbl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s], vbh, acc, 0, 0, 0);
-    }
-    if (a.dbgbuf) {                              // what the matrix phase read of z (row j, head h), its agg slice and sigma
-      unsigned c = czr * (2u * g + 1u);
-      c ^= (unsigned)__shfl_xor((int)c, 16, 64);
-      c ^= (unsigned)__shfl_xor((int)c, 32, 64);
-      if (valid && g == 0) a.dbgbuf[(size_t)row * 12 + 4 + h] = c;
-    }
-    if (valid) {
-      const float sg = SG[jl * H + h];
-      const float4 bvr = *reinterpret_cast<const float4*>(a.pack + AL_BVR + DH * h + 4 * g);
-      const float4 ag = *reinterpret_cast<const float4*>(AG + jl * EF_LDA + DH * h + 4 * g);
-      float4 o;
-      o.x = ag.x + (acc[0] * zinv + bvr.x * sg);
-      o.y = ag.y + (acc[1] * zinv + bvr.y * sg);
-      o.z = ag.z + (acc[2] * zinv + bvr.z * sg);
-      o.w = ag.w + (acc[3] * zinv + bvr.w * sg);
-      *reinterpret_cast<float4*>(a.AGG + (size_t)row * D + DH * h + 4 * g) = o;
-    }
-  }
-  }   // tile slots of this workgroup
-}
-
 template __global__ void k_edge_fused<4, false, 2, 16>(EdgeFusedArgs);
 template __global__ void k_edge_fused<6, false, 2, 16>(EdgeFusedArgs);
 template __global__ void k_edge_fused<8, false, 2, 16>(EdgeFusedArgs);
@@ -528,7 +282,5 @@ template __global__ void k_edge_fused<6, false, 1, 16>(EdgeFusedArgs);
 template __global__ void k_edge_fused<6, true, 1, 16>(EdgeFusedArgs);
 template __global__ void k_edge_fused<6, false, 1, 8>(EdgeFusedArgs);
 template __global__ void k_edge_fused<6, true, 1, 8>(EdgeFusedArgs);
-template __global__ void k_edge_fused_p<6>(EdgeFusedArgs);
-template __global__ void k_edge_fused_p<4>(EdgeFusedArgs);
 
 }  // namespace ig

@@ -163,38 +163,6 @@ __device__ __forceinline__ void store_rows_r24(const f32x4 (&v)[8], char* img, c
   }
 }
 
-// the same for H8 rows (kernels.h: fp16 of 2048 x, then fp8 of the remainder): same planes, same images, other bits
-__device__ __forceinline__ void store_rows_h8(const f32x4 (&v)[8], char* img, char* out, int row0, int E, int lane) {
-  const int j = lane & 15, rg = lane >> 4;
-  unsigned lo[8];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    unsigned h01, l01, h23, l23;
-    h8_pair(v[t][0], v[t][1], h01, l01);
-    h8_pair(v[t][2], v[t][3], h23, l23);
-    *reinterpret_cast<uint2*>(img + j * 272 + 32 * t + 8 * rg) = make_uint2(h01, h23);
-    lo[t] = l01 | (l23 << 16);
-  }
-  uint4 h[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) h[k] = *reinterpret_cast<const uint4*>(img + (4 * k + (lane >> 4)) * 272 + (lane & 15) * 16);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int r = row0 + 4 * k + (lane >> 4);
-    if (r < E) *reinterpret_cast<uint4*>(out + (size_t)r * H8_ROW_BYTES + (lane & 15) * 16) = h[k];
-  }
-#pragma unroll
-  for (int t = 0; t < 8; ++t) *reinterpret_cast<unsigned*>(img + j * 144 + 16 * t + 4 * rg) = lo[t];
-  uint4 l[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) l[k] = *reinterpret_cast<const uint4*>(img + (8 * k + (lane >> 3)) * 144 + (lane & 7) * 16);
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int r = row0 + 8 * k + (lane >> 3);
-    if (r < E) *reinterpret_cast<uint4*>(out + (size_t)r * H8_ROW_BYTES + H8_LO_PLANE + (lane & 7) * 16) = l[k];
-  }
-}
-
 #ifndef IG_FH_TRACE
 #define IG_FH_TRACE 0
 #endif

@@ -27,7 +27,7 @@ struct FourierArgs {
   float* out; int ldo;
   int normalize;
   unsigned long long* prof_rows;   // optional [8]: rows processed, indexed by n (profiling only)
-  int out_r24;             // k_fourier_h only: 1 rows in the packed 24-bit format (R24_ROW_BYTES per row, below) instead of fp32; 2: H8 rows
+  int out_r24;             // k_fourier_h only: 1 rows in the packed 24-bit format (R24_ROW_BYTES per row, below) instead of fp32
   // k_fourier_h only - the LAST input dim as a lookup (temporal edges: the time gap j - c is one of -1 .. -16, edge_kernels.hip):
   // dt_mode 1: dims 0 .. n - 2 are evaluated, row (int)(-raw[e][n - 1]) of dt_tab [DT_TAB_ROWS][128] is added to their sum
   //            (8 of the 4 (2 n + 1) weight quarters per tile are never staged);
@@ -72,20 +72,6 @@ struct FourierMultiArgs { FourierArgs set[4]; };      // (the fourth: the rows' 
 // (affine-free LayerNorm output): relative error 2^-17, 32 x below fp16; the edge loop is bound by the bytes it gathers.
 constexpr int R24_ROW_BYTES = 384;
 constexpr int R24_LO_PLANE = 256;
-// "H8" rows of the same embedding for k_edge_mfma (edge_mfma.hip), whose products with the rows run on the fp16 matrix pipe: the
-// same two planes and 384 bytes, but plane one holds fp16(2048 r) (round to nearest: |r| <= sqrt(127), so 2048 r < 2^15) and
-// plane two the remainder 2048 r - fp16(2048 r) as OCP fp8 e4m3 (|remainder| <= 8; three mantissa bits below the eleven of the
-// fp16: relative error 2^-16 for |r| >= 2^-6, absolute 2^-21 below) - both planes are MFMA operands as they are (the fp8 one
-// after v_cvt_scalef32_pk_f16_fp8, exact), with one common scale.  FourierArgs.out_r24 = 2 selects it.
-constexpr int H8_ROW_BYTES = 384;
-constexpr int H8_LO_PLANE = 256;
-// (x, y) -> fp16 pair `hi` and fp8 pair `lo` (low 16 bits) of the H8 form
-__device__ __forceinline__ void h8_pair(float x, float y, unsigned& hi, unsigned& lo) {
-  const float xs = x * 2048.0f, ys = y * 2048.0f;
-  const _Float16 hx = (_Float16)xs, hy = (_Float16)ys;
-  hi = (unsigned)__builtin_bit_cast(unsigned short, hx) | ((unsigned)__builtin_bit_cast(unsigned short, hy) << 16);
-  lo = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(xs - (float)hx, ys - (float)hy, 0, false) & 0xffffu;
-}
 
 // One edge set in CSR-by-destination form (built on the device every decode step).
 struct EdgeSet {
@@ -496,11 +482,8 @@ template <int WAVES, int TERMS> __global__ void k_attn_h(AttnHArgs a);
 template <int TERMS> __global__ void k_attn_hs(AttnHArgs a);             // attn_hs.hip: the same for few rows (one 16-row group per workgroup)   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);
-template <bool KV_ONCE> __global__ void k_edge_mfma(EdgeFusedArgs a);   // edge_mfma.hip (rhat rows in the H8 format)
-__global__ void k_rhat_to_h8(const float* in, int rows, char* out);
 template <int G, bool R24, int HALVES, int WAVES> __global__ void k_edge_fused(EdgeFusedArgs a);        // edge_fused.hip (R24: rhat rows in the packed format)
 template <bool R24, int ROWS> __global__ void k_layers_p(LayersPArgs a);          // layers_p.hip
-template <int G> __global__ void k_edge_fused_p(EdgeFusedArgs a);      // persistent workgroups, decoupled halves
 __global__ void k_edge_attn_wide(EdgeAttnArgs a);
 __global__ void k_attn_post(AttnPostArgs a);
 __global__ void k_heads(HeadsArgs a);

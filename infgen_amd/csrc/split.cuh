@@ -16,18 +16,18 @@ constexpr int QUARTER = 8192;            // fp16 elements of one quarter-matrix 
 constexpr int RING = 5;                  // quarter buffers in LDS (80 KB: at most one workgroup per CU)
 constexpr int DIST = RING - 1;           // quarters in flight ahead of the one being consumed
 
-__device__ __forceinline__ unsigned pk_rtz(float a, float b) {
-  return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-}
-
-// (a, b) -> packed fp16 pairs hi, lo with a = hi_a + lo_a (+ <= 2^-21 |a|): hi = a truncated to 11 significand bits
-// (the round-toward-zero conversion IS that truncation), lo = the remainder, again rounded toward zero
+// (a, b) -> packed fp16 pairs hi, lo with a = hi_a + lo_a (+ <= 2^-23 |a|): hi = a rounded to nearest even at 11 significand bits
+// (v_cvt_pk_f16_f32), lo = the remainder a - hi (exact in fp32, |a - hi| <= 2^-11 |a|) rounded to nearest even again.  Same five
+// instructions as a truncating split (round-toward-zero conversions: <= 2^-21 |a|), four times the accuracy: with both operands of a
+// product split this way, hi hi + hi lo + lo hi misses the exact product by the dropped lo lo term (<= 2^-22) plus the two
+// representation errors (<= 2^-23 each).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
-  hi = pk_rtz(a, b);
-  const f32x2 t = {__uint_as_float(__float_as_uint(a) & 0xFFFFE000u), __uint_as_float(__float_as_uint(b) & 0xFFFFE000u)};
-  const f32x2 r = f32x2{a, b} - t;
-  lo = pk_rtz(r[0], r[1]);
+  const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
+  const f32x2 r = f32x2{a, b} - __builtin_convertvector(h, f32x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
 
 // sum over lanes ^ 16, ^ 32 (the four lanes that hold one row): the gfx950 row / half swaps with both operands equal leave

@@ -370,11 +370,6 @@ class Ops:
         if wide == 'fused':         # u is the layer pack: U / Z / SIG stay on chip, agg already holds the positional part
             _lib.check(self.lib.infgen_edge_attn_fused(rows, _lib.ptr(q), _lib.ptr(u), *args[3:10], self.stream),
                        'infgen_edge_attn_fused')
-        elif wide == 'mfma':        # the same with the rows of rhat in the H8 form and the edge loop on the matrix pipe (k_edge_mfma)
-            h8 = torch.empty(max(rhat.shape[0], 1) * 384, device=rhat.device, dtype=torch.uint8)
-            _lib.check(self.lib.infgen_rhat_to_h8(_lib.ptr(rhat), rhat.shape[0], h8.data_ptr(), self.stream), 'infgen_rhat_to_h8')
-            _lib.check(self.lib.infgen_edge_attn_fused_h8(rows, _lib.ptr(q), _lib.ptr(u), *args[3:8], h8.data_ptr(), _lib.ptr(agg),
-                                                          self.stream), 'infgen_edge_attn_fused_h8')
         elif wide is None:
             _lib.check(self.lib.infgen_edge_attn(*args, self.stream), 'infgen_edge_attn')
         else:
@@ -401,7 +396,7 @@ class Ops:
         agg = sc.get('AGG', torch.empty(rows, D, device=dev))
         z = sc.get('Z', torch.empty(rows, 8 * D, device=dev))
         sig = sc.get('SIG', torch.empty(rows, 8, device=dev))
-        fused = wide in ('fused', 'mfma')
+        fused = wide == 'fused'
         if x_src is None:
             k = torch.empty(rows, D, device=dev)
             v = torch.empty(rows, D, device=dev)
@@ -1040,8 +1035,10 @@ class RolloutEngine:
                 return self._prologue(map_only=map_only)
             self._mg_checked = True
         fused = os.environ.get('INFGEN_MAP_FUSE', '1') != '0'
-        # rhat rows of the pt <-> pt edges in the packed 24-bit form when both ends know it (split Fourier kernel -> k_edge_fused)
-        r24 = fused and os.environ.get('INFGEN_NO_R24', '0') != '1' and self._fourier_split()
+        # rhat rows of the pt <-> pt edges: fp32 by default; options['rhat_format'] = 1: the packed 24-bit form when both ends know
+        # it (split Fourier kernel -> k_edge_fused), like the rollout's own edge sets (include/infgen_hip.h: InfgenOptions.rhat_format)
+        eo = self._effective_options()
+        r24 = fused and eo.rhat_format == 1 and eo.fourier_mode != 0
         if r24:
             _lib.check(self.lib.infgen_fourier_embed_r24(_lib.ptr(g['raw']), 3, _lib.ptr(g['total']), g['cap'], _lib.ptr(w.four_pt),
                                                          g['rhat'].data_ptr(), ops.stream), 'infgen_fourier_embed_r24')

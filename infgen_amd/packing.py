@@ -176,17 +176,13 @@ LN_MAX = 11.3           # max |(x - mean) / std| over 128 values is sqrt(127)
 
 
 def split_f16(x: np.ndarray):
-    """x -> (hi, lo) fp16 bit patterns with x ~= hi + lo: hi = x truncated to 11 significand bits, lo = the
-    remainder rounded toward zero - the same split the kernel applies to activations."""
+    """x -> (hi, lo) fp16 bit patterns with x ~= hi + lo (error <= 2^-23 |x|): hi = x rounded to nearest even at 11
+    significand bits, lo = the remainder x - hi (exact in fp32) rounded to nearest even - the same split the kernels
+    apply to activations (csrc/split.cuh: split_pair, v_cvt_pk_f16_f32)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
-    hi32 = (x.view(np.uint32) & np.uint32(0xFFFFE000)).view(np.float32)
-    hi = hi32.astype(np.float16)
+    hi = x.astype(np.float16)
     assert np.all(np.isfinite(hi)), 'fp16 overflow in the weight split'
-    rem = x - hi.astype(np.float32)
-    lo = rem.astype(np.float16)
-    # round toward zero like v_cvt_pkrtz
-    over = np.abs(lo.astype(np.float32)) > np.abs(rem)
-    lo = np.where(over, np.nextafter(lo, np.float16(0)), lo).astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
     return hi.view(np.uint16), lo.view(np.uint16)
 
 

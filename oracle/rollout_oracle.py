@@ -166,10 +166,10 @@ def _t(a, dtype=None):
 def map_encoder(sd: Dict[str, torch.Tensor], scene, cfg, map_vocab: np.ndarray, prefix='map_encoder') -> torch.Tensor:
     """infgen/modules/map_decoder.py:70-130 -> x_pt (M, 128)"""
     pt = scene['pt_token']
-    pos = _t(pt['position'])[:, :2].contiguous().float()
-    orient = _t(pt['orientation']).float()
+    pos = _t(pt['position'])[:, :2].contiguous().to(torch.get_default_dtype())
+    orient = _t(pt['orientation']).to(torch.get_default_dtype())
     ovec = torch.stack([orient.cos(), orient.sin()], dim=-1)
-    tok = mlp_embedding(sd, prefix + '.token_emb', _t(map_vocab).float().view(map_vocab.shape[0], -1))
+    tok = mlp_embedding(sd, prefix + '.token_emb', _t(map_vocab).to(torch.get_default_dtype()).view(map_vocab.shape[0], -1))
     x = tok[_t(pt['token_idx']).long()]
     e = scene['pt_token__to__map_polygon']['edge_index']
     light = _t(scene['map_polygon']['light_type']).long()[_t(e).long()[1]]
@@ -198,7 +198,7 @@ class RolloutOracle:
     def __init__(self, sd: Dict[str, torch.Tensor], cfg, grid: np.ndarray, prefix: str = 'agent_encoder',
                  live_state: bool = False, all_columns: bool = False):
         self.sd, self.cfg, self.p = sd, cfg, prefix
-        self.grid = _t(grid).float()
+        self.grid = _t(grid).to(torch.get_default_dtype())
         self.live_state = live_state
         # "reference-shaped" control flow (CPU baseline only): every decode step pushes ALL A*T nodes through the
         # 18 layers like agent_decoder.py:2133-2158 does (edges only into column c; the other columns' outputs are discarded
@@ -214,7 +214,7 @@ class RolloutOracle:
         no = sd[p + '.no_token_emb.weight']
         tabs = []
         for name in ('veh', 'ped', 'cyc'):
-            v = _t(vocab[name]).float()
+            v = _t(vocab[name]).to(torch.get_default_dtype())
             e = mlp_embedding(sd, f'{p}.token_emb_{name}', v[:, -1].flatten(1, 2))
             tabs.append(torch.cat([e, bos, no]))
         grid_tab = torch.cat([mlp_embedding(sd, p + '.token_emb_grid', self.grid),
@@ -284,7 +284,7 @@ class RolloutOracle:
         dp[s_inv & d_inv] = INVALID_MOTION
         dth[s_inv & d_inv] = INVALID_HEAD
         hv = self._hv(st, rows, c)
-        r = torch.stack([torch.norm(dp, p=2, dim=-1), angle_between(hv, dp), dth, (js - c).float()], dim=-1)
+        r = torch.stack([torch.norm(dp, p=2, dim=-1), angle_between(hv, dp), dth, (js - c).to(torch.get_default_dtype())], dim=-1)
         r = fourier_embedding(sd, p + '.r_t_emb', r) if rows.numel() else torch.zeros(0, 128)
         return js, rows, r
 
@@ -394,14 +394,14 @@ class RolloutOracle:
                 return x
             shp = (x.shape[0], T - x.shape[1]) + tuple(x.shape[2:])
             return torch.cat([x, torch.full(shp, val, dtype=x.dtype)], dim=1)
-        pos = pad(take('token_pos', torch.float32), 0.0)
-        head = pad(take('token_heading', torch.float32), 0.0)
+        pos = pad(take('token_pos', torch.get_default_dtype()), 0.0)
+        head = pad(take('token_heading', torch.get_default_dtype()), 0.0)
         token = pad(take('token_idx', torch.long), -1)
         state = pad(state0[filt].clone(), INVALID)
         gridtok = pad(take('grid_token_idx', torch.long), -1)
         valid = pad(take('raw_agent_valid_mask', torch.bool), True)
         atype = take('type', torch.long)
-        shape10 = _t(ag['shape'])[filt][:, cfg.num_historical_steps - 1].float()
+        shape10 = _t(ag['shape'])[filt][:, cfg.num_historical_steps - 1].to(torch.get_default_dtype())
         eval_mask = _t(ag['valid_mask'])[filt][:, cfg.num_historical_steps - 1]
         A = pos.shape[0]
         hc = cfg.hist_columns  # 2
@@ -444,11 +444,11 @@ class RolloutOracle:
         st = dict(pos=pos, head=head, token=token, state=state, gridtok=gridtok, type=atype,
                   tmask=tmask, imask=imask, type_emb=type_emb, shape_emb=shape_emb,
                   tok_tab=tok_tab, grid_tab=grid_tab, x_pt=x_pt,
-                  map_pos=_t(scene['pt_token']['position'])[:, :2].contiguous().float(),
-                  map_orient=_t(scene['pt_token']['orientation']).float(),
+                  map_pos=_t(scene['pt_token']['position'])[:, :2].contiguous().to(torch.get_default_dtype()),
+                  map_orient=_t(scene['pt_token']['orientation']).to(torch.get_default_dtype()),
                   X=[torch.zeros(A, T, cfg.hidden_dim) for _ in range(cfg.num_agent_layers)],
                   edge_count=[])
-        tabs = torch.stack([_t(vocab[k]).float() for k in ('veh', 'ped', 'cyc')])   # (3, 2048, 6, 4, 2)
+        tabs = torch.stack([_t(vocab[k]).to(torch.get_default_dtype()) for k in ('veh', 'ped', 'cyc')])   # (3, 2048, 6, 4, 2)
 
         # column 0: edgeless chain (a-Q3); column 1 is the first current column
         self.run_stack(st, 0, self.raw_feature(st, 0), edgeless=True)
@@ -472,7 +472,7 @@ class RolloutOracle:
                 # top-k probabilities driven by caller-supplied uniforms (torch RNG cannot be bit-matched)
                 pk, ik = torch.topk(prob, k=sample_k, dim=-1)
                 cdf = torch.cumsum(pk, dim=-1)
-                u = _t(sample_uniforms[t, :prob.shape[0]]).float() * cdf[:, -1]
+                u = _t(sample_uniforms[t, :prob.shape[0]]).to(torch.get_default_dtype()) * cdf[:, -1]
                 pick = (u[:, None] >= cdf).sum(-1).clamp(max=sample_k - 1)
                 next_tok = ik.gather(1, pick[:, None])[:, 0]
                 self.sample_margin = getattr(self, 'sample_margin', []) + [((u[:, None] - cdf).abs().min(-1)[0] / cdf[:, -1]).numpy()]
@@ -494,7 +494,7 @@ class RolloutOracle:
             diff = contour[:, 1:, 0, :] - contour[:, 1:, 3, :]
             pred_traj[:, t * 5:(t + 1) * 5] = contour[:, 1:].mean(dim=2)
             pred_head[:, t * 5:(t + 1) * 5] = torch.arctan2(diff[:, :, 1], diff[:, :, 0])
-            pred_state[:, t * 5:(t + 1) * 5] = nstate[:, None].float().repeat(1, 5)
+            pred_state[:, t * 5:(t + 1) * 5] = nstate[:, None].to(torch.get_default_dtype()).repeat(1, 5)
             pos[:, n] = contour[:, -1].mean(dim=1)
             d = contour[:, -1, 0, :] - contour[:, -1, 3, :]
             th_n = torch.arctan2(d[:, 1], d[:, 0])
@@ -520,9 +520,9 @@ class RolloutOracle:
         pred_traj = torch.cat([torch.zeros(A, H, 2), pred_traj], dim=1)
         pred_head = torch.cat([torch.zeros(A, H), pred_head], dim=1)
         pred_state = torch.cat([torch.zeros(A, H), pred_state], dim=1)
-        pred_traj[:, 0] = _t(ag['position'])[filt][:, 0, :2].float()
-        pred_head[:, 0] = _t(ag['heading'])[filt][:, 0].float()
-        pred_state[:, 1:H] = state0[filt][:, :hc].repeat_interleave(cfg.shift, dim=1).float()
+        pred_traj[:, 0] = _t(ag['position'])[filt][:, 0, :2].to(torch.get_default_dtype())
+        pred_head[:, 0] = _t(ag['heading'])[filt][:, 0].to(torch.get_default_dtype())
+        pred_state[:, 1:H] = state0[filt][:, :hc].repeat_interleave(cfg.shift, dim=1).to(torch.get_default_dtype())
         htok = _t(ag['token_idx'])[filt][:, :hc].long().clone()
         htok[htok < 0] = 0
         hcont = tabs[atype[:, None].expand(A, hc), htok]                        # (A, hc, 6, 4, 2)
@@ -535,7 +535,7 @@ class RolloutOracle:
         return dict(
             ego_index=av, agent_id=_t(ag['id'])[filt].clone(), valid_mask=valid, pos_a=pos, head_a=head,
             pred_traj=pred_traj, pred_head=pred_head, pred_state=pred_state, pred_valid=pred_valid,
-            pred_type=atype, pred_shape=_t(ag['shape'])[filt][:, hc - 1].float(), eval_shape=eval_shape,
+            pred_type=atype, pred_shape=_t(ag['shape'])[filt][:, hc - 1].to(torch.get_default_dtype()), eval_shape=eval_shape,
             next_token_idx=torch.cat(tok_hist, dim=-1), next_state_idx=torch.cat(st_hist, dim=-1),
             logits=torch.stack(logits_all), edge_count=np.asarray(st['edge_count'], dtype=np.int64),
             X=st['X'], imask=imask, tmask=tmask, gridtok=gridtok,

@@ -1,0 +1,257 @@
+"""GPU: is the fp16 hi/lo split "narrower than fp32" in effect?  
+
+The reference computes in fp32 end to end (infgen/modules/layers.py:61-113; run.py never passes a precision).  The
+library's hot GEMM kernels feed the f16 matrix pipe with every fp32 operand split into two fp16 numbers (hi = round to
+nearest even, lo = round to nearest even of the exact remainder: csrc/split.cuh split_pair, packing.split_f16) and
+accumulate hi hi + hi lo + lo hi in fp32; the fp32-input MFMA kernels (infgen_set_fourier_mode(0) / attn_mode 0) run the
+same operators with fp32 operands.  Each test runs ONE operator on the SAME inputs through both kernel families and
+compares both with an fp64 evaluation of the reference operator (oracle/rollout_oracle.py under
+torch.set_default_dtype(float64)):
+
+    max |split - fp64|  <=  1.5 x max |fp32 MFMA - fp64|
+
+i.e. the split kernels' error is fp32 round-off, not a lower precision.  The measured pairs go to
+gpurun_out/precision_r06.json (copied to profiles/ by the builder).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_case, make_weights
+
+pytestmark = pytest.mark.gpu
+
+RATIO = 1.5
+FLOOR = 2e-7          # absolute slack (one fp32 ulp of the O(1) outputs): both errors at the noise floor
+
+
+@pytest.fixture(scope='module')
+def env():
+    from infgen_amd import _lib, packing, engine
+    assert torch.cuda.is_available(), 'these tests need the GPU box'
+    dev = torch.device('cuda:0')
+    sd = make_weights(seed=3)
+    tsd64 = {k: torch.from_numpy(v).double() if v.dtype.kind == 'f' else torch.from_numpy(v) for k, v in sd.items()}
+    return dict(lib=_lib.load(), packing=packing, ops=engine.Ops(dev), dev=dev, sd=sd, tsd64=tsd64)
+
+
+class _f64:
+    """oracle operators evaluated in float64 (the oracle allocates with torch's default dtype)"""
+
+    def __enter__(self):
+        self.old = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+
+    def __exit__(self, *exc):
+        torch.set_default_dtype(self.old)
+        return False
+
+
+def _modes(env, **kw):
+    """the calling thread's option block for the operator-level entries (no process-wide state is edited)"""
+    import ctypes as C
+    from infgen_amd import _lib
+    o = _lib.Options()
+    _lib.check(env['lib'].infgen_get_options(C.byref(o)))
+    for k, v in kw.items():
+        setattr(o, k, int(v))
+    o.use = 0
+    return _lib.thread_options(o)
+
+
+def _dev(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+def _record(name, **vals):
+    d = os.path.join(REPO, 'gpurun_out')
+    if not os.path.isdir(d):
+        return
+    p = os.path.join(d, 'precision_r06.json')
+    try:
+        with open(p) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        rec = {}
+    rec[name] = {k: float(v) for k, v in vals.items()}
+    with open(p, 'w') as f:
+        json.dump(rec, f, indent=1, sort_keys=True)
+
+
+def _judge(name, split, fp32, ref64):
+    ref = np.asarray(ref64, np.float64)
+    es = float(np.abs(np.asarray(split, np.float64) - ref).max())
+    ef = float(np.abs(np.asarray(fp32, np.float64) - ref).max())
+    rs = float(np.sqrt(np.mean((np.asarray(split, np.float64) - ref) ** 2)))
+    rf = float(np.sqrt(np.mean((np.asarray(fp32, np.float64) - ref) ** 2)))
+    _record(name, max_err_split=es, max_err_fp32_mfma=ef, rms_err_split=rs, rms_err_fp32_mfma=rf, scale=float(np.abs(ref).max()))
+    assert es <= RATIO * ef + FLOOR, (name, 'split', es, 'fp32 MFMA', ef)
+    assert rs <= RATIO * rf + FLOOR, (name, 'rms: split', rs, 'fp32 MFMA', rf)
+    return es, ef
+
+
+# ------------------------------------------------------------------------------------------ FourierEmbedding
+@pytest.mark.parametrize('n,prefix,E', [(2, 'agent_encoder.x_a_emb', 20000), (3, 'agent_encoder.r_a2a_emb', 70001),
+                                        (4, 'agent_encoder.r_t_emb', 70001), (3, 'map_encoder.r_pt2pt_emb', 200000)],
+                         ids=['x_a(n=2)', 'a2a(n=3)', 't(n=4)', 'pt2pt(n=3,three-wave-group kernel)'])
+@pytest.mark.parametrize('normalize', [False, True], ids=['plain', 'normalised'])
+def test_fourier_split_error_is_fp32_round_off(env, n, prefix, E, normalize):
+    """k_fourier_h (E < 150 k) / k_fourier_h12 (E = 200 k) against k_fourier, reference layers.py:142-160 (+ the affine-free
+    LayerNorm the edge kernels consume).  Inputs in the rollout's ranges: distances up to 60 m, angles, time gaps -1 .. -12"""
+    from oracle import rollout_oracle as ro
+    rng = np.random.default_rng(100 + n)
+    raw = np.zeros((E, 4), np.float32)
+    raw[:, 0] = rng.uniform(0, 60, E)
+    raw[:, 1:n] = rng.uniform(-np.pi, np.pi, (E, n - 1))
+    if n == 4:
+        raw[:, 3] = -rng.integers(1, 13, E)
+    dev = env['dev']
+    pack = _dev(env['packing'].pack_fourier(env['sd'], prefix, n), dev)
+    outs = {}
+    for mode in (1, 0):
+        with _modes(env, fourier_mode=mode):
+            o = torch.empty(E, 128, device=dev)
+            env['ops'].fourier(_dev(raw, dev), n, pack, o, normalize=normalize)
+            outs[mode] = o.cpu().numpy()
+    with _f64(), torch.no_grad():
+        ref = ro.fourier_embedding(env['tsd64'], prefix, torch.from_numpy(raw[:, :n]).double())
+        if normalize:
+            ref = torch.nn.functional.layer_norm(ref, (128,))
+    assert not np.array_equal(outs[1], outs[0])          # (two different kernels ran)
+    _judge(f'fourier[{prefix},n={n},E={E},{"norm" if normalize else "plain"}]', outs[1], outs[0], ref.numpy())
+
+
+# ------------------------------------------------------------------------------------------ AttentionLayer
+def _graph(rng, n_dst, n_src, max_deg):
+    cnt = rng.integers(0, max_deg + 1, n_dst).astype(np.int32)
+    cnt[[0, 7, n_dst - 1]] = 0
+    off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int32)
+    src = rng.integers(0, n_src, int(cnt.sum())).astype(np.int32)
+    dst = np.repeat(np.arange(n_dst, dtype=np.int64), cnt)
+    return off, cnt, src, dst
+
+
+@pytest.mark.parametrize('rows,split_mode', [(12000, 1), (512, 3)], ids=['k_attn_h + k_edge_fused(big)', 'k_attn_hs + k_edge_fused(small)'])
+@pytest.mark.parametrize('prefix,bip', [('agent_encoder.a2a_attn_layers.2', False), ('agent_encoder.pt2a_attn_layers.1', True),
+                                        ('agent_encoder.t_attn_layers.0', False)])
+def test_attention_layer_split_error_is_fp32_round_off(env, rows, split_mode, prefix, bip):
+    """One AttentionLayer.forward (reference layers.py:61-113) three ways on the same inputs:
+      split       k_attn_h / k_attn_hs node GEMMs + k_edge_fused (u = q W'_kr and W'_vr z on the split matrix pipe: phases 1 / 3)
+      edge-split  fp32-MFMA node kernels + k_edge_fused: only phases 1 / 3 of the edge kernel are split arithmetic
+      fp32        fp32-MFMA node kernels + the unfused edge kernel (U and W'_vr Z by the fp32-MFMA kernels, fp32 vector edge loop)
+    each against the fp64 operator"""
+    from oracle import rollout_oracle as ro
+    rng = np.random.default_rng(rows + len(prefix))
+    n_src = 3000 if bip else rows
+    x = rng.standard_normal((rows, 128)).astype(np.float32)
+    xs = rng.standard_normal((n_src, 128)).astype(np.float32) if bip else None
+    off, cnt, src, dst = _graph(rng, rows, n_src, 40)
+    r = (rng.standard_normal((len(src), 128)) * rng.uniform(0.3, 3.0, (len(src), 1))).astype(np.float32)
+    dev = env['dev']
+    pack = _dev(env['packing'].pack_attention_layer(env['sd'], prefix), dev)
+    # the kernels take the affine-free LayerNorm of r (written by the Fourier kernel in the rollout); evaluated in fp64 and rounded
+    # once, so that all three variants and the reference start from the same fp32 rows
+    rhat = torch.nn.functional.layer_norm(torch.from_numpy(r).double(), (128,)).float()
+    offd, cntd, srcd = (torch.from_numpy(a).to(dev) for a in (off, cnt, src))
+    rhd = rhat.to(dev).contiguous()
+    outs = {}
+    for tag, mode, wide in (('split', split_mode, 'fused'), ('edge-split', 0, 'fused'), ('fp32', 0, False)):
+        with _modes(env, attn_mode=mode):
+            xd = _dev(x, dev)
+            env['ops'].attention_layer(xd, pack, offd, cntd, srcd, rhd, x_src=_dev(xs, dev) if bip else None, wide=wide)
+            outs[tag] = xd.cpu().numpy()
+    with _f64(), torch.no_grad():
+        # the reference operator on r itself (its attn_prenorm_r = the affine LayerNorm of r); the one rounding of rhat to fp32 is
+        # common to the three variants
+        ref = ro.attention_layer(env['tsd64'], prefix, torch.from_numpy(x).double(), torch.from_numpy(r).double(),
+                                 torch.from_numpy(src).long(), torch.from_numpy(dst),
+                                 x_src_raw=torch.from_numpy(xs).double() if bip else None).numpy()
+    name = f'attention[{prefix},rows={rows}]'
+    _judge(name + ':node+edge split', outs['split'], outs['fp32'], ref)
+    _judge(name + ':edge phases 1/3 split', outs['edge-split'], outs['fp32'], ref)
+
+
+# ------------------------------------------------------------------------------------------ heads
+def test_heads_split_error_is_fp32_round_off(env):
+    """k_heads_h against k_heads: token_predict_head logits (reference agent_decoder.py:2161-2167, layers.py:195-215)"""
+    from oracle import rollout_oracle as ro
+    from infgen_amd import _lib
+    rng = np.random.default_rng(13)
+    rows = 12000
+    x = rng.standard_normal((rows, 128)).astype(np.float32)
+    dev = env['dev']
+    tokp = _dev(env['packing'].pack_mlp_layer(env['sd'], 'agent_encoder.token_predict_head'), dev)
+    stp = _dev(env['packing'].pack_mlp_layer(env['sd'], 'agent_encoder.state_predict_head', row_major_out=True), dev)
+    outs = {}
+    for mode in (1, 0):
+        with _modes(env, attn_mode=mode):
+            logits = torch.empty(rows, 2048, device=dev)
+            nt = torch.zeros(rows, dtype=torch.int32, device=dev)
+            ns = torch.zeros(rows, dtype=torch.int32, device=dev)
+            _lib.check(env['lib'].infgen_heads(_dev(x, dev).data_ptr(), rows, tokp.data_ptr(), stp.data_ptr(), 2048,
+                                               logits.data_ptr(), nt.data_ptr(), ns.data_ptr(), env['ops'].stream))
+            outs[mode] = logits.cpu().numpy()
+    with _f64(), torch.no_grad():
+        ref = ro.mlp_layer(env['tsd64'], 'agent_encoder.token_predict_head', torch.from_numpy(x).double()).numpy()
+    assert not np.array_equal(outs[1], outs[0])
+    _judge('heads[token_predict_head,rows=12000]', outs[1], outs[0], ref)
+
+
+# ------------------------------------------------------------------------------------------ MLPEmbedding
+@pytest.mark.parametrize('rows', [12000, 300])
+def test_mlp_embedding_split_error_is_fp32_round_off(env, rows):
+    """k_mlpemb_h against three k_linear launches: fusion_emb (reference layers.py:163-192, agent_decoder.py:2286)"""
+    from oracle import rollout_oracle as ro
+    from infgen_amd import _lib
+    rng = np.random.default_rng(rows)
+    x = rng.standard_normal((rows, 512)).astype(np.float32)
+    dev = env['dev']
+    pack = _dev(env['packing'].pack_mlp_embedding(env['sd'], 'agent_encoder.fusion_emb'), dev)
+    outs = {}
+    for mode in (1, 0):
+        with _modes(env, attn_mode=mode):
+            y = torch.empty(rows, 128, device=dev)
+            t1, t2 = torch.empty(rows, 128, device=dev), torch.empty(rows, 128, device=dev)
+            _lib.check(env['lib'].infgen_mlp_embedding(_dev(x, dev).data_ptr(), 512, rows, 512, pack.data_ptr(), t1.data_ptr(),
+                                                       t2.data_ptr(), y.data_ptr(), 128, env['ops'].stream))
+            outs[mode] = y.cpu().numpy()
+    with _f64(), torch.no_grad():
+        ref = ro.mlp_embedding(env['tsd64'], 'agent_encoder.fusion_emb', torch.from_numpy(x).double()).numpy()
+    assert not np.array_equal(outs[1], outs[0])
+    _judge(f'mlp_embedding[fusion_emb,rows={rows}]', outs[1], outs[0], ref)
+
+
+# ------------------------------------------------------------------------------------------ k_layers_p / whole decode steps
+def test_rollout_logits_split_error_is_fp32_round_off():
+    """Whole decode steps: the logits of a free-running 8-scene rollout through
+      k_layers_p        (the 18 sublayers of a step in one launch, split arithmetic: the default of small batches)
+      per-sublayer      (k_attn_hs + k_edge_fused, split arithmetic)
+      fp32 MFMA         (fourier_mode 0, attn_mode 0, unfused edge kernel: fp32 operands everywhere)
+    against the fp64 oracle rollout of every scene (reference agent_decoder.py:1605-2389).  All four decode the same tokens."""
+    from infgen_amd import engine, synth
+    from oracle import rollout_oracle as ro
+    c = load_case('c2_a32_m512')
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], c['cfg'], dev)
+    scenes = [synth.make_scene(4100 + i, 24 + i, 200, c['cfg'], vocab=c['vocab'], grid=c['grid'], slip=0.2) for i in range(8)]
+    variants = {'k_layers_p': dict(layers_p=1), 'per-sublayer split': dict(layers_p=0),
+                'fp32 MFMA': dict(layers_p=0, fourier_mode=0, attn_mode=0, edge_fuse=0)}
+    outs = {}
+    for tag, opt in variants.items():
+        e = engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=True, options=opt, use_graph=False)
+        e.rollout()
+        outs[tag] = e.outputs()
+        del e
+    with _f64(), torch.no_grad():
+        sd64 = {k: torch.from_numpy(v).double() if v.dtype.kind == 'f' else torch.from_numpy(v) for k, v in c['sd'].items()}
+        refs = [ro.run_scene(sd64, sc, c['cfg'], c['vocab'], c['map_vocab'], c['grid']) for sc in scenes]
+    for tag in variants:
+        for o, r in zip(outs[tag], refs):
+            assert np.array_equal(o['next_token_idx'], r['next_token_idx'].numpy()), tag
+    cat = lambda tag: np.concatenate([o['logits'].reshape(-1) for o in outs[tag]])
+    ref = np.concatenate([r['logits'].numpy().reshape(-1) for r in refs])
+    _judge('rollout logits: k_layers_p', cat('k_layers_p'), cat('fp32 MFMA'), ref)
+    _judge('rollout logits: per-sublayer split kernels', cat('per-sublayer split'), cat('fp32 MFMA'), ref)
