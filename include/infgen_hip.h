@@ -45,8 +45,13 @@
  * Conventions: every pointer is a DEVICE pointer (fp32 / int32 / uint8) borrowed for the duration
  * of the call; outputs are pre-allocated by the caller; `stream` is a hipStream_t; nothing
  * synchronises with the host; functions return 0 on success or a negative code and leave a message
- * retrievable with infgen_last_error() (thread-local).  The only process-wide state are the switches
- * infgen_set_* (kernel choice, arithmetic, overlap, padded-row lists): they are read at launch time.
+ * retrievable with infgen_last_error() (thread-local).
+ * Re-entrancy: every switch that changes what a launch computes (kernel family, arithmetic, rhat row format, overlap, padded-row lists)
+ * is a field of InfgenOptions.  A rollout context carries its own block (InfgenRollout.opts, use = 1) and a thread may install one for
+ * the operator-level entries (infgen_thread_options): contexts with different arithmetic coexist in one process.  The infgen_set_*
+ * functions only edit the process-wide DEFAULT block that contexts / threads without their own inherit.  Environment variables
+ * (INFGEN_*) are tuning thresholds and diagnostics of the launch shapes (which kernel variant from how many rows); each is read once
+ * per process and none changes the arithmetic.
  */
 #ifndef INFGEN_HIP_H_
 #define INFGEN_HIP_H_
@@ -257,9 +262,11 @@ int infgen_set_overlap(int mode);
  * rounding-level differences only.  Needs fused edge attention (infgen_set_edge_fuse != 0) and the split GEMM kernels; otherwise
  * the per-sublayer launches run (a row-group list of an insertion context is ignored by this kernel: it visits every group).
  * Process-wide default like the other infgen_set_*: a context with opts.use != 0 takes InfgenOptions.layers_p instead.
- * Concurrency: a launch never exceeds the workgroups the device keeps resident for this kernel (occupancy query x CUs), the
- * launches of different streams of one process are ordered behind each other by the library, and the wait at the counters has no
- * time limit - contexts may run concurrently on several streams or host threads, next to other kernels (tests/test_rollout_gpu.py).
+ * Concurrency: a launch never exceeds the workgroups the CURRENT device keeps resident for this kernel (occupancy query x CUs; also on
+ * partitions with fewer CUs), the launches of different streams of one process are ordered behind each other by the library (an event
+ * recorded behind every launch on its own stream - no stream handle is kept), and the wait at the counters is bounded only by a
+ * trap after 2^24 polls (tens of seconds; INFGEN_LP_SPIN_LIMIT) - contexts may run concurrently on several streams or host threads,
+ * next to other kernels (tests/test_rollout_gpu.py).
  * mode 2: the same through hipLaunchCooperativeKernel (device-wide cooperative queue: also safe next to ANOTHER PROCESS that runs
  * such kernels on the same GPU; ~25 us more per launch; a runtime that refuses the launch gets the per-sublayer launches from
  * then on).  (A stream that is being captured into a HIP graph takes a plain launch with a bounded wait: graph replay is an

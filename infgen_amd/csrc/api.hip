@@ -7,6 +7,7 @@
 #include <vector>
 #include <atomic>
 #include <mutex>
+#include <unordered_map>
 #include "kernels.h"
 #include "../../include/infgen_hip.h"
 
@@ -93,11 +94,13 @@ struct Prof {
 } g_prof;
 
 static thread_local int t_prof_phase = 0;       // 1: the calling thread is inside a decode step (ProfPhase below)
+static std::mutex g_prof_mu;                    // slot allocation and the launch counters (two host threads may drive two contexts)
 struct ProfScope {
   int slot = -1;
   hipStream_t s;
   ProfScope(int kid, void* stream, double macs = 0.0) : s((hipStream_t)stream) {
     if ((g_prof.mask >> kid) & 1u) {
+      std::lock_guard<std::mutex> lk(g_prof_mu);
       ++g_prof.seen[kid];
       // an event pair costs ~5 us of launch-stream time: inside the timed region only every stride-th decode-step launch carries one
       const bool take = t_prof_phase != 1 || (g_prof.seen_step[kid]++ % g_prof.stride) == 0;
@@ -1096,52 +1099,74 @@ static int lp_max_groups() {
 //    layers_p_shape) - what fits becomes resident as soon as kernels of other streams leave the CUs, so the wait at the counters
 //    has no limit (no trap);
 //  * launches of different streams of this process are ordered behind each other (two half-resident launches would wait for each
-//    other for ever): g_lp_mu / g_lp_ev below;
+//    other for ever): g_lp_mu / g_lp_order below (an event recorded behind every launch on its own stream);
 //  * layers_p == 2 additionally launches through hipLaunchCooperativeKernel (the runtime's own residency contract, and the
 //    cooperative queue is device-wide - this also covers another PROCESS running such a kernel on the same GPU); measured cost of
 //    the queue hand-over: 8 scenes 9.54 -> 9.97 ms per rollout, 64 scenes 17.01 -> 17.36 (tools/lp_coop_ab.sh).  A refused
 //    cooperative launch falls back to the per-sublayer kernels for good (g_lp_refused).
 static std::atomic<bool> g_lp_refused{false};
-static std::mutex g_lp_mu;                  // orders the k_layers_p launches of the process's streams
-static hipEvent_t g_lp_ev = nullptr;        // recorded behind the last k_layers_p launch
-static hipStream_t g_lp_last = nullptr;     // ... on this stream
-static bool g_lp_any = false;
-struct LpDevice { int n_cu = 1; int coop = 0; int wg_per_cu = 0; };
+static std::mutex g_lp_mu;                  // orders the k_layers_p launches of the process's streams (per device: LpOrder)
+constexpr int LP_MAX_DEVICES = 16;
+struct LpOrder { hipEvent_t ev = nullptr; bool any = false; };     // ev: recorded behind the device's last k_layers_p launch, on the
+static LpOrder g_lp_order[LP_MAX_DEVICES];                         // stream that launched it (no stream handle is kept)
+struct LpDevice { bool init = false; int n_cu = 1; int coop = 0; int wg_per_cu = 0; };
+static int lp_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  return dev < 0 || dev >= LP_MAX_DEVICES ? 0 : dev;
+}
 static const LpDevice& lp_device() {
-  static LpDevice d = [] {
-    LpDevice v;
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+  static LpDevice devs[LP_MAX_DEVICES];
+  static std::mutex mu;
+  const int dev = lp_current_device();
+  std::lock_guard<std::mutex> lk(mu);
+  LpDevice& v = devs[dev];
+  if (!v.init) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
       v.n_cu = prop.multiProcessorCount;
       (void)hipDeviceGetAttribute(&v.coop, hipDeviceAttributeCooperativeLaunch, dev);
       // resident workgroups per CU of the largest variant (the 120 KB of LDS set it: 1)
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v.wg_per_cu, k_layers_p<true, 16>, 512, 0) != hipSuccess) v.wg_per_cu = 0;
-      (void)hipGetLastError();
     }
-    return v;
-  }();
-  return d;
+    (void)hipGetLastError();
+    v.init = true;
+  }
+  return v;
 }
-extern "C" int infgen_layers_p_capacity(void) {       // workgroups one k_layers_p launch may have on this device (0: not available)
+extern "C" int infgen_layers_p_capacity(void) {       // workgroups one k_layers_p launch may have on the current device (0: not available)
   const LpDevice& d = lp_device();
   if (d.wg_per_cu <= 0) return 0;
   return d.n_cu * (d.wg_per_cu > 1 ? 1 : d.wg_per_cu);      // (the launch shapes assume one workgroup per CU)
 }
+// workgroups a launch may have: the device's resident capacity (a partition with fewer CUs than 256 - DPX / QPX / CPX modes, smaller
+// parts - lowers it), and INFGEN_LP_MAX_GROUPS
+static int lp_limit() {
+  const int cap = infgen_layers_p_capacity(), mx = lp_max_groups();
+  return cap < mx ? cap : mx;
+}
 // k_layers_p bounds a row's LayerNorm output with header slots 10..13 of the attention packs; a pack without them (an older or
 // foreign packer: slot 14 != AH_HDR_VERSION) would scale its operands by 2^126.  Checked once per pack pointer (a 64-byte
 // device -> host copy at a context's first launch); contexts with such a pack take the per-sublayer launches.
-static bool lp_packs_ok(const InfgenRollout* r, bool refresh = false) {
+static bool lp_packs_ok(const InfgenRollout* r, bool refresh = false, void* stream = nullptr) {
   static std::mutex mu;
-  static std::vector<std::pair<const float*, bool>> seen;
+  static std::unordered_map<const float*, bool> seen;      // verdict per pack address, overwritten in place on refresh
   std::lock_guard<std::mutex> lk(mu);
+  // a pack that was never examined needs a synchronous 64-byte copy: not while `stream` is being captured into a graph (the copy
+  // would fail and the verdict would stick) - such a launch takes the per-sublayer kernels, the verdict stays open
+  bool capturing = false;
+  if (stream) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    capturing = hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  }
   auto ok = [&](const float* pack) {
     if (!pack) return false;
-    for (auto& e : seen) if (e.first == pack) { if (!refresh) return e.second; e.first = nullptr; }      // (refresh: look again)
+    if (!refresh) { auto it = seen.find(pack); if (it != seen.end()) return it->second; }
+    if (capturing) return false;
     float hdr[16] = {};
     const bool good = hipMemcpy(hdr, pack + AH_HDR, sizeof(hdr), hipMemcpyDeviceToHost) == hipSuccess && hdr[14] == AH_HDR_VERSION &&
                       hdr[10] > 0.f && hdr[12] > 0.f;
-    if (seen.size() > 4096) seen.clear();
-    seen.emplace_back(pack, good);
+    seen[pack] = good;
     return good;
   };
   for (int i = 0; i < r->num_layers; ++i)
@@ -1155,10 +1180,9 @@ extern "C" int infgen_rollout_validate(const InfgenRollout* r) {
   (void)lp_packs_ok(r, true);
   return 0;
 }
-static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless) {
+static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless, void* stream) {
   const LpDevice& lpd = lp_device();
   if (lpd.wg_per_cu <= 0 || (O().layers_p == 2 && (!lpd.coop || g_lp_refused.load()))) return false;
-  const int n_cu = lpd.n_cu;
   // all workgroups must be resident at once (they meet at per-scene counters): at most one workgroup per CU (120 KB of LDS each).
   // Up to that limit the one-launch kernel wins at every size measured (scenes of 64 agents, ms per rollout, k_layers_p vs the
   // per-sublayer launches): 8 scenes 10.7 / 15.4, 16: 11.7 / 16.4, 32: 13.7 / 18.0 (8 rows per workgroup), 48: 16.8 / 20.1,
@@ -1166,18 +1190,17 @@ static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless) {
   // sat at ~40 scenes: 2,048 L2 write-backs per layer.)  INFGEN_LP_MAX_GROUPS lowers the limit.
   // (a row-group list of an insertion context is ignored: the launch visits every group - the ones without agents have empty edge
   // lists and run in parallel on CUs that would idle)
-  const int max_groups = lp_max_groups();
   return O().layers_p && O().edge_fuse != 0 && O().attn_mode != 0 && O().gemm_terms == 3 && O().fourier_mode != 0 &&
-         !(O().overlap && g_side) && r->A_cap % 16 == 0 && lp_chunk_scenes(r, max_groups < n_cu ? max_groups : n_cu) > 0 &&
-          r->num_layers <= LP_MAX_LAYERS && r->U && r->SIG && lp_packs_ok(r);
+         !(O().overlap && g_side) && r->A_cap % 16 == 0 && lp_chunk_scenes(r, lp_limit()) > 0 &&
+          r->num_layers <= LP_MAX_LAYERS && r->U && r->SIG && lp_packs_ok(r, false, stream);
 }
 
 // ---- a decode step in two halves: the edge sets of a column with their embeddings, and the 18 sublayers that consume them
 struct StepMode { bool overlap, fuse, lp; int r24; int ra; const float* dt; };
-static StepMode step_mode(const InfgenRollout* r, int rows, int edgeless) {
+static StepMode step_mode(const InfgenRollout* r, int rows, int edgeless, void* stream) {
   StepMode m;
   m.overlap = O().overlap && g_side && !edgeless;
-  m.lp = layers_p_shape(r, rows, edgeless);
+  m.lp = layers_p_shape(r, rows, edgeless, stream);
   m.fuse = O().edge_fuse == 2 || (O().edge_fuse == 1 && (rows > 256 || m.lp));      // U / Z / SIG stay on chip inside k_edge_fused / k_layers_p
   // the step's rhat rows never leave the library: fp32 rows by default (the reference's arithmetic); rhat_format 1: packed 24-bit
   // rows (kernels.h) when both ends are the kernels that know them - a reduced-precision mode, tests/test_rollout_gpu.py compares the two
@@ -1199,7 +1222,7 @@ static int prepare_edges(const InfgenRollout* r, int c, int edgeless, void* stre
                          unsigned long long* clear_keys = nullptr, bool clear_sync = false) {
   const int rows = r->S * r->A_cap;
   RET_IF(build_edges_impl(r, c, edgeless, stream, zero_totals, clear_keys, clear_sync));
-  const StepMode sm = step_mode(r, rows, edgeless);
+  const StepMode sm = step_mode(r, rows, edgeless, stream);
   const bool overlap = sm.overlap; const int r24 = sm.r24, ra = sm.ra; const float* dt = sm.dt;
   if (overlap) {
     hipStream_t ms = (hipStream_t)stream;
@@ -1272,16 +1295,18 @@ static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, vo
   // 4 (a row's edge list halved between two waves) up to 128
   static const int lp_rows_min = getenv("INFGEN_LP_ROWS8") ? (atoi(getenv("INFGEN_LP_ROWS8")) ? 8 : 16)
                                : getenv("INFGEN_LP_ROWS_MIN") ? atoi(getenv("INFGEN_LP_ROWS_MIN")) : 4;
+  // (every bound below is the launch limit lp_limit() = min(resident capacity of THIS device, INFGEN_LP_MAX_GROUPS): a grid beyond the
+  // capacity would leave workgroups that never become resident while the resident ones wait for them at the scene counters)
+  const int limit = lp_limit();
   a.rows_per_wg = 16;
   for (int rr = 8; rr >= 4 && rr >= lp_rows_min; rr >>= 1)
-    if (r->A_cap % rr == 0 && rows / rr <= (rr == 4 ? lp_max_groups() / 2 : lp_max_groups())) a.rows_per_wg = rr;
+    if (r->A_cap % rr == 0 && rows / rr <= (rr == 4 ? limit / 2 : limit)) a.rows_per_wg = rr;
   const int gps = r->A_cap / a.rows_per_wg;
   // a batch beyond one launch's workgroups: chunks of whole scenes, one launch after the other (each launch's workgroups are all
-  // resident; the stream orders them)
-  const int n_cu = lp_device().n_cu;
-  const int limit = lp_max_groups() < n_cu ? lp_max_groups() : n_cu;
-  const int per = rows / a.rows_per_wg <= limit ? r->S : lp_chunk_scenes(r, limit);
-  if (per <= 0) return fail("infgen_decode_layers", "k_layers_p: batch does not fit");
+  // resident; the stream orders them).  Only 16-row workgroups get here with more than one chunk (fewer rows per workgroup are
+  // chosen only when the whole batch fits), so lp_chunk_scenes' groups per scene are this launch's
+  const int per = rows / a.rows_per_wg <= limit ? r->S : (a.rows_per_wg == 16 ? lp_chunk_scenes(r, limit) : 0);
+  if (per <= 0 || per * gps > infgen_layers_p_capacity()) return fail("infgen_decode_layers", "k_layers_p: batch does not fit the device's resident capacity");
   auto kern = a.rows_per_wg == 4 ? (sm.r24 ? k_layers_p<true, 4> : k_layers_p<false, 4>)
             : a.rows_per_wg == 8 ? (sm.r24 ? k_layers_p<true, 8> : k_layers_p<false, 8>)
                                  : (sm.r24 ? k_layers_p<true, 16> : k_layers_p<false, 16>);
@@ -1289,18 +1314,26 @@ static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, vo
   // (opt-in) graph modes keep the plain launch with the spin limit - their caller owns the GPU
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-  static const unsigned spin_env = getenv("INFGEN_LP_SPIN_LIMIT") ? (unsigned)strtoul(getenv("INFGEN_LP_SPIN_LIMIT"), nullptr, 0) : 0u;
-  a.spin_limit = capturing ? (1u << 22) : spin_env;
+  // polls at a scene counter before the kernel traps: plain launches 2^24 (tens of seconds - a legitimate wait lasts as long as other
+  // streams' kernels, milliseconds; only another process's k_layers_p on the same GPU can hold a workgroup off its CU for longer,
+  // and a trap is better than a hung device), cooperative launches unlimited, captured launches 2^22; INFGEN_LP_SPIN_LIMIT overrides
+  static const char* spin_str = getenv("INFGEN_LP_SPIN_LIMIT");
+  static const unsigned spin_env = spin_str ? (unsigned)strtoul(spin_str, nullptr, 0) : 0u;
+  a.spin_limit = capturing ? (1u << 22) : spin_str ? spin_env : (O().layers_p == 2 ? 0u : (1u << 24));
+  // launches of different streams are ordered behind each other (two half-resident launches would wait for each other for ever):
+  // every launch is followed by an event record on ITS stream, the next launch - whatever its stream - waits for that event first
+  // (a wait on an event of the same stream is a no-op for the hardware queue).  No stream handle outlives the call: a caller may
+  // destroy its stream at any time.
   std::unique_lock<std::mutex> lk(g_lp_mu, std::defer_lock);
+  LpOrder& ord = g_lp_order[lp_current_device()];
   if (!capturing) {
     lk.lock();
-    if (!g_lp_ev && hipEventCreateWithFlags(&g_lp_ev, hipEventDisableTiming) != hipSuccess)
+    if (!ord.ev && hipEventCreateWithFlags(&ord.ev, hipEventDisableTiming) != hipSuccess)
       return fail("infgen_decode_layers", "event creation failed");
-    // a launch from ANOTHER stream than the previous one waits for that stream's work enqueued so far (which includes its
-    // k_layers_p launch): the event is recorded only now, on the switch - a single-stream caller never pays for it
-    if (g_lp_any && g_lp_last != (hipStream_t)stream &&
-        (hipEventRecord(g_lp_ev, g_lp_last) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, g_lp_ev, 0) != hipSuccess))
-      return fail("infgen_decode_layers", "k_layers_p: ordering behind the previous launch failed");
+    if (ord.any && hipStreamWaitEvent((hipStream_t)stream, ord.ev, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      ord.any = false;            // (the event is unusable: start over rather than fail every later launch)
+    }
   }
   const bool lp_coop = O().layers_p == 2;
   for (int s0 = 0; s0 < r->S; s0 += per) {
@@ -1323,8 +1356,8 @@ static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, vo
     }
   }
   if (!capturing) {
-    g_lp_last = (hipStream_t)stream;
-    g_lp_any = true;
+    ord.any = hipEventRecord(ord.ev, (hipStream_t)stream) == hipSuccess;
+    if (!ord.any) (void)hipGetLastError();
     lk.unlock();
   }
   if (lp_trace) {          // synchronous dump of the last launch's stamps (diagnostic runs only)
@@ -1342,7 +1375,7 @@ static int layers_p_launch(const InfgenRollout* r, int c, const StepMode& sm, vo
 
 static int layers_core(const InfgenRollout* r, int c, int edgeless, void* stream, bool lp_sync_clear = true) {
   const int rows = r->S * r->A_cap;
-  const StepMode sm = step_mode(r, rows, edgeless);
+  const StepMode sm = step_mode(r, rows, edgeless, stream);
   if (sm.lp && sm.fuse) {
     const int rc = layers_p_launch(r, c, sm, stream, lp_sync_clear);
     if (rc != LP_REFUSED) return rc;
@@ -1407,7 +1440,7 @@ extern "C" int infgen_decode_layers(const InfgenRollout* r, int c, int edgeless,
   RET_IF(validate(r, "infgen_decode_layers"));
   OptScope _opts(r);
   ProfPhase _pp(edgeless ? t_prof_phase : 1);        // (the edgeless column-0 chain belongs to the prologue)
-  const StepMode sm = step_mode(r, r->S * r->A_cap, edgeless);
+  const StepMode sm = step_mode(r, r->S * r->A_cap, edgeless, stream);
   const bool lp = sm.lp && sm.fuse && r->SIG != nullptr;      // (k_build_edges zeroes k_layers_p's counters: infgen_rollout_run)
   RET_IF(prepare_edges(r, c, edgeless, stream, true, false, nullptr, lp));
   return layers_core(r, c, edgeless, stream, !lp);
@@ -1457,7 +1490,7 @@ extern "C" int infgen_rollout_run(const InfgenRollout* r, int t0, int t1, void* 
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(r->tmp2);     // (free scratch under attn_mode != 0)
   if (hipMemsetAsync(keys, 0, (size_t)rows * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess)
     return fail("infgen_rollout_run", "memset failed");
-  const StepMode sm0 = step_mode(r, rows, 0);
+  const StepMode sm0 = step_mode(r, rows, 0, stream);
   const bool lp_steps = sm0.lp && sm0.fuse && r->SIG != nullptr;       // the steps' sublayers run as k_layers_p launches
   // (their per-scene counters are zeroed by the kernel in front of every launch - k_build_edges before the first step, k_integrate
   // before the later ones - not by a fill: one launch less per step, and no memset node between the kernels of a captured graph)

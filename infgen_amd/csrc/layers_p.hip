@@ -735,10 +735,12 @@ __global__ __launch_bounds__(512, 1) void k_layers_p(LayersPArgs a) {
       if (tid == 0) {
         __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int target = (i + 1) * gps;
-        // (the launch is a COOPERATIVE one - api.hip: layers_p_launch - so every workgroup is resident or will be as soon as kernels
-        // of other streams leave the CUs, and the library serialises k_layers_p launches across streams: the wait is bounded by
-        // other work's duration and has no limit.  a.spin_limit != 0 - diagnostic builds / runs, and launches captured into a HIP
-        // graph, which cannot be cooperative - traps after that many polls instead of waiting for ever)
+        // (api.hip: layers_p_launch never launches more workgroups than the device keeps resident for this kernel and orders the
+        // k_layers_p launches of the process's streams behind each other, so every workgroup is resident or will be as soon as kernels
+        // of other streams leave the CUs: the wait is bounded by other work's duration.  The default launch (layers_p = 1) is a PLAIN
+        // one with a.spin_limit = 2^24 polls (tens of seconds: only another PROCESS running such a kernel on the same GPU can hold
+        // it that long - it traps instead of hanging the device); layers_p = 2 launches cooperatively (device-wide queue, safe next
+        // to other processes) and waits without a limit; launches captured into a HIP graph trap after 2^22 polls)
         unsigned spins = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
           __builtin_amdgcn_s_sleep(2);

@@ -422,9 +422,18 @@ class RolloutEngine:
                  force_enter: bool = False, insert_headroom: Optional[int] = None,
                  sample_k: int = 1, sample_uniforms: Optional[np.ndarray] = None, options: Optional[Mapping[str, int]] = None,
                  insert_k: int = 1, insert_uniforms: Optional[np.ndarray] = None, seed_outputs: bool = False,
-                 use_graph: Optional[bool] = None, copies: int = 1):
+                 use_graph: Optional[bool] = None, copies: int = 1, flags: Optional[Mapping[str, bool]] = None):
         self.w = weights
         self.options = dict(options) if options else None      # per-engine kernel switches (fields of InfgenOptions)
+        # per-engine launch-sequence switches (none changes what is computed beyond fp32 summation order): read from the environment
+        # ONCE, here, as defaults (diagnostic A/B runs), overridden by ``flags`` - two engines of one process may differ
+        env = os.environ.get
+        self.flags = dict(dt_table=env('INFGEN_NO_DT_TAB', '0') != '1',        # the temporal edges' time-gap branch as a lookup
+                          map_fuse=env('INFGEN_MAP_FUSE', '1') != '0',        # map encoder's edge side through k_edge_fused
+                          row_groups=env('INFGEN_ROW_GROUPS', '1') != '0',    # insertion: visit only the 16-row groups that hold agents
+                          row_groups_tight=env('INFGEN_ROW_GROUPS_TIGHT', '1') != '0',
+                          graph=env('INFGEN_GRAPH', '0'))                     # '1': replay decode steps from a HIP graph, '2': whole rollout
+        self.flags.update(flags or {})
         self.cfg = cfg = weights.cfg
         self.device = dev = weights.device
         self.ops = Ops(dev)
@@ -461,7 +470,7 @@ class RolloutEngine:
         # use_graph = 'all': the WHOLE rollout (reset, map encoder, column-0 chain, every decode step) as one graph, replayed on a
         # stream of the engine's own - what lets one host thread keep several engines on several streams busy (rollout_many): a
         # rollout is ~1,000 launches, and issuing four engines' launches one after the other takes longer than the GPU needs
-        self._graph_all = use_graph == 'all' or (use_graph is None and os.environ.get('INFGEN_GRAPH') == '2')
+        self._graph_all = use_graph == 'all' or (use_graph is None and str(self.flags['graph']) == '2')
         if self._graph_all:
             use_graph = False
         self._wgraph = None
@@ -497,7 +506,7 @@ class RolloutEngine:
         if self._use_graph_arg is None:
             # replaying the decode steps from a captured HIP graph: opt-in (use_graph=True or INFGEN_GRAPH=1).  Measured in round 3:
             # 64 scenes 25.9 ms with and without it (the step is its kernels' dependency chains, not launch overhead)
-            self.use_graph = os.environ.get('INFGEN_GRAPH') == '1' and not self.insertion
+            self.use_graph = str(self.flags['graph']) == '1' and not self.insertion
 
         arr = self._map_side(self._scene_arrays(hosts))
         t = lambda a: torch.from_numpy(a).to(dev)
@@ -1034,7 +1043,7 @@ class RolloutEngine:
                 self._mg = None
                 return self._prologue(map_only=map_only)
             self._mg_checked = True
-        fused = os.environ.get('INFGEN_MAP_FUSE', '1') != '0'
+        fused = bool(self.flags['map_fuse'])
         # rhat rows of the pt <-> pt edges: fp32 by default; options['rhat_format'] = 1: the packed 24-bit form when both ends know
         # it (split Fourier kernel -> k_edge_fused), like the rollout's own edge sets (include/infgen_hip.h: InfgenOptions.rhat_format)
         eo = self._effective_options()
@@ -1335,11 +1344,11 @@ class RolloutEngine:
         # the temporal edges' time-gap input as a lookup of its r_t_emb branch (include/infgen_hip.h: four_t_dt), built once per
         # weight pack and arithmetic; INFGEN_NO_DT_TAB=1: evaluated per edge as before
         self._ctx.four_t_dt = None
-        if o.fourier_mode != 0 and os.environ.get('INFGEN_NO_DT_TAB', '0') != '1':
+        if o.fourier_mode != 0 and self.flags['dt_table']:
             self._ctx.four_t_dt = _lib.ptr(self.w.time_gap_table(self.lib, int(o.gemm_terms), self.ops.stream))
         o.row_groups = o.n_row_groups = None
         o.row_group_margin = 0
-        if groups and self.insertion and self.ins is not None and os.environ.get('INFGEN_ROW_GROUPS', '1') != '0':
+        if groups and self.insertion and self.ins is not None and self.flags['row_groups']:
             # rows are padded to A_cap per scene: the split node kernels and the edge kernels visit only the 16-row groups
             # that hold agents (or may receive one of the <= 10 rows a step appends)
             o.row_groups, o.n_row_groups, o.row_group_margin = _lib.ptr(self.ins['groups']), _lib.ptr(self.ins['n_groups']), 10
@@ -1375,7 +1384,7 @@ class RolloutEngine:
             if t > 0:
                 yield from self._insert_step(t)
             self._decoded_rows.add_(self.n_agents.sum())       # A_t: rows decoded at this step, incl. the inserted ones
-            tight = use_groups and os.environ.get('INFGEN_ROW_GROUPS_TIGHT', '1') != '0'
+            tight = use_groups and self.flags['row_groups_tight']
             if tight:
                 # the step's insertions are done: the motion stage runs on exactly the rows that hold agents now - the ten rows of
                 # head-room the sub-loop's lists carry put one more 16-row group per scene into 60 % of the node / edge launches
@@ -1671,8 +1680,9 @@ def rollout_many(engines: Sequence[RolloutEngine], streams: Optional[Sequence[to
         for e in engines:
             e.rollout()
         return
-    # (k_layers_p launches of several streams: the library launches the kernel cooperatively and orders such launches of different
-    # streams behind each other - csrc/api.hip: layers_p_launch - so engines of any size may share the GPU)
+    # (k_layers_p launches of several streams: the library keeps every launch within the device's resident capacity and orders such
+    # launches of different streams behind each other - csrc/api.hip: layers_p_launch - so engines of any size may share the GPU;
+    # the launch itself is a plain one by default, cooperative with options['layers_p'] = 2)
     return _rollout_many_streams(engines, streams, dev)
 
 

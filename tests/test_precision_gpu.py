@@ -8,7 +8,7 @@ same operators with fp32 operands.  Each test runs ONE operator on the SAME inpu
 compares both with an fp64 evaluation of the reference operator (oracle/rollout_oracle.py under
 torch.set_default_dtype(float64)):
 
-    max |split - fp64|  <=  1.5 x max |fp32 MFMA - fp64|
+    max |split - fp64|  <=  1.25 x max |fp32 MFMA - fp64|      (and the same for the rms error)
 
 i.e. the split kernels' error is fp32 round-off, not a lower precision.  The measured pairs go to
 gpurun_out/precision_r06.json (copied to profiles/ by the builder).
@@ -24,7 +24,7 @@ from conftest import REPO, load_case, make_weights
 
 pytestmark = pytest.mark.gpu
 
-RATIO = 1.5
+RATIO = 1.25        # (VERDICT r5 asked for 1.5; measured 0.53 - 1.07: profiles/r06_precision.json)
 FLOOR = 2e-7          # absolute slack (one fp32 ulp of the O(1) outputs): both errors at the noise floor
 
 

@@ -680,24 +680,20 @@ def test_packed_rhat_rows_match_fp32_rows():
 
 def test_time_gap_lookup_matches_per_edge_evaluation():
     """the temporal edges' time-gap branch of r_t_emb looked up (InfgenRollout.four_t_dt) against the same rollout with
-    the branch evaluated per edge (INFGEN_NO_DT_TAB=1): tokens identical, logits within 2e-5 (fp32 summation order only) - and
-    different at all, i.e. the lookup really ran"""
-    import os
+    the branch evaluated per edge (RolloutEngine(flags={'dt_table': False})): tokens identical, logits within 2e-5 (fp32 summation
+    order only) - and different at all, i.e. the lookup really ran.  A per-engine flag: both engines exist side by side"""
     from infgen_amd import engine, synth
     c = load_case('c2_a32_m512')
     dev = torch.device('cuda:0')
     w = engine.PackedWeights(c['sd'], c['cfg'], dev)
     scenes = [synth.make_scene(900 + i, 20 + i, 300, c['cfg'], vocab=c['vocab'], grid=c['grid'], slip=0.2) for i in range(12)]
+    engs = [engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=True, flags={'dt_table': on})
+            for on in (False, True)]
     outs = []
-    try:
-        for off in ('1', '0'):
-            os.environ['INFGEN_NO_DT_TAB'] = off
-            eng = engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=True)
-            eng.rollout()
-            assert bool(eng._ctx.four_t_dt) == (off == '0')
-            outs.append(eng.outputs())
-    finally:
-        os.environ.pop('INFGEN_NO_DT_TAB', None)
+    for eng, on in zip(engs, (False, True)):
+        eng.rollout()
+        assert bool(eng._ctx.four_t_dt) == on
+        outs.append(eng.outputs())
     worst = 0.0
     for a, b in zip(*outs):
         assert np.array_equal(a['next_token_idx'], b['next_token_idx'])
@@ -706,41 +702,38 @@ def test_time_gap_lookup_matches_per_edge_evaluation():
 
 
 def test_bench_size_batch_properties():
-    """BASELINE C3 shapes at the bench's full size (512 scenes x 64 agents x 1024 map tokens, R = 80), checked through
-    size-independent properties: a second rollout of the same batch is bitwise identical; scenes are independent units,
-    so sampled scenes run alone with the same kernels (split forced: the by-size choice would pick the fp32 kernels for a
-    single scene) reproduce their rows of the batch bit for bit; every decoded token is a valid id and the poses finite"""
-    from infgen_amd import _lib, engine, synth
-    lib = _lib.load()
+    """BASELINE C3 shapes at the bench's full size - the headline batch: 1024 scenes x 64 agents x 1024 map tokens, R = 80 -
+    checked through size-independent properties: a second rollout of the same batch is bitwise identical; scenes are independent
+    units, so sampled scenes run alone with the same kernels (split forced through the engine's options: the by-size choice would
+    pick the fp32 kernels for a single scene) reproduce their rows of the batch bit for bit; every decoded token is a valid id and
+    the poses finite"""
+    from infgen_amd import engine, synth
     c = load_case('c1_a8_m128')
     cfg = synth.standard_config()
-    S = 512
+    S = 1024
     scenes = [synth.make_scene(synth.scene_seed(3, i), 64, 1024, cfg, vocab=c['vocab'], grid=c['grid'], slip=0.2)
               for i in range(S)]
     sd = make_weights(seed=1, head_gain=1.0)
     dev = torch.device('cuda:0')
     w = engine.PackedWeights(sd, cfg, dev)
-    _lib.check(lib.infgen_set_attn_mode(1))                 # the Fourier kernels are the split ones at every size already
-    try:
-        eng = engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=False)
-        eng.rollout()
-        first = eng.outputs()
-        eng.rollout()
-        second = eng.outputs()
-        for k in ('next_token_idx', 'next_state_idx', 'pos_a', 'head_a', 'pred_traj'):
-            assert all(np.array_equal(a[k], b[k]) for a, b in zip(first, second)), k
-        tok = np.stack([o['next_token_idx'] for o in first])
-        assert tok.shape == (S, 64, 18) and tok[:, :, 2:].min() >= 0 and tok.max() < cfg.token_size
-        assert all(np.isfinite(o['pred_traj']).all() for o in first)
-        assert eng.agent_steps() == S * 64 * 80
-        for i in (0, 137, 511):
-            one = engine.RolloutEngine(w, [scenes[i]], c['vocab'], c['map_vocab'], c['grid'], store_logits=False)
-            one.rollout()
-            o = one.outputs()[0]
-            for k in ('next_token_idx', 'pos_a', 'head_a', 'pred_traj'):
-                assert np.array_equal(o[k], first[i][k]), (i, k)
-    finally:
-        _lib.check(lib.infgen_set_attn_mode(2))
+    opt = dict(attn_mode=1)                 # (the Fourier kernels are the split ones at every size already)
+    eng = engine.RolloutEngine(w, scenes, c['vocab'], c['map_vocab'], c['grid'], store_logits=False, options=opt)
+    eng.rollout()
+    first = eng.outputs()
+    eng.rollout()
+    second = eng.outputs()
+    for k in ('next_token_idx', 'next_state_idx', 'pos_a', 'head_a', 'pred_traj'):
+        assert all(np.array_equal(a[k], b[k]) for a, b in zip(first, second)), k
+    tok = np.stack([o['next_token_idx'] for o in first])
+    assert tok.shape == (S, 64, 18) and tok[:, :, 2:].min() >= 0 and tok.max() < cfg.token_size
+    assert all(np.isfinite(o['pred_traj']).all() for o in first)
+    assert eng.agent_steps() == S * 64 * 80
+    for i in (0, 137, 511, 1023):
+        one = engine.RolloutEngine(w, [scenes[i]], c['vocab'], c['map_vocab'], c['grid'], store_logits=False, options=opt)
+        one.rollout()
+        o = one.outputs()[0]
+        for k in ('next_token_idx', 'pos_a', 'head_a', 'pred_traj'):
+            assert np.array_equal(o[k], first[i][k]), (i, k)
 
 
 def test_reduced_precision_mode_stays_close():
