@@ -55,3 +55,12 @@ class _AliasLoader(importlib.abc.Loader):
 
 sys.meta_path.insert(0, _AliasFinder())
 __path__ = list(infgen_amd.__path__)
+# Sub-packages this repository does not rebuild (the dataset module ``infgen.datasets.*``, visualisation, the
+# WOMD proto readers) stay the reference's own: with INFGEN_REFERENCE_ROOT = a checkout of the reference, ``infgen.X`` for an X that
+# infgen_amd lacks resolves to <root>/infgen/X through the ordinary path finder - so the reference's run.py / val.py import
+# ``infgen.model.infgen.InfGen`` (this implementation), ``infgen.utils.func`` (this implementation) and
+# ``infgen.datasets.scalable_dataset`` (theirs) side by side, unchanged.
+import os as _os
+_ref = _os.environ.get('INFGEN_REFERENCE_ROOT')
+if _ref and _os.path.isdir(_os.path.join(_ref, 'infgen')):
+    __path__.append(_os.path.join(_ref, 'infgen'))

@@ -172,6 +172,11 @@ typedef struct InfgenRollout {
    * indexed by slot = map_scene[s]: the n rollouts of one scene (reference infgen/model/infgen.py:704-706, inference_no_map
    * infgen_decoder.py:132-134) encode their map once and keep one copy of its K / V rows */
   const int* map_scene;
+  /* optional [num_layers][S * A_cap][128] (test hook): infgen_decode_layers copies the residual stream X there after every
+   * (temporal, map -> agent, agent <-> agent) triple - the reference's feat_a after a2a_attn_layers[i] for the current column
+   * (infgen/modules/agent_decoder.py:2133-2158).  A context with tap_x runs the per-sublayer launches (k_layers_p keeps the
+   * stream in registers across the triples) */
+  float* tap_x;
 } InfgenRollout;
 
 int infgen_linear(const float* X, int ldx, const int* gather, int rows, int K,

@@ -98,6 +98,7 @@ class Rollout(C.Structure):
         ('four_t_dt', _p),
         ('teacher_pos', _p), ('teacher_head', _p),
         ('map_scene', _p),
+        ('tap_x', _p),
     ]
 
 

@@ -1192,7 +1192,7 @@ static bool layers_p_shape(const InfgenRollout* r, int rows, int edgeless, void*
   // lists and run in parallel on CUs that would idle)
   return O().layers_p && O().edge_fuse != 0 && O().attn_mode != 0 && O().gemm_terms == 3 && O().fourier_mode != 0 &&
          !(O().overlap && g_side) && r->A_cap % 16 == 0 && lp_chunk_scenes(r, lp_limit()) > 0 &&
-          r->num_layers <= LP_MAX_LAYERS && r->U && r->SIG && lp_packs_ok(r, false, stream);
+          r->num_layers <= LP_MAX_LAYERS && r->U && r->SIG && !r->tap_x && lp_packs_ok(r, false, stream);
 }
 
 // ---- a decode step in two halves: the edge sets of a column with their embeddings, and the 18 sublayers that consume them
@@ -1432,6 +1432,10 @@ static int layers_core(const InfgenRollout* r, int c, int edgeless, void* stream
     } else {
       RET_IF(infgen_attn_post(r->X, rows, r->attn_a[i], r->AGG, Z, SIG, has_pos, stream));
     }
+    // test hook (InfgenRollout.tap_x): the residual stream after triple i
+    if (r->tap_x && hipMemcpyAsync(r->tap_x + (size_t)i * rows * D, r->X, (size_t)rows * D * sizeof(float), hipMemcpyDeviceToDevice,
+                                   (hipStream_t)stream) != hipSuccess)
+      return fail("infgen_decode_layers", "tap copy failed");
   }
   return 0;
 }

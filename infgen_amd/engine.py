@@ -422,7 +422,8 @@ class RolloutEngine:
                  force_enter: bool = False, insert_headroom: Optional[int] = None,
                  sample_k: int = 1, sample_uniforms: Optional[np.ndarray] = None, options: Optional[Mapping[str, int]] = None,
                  insert_k: int = 1, insert_uniforms: Optional[np.ndarray] = None, seed_outputs: bool = False,
-                 use_graph: Optional[bool] = None, copies: int = 1, flags: Optional[Mapping[str, bool]] = None):
+                 use_graph: Optional[bool] = None, copies: int = 1, flags: Optional[Mapping[str, bool]] = None,
+                 tap_layers: bool = False):
         self.w = weights
         self.options = dict(options) if options else None      # per-engine kernel switches (fields of InfgenOptions)
         # per-engine launch-sequence switches (none changes what is computed beyond fp32 summation order): read from the environment
@@ -434,6 +435,9 @@ class RolloutEngine:
                           row_groups_tight=env('INFGEN_ROW_GROUPS_TIGHT', '1') != '0',
                           graph=env('INFGEN_GRAPH', '0'))                     # '1': replay decode steps from a HIP graph, '2': whole rollout
         self.flags.update(flags or {})
+        # test hook (InfgenRollout.tap_x): the residual stream after every (temporal, map, agent) triple of the last decode step
+        self._tap_layers = bool(tap_layers)
+        self.tap_x = None
         self.cfg = cfg = weights.cfg
         self.device = dev = weights.device
         self.ops = Ops(dev)
@@ -547,6 +551,8 @@ class RolloutEngine:
         i32 = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.int32)
         L = cfg.num_agent_layers
         self.X, self.Q, self.U = f(rows, D), f(rows, D), f(rows, 8 * D)
+        if self._tap_layers:
+            self.tap_x = f(cfg.num_agent_layers, rows, D)
         self.Ka, self.Va, self.AGG, self.Z, self.SIG = f(rows, D), f(rows, D), f(rows, D), f(rows, 8 * D), f(rows, 8)
         self.ringK = [f(self.ring, rows, D) for _ in range(L)]
         self.ringV = [f(self.ring, rows, D) for _ in range(L)]
@@ -1307,6 +1313,7 @@ class RolloutEngine:
         c.tmask, c.imask, c.catflag, c.type, c.bos = P(self.tmask), P(self.imask), P(self.catflag), P(self.atype), P(self.bos)
         c.map_pos, c.map_orient = P(self.map_pos), P(self.map_orient)
         c.map_scene = P(self.map_scene)
+        c.tap_x = P(self.tap_x)
         for i in range(cfg.num_agent_layers):
             c.attn_t[i], c.attn_m[i], c.attn_a[i] = P(w.attn_t[i]), P(w.attn_m[i]), P(w.attn_a[i])
             c.ringK[i], c.ringV[i], c.mapK[i], c.mapV[i] = P(self.ringK[i]), P(self.ringV[i]), P(self.mapK[i]), P(self.mapV[i])

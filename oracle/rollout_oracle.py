@@ -196,8 +196,13 @@ class RolloutOracle:
     (``motion_beam_size = 1``; ``disable_insertion`` as in BASELINE configs C1-C3)."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], cfg, grid: np.ndarray, prefix: str = 'agent_encoder',
-                 live_state: bool = False, all_columns: bool = False):
+                 live_state: bool = False, all_columns: bool = False, trace: Optional[dict] = None):
         self.sd, self.cfg, self.p = sd, cfg, prefix
+        # test hook: a dict that receives, per decode step, the three edge lists ('edges') and the residual stream of the current
+        # column after every layer triple ('x') - compared with the reference's own (tests/golden/make_golden_internals.py)
+        self.trace = trace
+        if trace is not None:
+            trace.setdefault('edges', []), trace.setdefault('x', [])
         self.grid = _t(grid).to(torch.get_default_dtype())
         self.live_state = live_state
         # "reference-shaped" control flow (SURVEY 8d, CPU baseline only): every decode step pushes ALL A*T nodes through the
@@ -335,10 +340,15 @@ class RolloutOracle:
             msrc, mdst, r_m = self.map_edges(st, c)
             asrc, adst, r_a = self.agent_edges(st, c)
             st['edge_count'].append((int(trow.numel()), int(adst.numel()), int(mdst.numel())))
+            if self.trace is not None:        # test hook: (source column | map token | agent, destination row) of the step's three sets
+                self.trace['edges'].append(dict(t=(tj.clone(), trow.clone()), m=(msrc.clone(), mdst.clone()), a=(asrc.clone(), adst.clone())))
+                self.trace['x'].append([])
         for i in range(cfg.num_agent_layers):
             st['X'][i][:, c] = x
             if self.all_columns and not edgeless:
                 x = self._triple_all_columns(st, c, i, (tj, trow, r_t), (msrc, mdst, r_m), (asrc, adst, r_a))
+                if self.trace is not None:
+                    self.trace['x'][-1].append(x.clone())
                 continue
             if edgeless:
                 x = attention_layer(sd, f'{p}.t_attn_layers.{i}', x, None, z, z)
@@ -355,6 +365,8 @@ class RolloutOracle:
                 x = attention_layer(sd, f'{p}.t_attn_layers.{i}', x, None, z, z)
             x = attention_layer(sd, f'{p}.pt2a_attn_layers.{i}', x, r_m, msrc, mdst, x_src_raw=st['x_pt'])
             x = attention_layer(sd, f'{p}.a2a_attn_layers.{i}', x, r_a, asrc, adst)
+            if self.trace is not None:        # the residual stream of column c after triple i (agent_decoder.py:2133-2158)
+                self.trace['x'][-1].append(x.clone())
         return x
 
     def _triple_all_columns(self, st, c, i, te, me, ae):
@@ -543,11 +555,11 @@ class RolloutOracle:
 
 
 def run_scene(sd, scene, cfg, vocab, map_vocab, grid, live_state=False, teacher=None, sample_k=1,
-              sample_uniforms=None, all_columns=False):
+              sample_uniforms=None, all_columns=False, trace=None):
     """map prologue + rollout; returns the rollout dict plus ``x_pt``."""
     with torch.no_grad():
         x_pt = map_encoder(sd, scene, cfg, map_vocab)
-        orc = RolloutOracle(sd, cfg, grid, live_state=live_state, all_columns=all_columns)
+        orc = RolloutOracle(sd, cfg, grid, live_state=live_state, all_columns=all_columns, trace=trace)
         tt = ts = None
         if teacher is not None:
             tt, ts = teacher

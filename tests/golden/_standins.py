@@ -180,9 +180,11 @@ def assert_reference(obj):
     return obj
 
 
-def install():
-    """Register the stand-in modules in sys.modules (idempotent) and bind ``infgen`` to the reference."""
-    bind_reference()
+def install(bind: bool = True):
+    """Register the stand-in modules in sys.modules (idempotent) and bind ``infgen`` to the reference (bind=False: the
+    third-party stand-ins only - tests/test_compat_entry_cpu.py imports the reference's entry scripts against compat/infgen)."""
+    if bind:
+        bind_reference()
     if 'torch_cluster' in sys.modules and getattr(sys.modules['torch_cluster'], '_is_standin', False):
         return
 

@@ -1,0 +1,125 @@
+#!/usr/bin/env python
+"""Golden vectors BELOW the logits level, from the REFERENCE's own modules (build container only, like make_golden.py).
+
+For the fixtures ``c1_a8_m128`` and ``a24_m256_edge`` the reference's ``InfGenDecoder.inference`` runs once more with hooks on
+  * ``_build_temporal_edge`` / ``_build_interaction_edge`` / ``_build_map2agent_edge`` (infgen/modules/agent_decoder.py:540-758):
+    the edge LISTS of every decode step, decoded from the reference's node numbering into canonical sorted triples
+        temporal  (step, destination agent, source column)          node id = agent * T + column   (dense_to_sparse, :585)
+        agent     (step, destination agent, source agent)           node id = column * A + agent   (step-major pos_s, :626)
+        map       (step, destination agent, source map token)       map id  = column * M + token   (pos_pl.repeat, :703)
+    (every destination is the current column c = 1 + step: asserted here);
+  * ``a2a_attn_layers[0]`` and ``a2a_attn_layers[L - 1]`` (:2133-2158): the rows of column c of their outputs - the residual
+    stream after the first and the last (temporal, map -> agent, agent <-> agent) triple - for decode steps 0..2.
+
+Writes tests/golden/<case>_internals.npz.  Usage: python tests/golden/make_golden_internals.py [--out DIR]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+import make_golden as mg  # noqa: E402
+from infgen_amd import synth  # noqa: E402
+
+CASES = ('c1_a8_m128', 'a24_m256_edge')
+ACT_STEPS = 3
+
+
+def run_case(name: str, out_dir: str):
+    spec = mg.CASES[name]
+    cfg = synth.smart_config() if spec['cfg'] == 'smart' else synth.standard_config()
+    os.environ['DEBUG'] = '0'
+    vocab = synth.make_agent_vocab(cfg.token_size)
+    map_vocab = synth.make_map_vocab()
+    grid = synth.build_grid(cfg.grid_range, cfg.grid_interval, cfg.pl2seed_radius)
+    scene = synth.make_scene(spec['seed'], spec['A'], spec['M'], cfg, ego_last=spec['ego_last'],
+                             edge_cases=spec['edge_cases'], vocab=vocab, grid=grid, slip=float(spec.get('slip', 0.0)))
+    dec, tok = mg.build_reference(cfg, map_vocab)
+    mg.load_weights(dec, seed=1, head_gain=spec['head_gain'])
+    ae = dec.agent_encoder
+    ae.motion_beam_size = 1
+    T, hc, L = cfg.num_columns, cfg.hist_columns, cfg.num_agent_layers
+    M = int(spec['M'])
+
+    lists = {'t': [], 'a': [], 'm': []}
+
+    def wrap(kind, fname):
+        orig = getattr(ae, fname)
+
+        def wrapped(*a, **k):
+            out = orig(*a, **k)
+            ei = out[0].detach().numpy().astype(np.int64)
+            A = int(a[1].shape[0])                       # pos_a: (A, T, 2)
+            step = len(lists[kind])
+            c = hc - 1 + step
+            src, dst = ei[0], ei[1]
+            if kind == 't':                                # node id = agent * T + column
+                assert np.all(dst % T == c) and np.all(src // T == dst // T)
+                tri = np.stack([np.full_like(dst, step), dst // T, src % T], 1)
+            elif kind == 'a':                              # node id = column * A + agent
+                assert np.all(dst // A == c) and np.all(src // A == c)
+                tri = np.stack([np.full_like(dst, step), dst % A, src % A], 1)
+            else:                                          # map id = column * M + token, agent node = column * A + agent
+                assert np.all(dst // A == c) and np.all(src // M == c)
+                tri = np.stack([np.full_like(dst, step), dst % A, src % M], 1)
+            tri = tri.reshape(-1, 3)
+            lists[kind].append(tri[np.lexsort((tri[:, 2], tri[:, 1]))] if len(tri) else tri)
+            return out
+        setattr(ae, fname, wrapped)
+    for kind, fname in (('t', '_build_temporal_edge'), ('a', '_build_interaction_edge'), ('m', '_build_map2agent_edge')):
+        wrap(kind, fname)
+
+    acts = {0: [], L - 1: []}
+
+    def act_hook(layer):
+        def fn(m, i, o):
+            step = len(acts[layer])
+            if step < ACT_STEPS:
+                x = o.detach().numpy()                     # (T * A, 128), step-major rows (column * A + agent)
+                A = x.shape[0] // T
+                acts[layer].append(x.reshape(T, A, -1)[hc - 1 + step].copy())
+            else:
+                acts[layer].append(None)
+        return fn
+    for layer in acts:
+        ae.a2a_attn_layers[layer].register_forward_hook(act_hook(layer))
+
+    data = mg.to_hetero(scene)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        out = dec.inference(data.clone())
+    nsteps = cfg.num_decode_steps
+    assert all(len(v) == nsteps for v in lists.values()) and all(len(v) == nsteps for v in acts.values())
+    cat = lambda k: (np.concatenate(lists[k]) if sum(len(x) for x in lists[k]) else np.zeros((0, 3), np.int64)).astype(np.int32)
+    meta = dict(case=name, steps=nsteps, act_steps=ACT_STEPS, act_layers=[0, L - 1], hist_columns=hc, T=T)
+    np.savez_compressed(
+        os.path.join(out_dir, name + '_internals.npz'), meta=json.dumps(meta),
+        edges_t=cat('t'), edges_a=cat('a'), edges_m=cat('m'),
+        edge_count=np.asarray([[len(lists[k][s]) for k in 'tam'] for s in range(nsteps)], np.int64),
+        act_first=np.stack(acts[0][:ACT_STEPS]).astype(np.float32), act_last=np.stack(acts[L - 1][:ACT_STEPS]).astype(np.float32),
+        next_token_idx=out['next_token_idx'].numpy())
+    print(f'{name}: edges t/a/m = {len(cat("t"))}/{len(cat("a"))}/{len(cat("m"))}, activations {np.stack(acts[0][:ACT_STEPS]).shape}')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', nargs='*', default=list(CASES))
+    ap.add_argument('--out', default=HERE)
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    for c in args.cases:
+        run_case(c, args.out)
+
+
+if __name__ == '__main__':
+    main()

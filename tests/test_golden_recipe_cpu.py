@@ -51,6 +51,15 @@ def test_rollout_fixture_regenerates_bit_for_bit(tmp_path):
     _same(os.path.join(str(tmp_path), 'c1_a8_m128.npz'), os.path.join(GOLDEN, 'c1_a8_m128.npz'))
 
 
+def test_internals_fixture_regenerates_bit_for_bit(tmp_path):
+    """make_golden_internals.py: edge lists and triple outputs hooked out of the reference's own agent_decoder.py:540-758, :2133-2158"""
+    code = ('import sys, runpy; sys.argv = ["make_golden_internals.py", "--cases", "c1_a8_m128", "--out", %r]; '
+            'runpy.run_path(%r, run_name="__main__")' % (str(tmp_path), os.path.join(GOLDEN, 'make_golden_internals.py')))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900, env=_env(), cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    _same(os.path.join(str(tmp_path), 'c1_a8_m128_internals.npz'), os.path.join(GOLDEN, 'c1_a8_m128_internals.npz'))
+
+
 @pytest.mark.parametrize('script, fixtures', [
     ('make_golden_tokenizer.py', ['attr_tokenizer.npz']),                # Attr_Tokenizer, attr_tokenizer.py:8-110
     ('make_golden_tokens.py', ['tok_a7.npz', 'maptok_p3.npz']),          # 8f rank 1: preprocess.py:552-653, infgen.py:918-936

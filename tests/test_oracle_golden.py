@@ -48,6 +48,37 @@ def test_reference_shaped_oracle_matches_reference_fixture(case):
     assert np.array_equal(out['edge_count'], z['edge_count'])
 
 
+def _sorted_triples(step, dst, src):
+    tri = np.stack([np.full(len(dst), step, np.int64), np.asarray(dst, np.int64), np.asarray(src, np.int64)], 1).reshape(-1, 3)
+    return tri[np.lexsort((tri[:, 2], tri[:, 1]))].astype(np.int32)
+
+
+@pytest.mark.parametrize('case', ['c1_a8_m128', 'a24_m256_edge'])
+def test_oracle_edge_lists_and_triple_outputs_match_the_reference(case):
+    """below the logits level: the edge LISTS of every decode step - sorted (step, destination agent, source
+    column | source agent | source map token) of the temporal / agent / map sets, agent_decoder.py:540-758 - are the reference's
+    own (tests/golden/make_golden_internals.py hooks its three builders), and so is the residual stream of the current column
+    after the first and the last layer triple of decode steps 0..2 (hooks on a2a_attn_layers[0] / [L-1], :2133-2158)"""
+    import os
+    from conftest import GOLDEN
+    c = load_case(case)
+    zi = np.load(os.path.join(GOLDEN, case + '_internals.npz'))
+    sd = {k: torch.from_numpy(v) for k, v in c['sd'].items()}
+    torch.set_num_threads(8)
+    tr = {}
+    out = ro.run_scene(sd, c['scene'], c['cfg'], c['vocab'], c['map_vocab'], c['grid'], live_state=c['meta']['live_state'], trace=tr)
+    assert np.array_equal(out['next_token_idx'].numpy(), zi['next_token_idx'])
+    assert np.array_equal(zi['edge_count'], c['z']['edge_count'])             # (both generators saw the same run)
+    for kind, key in (('t', 'edges_t'), ('a', 'edges_a'), ('m', 'edges_m')):
+        mine = [_sorted_triples(s, e[kind][1].numpy(), e[kind][0].numpy()) for s, e in enumerate(tr['edges'])]
+        mine = np.concatenate(mine) if sum(len(x) for x in mine) else np.zeros((0, 3), np.int32)
+        assert np.array_equal(mine, zi[key]), kind
+    L = c['cfg'].num_agent_layers
+    for s in range(zi['act_first'].shape[0]):
+        assert np.abs(tr['x'][s][0].numpy() - zi['act_first'][s]).max() <= 2e-5, s
+        assert np.abs(tr['x'][s][L - 1].numpy() - zi['act_last'][s]).max() <= 2e-5, s
+
+
 def test_quirk_last_ten_rows_have_no_temporal_edges():
     """SURVEY a-Q1: with A <= 10 there are no temporal edges at all (fixture c1 has A = 8)."""
     z = load_case('c1_a8_m128')['z']

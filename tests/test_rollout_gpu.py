@@ -87,6 +87,71 @@ def test_free_running_rollout_matches_reference_fixture(name, attn_mode):
     assert o['ego_index'] == int(z['ego_index'])
 
 
+@pytest.mark.parametrize('copies', [1, 336], ids=['single scene', '336 copies (the big-batch kernels)'])
+@pytest.mark.parametrize('name', ['c1_a8_m128', 'a24_m256_edge'])
+def test_edge_lists_and_triple_outputs_match_the_reference(name, copies):
+    """below the logits level: after every decode step the device's three edge sets (k_build_edges: CSR by
+    destination row) decoded to sorted (step, destination agent, source column | agent | map token) triples are the REFERENCE's
+    own edge lists (agent_decoder.py:540-758, hooked by tests/golden/make_golden_internals.py), and the residual stream after the
+    first and the last (temporal, map, agent) triple of steps 0..2 (InfgenRollout.tap_x) equals the outputs of the reference's
+    a2a_attn_layers[0] / [L-1] (:2133-2158) within 1e-4.  Checked for the first and the last scene of the batch."""
+    import os
+    from conftest import GOLDEN
+    from infgen_amd import engine
+    c = load_case(name)
+    zi = np.load(os.path.join(GOLDEN, name + '_internals.npz'))
+    cfg = c['cfg']
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], cfg, dev)
+    eng = engine.RolloutEngine(w, [c['scene']] * copies, c['vocab'], c['map_vocab'], c['grid'], store_logits=False,
+                               live_state=c['meta']['live_state'], tap_layers=True, use_graph=False)
+    eng.prologue()
+    A, A_cap, M_cap, rows, ring, L = eng.hosts[0]['A'], eng.A_cap, eng.M_cap, eng.rows, eng.ring, cfg.num_agent_layers
+    n_act = zi['act_first'].shape[0]
+    scenes = sorted({0, copies - 1})
+    got = {s: {k: [] for k in 'tma'} for s in scenes}
+    for t in range(cfg.num_decode_steps):
+        eng.step(t)
+        torch.cuda.synchronize()
+        col = cfg.hist_columns - 1 + t
+        for kind in 'tma':
+            e = eng.edges[kind]
+            off, cnt, src = (e[k].cpu().numpy() for k in ('off', 'cnt', 'src'))
+            for s in scenes:
+                for a in range(A_cap):
+                    r = s * A_cap + a
+                    if cnt[r] == 0:
+                        continue
+                    assert a < A, (kind, t, s, a)
+                    ss = src[off[r]:off[r] + cnt[r]].astype(np.int64)
+                    if kind == 't':                   # src = (column % ring) * rows + row, column in [col - 12, col - 1]
+                        assert np.all(ss % rows == r)
+                        slot = ss // rows
+                        j = col - ((col - slot) % ring)
+                        assert np.all((j >= col - (ring - 1)) & (j < col))
+                        val = j
+                    elif kind == 'm':                 # src = scene * M_cap + token
+                        assert np.all(ss // M_cap == s)
+                        val = ss % M_cap
+                    else:                             # src = scene * A_cap + agent
+                        assert np.all(ss // A_cap == s)
+                        val = ss % A_cap
+                    got[s][kind] += [(t, a, int(v)) for v in val]
+        if t < n_act:
+            tap = eng.tap_x.cpu().numpy()
+            for s in scenes:
+                x0, x1 = tap[0, s * A_cap:s * A_cap + A], tap[L - 1, s * A_cap:s * A_cap + A]
+                assert np.abs(x0 - zi['act_first'][t]).max() <= 1e-4, (t, s, 'first triple')
+                assert np.abs(x1 - zi['act_last'][t]).max() <= 1e-4, (t, s, 'last triple')
+    for s in scenes:
+        for kind, key in (('t', 'edges_t'), ('a', 'edges_a'), ('m', 'edges_m')):
+            mine = np.asarray(sorted(got[s][kind]), np.int32).reshape(-1, 3)
+            ref = zi[key]
+            ref = ref[np.lexsort((ref[:, 2], ref[:, 1], ref[:, 0]))]
+            assert np.array_equal(mine, ref), (s, kind, len(mine), len(ref))
+    assert np.array_equal(eng.outputs()[0]['next_token_idx'], zi['next_token_idx'])
+
+
 @pytest.mark.parametrize('name', ['c2_a32_m512', 'a16_m128_egofirst_state', 'a24_m256_edge'])
 def test_teacher_forced_logits(name, attn_mode):
     """feed the reference's tokens/states back in: every step's logits within 1e-3 (fp32)"""
