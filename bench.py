@@ -351,6 +351,8 @@ def main():
     ap.add_argument('--edge-fuse', type=int, default=-1, choices=(-1, 0, 1, 2),
                     help='infgen_set_edge_fuse: 1 (library default) k_edge_fused from 257 rows, 0 the unfused sequence with U / Z in HBM')
     ap.add_argument('--edge-loop', type=int, default=-1, choices=(-1, 4, 6, 8))
+    ap.add_argument('--edge-kernel', type=int, default=-1, choices=(-1, 0, 1, 2),
+                    help='infgen_set_edge_kernel: 0 k_edge_fused, 1 k_edge_fused3 for launches beyond 4 k rows, 2 k_edge_fused3 always')
     ap.add_argument('--graph', type=int, default=-1, choices=(-1, 0, 1, 2),
                     help='replay the decode steps of a rollout from a captured HIP graph: 1 always, 0 never, -1 (default) the '
                          'engine\'s rule (off unless INFGEN_GRAPH=1)')
@@ -397,6 +399,8 @@ def main():
         _lib.check(lib.infgen_set_edge_loop(args.edge_loop))
     if args.edge_fuse >= 0:
         _lib.check(lib.infgen_set_edge_fuse(args.edge_fuse))
+    if args.edge_kernel >= 0:
+        _lib.check(lib.infgen_set_edge_kernel(args.edge_kernel))
 
     parity = None
     if rank == 0 and not args.no_parity and args.gemm_terms == 3:

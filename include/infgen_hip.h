@@ -108,6 +108,11 @@ typedef struct InfgenOptions {
   int layers_p;         /* infgen_set_layers_p: 1 = small launches run a decode step's sublayers in one launch (k_layers_p) */
   int rhat_format;      /* infgen_set_rhat_format: 0 (default) fp32 rows of the normalised relative-position embedding between the
                          * Fourier and the edge kernels, 1 packed 24-bit rows (384 B, 2^-17 relative: a reduced-precision mode) */
+  int edge_kernel;      /* infgen_set_edge_kernel: lane layout of the fused edge kernel's loop - 0: lane = two columns of every row
+                         * (k_edge_fused), 1 (default): lane = (head, 16-column slice) with the rhat rows staged through LDS
+                         * (k_edge_fused3) for launches beyond 4 k rows, 2: the same at every size.  Same results up to fp32
+                         * summation order; packed 24-bit rhat rows (rhat_format 1) always take k_edge_fused. */
+  int _pad0;
   const int* row_groups; const int* n_row_groups;   /* optional list of the 16-row groups that hold agents (infgen_set_row_groups) */
 } InfgenOptions;
 
@@ -241,6 +246,7 @@ int infgen_edge_attn_fused_r24(int rows, const float* Q, const float* pack, cons
  * 1 the packed 24-bit rows above (-25 % of the rhat bytes, ~1 % of a rollout; outside the fp32 contract, a named secondary leg of
  * bench.py).  Process-wide default; a context with opts.use != 0 takes InfgenOptions.rhat_format. */
 int infgen_set_rhat_format(int format);
+int infgen_set_edge_kernel(int kernel);
 int infgen_set_edge_fuse(int mode);
 /* the process-wide defaults (what the infgen_set_* functions edited so far), e.g. to seed a context's own InfgenOptions */
 int infgen_get_options(InfgenOptions* out);

@@ -64,10 +64,10 @@ class Insertion(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [('use', _i), ('attn_mode', _i), ('gemm_terms', _i), ('fourier_mode', _i), ('edge_fuse', _i), ('edge_loop', _i),
-                ('overlap', _i), ('row_group_margin', _i), ('layers_p', _i), ('rhat_format', _i), ('row_groups', _p), ('n_row_groups', _p)]
+                ('overlap', _i), ('row_group_margin', _i), ('layers_p', _i), ('rhat_format', _i), ('edge_kernel', _i), ('_pad0', _i), ('row_groups', _p), ('n_row_groups', _p)]
 
 
-OPTIONS_VALUE_BYTES = C.sizeof(_i) * 10       # the integer switches of Options (the two pointers follow)
+OPTIONS_VALUE_BYTES = C.sizeof(_i) * 12       # the integer switches of Options (the two pointers follow)
 
 
 class Rollout(C.Structure):
@@ -122,6 +122,7 @@ SYMBOLS = {
     'infgen_rollout_validate': (_i, [_p]),
     'infgen_set_edge_loop': (_i, [_i]),
     'infgen_set_rhat_format': (_i, [_i]),
+    'infgen_set_edge_kernel': (_i, [_i]),
     'infgen_mlp_embedding': (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
     'infgen_get_options': (_i, [C.POINTER(Options)]),
     'infgen_thread_options': (_i, [C.POINTER(Options)]),

@@ -36,7 +36,7 @@ extern "C" const char* infgen_last_error(void) { return g_err.c_str(); }
 namespace {
 int layers_p_default() { const char* e = getenv("INFGEN_LAYERS_P"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : v > 2 ? 2 : v; }
 InfgenOptions g_def = {0, /*attn_mode*/ 2, /*gemm_terms*/ 3, /*fourier_mode*/ 1, /*edge_fuse*/ 1, /*edge_loop*/ 6, /*overlap*/ 0,
-                       /*row_group_margin*/ 0, /*layers_p*/ layers_p_default(), /*rhat_format*/ 0, nullptr, nullptr};
+                       /*row_group_margin*/ 0, /*layers_p*/ layers_p_default(), /*rhat_format*/ 0, /*edge_kernel*/ 1, 0, nullptr, nullptr};
 int g_def_group_rows = 0;                  // rows of the layout the process-wide group list belongs to
 const int* g_def_limit_n_agents = nullptr; // process-wide row limits (infgen_set_row_limits)
 int g_def_limit_A_cap = 0;
@@ -519,6 +519,13 @@ extern "C" int infgen_set_rhat_format(int format) {
   return 0;
 }
 
+// lane layout of the fused edge kernel's loop: 0 k_edge_fused, 1 k_edge_fused3 for launches beyond 4 k rows, 2 k_edge_fused3 always
+extern "C" int infgen_set_edge_kernel(int kernel) {
+  if (kernel < 0 || kernel > 2) return fail("infgen_set_edge_kernel", "kernel must be 0, 1 or 2");
+  g_def.edge_kernel = kernel;
+  return 0;
+}
+
 // edges per trip of k_edge_fused's edge loop (their K / V / rhat rows are requested together): 4, 6 (default) or 8
 extern "C" int infgen_set_edge_loop(int v) {
   if (v != 4 && v != 6 && v != 8) return fail("infgen_set_edge_loop", "edges per trip must be 4, 6 or 8");
@@ -558,6 +565,23 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
     grid = ceil_div(grid, grp) * grp;
   }
   if (no_xcd & 2) a.kv_once = 0;
+  if (!r24 && (O().edge_kernel == 2 || (O().edge_kernel == 1 && !small))) {
+    // k_edge_fused3 (edge_fused3.hip): one 8-wave workgroup per 16-row group at every size, fp32 rhat rows
+    EdgeFusedArgs m = a;
+    int mg = ceil_div(rows, 16);
+    m.tiles_per_scene = 0;
+    if (!m.groups && rows_per_scene > 16 && rows_per_scene % 16 == 0 && !(no_xcd & 1)) {
+      m.tiles_per_scene = rows_per_scene / 16;
+      const int grp = 8 * m.tiles_per_scene;
+      mg = ceil_div(mg, grp) * grp;
+    }
+    m.n_virtual = mg;
+    t_warm = WarmArgs{};
+    { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
+      auto k3 = G == 4 ? k_edge_fused3<4> : G == 8 ? k_edge_fused3<8> : k_edge_fused3<6>;
+      hipLaunchKernelGGL(k3, dim3(mg), dim3(512), 0, (hipStream_t)stream, m); }
+    return check_launch("infgen_edge_attn_fused(k_edge_fused3)");
+  }
   a.n_virtual = grid;
   if (small) grid = warm_take(a.warm, grid); else t_warm = WarmArgs{};
   static unsigned long long* ef_trace = nullptr;       // (timing experiment: INFGEN_EDGE_DBG bit 7 with an -DIG_EF_TRACE=1 build)

@@ -482,6 +482,7 @@ template <int WAVES, int TERMS> __global__ void k_attn_h(AttnHArgs a);
 template <int TERMS> __global__ void k_attn_hs(AttnHArgs a);             // attn_hs.hip: the same for few rows (one 16-row group per workgroup)   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);
+template <int G> __global__ void k_edge_fused3(EdgeFusedArgs a);       // edge_fused3.hip: lane = (head, 16-column slice), rhat rows through LDS
 template <int G, bool R24, int HALVES, int WAVES> __global__ void k_edge_fused(EdgeFusedArgs a);        // edge_fused.hip (R24: rhat rows in the packed format)
 template <bool R24, int ROWS> __global__ void k_layers_p(LayersPArgs a);          // layers_p.hip
 __global__ void k_edge_attn_wide(EdgeAttnArgs a);

@@ -413,3 +413,44 @@ def test_heads_argmax_and_logits(env, attn_mode):
     assert np.abs(lg - ref.numpy()).max() <= 2e-5
     assert np.array_equal(nt.cpu().numpy(), lg.argmax(-1))
     assert np.array_equal(ns.cpu().numpy(), refs.numpy().argmax(-1))
+
+
+@pytest.mark.parametrize('n_dst,n_src,max_deg', [(45, 45, 44), (200, 260, 255), (16, 1500, 1200), (1000, 64, 63), (5000, 300, 70)])
+def test_edge_fused3_equals_the_vector_loop(env, n_dst, n_src, max_deg):
+    """k_edge_fused3 (lane = (head, 16-column slice), rhat rows staged through LDS-DMA into the row's own U / Z slot; InfgenOptions.
+    edge_kernel) against k_edge_fused on the same fp32 rows (reference layers.py:78-92,109): the same agg' up to fp32 summation
+    order, over ragged degrees from 0 to beyond the 300-neighbour cap (lists of more than 64 edges: several index chunks), rows
+    without edges (exactly b' * 0), odd list lengths (the last LDS-DMA pair repeats the last row), score ranges that move the
+    online-softmax reference (x8 queries), and twice the same bits"""
+    import ctypes as C
+    from infgen_amd import _lib
+    rng = np.random.default_rng(n_dst + max_deg)
+    dev, lib = env['dev'], env['lib']
+    prefix = 'agent_encoder.a2a_attn_layers.1'
+    pack = _dev(env['packing'].pack_attention_layer(env['sd'], prefix), dev)
+    off, cnt, src, dst = _random_graph(rng, n_dst, n_src, max_deg, empty_rows=(0, 7, n_dst - 1))
+    E = len(src)
+    r = torch.nn.functional.layer_norm(torch.from_numpy(rng.standard_normal((E, 128)).astype(np.float32) *
+                                                        rng.uniform(0.2, 5.0, (E, 1)).astype(np.float32)), (128,)).to(dev).contiguous()
+    o = _lib.Options()
+    _lib.check(lib.infgen_get_options(C.byref(o)))
+    for qscale in (1.0, 8.0):
+        q = _dev(rng.standard_normal((n_dst, 128)) * qscale, dev)
+        k = _dev(rng.standard_normal((n_src, 128)), dev)
+        v = _dev(rng.standard_normal((n_src, 128)) * 3.0, dev)
+        offd, cntd, srcd = (torch.from_numpy(a).to(dev) for a in (off, cnt, src))
+        outs = []
+        for kern in (0, 2, 2):
+            o.edge_kernel, o.use = kern, 0
+            agg = torch.full((n_dst, 128), float('nan'), device=dev)
+            with _lib.thread_options(o):
+                env['ops'].edge_attn(n_dst, q, pack, k, v, offd, cntd, srcd, r, agg, None, None, wide='fused')
+            outs.append(agg)
+        torch.cuda.synchronize()
+        ref, a1, a2 = outs
+        assert torch.equal(a1.view(torch.int32), a2.view(torch.int32))
+        assert not torch.equal(a1, ref)                                  # (another kernel ran)
+        scale = float(ref.abs().max())
+        err = float((a1 - ref).abs().max())
+        assert err <= 2e-5 * scale, (qscale, err, scale)
+        assert torch.equal(a1[0], ref[0]) and torch.equal(a1[7], ref[7])       # rows without edges
