@@ -6,7 +6,8 @@
 // selects), and the eight aggregates z_h += p_h rhat_e need every head's p_h in every lane (8 v_readlane + 8 packed FMAs):
 // ~61 vector instructions per edge, the kernel's bound (vector pipe 77 % busy).
 //
-// Here lane l = (head h = l >> 3, slice i = l & 7) owns, for ITS head only, the 16 columns [16 i, 16 i + 16) of rhat:
+// Here lane l = (head h = l >> 3, slice i = l & 7) owns, for ITS head only, 16 columns of rhat - the four 4-column chunks
+// 32 k + 4 i .. + 3 (k = 0..3), so that the eight slices' 16-byte reads of one chunk tile 128 contiguous bytes (no LDS bank conflict):
 //   score    u_h . rhat_e   = 8 packed FMAs in the lane + the 8-lane sum that q_h . k_j needs anyway (3 DPP adds)
 //   z_h     += p_h rhat_e   = 8 packed FMAs with the lane's OWN p_h (no cross-lane broadcast)
 // ~34 vector instructions per edge.  Every head needs all 128 columns of an edge's rhat row, so the row goes global -> LDS once
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(512, 4) void k_edge_fused3(EdgeFusedArgs a) {
   }
   __syncthreads();
 
-  // ---- phase 2: the edge loop; lane = (head eh, slice ei): columns [16 ei, 16 ei + 16) of head eh
+  // ---- phase 2: the edge loop; lane = (head eh, slice ei): columns 32 k + 4 ei .. + 3 (k = 0..3) of head eh
   {
     const int eh = lane >> 3, ei = lane & 7;
     const bool kv_once = a.kv_once != 0;
@@ -143,10 +144,10 @@ __global__ __launch_bounds__(512, 4) void k_edge_fused3(EdgeFusedArgs a) {
       // this lane's 16 columns of u_h (pairs of consecutive columns), q of its two K columns
       pk2 ux[8];
       {
-        const float* up = uz + eh * D + 16 * ei;
+        const float* up = uz + eh * D + 4 * ei;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float4 t = *reinterpret_cast<const float4*>(up + 4 * k);
+          const float4 t = *reinterpret_cast<const float4*>(up + 32 * k);
           ux[2 * k] = pk2{t.x, t.y};
           ux[2 * k + 1] = pk2{t.z, t.w};
         }
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(512, 4) void k_edge_fused3(EdgeFusedArgs a) {
       // the slot is the ring from here on: the u reads above have returned before the first LDS-DMA write can land
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const unsigned ring = lds_addr(uz);
-      const float* rbase = uz + 16 * ei;                  // + 128 s: this lane's 16 columns of ring row s
+      const float* rbase = uz + 4 * ei;                   // + 128 s + 32 k: chunk k of this lane's 16 columns of ring row s
       pk2 zz[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) zz[k] = pk2{0.f, 0.f};
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(512, 4) void k_edge_fused3(EdgeFusedArgs a) {
             pk2 r[8];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              const float4 t = *reinterpret_cast<const float4*>(rbase + 128 * s + 4 * k);
+              const float4 t = *reinterpret_cast<const float4*>(rbase + 128 * s + 32 * k);
               r[2 * k] = pk2{t.x, t.y};
               r[2 * k + 1] = pk2{t.z, t.w};
             }
@@ -231,10 +232,10 @@ __global__ __launch_bounds__(512, 4) void k_edge_fused3(EdgeFusedArgs a) {
       const float inv = 1.0f / (lsum + 1e-16f);
       *reinterpret_cast<float2*>(AG + rl * E3_LDA + 2 * lane) = make_float2(ag[0] * inv, ag[1] * inv);
       {
-        float* zp = uz + eh * D + 16 * ei;
+        float* zp = uz + eh * D + 4 * ei;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          *reinterpret_cast<float4*>(zp + 4 * k) = make_float4(zz[2 * k][0] * inv, zz[2 * k][1] * inv, zz[2 * k + 1][0] * inv, zz[2 * k + 1][1] * inv);
+          *reinterpret_cast<float4*>(zp + 32 * k) = make_float4(zz[2 * k][0] * inv, zz[2 * k][1] * inv, zz[2 * k + 1][0] * inv, zz[2 * k + 1][1] * inv);
       }
       if (ei == 0) SG[rl * H + eh] = lsum * inv;
     }

@@ -37,7 +37,9 @@ if len(sys.argv) > 7:            # <pmc_FETCH_SIZE.bygrid.csv> <pmc_WRITE_SIZE.b
         # the group holds, per rollout, the 16 x 18 decode-step launches AND the 18 edgeless launches of the column-0 chain (same
         # grid; they read q and write agg only, ~2 x 512 B per row).  All of the group's bytes are charged to the decode-step
         # launches: a slight over-estimate of their traffic, never an under-estimate
-        n_step = sf[1] * 288 // 306
+        # (since round 4 the edgeless chain skips its edge launches - api.hip: skip_edges - and the group is the decode-step launches
+        # alone: a multiple of 288; older builds: 306 per rollout)
+        n_step = sf[1] if sf[1] % 288 == 0 else sf[1] * 288 // 306
         kern['k_edge_attn_step'] = dict(fetch_bytes_per_launch=sf[0] / n_step / f8, fetch_counter_bytes_per_launch=sf[0] / n_step,
                                         fetch_counter_factor=f8, write_bytes_per_launch=sw[0] / n_step, dispatches=n_step,
                                         group=sf[2], group_dispatches=sf[1])

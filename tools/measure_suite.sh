@@ -16,6 +16,7 @@ timeout 900 python bench.py --insertion --rollout-steps 800 --scenes 128 --inser
 timeout 900 python bench.py --agents 256 --map-tokens 4096 --rollout-steps 800 --scenes 32 --steps 2 --warmup 1 $B > $O/bench_c5shape_s32.json 2> $O/bench_c5shape_s32.err
 timeout 300 python tools/bench_dropin.py 512 > $O/dropin.log 2>&1
 for s in 1024 64 8; do timeout 300 python tools/soak_determinism.py $s 12 2>&1 | tail -1 >> $O/soak.log; done
+bash tools/edge_by_set2.sh "" k_edge_fused3 > $O/edge_by_set.txt 2>&1
 for f in $O/bench_*.json; do python -c "
 import json,sys
 d=json.load(open('$f')); r=d['roofline']; print('$f', round(d['value']/1e6,3),'M', round(d['ms_per_step'],2),'ms frac', round(r['frac'],4), 'traffic_ratio', r.get('traffic_ratio'), d['config'].get('agents_inserted_last_rollout'))"; done
