@@ -215,7 +215,8 @@ int infgen_fourier_last_dim_table(const float* pack, int n_dims, float* table, v
 int infgen_fourier_embed_tab(const float* raw, int n_dims, const int* count_dev, int e_cap, const float* pack,
                              const float* table, float* out, int ldo, int normalize, void* stream);
 /* arithmetic of infgen_fourier_embed: 1 (default) = fp16 MFMA with a three-term hi/lo split of both operands and fp32
- * accumulation (2^-21 relative error per product, 5.3x the fp32 matrix rate), 0 = fp32-input MFMA.  Process-wide. */
+ * accumulation (operands to 2^-23, round to nearest; measured at least as close to fp64 as mode 0: tests/test_precision_gpu.py; 5.3x the
+ * fp32 matrix rate), 0 = fp32-input MFMA.  Process-wide default (InfgenOptions.fourier_mode per context / thread). */
 int infgen_set_fourier_mode(int mode);
 /* the switch for infgen_attn_pre / infgen_attn_post / infgen_attn_post_pre: 0 fp32 MFMA, 1 fp16 split, 2 (default) by
  * row count (split from ~10 k rows, where its one-workgroup-per-CU tiles fill the chip) */

@@ -5,7 +5,8 @@
 // (32x32x16) is 16x faster.  Every operand is split into two fp16 numbers, x*2^s = hi + lo with hi the top
 // 11 significand bits and lo the next 11 (power-of-two prescales chosen at pack time keep both in the
 // fp16 normal range), and  x*w ~= hi_x*hi_w + hi_x*lo_w + lo_x*hi_w  is accumulated in fp32 by three
-// MFMAs: 2^-21 relative error per product (fp32: 2^-24), 16/3 = 5.3x the fp32 matrix rate.
+// MFMAs: operands represented to 2^-23 (round-to-nearest hi + lo, split.cuh), the dropped lo x lo term <= 2^-22 of a product;
+// 16/3 = 5.3x the fp32 matrix rate.
 // Logit error of a full rollout with every GEMM split like this stays at the fp32 noise floor
 // (DESIGN.md section 5).
 //
@@ -69,7 +70,7 @@ __device__ __forceinline__ void sincos_fast(float z, float& s, float& c) {
 // |r| <= 0.5, 3e-8 of a revolution = 1.9e-7 rad, for every |z| < 1e8).  Four vector instructions and two transcendental ones per
 // pair instead of ~30: the sine / cosine features were a quarter of the kernel's vector work, and the kernel is bound by that work
 // (tools/bench_fourier.py with the matrix phases removed: 292 of 409 us; with the vector phases removed: 195).  Measured against fp64
-// (tools/hw_sincos_probe.hip): max |error| 2.6e-7 (sincos_fast: 6e-8) - under the 2^-21 per product of the three-term split that
+// (tools/hw_sincos_probe.hip): max |error| 2.6e-7 (sincos_fast: 6e-8) - the order of the three-term split's own error per product (2^-22) that
 // consumes the features, and 30 x under the 2^-17 of the packed 24-bit output rows.  IG_FH_HWSIN=0 restores sincos_fast.
 #ifndef IG_FH_HWSIN
 #define IG_FH_HWSIN 1

@@ -8,8 +8,9 @@ insertion sub-loop when ``disable_insertion`` is False.  Motion tokens: greedy f
 ``motion_beam_size = 1``, otherwise top-k inverse-CDF sampling on supplied uniforms (the reference's
 top-5 multinomial, reproducible); the cell of an inserted agent: arg-max for ``insert_beam_size = 1`` (the default here),
 otherwise drawn from the top-k cells the same way (the reference's top-10 multinomial, agent_decoder.py:1900-1909, incl. its
-retry after an occupied cell).  The seed-loop outputs that exist
-only for plotting (``next_pos_rel_prob_seed``, ``grid_*_occ_seed``) are returned as zeros.
+retry after an occupied cell).  The seed-loop outputs (``next_state_prob_seed``, ``next_pos_rel_prob_seed``, ``grid_*_occ_seed``,
+``agent_labels``) are filled like the reference's by ``inference`` / ``inference_rollouts``; ``inference_batch`` returns zeros
+there unless called with ``seed_outputs=True``.
 """
 from __future__ import annotations
 
