@@ -579,7 +579,10 @@ static int edge_fused_launch(int rows, const float* Q, const float* pack, const 
     t_warm = WarmArgs{};
     { ProfScope _ps(INFGEN_KID_EDGE_ATTN, stream);
       auto k3 = G == 4 ? k_edge_fused3<4> : G == 8 ? k_edge_fused3<8> : k_edge_fused3<6>;
-      hipLaunchKernelGGL(k3, dim3(mg), dim3(512), 0, (hipStream_t)stream, m); }
+      // (INFGEN_EDGE_LDS_PAD=<bytes>, experiment: dynamic LDS on top of the kernel's 75 KB - from ~6 KB on only ONE workgroup fits a
+      // CU, which leaves room for another stream's node kernel; profiles/r06_coresidency_ab.txt)
+      static const int lds_pad = getenv("INFGEN_EDGE_LDS_PAD") ? atoi(getenv("INFGEN_EDGE_LDS_PAD")) : 0;
+      hipLaunchKernelGGL(k3, dim3(mg), dim3(512), lds_pad, (hipStream_t)stream, m); }
     return check_launch("infgen_edge_attn_fused(k_edge_fused3)");
   }
   a.n_virtual = grid;
