@@ -178,7 +178,7 @@ def parity_gate(dev):
         c = load_case(name)
         z = c['z']
         w = engine.PackedWeights(c['sd'], c['cfg'], dev)
-        tol = 1e-3 * max(1.0, c['meta']['head_gain'] / 16)
+        tol = 1e-3                                  # (flat, also on the x64-sharpened heads of these fixtures)
         r = {}
         ref_tok = torch.from_numpy(z['next_token_idx'].astype(np.int64)).to(dev)
         ref_st = torch.from_numpy(z['next_state_idx'].astype(np.int64)).to(dev)

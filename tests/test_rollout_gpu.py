@@ -3,8 +3,9 @@ reference's own modules, and against the CPU oracle on fresh seeded scenes.
 
 Bars (BASELINE.json north_star): greedy token indices bit-exact; logits within 1e-3 (fp32).
 Fixtures with a sharpened token head (``head_gain`` 64) scale the logits — and their error —
-by the gain, so the tolerance is 1e-3 * gain / 16 there (still far below the top-1/top-2
-margins stored in the fixture)."""
+by the gain; until round 5 their tolerance was 1e-3 * gain / 16.  Since the round-to-nearest operand
+split (round 6) the flat 1e-3 holds on them too (measured 9e-5 - 3.2e-4, the reference's own fp32
+noise at that gain), and that is what is asserted."""
 import numpy as np
 import pytest
 import torch
@@ -61,7 +62,7 @@ def test_free_running_rollout_matches_reference_fixture(name, attn_mode):
     o = outs[0]
     assert np.abs(o['x_pt'] - z['x_pt']).max() <= 1e-4, 'map encoder'
     gain = max(1.0, m['head_gain'])
-    tol = 1e-3 * max(1.0, gain / 16)
+    tol = 1e-3
     steps = z['logits'].shape[0]
     assert (z['margin'].min() > tol) == STRICT_CASES[name], 'fixture changed class: regenerate STRICT_CASES deliberately'
     # per-step edge totals of the device's edge-set builder against the reference's own edge lists (a6 - a8)
@@ -159,7 +160,7 @@ def test_teacher_forced_logits(name, attn_mode):
     z, m = c['z'], c['meta']
     eng, outs = _engine(c, teacher=[(z['next_token_idx'], z['next_state_idx'])])
     o = outs[0]
-    tol = 1e-3 * max(1.0, m['head_gain'] / 16)
+    tol = 1e-3
     assert np.abs(o['logits'] - z['logits']).max() <= tol
     assert np.abs(o['pos_a'] - z['pos_a']).max() <= 1e-3
     # argmax agreement wherever the reference's own margin exceeds the tolerance
@@ -188,7 +189,7 @@ def test_batched_scenes_equal_single_scene_runs():
 @pytest.mark.parametrize('wseed,sseed', [(14, 4251), (16, 4253)])
 def test_rollout_vs_oracle_fresh_seed(wseed, sseed):
     """scene / weight seeds that have no committed fixture: HIP vs the CPU oracle run in-process.  The seeds were picked so that
-    the oracle's own arg-max margin clears the bar at every (step, row) - 0.081 / 0.060 against 4 x 4e-3 - which is asserted,
+    the oracle's own arg-max margin clears the bar at every (step, row) - 0.081 / 0.060 against 4 x 1e-3 - which is asserted,
     so the token comparison below is unconditional over all 16 free-running steps (it used to sit behind an
     `if` that a seed with one near-tie silently skipped)"""
     from infgen_amd import synth
@@ -205,7 +206,7 @@ def test_rollout_vs_oracle_fresh_seed(wseed, sseed):
     lg = ref['logits'].numpy()
     part = np.partition(lg, -2, axis=-1)
     margin = part[..., -1] - part[..., -2]
-    tol = 4e-3
+    tol = 1e-3
     assert margin.min() > 4 * tol, f'seed no longer has a clear margin: {margin.min()}'
     assert np.array_equal(o['next_token_idx'], ref['next_token_idx'].numpy())
     assert np.array_equal(o['next_state_idx'], ref['next_state_idx'].numpy())
@@ -237,7 +238,7 @@ def test_insertion_rollout_matches_reference_fixture(name):
     assert np.array_equal(o['agent_id'], z['agent_id'])
     assert np.array_equal(o['pred_type'], z['pred_type'])
     assert np.abs(o['pred_shape'] - z['pred_shape']).max() <= 1e-4
-    tol = 1e-3 * max(1.0, m['head_gain'] / 16)
+    tol = 1e-3
     for i, n in enumerate(z['n_agents_step']):
         assert np.abs(o['logits'][i, :n] - z['logits'][i, :n]).max() <= tol, i
     assert np.abs(o['pos_a'] - z['pos_a']).max() <= 1e-3
@@ -321,7 +322,7 @@ def test_long_insertion_fixture_and_row_headroom():
     assert np.array_equal(o['next_state_idx'][:, cols], z['next_state_idx'][:n, cols])
     assert np.abs(o['pos_a'][:, cols] - z['pos_a'][:n, cols]).max() <= 2e-3
     assert np.abs(o['head_a'][:, cols] - z['head_a'][:n, cols]).max() <= 1e-3
-    tol = 1e-3 * m['head_gain'] / 16
+    tol = 1e-3
     for t in range(t_ok):
         k = int(z['n_agents_step'][t])
         assert np.abs(o['logits'][t, :k].max(-1) - z['logit_max'][t, :k]).max() <= tol, t
@@ -571,7 +572,7 @@ def test_long_horizon_rollout_vs_oracle():
     o = eng.outputs()[0]
     lg = ref['logits'].numpy()
     assert lg.shape[0] == 60
-    assert np.abs(o['logits'] - lg).max() <= 4e-3           # head sharpened x64
+    assert np.abs(o['logits'] - lg).max() <= 1e-3           # head sharpened x64
     assert np.abs(o['pos_a'] - ref['pos_a'].numpy()).max() <= 2e-3
     part = np.partition(lg, -2, axis=-1)
     ok = (part[..., -1] - part[..., -2]) > 2e-2
@@ -615,7 +616,7 @@ def test_topk_sampling_with_supplied_uniforms():
     assert np.array_equal(eng2.outputs()[0]['next_token_idx'], o['next_token_idx'])
 
 
-def _oracle_vs_engine(cfg, scene, sd, c, tol=4e-3, min_margin=2e-2, **eng_kw):
+def _oracle_vs_engine(cfg, scene, sd, c, tol=1e-3, min_margin=2e-2, **eng_kw):
     from infgen_amd import engine
     from oracle import rollout_oracle as ro
     tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
@@ -961,7 +962,7 @@ def test_layers_p_matches_per_sublayer_launches_and_reruns_bitwise():
     assert torch.allclose(old['pos'], new['pos'], atol=1e-4) and torch.allclose(old['head'], new['head'], atol=1e-5)
     gain = 64.0                                                   # the fixture's sharpened token head (make_golden.py: head_gain)
     err = (old['logits'] - new['logits']).abs().max().item()
-    assert err <= 1e-3 * gain / 16, err
+    assert err <= 1e-3, err
     assert not torch.equal(old['logits'], new['logits'])          # (it IS another kernel: the switch took effect)
 
 
