@@ -522,7 +522,21 @@ def main():
     step_roof['bound'] = 'hbm' if step_roof['hbm_fraction'] >= step_roof['mfma_fraction'] else 'mfma'
 
     roof = None
-    common = {'launches': dom['calls'], 'avg_launch_us': 1e3 * dom['ms'] / max(1, dom['calls']),
+    # the other GEMM kernels of the rollout by the same rule (leg 1's events around every launch: algorithmic FLOPs of the launches -
+    # DESIGN.md 5.2's per-unit figures x the units the device counted - over their summed duration, against the peak of their arithmetic)
+    total_ms = max(1e-9, sum(v['ms'] for v in per_kernel.values()))
+    others = {}
+    big = len(scenes) * engines[0].A_cap > 10240              # (the by-size rule of the node-side kernels: split arithmetic beyond 10,240 rows)
+    for k in ('k_fourier', 'k_attn_post', 'k_attn_pre', 'k_heads'):
+        v = per_kernel.get(k)
+        if not v or v['calls'] <= 0 or v['macs'] <= 0 or k == dominant:
+            continue
+        split = k == 'k_fourier' or big
+        peak = mm_peak if split else FP32_MATRIX_PEAK_TFLOPS
+        tf = 2.0 * v['macs'] / (v['ms'] * 1e-3) / 1e12
+        others[k] = {'bound': 'mfma', 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak, 'launches': v['calls'],
+                     'avg_launch_us': 1e3 * v['ms'] / v['calls'], 'share_of_gpu_time': v['ms'] / total_ms}
+    common = {'launches': dom['calls'], 'avg_launch_us': 1e3 * dom['ms'] / max(1, dom['calls']), 'other_kernels': others,
               'share_of_gpu_time': per_kernel[dominant]['ms'] / max(1e-9, sum(v['ms'] for v in per_kernel.values())),
               'per_kernel_ms_one_rollout': {k: round(v['ms'], 3) for k, v in per_kernel.items()}, 'step': step_roof}
     if dom['calls'] > 0 and dominant == 'k_edge_attn':
