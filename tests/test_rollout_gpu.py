@@ -215,6 +215,57 @@ def test_rollout_vs_oracle_fresh_seed(wseed, sseed):
     assert err <= tol, err
 
 
+def test_batch_of_fresh_scenes_through_the_big_launch_kernels_vs_oracle():
+    """24 scenes no fixture knows - 8 to 64 agents, 128 to 1024 map tokens, ego first / last, history edge cases - as ONE batch of 192
+    (8 copies each: 12,288 rows, i.e. the kernels of the headline batch: k_edge_fused3, k_attn_h, k_fourier_h(12), k_heads_h), every
+    scene against its own CPU-oracle rollout (reference agent_decoder.py:1605-2389), step by step: as long as the tokens agreed so
+    far the logits of a step must agree within 1e-3, and a token may differ ONLY in a row whose arg-max margin in the oracle is below
+    4 x 1e-3 (a near-tie; the comparison of that rollout ends there).  The first and the last copy of every scene are checked; at
+    least 40 of the 48 checked rollouts must agree over all 16 steps"""
+    from infgen_amd import engine, synth
+    from oracle import rollout_oracle as ro
+    c = load_case('a24_m256_edge')
+    cfg = c['cfg']
+    sd = make_weights(seed=21, head_gain=64.0)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    A_of, M_of = (8, 11, 17, 24, 33, 40, 48, 64), (128, 300, 700, 1024)
+    scenes = [synth.make_scene(7300 + i, A_of[i % 8], M_of[(i // 2) % 4], cfg, ego_last=bool(i % 2), edge_cases=bool((i // 3) % 2),
+                               vocab=c['vocab'], grid=c['grid'], slip=0.2) for i in range(24)]
+    copies = 8
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(sd, cfg, dev)
+    eng = engine.RolloutEngine(w, [sc for sc in scenes for _ in range(copies)], c['vocab'], c['map_vocab'], c['grid'], store_logits=True,
+                               use_graph=False)
+    assert eng.rows > 10240
+    eng.rollout()
+    outs = eng.outputs()
+    torch.set_num_threads(16)
+    full, worst, steps_checked = 0, 0.0, 0
+    hc = cfg.hist_columns
+    for i, sc in enumerate(scenes):
+        ref = ro.run_scene(tsd, sc, cfg, c['vocab'], c['map_vocab'], c['grid'])
+        lg = ref['logits'].numpy()                                   # [steps][A][2048]
+        part = np.partition(lg, -2, axis=-1)
+        margin = part[..., -1] - part[..., -2]                       # [steps][A]
+        rtok = ref['next_token_idx'].numpy()
+        for o in (outs[i * copies], outs[i * copies + copies - 1]):
+            done = lg.shape[0]
+            for t in range(lg.shape[0]):
+                # same inputs so far: the logits of step t must agree; a token may differ only where the oracle's own margin is a near-tie
+                err = float(np.abs(o['logits'][t] - lg[t]).max())
+                worst = max(worst, err)
+                assert err <= 1e-3, (i, t, err)
+                diff = o['next_token_idx'][:, hc + t] != rtok[:, hc + t]
+                assert not (diff & (margin[t] >= 4e-3)).any(), (i, t, 'a token with a clear margin differs')
+                steps_checked += 1
+                if diff.any():                                       # (legitimate near-tie: the rollouts part ways here)
+                    done = t
+                    break
+            full += done == lg.shape[0]
+    print(f'fresh batch: {full} of 48 checked rollouts agree over all 16 steps, {steps_checked} steps compared, worst logits error {worst:.2e}')
+    assert full >= 40 and steps_checked >= 700, (full, steps_checked)
+
+
 @pytest.mark.parametrize('name', ['ins_forced_a16_m256', 'ins_natural_a20_m256', 'ins_sampled_a16_m256'])
 def test_insertion_rollout_matches_reference_fixture(name):
     """scenario insertion (agent_decoder.py:1773-2105): same agents inserted at the same steps with the same
