@@ -54,8 +54,14 @@ __global__ __launch_bounds__(512, 4) void k_edge_fused3(EdgeFusedArgs a) {
   const int row = r0 + j;
   const bool valid = row < a.rows;
   const float* hdr = a.pack + AH_HDR;
+  // The lists' bookkeeping first: the two small loads (edge counts, first edges of the tile's 16 rows) go out in FRONT of the q tile and
+  // the 64 KB of weight fragments - vmcnt retires in order, so they return after one short round trip instead of behind that burst
+  // (cycle stamps: ~6,000 cycles for the burst) - and the rows' source indices are requested while the burst is still landing.
+  const int bk_rl = lane & 15;
+  const int bk_dr = r0 + bk_rl;
+  const int bk_cnt = bk_dr < a.rows ? a.es.cnt[bk_dr] : 0;
+  const int bk_off = bk_dr < a.rows ? a.es.off[bk_dr] : 0;
   // ---- phase 1: u_h = q_h W'_kr,h (K = 16: v_mfma_f32_16x16x16_f16; B fragment = the head's 16 query values of row j), wave = head
-  // (its loads - the q tile, the weight fragments - are requested first, the lists' bookkeeping right behind them)
   float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (valid) qv = *reinterpret_cast<const float4*>(a.Q + (size_t)row * D + DH * h + 4 * g);
   v4h ah[8], al[8];
@@ -69,20 +75,18 @@ __global__ __launch_bounds__(512, 4) void k_edge_fused3(EdgeFusedArgs a) {
     }
   }
   // Every wave ranks the tile's rows by edge count itself (16 counts, 16 compares: the same two loads in all eight waves) and takes
-  // the (w + 1)-th longest and the (w + 1)-th shortest row.  The lists' bookkeeping - count, first edge, the first 64 source indices
-  // of both rows - is requested HERE, in front of phase 1: a workgroup's life is a chain of dependent memory round trips (count ->
-  // indices -> K / V rows, for two rows), and with two workgroups per CU that chain, not the arithmetic, is what a launch with short
-  // lists costs (map set: 5 edges per row, ~115 us per launch); these three round trips now run under phase 1 and its barrier.
+  // the (w + 1)-th longest and the (w + 1)-th shortest row; the first 64 source indices of both rows are requested HERE, in front of
+  // phase 1's arithmetic: a workgroup's life is a chain of dependent memory round trips (count -> indices -> K / V rows, for two rows),
+  // and with two workgroups per CU that chain, not the arithmetic, is what a launch with short lists costs (map set: 5 edges per row,
+  // ~110 us per launch).  Cycle stamps of one workgroup (map set, ~26,000 cycles): first loads back 2,700, ranked 3,300, indices
+  // requested 6,800 (queued behind the weight burst), phase 1 done 9,400, rows 5,000 each, phase 3 3,000.
   int E2[2], eb2[2], sv2[2], rl2[2];
   {
-    const int rl = lane & 15;
-    const int dr = r0 + rl;
-    const int cnt = dr < a.rows ? a.es.cnt[dr] : 0;
-    const int off = dr < a.rows ? a.es.off[dr] : 0;
+    const int rl = bk_rl, cnt = bk_cnt, off = bk_off;
     int rank = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const int ck = __shfl(cnt, k, 64);
+      const int ck = __builtin_amdgcn_readlane(cnt, k);          // (lanes 0..15 hold the 16 counts: no LDS round trip like __shfl)
       rank += (ck > cnt || (ck == cnt && k < rl)) ? 1 : 0;
     }
 #pragma unroll
@@ -96,7 +100,6 @@ __global__ __launch_bounds__(512, 4) void k_edge_fused3(EdgeFusedArgs a) {
       sv2[p] = E2[p] > 0 ? a.es.src[eb2[p] + min(lane, min(E2[p], 64) - 1)] : 0;
     }
   }
-
   {
     *reinterpret_cast<float4*>(AG + j * E3_LDA + DH * h + 4 * g) = qv;
     float m = fmaxf(fmaxf(fabsf(qv.x), fabsf(qv.y)), fmaxf(fabsf(qv.z), fabsf(qv.w)));
