@@ -151,11 +151,13 @@ __global__ __launch_bounds__(512, 4) void k_edge_fused3(EdgeFusedArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float4 t = *reinterpret_cast<const float4*>(up + 32 * k);
-          ux[2 * k] = pk2{t.x, t.y};
-          ux[2 * k + 1] = pk2{t.z, t.w};
+          // (scores live in the log2 domain: u and q carry the factor log2 e, one multiply per row instead of one per edge)
+          ux[2 * k] = pk2{t.x, t.y} * pk2{EA_LOG2E, EA_LOG2E};
+          ux[2 * k + 1] = pk2{t.z, t.w} * pk2{EA_LOG2E, EA_LOG2E};
         }
       }
-      const float2 q = *reinterpret_cast<const float2*>(AG + rl * E3_LDA + 2 * lane);
+      const float2 q0 = *reinterpret_cast<const float2*>(AG + rl * E3_LDA + 2 * lane);
+      const pk2 q = pk2{q0.x, q0.y} * pk2{EA_LOG2E, EA_LOG2E};
       // the slot is the ring from here on: the u reads above have returned before the first LDS-DMA write can land
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const unsigned ring = lds_addr(uz);
@@ -193,41 +195,50 @@ __global__ __launch_bounds__(512, 4) void k_edge_fused3(EdgeFusedArgs a) {
           // the 2 G loads above are the only vector-memory operations younger than the LDS-DMA pieces: at most 2 G outstanding
           // means every piece has landed (vmcnt retires in order; the compiler barrier keeps the loads in front of the wait)
           asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * G) : "memory");
+          // The loop is bound by the SIMD's issue slots (four waves x ~175 issue cycles per edge = the ~700 cycles per edge and wave
+          // the cycle stamps show), so every instruction counts: q . k rides in the packed FMA chains of u . rhat, the log2 e factor
+          // sits in u and q, the dead-slot mask is one scalar select + one v_min.
+          {
 #pragma unroll
-          for (int s = 0; s < G; ++s) {
-            pk2 r[8];
+            for (int s = 0; s < G; ++s) {
+              pk2 r[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const float4 t = *reinterpret_cast<const float4*>(rbase + 128 * s + 32 * k);
-              r[2 * k] = pk2{t.x, t.y};
-              r[2 * k + 1] = pk2{t.z, t.w};
+              for (int k = 0; k < 4; ++k) {
+                const float4 t = *reinterpret_cast<const float4*>(rbase + 128 * s + 32 * k);
+                r[2 * k] = pk2{t.x, t.y};
+                r[2 * k + 1] = pk2{t.z, t.w};
+              }
+              // score of head eh in the log2 domain: q_h . k_j + u_h . rhat_e, two chains of packed FMAs, then the head's 8-lane sum
+              pk2 d2 = q * kb[s], d3 = ux[0] * r[0];
+#pragma unroll
+              for (int k = 1; k < 8; k += 2) d2 = pk_fma(ux[k], r[k], d2);
+#pragma unroll
+              for (int k = 2; k < 8; k += 2) d3 = pk_fma(ux[k], r[k], d3);
+              d2 += d3;
+              float val = sum8(d2[0] + d2[1]);
+              // (-inf for the slots beyond the end of the list: the limit is wave-uniform - one scalar select, one v_min)
+              {
+                const unsigned lim = __builtin_amdgcn_readfirstlane(i0 + s < mc ? 0x7f800000u : 0xff800000u);
+                asm("v_min_f32 %0, %1, %2" : "=v"(val) : "s"(lim), "v"(val));      // (fminf would add a quieting v_max of the limit)
+              }
+              const bool grow = val > m + EA_TAU;                // first edge: m = -inf
+              if (__any(grow)) {
+                const float mn = grow ? val : m;
+                const float sc = __builtin_amdgcn_exp2f(m - mn);      // 0 on the first edge, 1 for heads that keep their reference
+                lsum *= sc;
+                const pk2 sc2 = bc_v(sc);
+                ag *= sc2;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) zz[k] *= sc2;
+                m = mn;
+              }
+              const float pe = __builtin_amdgcn_exp2f(val - m);
+              lsum += pe;
+              const pk2 pe2 = bc_v(pe);
+              ag = pk_fma(pe2, vb[s], ag);
+#pragma unroll
+              for (int k = 0; k < 8; ++k) zz[k] = pk_fma(pe2, r[k], zz[k]);
             }
-            const bool alive = i0 + s < mc;
-            // score of head eh in the log2 domain: q_h . k_j + u_h . rhat_e, summed over the head's 8 lanes
-            pk2 d2 = ux[0] * r[0], d3 = ux[1] * r[1];             // (two independent chains of four dependent packed FMAs)
-#pragma unroll
-            for (int k = 2; k < 8; k += 2) { d2 = pk_fma(ux[k], r[k], d2); d3 = pk_fma(ux[k + 1], r[k + 1], d3); }
-            d2 += d3;
-            float val = fmaf(q.y, kb[s][1], q.x * kb[s][0]);
-            val += d2[0] + d2[1];
-            val = fminf(sum8(val) * EA_LOG2E, alive ? INFINITY : -INFINITY);
-            const bool grow = val > m + EA_TAU;                // first edge: m = -inf
-            if (__any(grow)) {
-              const float mn = grow ? val : m;
-              const float sc = __builtin_amdgcn_exp2f(m - mn);      // 0 on the first edge, 1 for heads that keep their reference
-              lsum *= sc;
-              const pk2 sc2 = bc_v(sc);
-              ag *= sc2;
-#pragma unroll
-              for (int k = 0; k < 8; ++k) zz[k] *= sc2;
-              m = mn;
-            }
-            const float pe = __builtin_amdgcn_exp2f(val - m);
-            lsum += pe;
-            ag = pk2{fmaf(pe, vb[s][0], ag[0]), fmaf(pe, vb[s][1], ag[1])};
-            const pk2 pe2 = bc_v(pe);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) zz[k] = pk_fma(pe2, r[k], zz[k]);
           }
           // (the ring reads of this trip are consumed: the next trip's LDS-DMA may overwrite the slot)
         }
