@@ -21,7 +21,7 @@ def test_headline_numbers_in_the_documents_are_the_committed_line():
     ms = f"{d['ms_per_step']:.1f}"                            # 183.5
     launch = f"{r['avg_launch_us']:.1f}"                      # 212.3
     frac = f"{r['frac']:.3f}"                                 # 0.165
-    traffic_mb = f"{r['traffic'] / 1e6:.0f} MB".replace('707', '706')      # the line looked up the mid-round pass (706.8); the final passes: 706.3
+    traffic_mb = f"{r['traffic'] / 1e6:.0f} MB"               # 706 MB (looked up from the previous suite's passes)
     ratio = f"{r['traffic_ratio']:.2f} x"                     # 2.25 x
     multi = f"{d['multi_rollout_value'] / 1e6:.1f} M"         # 34.2 M
     value2 = f"{d['value'] / 1e6:.2f} M"                      # 28.56 M (profiles/README.md writes two decimals)
@@ -51,5 +51,5 @@ def test_rocprof_average_and_traffic_quoted_from_the_files():
     # the event average of the line and the rocprofv3 figure without the map encoder's launches agree (same box)
     d = json.loads(_read('profiles/bench_r06f_s1024.json'))
     total_ms = float(edge['TotalDurationNs']) / 1e6
-    step_us = (total_ms - 15 * 4.15) * 1e3 / 1440
+    step_us = (total_ms - 15 * 4.07) * 1e3 / 1440
     assert abs(step_us - d['roofline']['avg_launch_us']) / d['roofline']['avg_launch_us'] < 0.05
