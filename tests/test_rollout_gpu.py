@@ -313,6 +313,38 @@ def test_insertion_rollout_matches_reference_fixture(name):
     assert np.array_equal(o2['next_state_prob_seed'], o['next_state_prob_seed'])
 
 
+@pytest.mark.parametrize('name', ['ins_forced_a16_m256', 'ins_natural_a20_m256'])
+def test_insertion_fixture_as_a_big_batch(name):
+    """the insertion fixtures as 128 copies in one batch (128 x 96 rows = 12,288: the big-launch kernels - k_edge_fused3 and k_attn_h
+    over the 16-row GROUP LISTS of the padded layout, the row limits of the edge kernel): the first, a middle and the last copy
+    insert the reference's agents at the reference's steps (agent_decoder.py:1773-2105) with its tokens, states, ids and types, poses
+    within 1e-3, and a second rollout is bitwise the first"""
+    from infgen_amd import engine
+    c = load_case(name)
+    z, m = c['z'], c['meta']
+    cfg = c['cfg']
+    cfg.disable_insertion = False
+    dev = torch.device('cuda:0')
+    w = engine.PackedWeights(c['sd'], cfg, dev)
+    copies = 128
+    eng = engine.RolloutEngine(w, [c['scene']] * copies, c['vocab'], c['map_vocab'], c['grid'], store_logits=False,
+                               force_enter=(m['insertion'] == 'forced'), a_cap=96)
+    assert eng.rows > 10240
+    eng.rollout()
+    outs = eng.outputs()
+    tok0 = eng.token.clone()
+    for i in (0, copies // 2, copies - 1):
+        o = outs[i]
+        assert o['pos_a'].shape[0] == z['pos_a'].shape[0], (i, o['pos_a'].shape, z['pos_a'].shape)
+        assert np.array_equal(o['next_state_idx'], z['next_state_idx']), i
+        assert np.array_equal(o['next_token_idx'], z['next_token_idx']), i
+        assert np.array_equal(o['agent_id'], z['agent_id']) and np.array_equal(o['pred_type'], z['pred_type']), i
+        assert np.abs(o['pos_a'] - z['pos_a']).max() <= 1e-3 and np.abs(o['head_a'] - z['head_a']).max() <= 1e-4, i
+        assert np.array_equal(o['pred_state'], z['pred_state']), i
+    eng.rollout()
+    assert torch.equal(tok0, eng.token)
+
+
 def _first_ill_conditioned_step(z, grid, ego, hist=2):
     """first decode step whose input column is ill-conditioned in the reference itself, so that everything downstream may
     legitimately differ between two correct implementations (the reference's CPU and GPU builds disagree there as well):
