@@ -346,7 +346,7 @@ def main():
     ap.add_argument('--rollout-steps', type=int, default=80, help='R = num_recurrent_steps_val (multiple of 5)')
     ap.add_argument('--streams', type=int, default=1, help='split the per-GPU batch over this many HIP streams')
     ap.add_argument('--gemm-terms', type=int, default=3, choices=(1, 3),
-                    help='3: fp16 three-term split = fp32 accuracy (default); 1: plain fp16 operands, the reduced-precision mode '
+                    help='3: round-to-nearest hi + lo fp16 operand split, three MFMA terms = fp32 arithmetic (default); 1: plain fp16 operands, the reduced-precision mode '
                          'for BASELINE config C5 (outside the 1e-3 parity bar)')
     ap.add_argument('--edge-fuse', type=int, default=-1, choices=(-1, 0, 1, 2),
                     help='infgen_set_edge_fuse: 1 (library default) k_edge_fused from 257 rows, 0 the unfused sequence with U / Z in HBM')
