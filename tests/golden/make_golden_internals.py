@@ -31,7 +31,7 @@ sys.path.insert(0, HERE)
 import make_golden as mg  # noqa: E402
 from infgen_amd import synth  # noqa: E402
 
-CASES = ('c1_a8_m128', 'a24_m256_edge')
+CASES = ('c1_a8_m128', 'a24_m256_edge', 'c3_a64_m1024')
 ACT_STEPS = 3
 
 

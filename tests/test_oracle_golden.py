@@ -53,7 +53,7 @@ def _sorted_triples(step, dst, src):
     return tri[np.lexsort((tri[:, 2], tri[:, 1]))].astype(np.int32)
 
 
-@pytest.mark.parametrize('case', ['c1_a8_m128', 'a24_m256_edge'])
+@pytest.mark.parametrize('case', ['c1_a8_m128', 'a24_m256_edge', 'c3_a64_m1024'])
 def test_oracle_edge_lists_and_triple_outputs_match_the_reference(case):
     """below the logits level: the edge LISTS of every decode step - sorted (step, destination agent, source
     column | source agent | source map token) of the temporal / agent / map sets, agent_decoder.py:540-758 - are the reference's

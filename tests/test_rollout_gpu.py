@@ -88,14 +88,16 @@ def test_free_running_rollout_matches_reference_fixture(name, attn_mode):
     assert o['ego_index'] == int(z['ego_index'])
 
 
-@pytest.mark.parametrize('copies', [1, 336], ids=['single scene', '336 copies (the big-batch kernels)'])
-@pytest.mark.parametrize('name', ['c1_a8_m128', 'a24_m256_edge'])
+@pytest.mark.parametrize('name,copies', [('c1_a8_m128', 1), ('c1_a8_m128', 336), ('a24_m256_edge', 1), ('a24_m256_edge', 336),
+                                         ('c3_a64_m1024', 1), ('c3_a64_m1024', 72)],
+                         ids=['c1-single', 'c1-336 copies', 'a24-single', 'a24-336 copies', 'c3-single', 'c3-72 copies (4,608 rows)'])
 def test_edge_lists_and_triple_outputs_match_the_reference(name, copies):
     """below the logits level: after every decode step the device's three edge sets (k_build_edges: CSR by
     destination row) decoded to sorted (step, destination agent, source column | agent | map token) triples are the REFERENCE's
     own edge lists (agent_decoder.py:540-758, hooked by tests/golden/make_golden_internals.py), and the residual stream after the
     first and the last (temporal, map, agent) triple of steps 0..2 (InfgenRollout.tap_x) equals the outputs of the reference's
-    a2a_attn_layers[0] / [L-1] (:2133-2158) within 1e-4.  Checked for the first and the last scene of the batch."""
+    a2a_attn_layers[0] / [L-1] (:2133-2158) within 1e-4.  Checked for the first and the last scene of the batch; the batches of copies
+    take the big-launch kernels (k_edge_fused3 etc.), c3 is BASELINE C3's scene shape (64 agents, 1024 map tokens: 26,726 agent edges)."""
     import os
     from conftest import GOLDEN
     from infgen_amd import engine
