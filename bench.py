@@ -345,9 +345,12 @@ def main():
                          'rollout fits; A_cap <= 1024)')
     ap.add_argument('--rollout-steps', type=int, default=80, help='R = num_recurrent_steps_val (multiple of 5)')
     ap.add_argument('--streams', type=int, default=1, help='split the per-GPU batch over this many HIP streams')
-    ap.add_argument('--gemm-terms', type=int, default=3, choices=(1, 3),
-                    help='3: round-to-nearest hi + lo fp16 operand split, three MFMA terms = fp32 arithmetic (default); 1: plain fp16 operands, the reduced-precision mode '
-                         'for BASELINE config C5 (outside the 1e-3 parity bar)')
+    ap.add_argument('--gemm-terms', type=int, default=3, choices=(1, 2, 3),
+                    help='3: round-to-nearest hi + lo fp16 operand split, three MFMA terms = fp32 arithmetic (default); the reduced-precision '
+                         'modes for BASELINE config C5 (outside the 1e-3 parity bar): 2 = bf16 operands (weights and activations rounded to '
+                         '8 significant bits, fp32 accumulation), 1 = fp16 operands')
+    ap.add_argument('--attn-mode', type=int, default=-1, choices=(-1, 0, 1, 2, 3),
+                    help='infgen_set_attn_mode: 2 (library default) node kernels by launch size, 1 the split kernels on 64-row tiles always')
     ap.add_argument('--edge-fuse', type=int, default=-1, choices=(-1, 0, 1, 2),
                     help='infgen_set_edge_fuse: 1 (library default) k_edge_fused from 257 rows, 0 the unfused sequence with U / Z in HBM')
     ap.add_argument('--edge-loop', type=int, default=-1, choices=(-1, 4, 6, 8))
@@ -395,6 +398,8 @@ def main():
     if args.overlap >= 0:
         _lib.check(lib.infgen_set_overlap(args.overlap))
     _lib.check(lib.infgen_set_gemm_terms(args.gemm_terms))
+    if args.attn_mode >= 0:
+        _lib.check(lib.infgen_set_attn_mode(args.attn_mode))
     if args.edge_loop >= 0:
         _lib.check(lib.infgen_set_edge_loop(args.edge_loop))
     if args.edge_fuse >= 0:
@@ -407,7 +412,7 @@ def main():
         parity = parity_gate(dev)
         log(f'parity: {parity}')
 
-    w = engine.PackedWeights(sd, cfg, dev)
+    w = engine.PackedWeights(sd, cfg, dev, operand_bits=8 if args.gemm_terms == 2 else 11)
     ns = max(1, args.streams)
     per = (len(scenes) + ns - 1) // ns
     use_graph = None if args.graph < 0 else ('all' if args.graph == 2 else bool(args.graph))       # 2: the whole rollout as one graph
@@ -765,8 +770,10 @@ def main():
             'higher_is_better': True,
             'scaling': args.scaling,
             'vs_baseline': None,
-            'dtype': 'f32' if args.gemm_terms == 3 else 'f16',
+            'dtype': {3: 'f32', 2: 'bf16', 1: 'f16'}[args.gemm_terms],
             'arithmetic': (ARITHMETIC_F32 if args.gemm_terms == 3 else
+                           'bf16-precision MFMA operands (weights and activations rounded to nearest even at 8 significant bits, carried '
+                           'on the f16 pipe), fp32 accumulate; outside the 1e-3 parity bar (BASELINE C5 "bf16")' if args.gemm_terms == 2 else
                            'fp16 MFMA operands (hi term only), fp32 accumulate; outside the 1e-3 parity bar (BASELINE C5 reduced mode)'),
             'data': 'synthetic',
             'config': {

@@ -515,8 +515,14 @@ int infgen_set_row_groups(const int* groups, const int* n_groups, int rows);
 /* the same bound for the edge kernel of those launches: n_agents [S], A_cap and the margin given to infgen_active_row_groups */
 int infgen_set_row_limits(const int* n_agents, int A_cap, int margin);
 
-/* Arithmetic of the split GEMM kernels: 3 (default) = fp16 three-term split, fp32 accuracy; 1 = the hi x hi term only = plain
- * fp16 operands with fp32 accumulation (reduced precision, for BASELINE config C5; outside the 1e-3 parity bar). */
+/* Arithmetic of the split GEMM kernels: 3 (default) = fp16 three-term split, fp32 accuracy.  Reduced precision, for BASELINE
+ * config C5 (the reference's optional bf16 trainer precision), outside the 1e-3 parity bar:
+ *   1 = the hi x hi term only: fp16 operands (11 significant bits), fp32 accumulation;
+ *   2 = bf16 operands: every activation operand is rounded to nearest even at 8 significant bits before it enters the matrix pipe
+ *       (k_*_b16 kernels), fp32 accumulation; takes packs whose fp16 planes hold bf16-rounded weights (infgen_amd.packing.
+ *       operand_bits(8) / PackedWeights(operand_bits=8)) - with default packs the weights keep 11 bits, which the library cannot
+ *       see: the Python engine refuses the mismatch.
+ * The edge kernels' two small GEMMs (u = q W'kr, W'vr z) stay three-term in every mode; their weights come from the same packs. */
 int infgen_set_gemm_terms(int terms);
 
 /* ---- optional profiling (bench.py roofline leg; process-global, off by default) ----

@@ -314,7 +314,7 @@ extern "C" int infgen_layernorm(const float* X, int rows, const float* gamma, co
 // arithmetic (11 bits per operand) in the split kernels - the reduced-precision mode for BASELINE config C5 ("bf16"), which
 // forfeits the 1e-3 logits bar.  Governs k_fourier_h, k_attn_h, k_mlpemb_h, k_heads_h.
 extern "C" int infgen_set_gemm_terms(int terms) {
-  if (terms != 1 && terms != 3) return fail("infgen_set_gemm_terms", "terms must be 3 (split, fp32 accuracy) or 1 (fp16)");
+  if (terms < 1 || terms > 3) return fail("infgen_set_gemm_terms", "terms must be 3 (split, fp32 accuracy), 2 (bf16 operands) or 1 (fp16 operands)");
   g_def.gemm_terms = terms;
   return 0;
 }
@@ -350,12 +350,13 @@ static int fourier_embed_impl(const float* raw, int n, const int* count_dev, int
   } else {
     // large sets: the three-wave-group variant (fourier_h12.hip); INFGEN_FH12_MIN = smallest capacity that takes it (0: never)
     static const int fh12_min = getenv("INFGEN_FH12_MIN") ? atoi(getenv("INFGEN_FH12_MIN")) : 150000;
-    const bool wide = fh12_min > 0 && e_cap >= fh12_min && O().gemm_terms != 1 && FH_WAVES == 8;
+    const bool wide = fh12_min > 0 && e_cap >= fh12_min && O().gemm_terms == 3 && FH_WAVES == 8;
     int grid = ceil_div(e_cap, wide ? FH12_TILE : FH_TILE);     // 128-row tiles (8 waves x 16 rows), persistent
     if (grid > 256 * FH_WG_PER_CU) grid = 256 * FH_WG_PER_CU;          // one workgroup per CU (fourier_h.hip explains why)
     ProfScope _ps(INFGEN_KID_FOURIER, stream);
     if (wide) hipLaunchKernelGGL(k_fourier_h12<3>, dim3(grid), dim3(FH12_NT), 0, (hipStream_t)stream, a);
     else if (O().gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h<1>, dim3(grid), dim3(FH_NT), 0, (hipStream_t)stream, a);
+    else if (O().gemm_terms == 2) hipLaunchKernelGGL(k_fourier_h_b16<1>, dim3(grid), dim3(FH_NT), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_fourier_h<3>, dim3(grid), dim3(FH_NT), 0, (hipStream_t)stream, a);
   }
   return check_launch("infgen_fourier_embed");
@@ -457,6 +458,7 @@ static void launch_attn_h(const AttnHArgs& a_in, void* stream) {
   if (attn_kind(a.rows) == 2) {            // one 16-row group per workgroup
     const int grid = warm_take(a.warm, ceil_div(a.rows, 16));
     if (O().gemm_terms == 1) hipLaunchKernelGGL(k_attn_hs<1>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    else if (O().gemm_terms == 2) hipLaunchKernelGGL(k_attn_hs_b16<1>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_attn_hs<3>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     return;
   }
@@ -466,6 +468,7 @@ static void launch_attn_h(const AttnHArgs& a_in, void* stream) {
     int grid = ceil_div(a.rows, 64);
     if (grid > 512) grid = 512;          // two workgroups per CU, persistent over the 64-row tiles beyond that
     if (O().gemm_terms == 1) hipLaunchKernelGGL((k_attn_h<4, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else if (O().gemm_terms == 2) hipLaunchKernelGGL((k_attn_h_b16<4, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((k_attn_h<4, 3>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   } else {
     int grid = ceil_div(a.rows, 128);
@@ -836,6 +839,7 @@ static int heads_impl(const float* X, int rows, const float* tok_pack, const flo
       int grid = ceil_div(rows, 64);
       if (grid > 512) grid = 512;
       if (O().gemm_terms == 1) hipLaunchKernelGGL(k_heads_h<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+      else if (O().gemm_terms == 2) hipLaunchKernelGGL(k_heads_h_b16<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
       else hipLaunchKernelGGL(k_heads_h<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     } else {
       hipLaunchKernelGGL(k_heads, dim3(ceil_div(rows, TR)), dim3(NT), 0, (hipStream_t)stream, a);
@@ -1002,6 +1006,7 @@ static int mlp_embedding_impl(const float* X, int ldx, int rows, int K0, const f
     if (grid > 512) grid = 512;
     { ProfScope _ps(INFGEN_KID_LINEAR, stream, (double)rows * (K0 + 128 + 128) * 128.0);
       if (O().gemm_terms == 1) hipLaunchKernelGGL(k_mlpemb_h<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m);
+      else if (O().gemm_terms == 2) hipLaunchKernelGGL(k_mlpemb_h_b16<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m);
       else hipLaunchKernelGGL(k_mlpemb_h<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m); }
     return check_launch(where);
   }
@@ -1052,6 +1057,7 @@ extern "C" int infgen_raw_feature_rows(const InfgenRollout* r, int col, const in
     if (grid > 512) grid = 512;
     { ProfScope _ps(INFGEN_KID_LINEAR, stream, (double)n * (512 + 128 + 128) * 128.0);
       if (O().gemm_terms == 1) hipLaunchKernelGGL(k_mlpemb_h<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m);
+      else if (O().gemm_terms == 2) hipLaunchKernelGGL(k_mlpemb_h_b16<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m);
       else hipLaunchKernelGGL(k_mlpemb_h<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m); }
     RET_IF(check_launch("infgen_raw_feature_rows/fusion"));
   } else {
@@ -1273,12 +1279,13 @@ static int prepare_edges(const InfgenRollout* r, int c, int edgeless, void* stre
     if (r->ea.cap > cap) cap = r->ea.cap;
     // (INFGEN_FH12_MULTI_ROWS: smallest launch, in rows, whose multi-set launch takes the three-wave-group kernel; default: never)
     static const int fh12_rows = getenv("INFGEN_FH12_MULTI_ROWS") ? atoi(getenv("INFGEN_FH12_MULTI_ROWS")) : 0;
-    const bool wide = fh12_rows > 0 && rows >= fh12_rows && O().gemm_terms != 1 && FH_WAVES == 8;
+    const bool wide = fh12_rows > 0 && rows >= fh12_rows && O().gemm_terms == 3 && FH_WAVES == 8;
     int grid = ceil_div(cap, wide ? FH12_TILE : FH_TILE);
     if (grid > 256 * FH_WG_PER_CU) grid = 256 * FH_WG_PER_CU;
     { ProfScope _ps(INFGEN_KID_FOURIER, stream);
       if (wide) hipLaunchKernelGGL(k_fourier_h12_multi<3>, dim3(grid, with_xa ? 4 : 3), dim3(FH12_NT), 0, (hipStream_t)stream, m);
       else if (O().gemm_terms == 1) hipLaunchKernelGGL(k_fourier_h_multi<1>, dim3(grid, with_xa ? 4 : 3), dim3(FH_NT), 0, (hipStream_t)stream, m);
+      else if (O().gemm_terms == 2) hipLaunchKernelGGL(k_fourier_h_multi_b16<1>, dim3(grid, with_xa ? 4 : 3), dim3(FH_NT), 0, (hipStream_t)stream, m);
       else hipLaunchKernelGGL(k_fourier_h_multi<3>, dim3(grid, with_xa ? 4 : 3), dim3(FH_NT), 0, (hipStream_t)stream, m); }
     RET_IF(check_launch("infgen_decode_layers(fourier)"));
   } else if (!edgeless) {

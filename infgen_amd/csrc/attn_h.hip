@@ -279,8 +279,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_attn_h(AttnH
   }
 }
 
+#if !IG_BF16_OPERANDS
 template __global__ void k_attn_h<4, 3>(AttnHArgs);
 template __global__ void k_attn_h<8, 3>(AttnHArgs);
+#endif
 template __global__ void k_attn_h<4, 1>(AttnHArgs);
 
 // k_active_groups: the 16-row groups of the [S][A_cap] row layout that hold at least one row below n_agents[s] + margin

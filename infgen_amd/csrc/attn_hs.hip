@@ -306,7 +306,9 @@ __global__ __launch_bounds__(512, 1) void k_attn_hs(AttnHArgs a) {
   }
 }
 
+#if !IG_BF16_OPERANDS
 template __global__ void k_attn_hs<3>(AttnHArgs);
+#endif
 template __global__ void k_attn_hs<1>(AttnHArgs);
 
 }  // namespace ig

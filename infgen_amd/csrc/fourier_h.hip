@@ -193,9 +193,13 @@ __global__ __launch_bounds__(FH_NT, 2) void k_fourier_h_multi(FourierMultiArgs m
 #endif
 }
 
+#if !IG_BF16_OPERANDS
 template __global__ void k_fourier_h_multi<3>(FourierMultiArgs);
+#endif
 template __global__ void k_fourier_h_multi<1>(FourierMultiArgs);
+#if !IG_BF16_OPERANDS
 template __global__ void k_fourier_h<3>(FourierArgs);
+#endif
 template __global__ void k_fourier_h<1>(FourierArgs);
 
 }  // namespace ig

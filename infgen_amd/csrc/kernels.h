@@ -479,6 +479,13 @@ __global__ void k_pt_grid_cells(EnteringsArgs a);
 __global__ void k_tokenize_state(TokenizeArgs a);
 __global__ void k_active_groups(ActiveGroupsArgs a);
 template <int WAVES, int TERMS> __global__ void k_attn_h(AttnHArgs a);
+// the *_b16 translation units: the same kernels with bf16-precision operands (gemm_terms = 2; TERMS = 1 only)
+template <int WAVES, int TERMS> __global__ void k_attn_h_b16(AttnHArgs a);
+template <int TERMS> __global__ void k_attn_hs_b16(AttnHArgs a);
+template <int TERMS> __global__ void k_mlpemb_h_b16(MlpEmbHArgs a);
+template <int TERMS> __global__ void k_heads_h_b16(HeadsArgs a);
+template <int TERMS> __global__ void k_fourier_h_b16(FourierArgs a);
+template <int TERMS> __global__ void k_fourier_h_multi_b16(FourierMultiArgs m);
 template <int TERMS> __global__ void k_attn_hs(AttnHArgs a);             // attn_hs.hip: the same for few rows (one 16-row group per workgroup)   // attn_h.hip     // fourier_h.hip: fp16 three-term split, register resident
 __global__ void k_attn_pre(AttnPreArgs a);
 __global__ void k_edge_attn(EdgeAttnArgs a);

@@ -194,9 +194,13 @@ __global__ __launch_bounds__(MH_NT, 2) void k_heads_h(HeadsArgs a) {
   }
 }
 
+#if !IG_BF16_OPERANDS
 template __global__ void k_mlpemb_h<3>(MlpEmbHArgs);
+#endif
 template __global__ void k_mlpemb_h<1>(MlpEmbHArgs);
+#if !IG_BF16_OPERANDS
 template __global__ void k_heads_h<3>(HeadsArgs);
+#endif
 template __global__ void k_heads_h<1>(HeadsArgs);
 
 }  // namespace ig

@@ -1,0 +1,6 @@
+// The k_mlpemb_h / k_heads_h kernels behind gemm_terms = 2 (BASELINE config C5's "bf16"): the same source with every operand rounded to bf16 precision
+// before it enters the f16 matrix pipe (split.cuh: IG_BF16_OPERANDS) - bf16 products, fp32 accumulation; hi term only.
+#define IG_BF16_OPERANDS 1
+#define k_mlpemb_h k_mlpemb_h_b16
+#define k_heads_h k_heads_h_b16
+#include "mlp_h.hip"

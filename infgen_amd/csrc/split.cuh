@@ -23,11 +23,26 @@ constexpr int DIST = RING - 1;           // quarters in flight ahead of the one 
 // representation errors (<= 2^-23 each).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// IG_BF16_OPERANDS = 1 (the *_b16.hip translation units: the kernels behind gemm_terms = 2, BASELINE config C5's "bf16"): an operand is
+// rounded to bf16 precision (8 significant bits, round to nearest even: v_cvt_pk_bf16_f32) before it enters the f16 pipe.  Every
+// operand is pre-scaled by a power of two into the fp16 range, so the bf16-rounded value is exactly representable in fp16: the
+// products are those of a bf16 MFMA, accumulated in fp32 - bf16 arithmetic on the f16 pipe, same rate.  hi only (TERMS = 1).
+#ifndef IG_BF16_OPERANDS
+#define IG_BF16_OPERANDS 0
+#endif
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+#if IG_BF16_OPERANDS
+  const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+  const f32x2 r = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+  lo = 0u;
+#else
   const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
   const f32x2 r = f32x2{a, b} - __builtin_convertvector(h, f32x2);
   hi = __builtin_bit_cast(unsigned, h);
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+#endif
 }
 
 // sum over lanes ^ 16, ^ 32 (the four lanes that hold one row): the gfx950 row / half swaps with both operands equal leave

@@ -163,7 +163,14 @@ class PackedWeights:
     """Device-resident packed weights of one checkpoint (shared by every engine on the GPU)."""
 
     def __init__(self, sd: Mapping[str, np.ndarray], cfg: RolloutConfig, device: torch.device,
-                 agent_prefix: str = 'agent_encoder', map_prefix: str = 'map_encoder'):
+                 agent_prefix: str = 'agent_encoder', map_prefix: str = 'map_encoder', operand_bits: int = 11):
+        """``operand_bits`` = 8: the fp16 planes of every pack hold bf16-precision weights (packing.operand_bits) - the packs
+        of the reduced bf16 mode, which only engines running ``gemm_terms = 2`` accept (and which accept no other)"""
+        self.operand_bits = int(operand_bits)
+        with packing.operand_bits(self.operand_bits):
+            self._pack(sd, cfg, device, agent_prefix, map_prefix)
+
+    def _pack(self, sd, cfg, device, agent_prefix, map_prefix):
         self.cfg = cfg
         self.device = device
         ap, mp = agent_prefix, map_prefix
@@ -1348,6 +1355,9 @@ class RolloutEngine:
         for k, v in (self.options or {}).items():
             setattr(o, k, int(v))
         o.use = 1
+        if (int(o.gemm_terms) == 2) != (self.w.operand_bits == 8):
+            raise ValueError(f'gemm_terms = {int(o.gemm_terms)} with packs of {self.w.operand_bits}-bit operands: the bf16 mode '
+                             '(gemm_terms = 2) takes PackedWeights(..., operand_bits=8), every other mode operand_bits=11')
         # the temporal edges' time-gap input as a lookup of its r_t_emb branch (include/infgen_hip.h: four_t_dt), built once per
         # weight pack and arithmetic; INFGEN_NO_DT_TAB=1: evaluated per edge as before
         self._ctx.four_t_dt = None

@@ -8,6 +8,7 @@ projections ``to_k_r`` / ``to_v_r`` are stored with the layer's ``attn_prenorm_r
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, Mapping
 
 import numpy as np
@@ -175,11 +176,39 @@ H_TARGET = 32000.0      # |scaled operand| bound: fp16 max is 65504
 LN_MAX = 11.3           # max |(x - mean) / std| over 128 values is sqrt(127)
 
 
+OPERAND_BITS = 11       # significand bits of the hi term: 11 = fp16 (default), 8 = bf16 (``operand_bits``: the gemm_terms = 2 packs)
+
+
+@contextlib.contextmanager
+def operand_bits(bits: int):
+    """Packs built inside carry bf16-precision weights (bits = 8) in their fp16 hi plane and an all-zero lo plane - the weights of the
+    ``*_b16`` kernels (InfgenOptions.gemm_terms = 2; csrc/split.cuh: IG_BF16_OPERANDS).  The fp32 planes of a pack are unchanged."""
+    global OPERAND_BITS
+    assert bits in (8, 11)
+    prev, OPERAND_BITS = OPERAND_BITS, bits
+    try:
+        yield
+    finally:
+        OPERAND_BITS = prev
+
+
+def round_bf16(x: np.ndarray) -> np.ndarray:
+    """fp32 -> the nearest bf16 value (round to nearest even on the upper 16 bits, as v_cvt_pk_bf16_f32), returned as fp32"""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    u = (u + np.uint32(0x7fff) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xffff0000)
+    return u.view(np.float32)
+
+
 def split_f16(x: np.ndarray):
     """x -> (hi, lo) fp16 bit patterns with x ~= hi + lo (error <= 2^-23 |x|): hi = x rounded to nearest even at 11
     significand bits, lo = the remainder x - hi (exact in fp32) rounded to nearest even - the same split the kernels
-    apply to activations (csrc/split.cuh: split_pair, v_cvt_pk_f16_f32)."""
+    apply to activations (csrc/split.cuh: split_pair, v_cvt_pk_f16_f32).  Under ``operand_bits(8)``: hi = x rounded to bf16
+    (exact in fp16 above the subnormal range: every weight is pre-scaled into it), lo = 0."""
     x = np.ascontiguousarray(x, dtype=np.float32)
+    if OPERAND_BITS == 8:
+        hi = round_bf16(x).astype(np.float16)
+        assert np.all(np.isfinite(hi)), 'fp16 overflow in the weight split'
+        return hi.view(np.uint16), np.zeros(hi.shape, np.uint16)
     hi = x.astype(np.float16)
     assert np.all(np.isfinite(hi)), 'fp16 overflow in the weight split'
     lo = (x - hi.astype(np.float32)).astype(np.float16)

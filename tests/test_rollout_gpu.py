@@ -919,7 +919,7 @@ def test_reduced_precision_mode_stays_close():
     err = np.abs(half - full)
     assert 1e-6 < err.max() <= 5e-3
     assert (half.argmax(-1) == full.argmax(-1)).mean() >= 0.99
-    assert lib.infgen_set_gemm_terms(2) != 0
+    assert lib.infgen_set_gemm_terms(4) != 0 and lib.infgen_set_gemm_terms(0) != 0
 
 
 def test_more_than_256_rows_per_scene():
