@@ -16,6 +16,10 @@ constexpr int QUARTER = 8192;            // fp16 elements of one quarter-matrix 
 constexpr int RING = 5;                  // quarter buffers in LDS (80 KB: at most one workgroup per CU)
 constexpr int DIST = RING - 1;           // quarters in flight ahead of the one being consumed
 
+// (Round 6 tried the remainders through v_fma_mixlo_f16 / v_fma_mixhi_f16 - convert, subtract and round in one instruction each, three
+// per pair instead of five, bit-identical (tools/split_mix_probe.hip): k_fourier_h 0 - 2 % faster, i.e. its vector phases are not
+// bound by instruction count - and the two half-register writes in front of an MFMA need more wait states than hipcc pads for an
+// asm block, depending on their order (tools/split_mix_mfma_probe.hip: k_attn_hs came out wrong at the fp16 level).  Not adopted.)
 // (a, b) -> packed fp16 pairs hi, lo with a = hi_a + lo_a (+ <= 2^-23 |a|): hi = a rounded to nearest even at 11 significand bits
 // (v_cvt_pk_f16_f32), lo = the remainder a - hi (exact in fp32, |a - hi| <= 2^-11 |a|) rounded to nearest even again.  Same five
 // instructions as a truncating split (round-toward-zero conversions: <= 2^-21 |a|), four times the accuracy: with both operands of a
