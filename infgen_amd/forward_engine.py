@@ -56,6 +56,9 @@ class ForwardEngine:
     def __init__(self, weights: PackedWeights, batch: Mapping, vocab: Mapping[str, np.ndarray], map_vocab: np.ndarray,
                  grid: np.ndarray):
         self.w, self.cfg, self.device = weights, weights.cfg, weights.device
+        if getattr(weights, 'operand_bits', 11) != 11:
+            raise ValueError('the teacher-forced forward runs in fp32 arithmetic: it takes default packs (operand_bits=11), not the '
+                             'bf16-operand packs of the rollout\'s reduced mode')
         self.ops = Ops(self.device)
         self.lib = self.ops.lib
         self.batch = batch
