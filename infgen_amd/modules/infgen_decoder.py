@@ -214,11 +214,17 @@ class InfGenDecoder(nn.Module):
                             time_span=time_span if time_span is not None else num_historical_steps,
                             seed_size=seed_size, buffer_size=buffer_size, disable_insertion=disable_insertion,
                             state_token=dict(state_token))
+        # arithmetic of the rollout's GEMM kernels - the counterpart of the trainer's `precision` flag, which the reference's run.py
+        # never passes (fp32): '32' (default) the fp32-accurate operand split; 'bf16' bf16 operands with fp32 accumulation (packs of
+        # bf16 weights, InfgenOptions.gemm_terms = 2; BASELINE config C5); '16' fp16 operands (gemm_terms = 1).  Set it before a call.
+        self.rollout_precision = '32'
         self._packed = None
         self._param_dicts = None
         self._last_w = None
         self._packed_ver = None
         self._engines = {}          # RolloutEngine per batch layout, reused across calls (RolloutEngine.reload)
+
+    _PRECISIONS = {'32': None, 'bf16': {'gemm_terms': 2}, '16': {'gemm_terms': 1}}
 
     # ------------------------------------------------------------------ weights
     def _weights(self) -> PackedWeights:
@@ -235,13 +241,16 @@ class InfGenDecoder(nn.Module):
         R = self.agent_encoder.num_recurrent_steps_val
         # the rollout length and the tokenizer geometry are part of the key: changing num_recurrent_steps_val between calls
         # (80 -> 300 for long-term validation) must not be ignored
+        prec = str(self.rollout_precision)
+        if prec not in self._PRECISIONS:
+            raise ValueError(f'rollout_precision must be one of {sorted(self._PRECISIONS)}, not {prec!r}')
         ver = (dev, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps), R, tok.grid_range, tok.grid_interval,
-               tok.angle_interval)
+               tok.angle_interval, prec)
         if self._packed_ver != ver:
             cfg = RolloutConfig(num_recurrent_steps_val=R if R != -1 else 80, grid_range=tok.grid_range,
                                 grid_interval=tok.grid_interval, angle_interval=tok.angle_interval, **self._cfg_kw)
             sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items()}
-            self._packed = PackedWeights(sd, cfg, dev)
+            self._packed = PackedWeights(sd, cfg, dev, operand_bits=8 if prec == 'bf16' else 11)
             self._packed_ver = ver
             self._engines = {}
         return self._packed
@@ -294,7 +303,7 @@ class InfGenDecoder(nn.Module):
                                  # single-scene entry and the n-copies batch of inference_rollouts; the throughput entry
                                  # (inference_batch) returns the zero arrays the reference initialises them to
                                  seed_outputs=(batch is None or batch_seed_outputs) and not w.cfg.disable_insertion and not map_only,
-                                 copies=copies)
+                                 copies=copies, options=self._PRECISIONS[str(self.rollout_precision)])
         # one engine per batch layout is kept across calls: a second call of the same shape re-uploads the scene arrays into
         # the first call's device buffers instead of building (and allocating) an engine again
         ekey = (len(scenes), PackedWeights.tables_key(*(vocab[k_] for k_ in ('veh', 'ped', 'cyc')), grid, map_vocab),

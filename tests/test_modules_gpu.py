@@ -233,3 +233,36 @@ def test_operator_modules_match_oracle():
     with torch.no_grad():
         ref = ro.mlp_layer(tsd, p, xi)
     assert (ml(xi.to(dev)).cpu() - ref).abs().max() <= 5e-5
+
+
+def test_rollout_precision_attribute_selects_the_arithmetic():
+    """InfGenDecoder.rollout_precision (the module-level counterpart of the trainer's precision flag): '32' is the default and
+    reproduces the fixture; 'bf16' repacks the weights at 8 bits and runs the rollout's engines with gemm_terms = 2 - the map
+    encoding moves by bf16-level amounts, the first decode step still mostly agrees; anything else is refused"""
+    c = load_case('c2_a32_m512')
+    z = c['z']
+    dev = torch.device('cuda:0')
+    dec = _decoder(c['cfg'])
+    _load(dec, c['sd'])
+    dec = dec.to(dev).eval()
+    assert dec.rollout_precision == '32'
+    full = dec.inference(_to_data(c['scene'], dev))
+    assert np.array_equal(full['next_token_idx'].cpu().numpy(), z['next_token_idx'])
+    assert dec._last_w.operand_bits == 11
+    dec.rollout_precision = 'bf16'
+    low = dec.inference(_to_data(c['scene'], dev))
+    assert dec._last_w.operand_bits == 8
+    eng = next(iter(dec._engines.values()))
+    assert int(eng._ctx.opts.gemm_terms) == 2 and int(eng._ctx.opts.use) == 1
+    d = np.abs(low['x_pt'].cpu().numpy() - full['x_pt'].cpu().numpy())
+    print(f'map encoding, bf16 operands vs fp32: max {d.max():.2e} mean {d.mean():.2e}')
+    assert 1e-5 < d.max() < 0.2 and d.mean() < 2e-2
+    t0, t1 = full['next_token_idx'].cpu().numpy(), low['next_token_idx'].cpu().numpy()
+    assert t0.shape == t1.shape and (t0[:, 0] == t1[:, 0]).mean() >= 0.8
+    assert np.isfinite(low['pos_a'].cpu().numpy()).all()
+    dec.rollout_precision = '32'
+    again = dec.inference(_to_data(c['scene'], dev))
+    assert torch.equal(again['next_token_idx'], full['next_token_idx']) and dec._last_w.operand_bits == 11
+    dec.rollout_precision = 'fp8'
+    with pytest.raises(ValueError, match='rollout_precision'):
+        dec.inference(_to_data(c['scene'], dev))
