@@ -59,7 +59,7 @@ F16_SPLIT_PEAK_TFLOPS = F16_DENSE_PEAK_TFLOPS / 3.0
 # accumulation and every vector operation is fp32; inside the hot GEMM kernels an fp32 operand x enters the f16 matrix pipe as
 # the exact pair hi = rne16(x), lo = rne16(x - hi) (|x - hi - lo| <= 2^-23 |x|) and a product is hi hi + hi lo + lo hi in fp32
 ARITHMETIC_F32 = ('fp32 storage, fp32 accumulation; GEMM operands enter the f16 matrix pipe as round-to-nearest hi + lo fp16 pairs '
-                  '(<= 2^-23 per operand), three MFMA terms per product; error against fp64 measured <= 1.5 x the fp32-input MFMA '
+                  '(<= 2^-23 per operand), three MFMA terms per product; error against fp64 measured 0.5 - 1.1 x (bar 1.25 x) the fp32-input MFMA '
                   'kernels\' on every operator (tests/test_precision_gpu.py, profiles/r06_precision.json); fp32 rhat rows')
 
 # ---- SURVEY section 8d, per decode step of one scene (1 MAC = 2 FLOP, D = 128) ----------------------------------
