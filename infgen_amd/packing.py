@@ -9,6 +9,7 @@ projections ``to_k_r`` / ``to_v_r`` are stored with the layer's ``attn_prenorm_r
 from __future__ import annotations
 
 import contextlib
+import threading
 from typing import Dict, Mapping
 
 import numpy as np
@@ -176,20 +177,29 @@ H_TARGET = 32000.0      # |scaled operand| bound: fp16 max is 65504
 LN_MAX = 11.3           # max |(x - mean) / std| over 128 values is sqrt(127)
 
 
-OPERAND_BITS = 11       # significand bits of the hi term: 11 = fp16 (default), 8 = bf16 (``operand_bits``: the gemm_terms = 2 packs)
+class _PackState(threading.local):
+    """significand bits of the hi term of the packs being built by THIS thread: 11 = fp16 (default), 8 = bf16 (``operand_bits``)"""
+    bits = 11
+
+
+_STATE = _PackState()
+
+
+def current_operand_bits() -> int:
+    return _STATE.bits
 
 
 @contextlib.contextmanager
 def operand_bits(bits: int):
-    """Packs built inside carry bf16-precision weights (bits = 8) in their fp16 hi plane and an all-zero lo plane - the weights of the
-    ``*_b16`` kernels (InfgenOptions.gemm_terms = 2; csrc/split.cuh: IG_BF16_OPERANDS).  The fp32 planes of a pack are unchanged."""
-    global OPERAND_BITS
+    """Packs built inside (by the calling thread) carry bf16-precision weights (bits = 8) in their fp16 hi plane and an all-zero lo
+    plane - the weights of the ``*_b16`` kernels (InfgenOptions.gemm_terms = 2; csrc/split.cuh: IG_BF16_OPERANDS).  The fp32 planes of
+    a pack are unchanged."""
     assert bits in (8, 11)
-    prev, OPERAND_BITS = OPERAND_BITS, bits
+    prev, _STATE.bits = _STATE.bits, bits
     try:
         yield
     finally:
-        OPERAND_BITS = prev
+        _STATE.bits = prev
 
 
 def round_bf16(x: np.ndarray) -> np.ndarray:
@@ -205,7 +215,7 @@ def split_f16(x: np.ndarray):
     apply to activations (csrc/split.cuh: split_pair, v_cvt_pk_f16_f32).  Under ``operand_bits(8)``: hi = x rounded to bf16
     (exact in fp16 above the subnormal range: every weight is pre-scaled into it), lo = 0."""
     x = np.ascontiguousarray(x, dtype=np.float32)
-    if OPERAND_BITS == 8:
+    if _STATE.bits == 8:
         hi = round_bf16(x).astype(np.float16)
         assert np.all(np.isfinite(hi)), 'fp16 overflow in the weight split'
         return hi.view(np.uint16), np.zeros(hi.shape, np.uint16)

@@ -88,7 +88,7 @@ def test_weight_planes_of_a_bf16_pack(env):
     want = torch.from_numpy(x).bfloat16().float().numpy()
     ok = np.abs(want) >= 2.0 ** -14                                    # (fp16 normal range)
     assert np.array_equal(h8.view(np.float16).astype(np.float32)[ok], want[ok])
-    assert packing.OPERAND_BITS == 11
+    assert packing.current_operand_bits() == 11
 
 
 @pytest.mark.parametrize('n,prefix,E', [(3, 'agent_encoder.r_a2a_emb', 70001), (4, 'agent_encoder.r_t_emb', 33000)])
